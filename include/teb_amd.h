@@ -1,0 +1,284 @@
+/*
+ * teb_amd.h — C-ABI of the MI355X-native TEB optimiser (libteb_amd.so).
+ *
+ * This is the drop-in boundary for ONE hot path of rst-tu-dortmund/teb_local_planner:
+ *
+ *   bool TebOptimalPlanner::optimizeTEB(int iterations_innerloop, int iterations_outerloop,
+ *                                       bool compute_cost_afterwards, double obst_cost_scale,
+ *                                       double viapoint_cost_scale, bool alternative_time_cost)
+ *        reference: include/teb_local_planner/optimal_planner.h:231-232, src/optimal_planner.cpp:182-231
+ *   void HomotopyClassPlanner::optimizeAllTEBs(int iter_innerloop, int iter_outerloop)
+ *        reference: src/homotopy_class_planner.cpp:466-493
+ *   TebOptimalPlannerPtr HomotopyClassPlanner::selectBestTeb()
+ *        reference: src/homotopy_class_planner.cpp:564-667
+ *
+ * Everything is plain C: POD structs, caller-owned fp64 / int32 buffers, an opaque handle, int status
+ * codes. No torch / HIP types appear in any signature (streams and device pointers are void*).
+ * All arithmetic is fp64 like the reference (Eigen double).
+ *
+ * The same POD types are consumed by the CPU oracle (oracle/teb_oracle.h, teb_oracle_* symbols); the
+ * oracle is test infrastructure and is never linked into libteb_amd.so.
+ */
+#ifndef TEB_AMD_H_
+#define TEB_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TEB_AMD_ABI_VERSION 1
+
+/* ---- status codes (library calls) ------------------------------------------------------------- */
+enum {
+  TEB_AMD_OK = 0,
+  TEB_AMD_ERR_INVALID_ARG = 1,   /* NULL pointer, negative size, n > max_poses, ...                */
+  TEB_AMD_ERR_NO_DEVICE = 2,     /* no HIP device / wrong architecture (no CPU fallback exists)    */
+  TEB_AMD_ERR_HIP = 3,           /* a HIP runtime call failed; see teb_amd_last_error()            */
+  TEB_AMD_ERR_CAPACITY = 4,      /* max_poses does not fit the per-workgroup LDS budget etc.       */
+  TEB_AMD_ERR_UNSUPPORTED = 5    /* feature combination not implemented by this build              */
+};
+
+/* ---- per-TEB result status (mirrors the bool returned by optimizeTEB) --------------------------- */
+enum {
+  TEB_AMD_TEB_OK = 0,            /* optimizeTEB would have returned true                            */
+  TEB_AMD_TEB_FAILED = 1,        /* optimizeTEB would have returned false (guards of               */
+                                 /*   src/optimal_planner.cpp:185-186, 370-382, 393-397)            */
+  TEB_AMD_TEB_NONFINITE = 2      /* a non-finite residual / state was produced (the reference only  */
+                                 /*   ROS_ASSERTs on this, e.g. g2o_types/edge_velocity.h:116)      */
+};
+
+/* ---- robot footprint models: include/teb_local_planner/robot_footprint_model.h:58-770 ----------- */
+enum {
+  TEB_AMD_FOOTPRINT_POINT = 0,       /* PointRobotFootprint      :104-176 */
+  TEB_AMD_FOOTPRINT_CIRCULAR = 1,    /* CircularRobotFootprint   :229-300 */
+  TEB_AMD_FOOTPRINT_TWO_CIRCLES = 2, /* TwoCirclesRobotFootprint :307-430 */
+  TEB_AMD_FOOTPRINT_LINE = 3,        /* LineRobotFootprint       :439-635 */
+  TEB_AMD_FOOTPRINT_POLYGON = 4      /* PolygonRobotFootprint    :644-770 */
+};
+#define TEB_AMD_MAX_FOOTPRINT_VERTICES 16
+
+/* ---- obstacle types: include/teb_local_planner/obstacles.h:67-1111 ------------------------------ */
+enum {
+  TEB_AMD_OBST_POINT = 0,    /* PointObstacle    (ax,ay)                          */
+  TEB_AMD_OBST_CIRCULAR = 1, /* CircularObstacle (ax,ay), radius                  */
+  TEB_AMD_OBST_LINE = 2,     /* LineObstacle     (ax,ay)-(bx,by)                  */
+  TEB_AMD_OBST_PILL = 3,     /* PillObstacle     (ax,ay)-(bx,by), radius          */
+  TEB_AMD_OBST_POLYGON = 4   /* PolygonObstacle  vertices [vert_offset[i], vert_offset[i+1]) */
+};
+
+/* ---- RotType: include/teb_local_planner/misc.h:53  (enum class RotType { left, none, right }) --- */
+enum { TEB_AMD_ROT_LEFT = 0, TEB_AMD_ROT_NONE = 1, TEB_AMD_ROT_RIGHT = 2 };
+
+/* ---- Jacobian modes (extension; the reference has only the g2o behaviour) ------------------------ */
+enum {
+  TEB_AMD_JACOBIAN_ANALYTIC = 0,    /* closed-form Jacobians, one-sided conventions of penalties.h:127-187 */
+  TEB_AMD_JACOBIAN_G2O_NUMERIC = 1  /* g2o central differences, delta = 1e-9 (Base*Edge::linearizeOplus);  */
+                                    /*   EdgeKinematicsDiffDrive / EdgeTimeOptimal stay analytic like the   */
+                                    /*   reference (edge_kinematics.h:107-151, edge_time_optimal.h:98-107)  */
+};
+
+/*
+ * Kernel-relevant subset of TebConfig (include/teb_local_planner/teb_config.h:62-230), same field
+ * names, same defaults (teb_config.h:245-390) via teb_amd_config_default(). bools are int32.
+ */
+typedef struct teb_amd_config {
+  /* trajectory */
+  int32_t teb_autosize;            /* declared double in the reference, used as bool (teb_config.h:74) */
+  double  dt_ref;
+  double  dt_hysteresis;
+  int32_t min_samples;
+  int32_t max_samples;
+  int32_t exact_arc_length;
+  int32_t via_points_ordered;
+  /* robot */
+  double  max_vel_x;
+  double  max_vel_x_backwards;
+  double  max_vel_y;
+  double  max_vel_trans;
+  double  max_vel_theta;
+  double  acc_lim_x;
+  double  acc_lim_y;
+  double  acc_lim_theta;
+  double  min_turning_radius;
+  /* obstacles */
+  double  min_obstacle_dist;
+  double  inflation_dist;
+  double  dynamic_obstacle_inflation_dist;
+  int32_t include_dynamic_obstacles;
+  int32_t obstacle_poses_affected;
+  int32_t legacy_obstacle_association;
+  double  obstacle_association_force_inclusion_factor;
+  double  obstacle_association_cutoff_factor;
+  double  obstacle_proximity_ratio_max_vel;
+  double  obstacle_proximity_lower_bound;
+  double  obstacle_proximity_upper_bound;
+  /* optim */
+  int32_t no_inner_iterations;
+  int32_t no_outer_iterations;
+  int32_t optimization_activate;
+  double  penalty_epsilon;
+  double  weight_max_vel_x;
+  double  weight_max_vel_y;
+  double  weight_max_vel_theta;
+  double  weight_acc_lim_x;
+  double  weight_acc_lim_y;
+  double  weight_acc_lim_theta;
+  double  weight_kinematics_nh;
+  double  weight_kinematics_forward_drive;
+  double  weight_kinematics_turning_radius;
+  double  weight_optimaltime;
+  double  weight_shortest_path;
+  double  weight_obstacle;
+  double  weight_inflation;
+  double  weight_dynamic_obstacle;
+  double  weight_dynamic_obstacle_inflation;
+  double  weight_velocity_obstacle_ratio;
+  double  weight_viapoint;
+  double  weight_prefer_rotdir;
+  double  weight_adapt_factor;
+  double  obstacle_cost_exponent;
+  /* hcp (selection) */
+  double  selection_cost_hysteresis;
+  double  selection_prefer_initial_plan;
+  double  selection_obst_cost_scale;
+  double  selection_viapoint_cost_scale;
+  int32_t selection_alternative_time_cost;
+  /* recovery */
+  int32_t divergence_detection_enable;           /* no constructor default in the reference; 0 here */
+  double  divergence_detection_max_chi_squared;  /* cfg default 10 (cfg/TebLocalPlannerReconfigure.cfg:429-445) */
+  /* robot_model (TebConfig::robot_model, teb_config.h:68) flattened */
+  int32_t footprint_type;          /* TEB_AMD_FOOTPRINT_*                                              */
+  double  footprint_radius;        /* circular: radius                                                 */
+  double  footprint_front_offset;  /* two circles                                                      */
+  double  footprint_front_radius;
+  double  footprint_rear_offset;
+  double  footprint_rear_radius;
+  int32_t footprint_n_vertices;    /* line: 2 (start,end); polygon: >=1                                */
+  double  footprint_vx[TEB_AMD_MAX_FOOTPRINT_VERTICES]; /* body-frame vertices                         */
+  double  footprint_vy[TEB_AMD_MAX_FOOTPRINT_VERTICES];
+  /* extension */
+  int32_t jacobian_mode;           /* TEB_AMD_JACOBIAN_*                                               */
+} teb_amd_config_t;
+
+/*
+ * Obstacle table (ObstContainer = std::vector<boost::shared_ptr<Obstacle>>, obstacles.h:262) as SoA.
+ * All arrays have `count` entries except vert_offset (count+1, CSR) and vert_x/vert_y (vert_offset[count]).
+ * vert_offset/vert_x/vert_y may be NULL when no TEB_AMD_OBST_POLYGON is present.
+ * `dynamic` mirrors Obstacle::isDynamic() (set by setCentroidVelocity, obstacles.h:199-245).
+ */
+typedef struct teb_amd_obstacles {
+  int32_t        count;
+  const int32_t* type;
+  const double*  ax;
+  const double*  ay;
+  const double*  bx;
+  const double*  by;
+  const double*  radius;
+  const double*  vx;
+  const double*  vy;
+  const int32_t* dynamic;
+  const int32_t* vert_offset;
+  const double*  vert_x;
+  const double*  vert_y;
+} teb_amd_obstacles_t;
+
+/*
+ * A batch of B candidate TEBs (TebOptPlannerContainer, optimal_planner.h:702) as padded SoA:
+ * pose i of TEB b lives at index b*stride + i. n[b] poses, n[b]-1 time differences.
+ * First and last pose of every TEB are fixed (src/timed_elastic_band.cpp:330,377,398,442).
+ * Per-TEB side inputs mirror TebOptimalPlanner members (optimal_planner.h:687-691):
+ *   vel_start_ / vel_goal_ (pair<bool, Twist>: linear.x, linear.y, angular.z), prefer_rotdir_,
+ *   and whether via_points_ is attached to this candidate (hcp.viapoints_all_candidates).
+ */
+typedef struct teb_amd_teb_batch {
+  int32_t  count;      /* B */
+  int32_t  stride;     /* >= max n[b]; <= max_poses of the handle */
+  int32_t* n;          /* [B]   in: #poses; out (download): #poses after autoResize */
+  double*  x;          /* [B*stride] */
+  double*  y;
+  double*  theta;
+  double*  dt;         /* [B*stride]; dt[b*stride+i] connects pose i and i+1 */
+  const int32_t* has_vel_start;   /* [B]  or NULL (= all 0) */
+  const double*  vel_start;       /* [B*3] (vx, vy, omega) or NULL */
+  const int32_t* has_vel_goal;    /* [B]  or NULL (= all 0) */
+  const double*  vel_goal;        /* [B*3] or NULL */
+  const int32_t* prefer_rotdir;   /* [B]  TEB_AMD_ROT_* or NULL (= none) */
+  const int32_t* via_points_enabled; /* [B] or NULL (= all 1) */
+} teb_amd_teb_batch_t;
+
+/* Per-TEB outputs of one optimize_batch call. Any pointer may be NULL. */
+typedef struct teb_amd_results {
+  int32_t* status;         /* [B] TEB_AMD_TEB_*                                                       */
+  int32_t* lm_iterations;  /* [B] LM iterations executed, summed over outer iterations (the "units")  */
+  int32_t* lm_trials;      /* [B] damped-solve trials executed                                        */
+  double*  chi2;           /* [B] chi^2 after the last LM iteration (g2o batchStatistics().back().chi2, */
+                           /*     used by hasDiverged, src/optimal_planner.cpp:1023-1039)              */
+  double*  cost;           /* [B] computeCurrentCost (src/optimal_planner.cpp:1041-1094); NaN if not asked */
+  double*  lambda;         /* [B] final LM damping                                                     */
+} teb_amd_results_t;
+
+typedef struct teb_amd_handle teb_amd_handle_t;
+
+/* -- library ------------------------------------------------------------------------------------ */
+int  teb_amd_abi_version(void);
+const char* teb_amd_last_error(void);           /* thread-local message of the last failing call */
+void teb_amd_config_default(teb_amd_config_t* cfg);   /* TebConfig::TebConfig(), teb_config.h:245-390 */
+
+/*
+ * create: one solver per GPU / host thread. device = HIP ordinal. stream = hipStream_t (as void*) to
+ * launch on, or NULL for the handle's own stream. Fails (never falls back to CPU) when no gfx950 device.
+ */
+int  teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_poses,
+                    int32_t max_obstacles, int32_t max_obstacle_vertices, int32_t max_via_points,
+                    int32_t device, void* stream, teb_amd_handle_t** out);
+void teb_amd_destroy(teb_amd_handle_t* h);
+int  teb_amd_set_config(teb_amd_handle_t* h, const teb_amd_config_t* cfg);       /* dynamic_reconfigure */
+
+/* Scene, once per plan(): obstacles_ and via_points_ (optimal_planner.h:683-684). Host pointers. */
+int  teb_amd_set_obstacles(teb_amd_handle_t* h, const teb_amd_obstacles_t* obst);
+int  teb_amd_set_via_points(teb_amd_handle_t* h, int32_t count, const double* x, const double* y);
+
+/* State strips host -> HBM and back. */
+int  teb_amd_upload_tebs(teb_amd_handle_t* h, const teb_amd_teb_batch_t* batch);
+int  teb_amd_download_tebs(teb_amd_handle_t* h, teb_amd_teb_batch_t* batch);
+
+/*
+ * The hot path: B x optimizeTEB (src/optimal_planner.cpp:182-231), i.e. optimizeAllTEBs
+ * (src/homotopy_class_planner.cpp:466-493) when called with compute_cost=1 and the selection_* scales.
+ * Asynchronous on the handle's stream; results are valid after teb_amd_synchronize / get_results.
+ */
+int  teb_amd_optimize_batch(teb_amd_handle_t* h, int32_t iterations_innerloop, int32_t iterations_outerloop,
+                            int32_t compute_cost_afterwards, double obst_cost_scale,
+                            double viapoint_cost_scale, int32_t alternative_time_cost);
+int  teb_amd_synchronize(teb_amd_handle_t* h);
+int  teb_amd_get_results(teb_amd_handle_t* h, teb_amd_results_t* out);   /* synchronises, copies D2H */
+
+/*
+ * selectBestTeb (src/homotopy_class_planner.cpp:564-667) on the device-resident costs:
+ * cost[last_best] *= selection_cost_hysteresis, cost[initial_plan] *= selection_prefer_initial_plan
+ * (indices < 0 = none), strict '<' so the lowest index wins ties; TEBs whose status != OK still take
+ * part exactly like in the reference (their stored cost_ is compared). Returns index in *best, its
+ * (scaled) cost in *best_cost. The switching_blocking_period logic stays in the caller (needs ros::Time).
+ */
+int  teb_amd_select_best(teb_amd_handle_t* h, int32_t last_best, int32_t initial_plan,
+                         int32_t* best, double* best_cost);
+
+/* -- zero-copy access for callers that already live on the GPU (benchmarks, torch interop) ---------- */
+/* Device pointers (hipDeviceptr as void*) of the resident SoA strips: x, y, theta, dt, each
+ * [max_tebs*max_poses] doubles, and n [max_tebs] int32. Valid until destroy.                          */
+int  teb_amd_device_state(teb_amd_handle_t* h, void** x, void** y, void** theta, void** dt, void** n,
+                          int32_t* stride);
+/* Snapshot / restore the resident strips device-to-device (used to re-run identical work per step). */
+int  teb_amd_snapshot_state(teb_amd_handle_t* h);
+int  teb_amd_restore_state(teb_amd_handle_t* h);
+/* Duration [ms] of the last optimize_batch kernel, measured with HIP events on the launch stream. */
+int  teb_amd_last_kernel_ms(teb_amd_handle_t* h, float* ms);
+/* LDS bytes per workgroup and the largest pose count this build can optimise. */
+int  teb_amd_capacity(teb_amd_handle_t* h, int32_t* lds_bytes, int32_t* max_poses_supported);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEB_AMD_H_ */

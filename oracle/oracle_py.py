@@ -1,0 +1,161 @@
+"""ctypes wrapper of libteb_oracle.so — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from teb_local_planner_amd import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+COST_REFERENCE, COST_FRESH = 0, 1
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libteb_oracle.so")
+    src = os.path.join(_HERE, "teb_oracle.cpp")
+    if force or not os.path.exists(so) or (
+            os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+        subprocess.check_call(["make", "-C", _HERE, "libteb_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libteb_oracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.teb_oracle_optimize_batch.restype = C.c_int
+        _LIB.teb_oracle_optimize_batch.argtypes = [
+            C.POINTER(_abi.Config), C.POINTER(_abi.Obstacles), C.c_int32, _abi.p_f64, _abi.p_f64,
+            C.POINTER(_abi.TebBatch), C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32,
+            C.c_int32, C.c_int32, C.POINTER(_abi.Results)]
+        _LIB.teb_oracle_select_best.restype = C.c_int
+        _LIB.teb_oracle_select_best.argtypes = [
+            C.POINTER(_abi.Config), C.c_int32, _abi.p_f64, C.c_int32, C.c_int32, _abi.p_i32, _abi.p_f64]
+        _LIB.teb_oracle_autoresize.restype = C.c_int
+        _LIB.teb_oracle_autoresize.argtypes = [
+            _abi.p_f64, _abi.p_f64, _abi.p_f64, _abi.p_f64, _abi.p_i32, C.c_int32, C.c_double, C.c_double,
+            C.c_int32, C.c_int32, C.c_int32]
+        _LIB.teb_oracle_linearize.restype = C.c_int
+        _LIB.teb_oracle_linearize.argtypes = [
+            C.POINTER(_abi.Config), C.POINTER(_abi.Obstacles), C.c_int32, _abi.p_f64, _abi.p_f64,
+            C.POINTER(_abi.TebBatch), C.c_int32, C.c_double, _abi.p_f64, _abi.p_f64, _abi.p_f64,
+            _abi.p_i32, _abi.p_i32]
+        _LIB.teb_oracle_associate.restype = C.c_int
+        _LIB.teb_oracle_associate.argtypes = [
+            C.POINTER(_abi.Config), C.POINTER(_abi.Obstacles), C.POINTER(_abi.TebBatch), C.c_int32,
+            _abi.p_i32, _abi.p_i32, C.c_int32, _abi.p_i32]
+        _LIB.teb_oracle_distance.restype = C.c_int
+        _LIB.teb_oracle_distance.argtypes = [
+            C.POINTER(_abi.Config), C.POINTER(_abi.Obstacles), C.c_int32, C.c_double, C.c_double, C.c_double,
+            C.c_int32, C.c_double, _abi.p_f64, _abi.p_f64]
+        _LIB.teb_oracle_centroid.restype = C.c_int
+        _LIB.teb_oracle_centroid.argtypes = [C.POINTER(_abi.Obstacles), C.c_int32, _abi.p_f64, _abi.p_f64]
+    return _LIB
+
+
+def _via_arrays(via):
+    vx = _abi.f64([v[0] for v in via]) if via else _abi.f64([0.0])
+    vy = _abi.f64([v[1] for v in via]) if via else _abi.f64([0.0])
+    return vx, vy
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed with status %d" % (what, rc))
+
+
+def optimize_batch(cfg, obst, via, batch, inner=None, outer=None, compute_cost=True, obst_cost_scale=None,
+                   viapoint_cost_scale=None, alternative_time_cost=None, cost_mode=COST_REFERENCE, threads=1):
+    """Runs B x optimizeTEB on a COPY of batch; returns (new_batch, ResultsHost)."""
+    c = cfg.to_c()
+    out = batch.copy()
+    res = _abi.ResultsHost(batch.count)
+    vx, vy = _via_arrays(via)
+    inner = cfg.optim.no_inner_iterations if inner is None else inner
+    outer = cfg.optim.no_outer_iterations if outer is None else outer
+    osc = cfg.hcp.selection_obst_cost_scale if obst_cost_scale is None else obst_cost_scale
+    vsc = cfg.hcp.selection_viapoint_cost_scale if viapoint_cost_scale is None else viapoint_cost_scale
+    atc = cfg.hcp.selection_alternative_time_cost if alternative_time_cost is None else alternative_time_cost
+    bs = out.c_struct()
+    rs = res.c_struct()
+    rc = lib().teb_oracle_optimize_batch(
+        C.byref(c), C.byref(obst.freeze()), len(via), _abi._ptr(vx, C.c_double), _abi._ptr(vy, C.c_double),
+        C.byref(bs), inner, outer, int(compute_cost), float(osc), float(vsc), int(atc), cost_mode, threads,
+        C.byref(rs))
+    _check(rc, "teb_oracle_optimize_batch")
+    return out, res
+
+
+def select_best(cfg, cost, last_best=-1, initial_plan=-1):
+    c = cfg.to_c()
+    cost = _abi.f64(cost)
+    best = C.c_int32(-1)
+    bc = C.c_double(0)
+    _check(lib().teb_oracle_select_best(C.byref(c), len(cost), _abi._ptr(cost, C.c_double), last_best,
+                                        initial_plan, C.byref(best), C.byref(bc)), "select_best")
+    return best.value, bc.value
+
+
+def autoresize(x, y, theta, dt, dt_ref, dt_hysteresis, min_samples, max_samples, fast_mode, cap=2048):
+    n = len(x)
+    X = np.zeros(cap); Y = np.zeros(cap); T = np.zeros(cap); D = np.zeros(cap)
+    X[:n] = x; Y[:n] = y; T[:n] = theta; D[:n - 1] = dt
+    nn = C.c_int32(n)
+    _check(lib().teb_oracle_autoresize(_abi._ptr(X, C.c_double), _abi._ptr(Y, C.c_double), _abi._ptr(T, C.c_double),
+                                       _abi._ptr(D, C.c_double), C.byref(nn), cap, dt_ref, dt_hysteresis,
+                                       min_samples, max_samples, int(fast_mode)), "autoresize")
+    n = nn.value
+    return X[:n].copy(), Y[:n].copy(), T[:n].copy(), D[:n - 1].copy()
+
+
+def linearize(cfg, obst, via, batch, b=0, weight_multiplier=1.0):
+    """Returns dict(H [4n,4n], b [4n], chi2 [4], n_edges, n_rows) in the canonical index space."""
+    c = cfg.to_c()
+    n = int(batch.n[b])
+    D = 4 * n
+    H = np.zeros((D, D)); bv = np.zeros(D); chi2 = np.zeros(4)
+    ne = C.c_int32(0); nr = C.c_int32(0)
+    vx, vy = _via_arrays(via)
+    bs = batch.c_struct()
+    _check(lib().teb_oracle_linearize(C.byref(c), C.byref(obst.freeze()), len(via), _abi._ptr(vx, C.c_double),
+                                      _abi._ptr(vy, C.c_double), C.byref(bs), b, weight_multiplier,
+                                      _abi._ptr(H, C.c_double), _abi._ptr(bv, C.c_double),
+                                      _abi._ptr(chi2, C.c_double), C.byref(ne), C.byref(nr)), "linearize")
+    return dict(H=H, b=bv, chi2=chi2, n_edges=ne.value, n_rows=nr.value)
+
+
+def associate(cfg, obst, batch, b=0, cap=1 << 16):
+    c = cfg.to_c()
+    ap = np.zeros(cap, np.int32); ao = np.zeros(cap, np.int32)
+    cnt = C.c_int32(0)
+    bs = batch.c_struct()
+    _check(lib().teb_oracle_associate(C.byref(c), C.byref(obst.freeze()), C.byref(bs), b,
+                                      _abi._ptr(ap, C.c_int32), _abi._ptr(ao, C.c_int32), cap, C.byref(cnt)),
+           "associate")
+    k = min(cnt.value, cap)
+    return ap[:k].copy(), ao[:k].copy()
+
+
+def distance(cfg, obst, index, x, y, theta, t=None):
+    c = cfg.to_c()
+    d = C.c_double(0)
+    g = np.zeros(3)
+    _check(lib().teb_oracle_distance(C.byref(c), C.byref(obst.freeze()), index, x, y, theta,
+                                     0 if t is None else 1, 0.0 if t is None else float(t), C.byref(d),
+                                     _abi._ptr(g, C.c_double)), "distance")
+    return d.value, g
+
+
+def centroid(obst, index):
+    cx = C.c_double(0); cy = C.c_double(0)
+    _check(lib().teb_oracle_centroid(C.byref(obst.freeze()), index, C.byref(cx), C.byref(cy)), "centroid")
+    return cx.value, cy.value

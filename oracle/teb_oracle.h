@@ -1,0 +1,80 @@
+/*
+ * teb_oracle.h — C interface of the CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * The oracle is a dependency-free fp64 restatement of the reference hot path
+ * (TebOptimalPlanner::optimizeTEB and its g2o/CSparse back end). Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load libteb_oracle.so; libteb_amd.so never links or calls it.
+ *
+ * PARITY UNPINNED for the optimiser as a whole: the reference ships no golden vectors for this path
+ * (test/teb_basics.cpp only pins autoResize post-conditions) and libg2o / SuiteSparse are not present
+ * in /root/reference. See oracle/README.md for what IS pinned (oracle/_ref).
+ */
+#ifndef TEB_ORACLE_H_
+#define TEB_ORACLE_H_
+
+#include "../include/teb_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* cost_mode for computeCurrentCost */
+enum {
+  TEB_ORACLE_COST_REFERENCE = 0, /* sum the edges' stored _error exactly like src/optimal_planner.cpp:1070-1072
+                                    (stale after a rejected final LM trial unless divergence_detection_enable) */
+  TEB_ORACLE_COST_FRESH = 1      /* recompute all errors at the final state first */
+};
+
+/* B x optimizeTEB + per-TEB results. batch is updated in place (state and n). threads<=1: sequential;
+ * else one std::thread per TEB capped at `threads` (src/homotopy_class_planner.cpp:476-483). */
+int teb_oracle_optimize_batch(const teb_amd_config_t* cfg, const teb_amd_obstacles_t* obst,
+                              int32_t n_via, const double* via_x, const double* via_y,
+                              teb_amd_teb_batch_t* batch,
+                              int32_t iterations_innerloop, int32_t iterations_outerloop,
+                              int32_t compute_cost_afterwards, double obst_cost_scale,
+                              double viapoint_cost_scale, int32_t alternative_time_cost,
+                              int32_t cost_mode, int32_t threads, teb_amd_results_t* out);
+
+/* selectBestTeb (src/homotopy_class_planner.cpp:564-667) on a cost array. */
+int teb_oracle_select_best(const teb_amd_config_t* cfg, int32_t count, const double* cost,
+                           int32_t last_best, int32_t initial_plan, int32_t* best, double* best_cost);
+
+/* TimedElasticBand::autoResize (src/timed_elastic_band.cpp:227-286) on one strip; arrays have capacity cap. */
+int teb_oracle_autoresize(double* x, double* y, double* theta, double* dt, int32_t* n, int32_t cap,
+                          double dt_ref, double dt_hysteresis, int32_t min_samples, int32_t max_samples,
+                          int32_t fast_mode);
+
+/*
+ * Test hook: build the graph of TEB `b` (buildGraph, src/optimal_planner.cpp:323-366) with the given
+ * weight_multiplier, compute all errors and linearise once. Outputs in the CANONICAL index space
+ * var(i,c) = 4*i + c, c in {x,y,theta,dt}, dimension 4*n (rows/cols of fixed vertices and of the
+ * non-existing dt_{n-1} are zero):
+ *   H_dense [4n*4n] row-major (full symmetric), b [4n], chi2[4] = {obstacle-type, via-point, time-optimal, other}
+ *   n_edges, n_rows (residual rows). Any output pointer may be NULL.
+ */
+int teb_oracle_linearize(const teb_amd_config_t* cfg, const teb_amd_obstacles_t* obst,
+                         int32_t n_via, const double* via_x, const double* via_y,
+                         const teb_amd_teb_batch_t* batch, int32_t b, double weight_multiplier,
+                         double* H_dense, double* bvec, double* chi2, int32_t* n_edges, int32_t* n_rows);
+
+/* Test hook: obstacle association of TEB b (AddEdgesObstacles, src/optimal_planner.cpp:444-548, or the
+ * legacy variant :551-643). assoc_pose/assoc_obst receive up to cap (pose, obstacle) pairs in edge
+ * insertion order; returns the pair count in *count. */
+int teb_oracle_associate(const teb_amd_config_t* cfg, const teb_amd_obstacles_t* obst,
+                         const teb_amd_teb_batch_t* batch, int32_t b,
+                         int32_t* assoc_pose, int32_t* assoc_obst, int32_t cap, int32_t* count);
+
+/* Test hook: footprint<->obstacle distance (robot_footprint_model.h calculateDistance /
+ * estimateSpatioTemporalDistance): spatio_temporal=0 ignores t. Also returns the analytic gradient
+ * (d/dx, d/dy, d/dtheta) used by the analytic Jacobian mode in grad[3] (may be NULL). */
+int teb_oracle_distance(const teb_amd_config_t* cfg, const teb_amd_obstacles_t* obst, int32_t obst_index,
+                        double x, double y, double theta, int32_t spatio_temporal, double t,
+                        double* dist, double* grad);
+
+/* Polygon centroid as PolygonObstacle::calcCentroid (src/obstacles.cpp:56-121), and the centroid of any obstacle. */
+int teb_oracle_centroid(const teb_amd_obstacles_t* obst, int32_t obst_index, double* cx, double* cy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
