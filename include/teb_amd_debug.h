@@ -1,0 +1,40 @@
+/*
+ * teb_amd_debug.h — test hooks of libteb_amd.so. NOT part of the drop-in boundary; used by tests/ to
+ * compare intermediate quantities (normal equations, association lists, distances) with the oracle.
+ */
+#ifndef TEB_AMD_DEBUG_H_
+#define TEB_AMD_DEBUG_H_
+#include "teb_amd.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* sizeof() of the POD structs as compiled into the library (ABI drift check for the ctypes mirror). */
+int teb_amd_sizeof_config(void);
+int teb_amd_sizeof_obstacles(void);
+int teb_amd_sizeof_teb_batch(void);
+int teb_amd_sizeof_results(void);
+
+/*
+ * Build the cost graph of resident TEB b with the given weight_multiplier and linearise once (no
+ * autoResize, state untouched). Outputs in the canonical index space var(i,c) = 4*i + c:
+ *   H_dense [4n*4n] row-major, bvec [4n], chi2[4] = {obstacle-type, via-point, time-optimal, other};
+ *   the (pose, obstacle) association pairs in edge order (up to assoc_cap) and their number.
+ * Any output pointer may be NULL.
+ */
+int teb_amd_debug_linearize(teb_amd_handle_t* h, int32_t b, double weight_multiplier, double* H_dense,
+                            double* bvec, double* chi2, int32_t* assoc_pose, int32_t* assoc_obst,
+                            int32_t assoc_cap, int32_t* assoc_count);
+
+/* footprint <-> obstacle distance and gradient (d/dx, d/dy, d/dtheta) for nq queries, on the GPU. */
+int teb_amd_debug_distance(teb_amd_handle_t* h, int32_t nq, const int32_t* obst_index, const double* x,
+                           const double* y, const double* theta, const int32_t* spatio_temporal,
+                           const double* t, double* dist, double* grad);
+
+/* per-TEB flags of the last launch: bit0 association list overflow, bit1 autoResize capacity overflow */
+int teb_amd_debug_assoc_overflow(teb_amd_handle_t* h, int32_t* flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,40 @@
+"""Builds libteb_amd.so (hipcc, gfx950 only) in-tree so it travels with the repo snapshot to the GPU box."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libteb_amd.so")
+SOURCES = ["teb_amd.hip"]
+HEADERS = ["teb_device.hpp", "teb_geometry.hpp", "teb_edges.hpp", "teb_kernel.hpp",
+           os.path.join("..", "..", "include", "teb_amd.h"), os.path.join("..", "..", "include", "teb_amd_debug.h")]
+
+# -ffp-contract=off: the parity contract is against a plain IEEE mul/add restatement of the reference;
+# letting the compiler fuse a*b+c would change which side of a penalty kink borderline residuals fall on.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    for f in SOURCES + HEADERS:
+        p = os.path.join(CSRC, f)
+        if os.path.exists(p) and os.path.getmtime(p) > t:
+            return True
+    return False
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP extension if sources are newer than the .so. Returns the library path."""
+    if force or _stale():
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

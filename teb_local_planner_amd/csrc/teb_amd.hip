@@ -1,0 +1,682 @@
+// teb_amd.hip — libteb_amd.so: host side of the C-ABI declared in include/teb_amd.h (+ teb_amd_debug.h).
+// Plain HIP runtime; no torch, no oracle, no CPU fallback: every entry point fails loudly without a gfx950 GPU.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/teb_amd.h"
+#include "../../include/teb_amd_debug.h"
+#include "teb_kernel.hpp"
+
+using namespace tebamd;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess)                                                                              \
+      return fail(TEB_AMD_ERR_HIP, std::string(#expr) + " -> " + hipGetErrorString(_e));               \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    n = count;
+    if (count == 0) count = 1;
+    return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+  }
+  void free() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+  }
+};
+
+// PolygonObstacle::calcCentroid (reference src/obstacles.cpp:56-121) — product-side implementation
+void polygon_centroid(const double* vx, const double* vy, int n, double& cx, double& cy) {
+  if (n <= 0) { cx = cy = std::numeric_limits<double>::quiet_NaN(); return; }
+  if (n == 1) { cx = vx[0]; cy = vy[0]; return; }
+  if (n == 2) { cx = 0.5 * (vx[0] + vx[1]); cy = 0.5 * (vy[0] + vy[1]); return; }
+  double A = 0;
+  for (int i = 0; i < n - 1; ++i) A += vx[i] * vy[i + 1] - vx[i + 1] * vy[i];
+  A += vx[n - 1] * vy[0] - vx[0] * vy[n - 1];
+  A *= 0.5;
+  if (A != 0) {
+    cx = 0; cy = 0;
+    for (int i = 0; i < n - 1; ++i) {
+      double aux = vx[i] * vy[i + 1] - vx[i + 1] * vy[i];
+      cx += (vx[i] + vx[i + 1]) * aux;
+      cy += (vy[i] + vy[i + 1]) * aux;
+    }
+    double aux = vx[n - 1] * vy[0] - vx[0] * vy[n - 1];
+    cx += (vx[n - 1] + vx[0]) * aux;
+    cy += (vy[n - 1] + vy[0]) * aux;
+    cx /= (6 * A);
+    cy /= (6 * A);
+    return;
+  }
+  int ic = 0, jc = 0;
+  double md = 0;
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j) {
+      double d = std::sqrt((vx[j] - vx[i]) * (vx[j] - vx[i]) + (vy[j] - vy[i]) * (vy[j] - vy[i]));
+      if (d > md) { md = d; ic = i; jc = j; }
+    }
+  cx = 0.5 * (vx[ic] + vx[jc]);
+  cy = 0.5 * (vy[ic] + vy[jc]);
+}
+
+// K9: selectBestTeb on the resident cost array (src/homotopy_class_planner.cpp:564-667)
+__global__ void select_best_kernel(const double* cost, int count, int last_best, int initial_plan, double hyst,
+                                   double prefer, double* out_cost, int* out_idx) {
+  __shared__ double sv[kThreads];
+  __shared__ int si[kThreads];
+  double best = 1.7976931348623157e308;   // min_cost starts at numeric_limits<double>::max(), strict '<'
+  int bi = -1;
+  for (int i = threadIdx.x; i < count; i += kThreads) {
+    double cst = cost[i];
+    if (i == last_best) cst = cst * hyst;
+    else if (i == initial_plan) cst = cst * prefer;
+    if (cst < best) { best = cst; bi = i; }
+  }
+  sv[threadIdx.x] = best; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      double ov = sv[threadIdx.x + s]; int oi = si[threadIdx.x + s];
+      double mv = sv[threadIdx.x]; int mi = si[threadIdx.x];
+      bool take = (oi >= 0) && (mi < 0 || ov < mv || (ov == mv && oi < mi));
+      if (take) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { *out_cost = sv[0]; *out_idx = si[0]; }
+}
+
+// debug: footprint_distance for a list of queries
+__global__ void distance_kernel(const teb_amd_config_t c, const SceneDev sc, int nq, const int* oi, const double* x,
+                                const double* y, const double* th, const int* st, const double* t, double* dist,
+                                double* grad) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  double g[3];
+  dist[q] = footprint_distance(c, sc, oi[q], x[q], y[q], th[q], st[q] != 0, t[q], g);
+  grad[3 * q] = g[0]; grad[3 * q + 1] = g[1]; grad[3 * q + 2] = g[2];
+}
+
+}  // namespace
+
+struct teb_amd_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  teb_amd_config_t cfg;
+  int max_tebs = 0, stride = 0, max_obst = 0, max_verts = 0, max_via = 0;
+  int B = 0, M = 0, nvia = 0, n_static = 0, n_dyn = 0;
+  size_t lds_bytes = 0;
+  // scene
+  DevBuf<int> o_type, o_dyn, o_voff, o_static, o_dynidx;
+  DevBuf<double> o_ax, o_ay, o_bx, o_by, o_rad, o_vx, o_vy, o_cx, o_cy, o_pvx, o_pvy, viax, viay;
+  // batch
+  DevBuf<int> n, has_vs, has_vg, rotdir, via_en, status, iters, trials, assoc_cnt, assoc, assoc_ovf, via_pose;
+  DevBuf<double> x, y, th, dt, vs, vg, chi2, cost, lambda, Hbackup, rs_scratch;
+  // snapshot
+  DevBuf<int> snap_n;
+  DevBuf<double> snap_x, snap_y, snap_th, snap_dt;
+  // debug / select
+  DevBuf<double> dbg_H, dbg_b, dbg_chi2, sel_cost;
+  DevBuf<int> sel_idx;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  std::vector<int> host_type;
+};
+
+namespace {
+
+int check_handle(teb_amd_handle* h) {
+  if (!h) return fail(TEB_AMD_ERR_INVALID_ARG, "null handle");
+  if (hipSetDevice(h->device) != hipSuccess) return fail(TEB_AMD_ERR_HIP, "hipSetDevice failed");
+  return TEB_AMD_OK;
+}
+
+SceneDev scene_of(teb_amd_handle* h) {
+  SceneDev s;
+  s.M = h->M;
+  s.type = h->o_type.p; s.ax = h->o_ax.p; s.ay = h->o_ay.p; s.bx = h->o_bx.p; s.by = h->o_by.p;
+  s.rad = h->o_rad.p; s.vx = h->o_vx.p; s.vy = h->o_vy.p; s.cx = h->o_cx.p; s.cy = h->o_cy.p;
+  s.dyn = h->o_dyn.p; s.voff = h->o_voff.p; s.pvx = h->o_pvx.p; s.pvy = h->o_pvy.p;
+  s.n_static = h->n_static; s.static_idx = h->o_static.p; s.n_dyn = h->n_dyn; s.dyn_idx = h->o_dynidx.p;
+  s.nvia = h->nvia; s.viax = h->viax.p; s.viay = h->viay.p;
+  return s;
+}
+
+BatchDev batch_of(teb_amd_handle* h) {
+  BatchDev b;
+  b.B = h->B; b.stride = h->stride;
+  b.n = h->n.p; b.x = h->x.p; b.y = h->y.p; b.th = h->th.p; b.dt = h->dt.p;
+  b.has_vs = h->has_vs.p; b.vs = h->vs.p; b.has_vg = h->has_vg.p; b.vg = h->vg.p;
+  b.rotdir = h->rotdir.p; b.via_en = h->via_en.p;
+  b.status = h->status.p; b.iters = h->iters.p; b.trials = h->trials.p;
+  b.chi2 = h->chi2.p; b.cost = h->cost.p; b.lambda = h->lambda.p;
+  b.assoc_cnt = h->assoc_cnt.p; b.assoc = h->assoc.p; b.assoc_cap = h->max_obst > 0 ? h->max_obst : 1;
+  b.assoc_overflow = h->assoc_ovf.p;
+  b.via_pose = h->via_pose.p; b.via_cap = h->max_via > 0 ? h->max_via : 1;
+  b.Hbackup = h->Hbackup.p; b.rs_scratch = h->rs_scratch.p;
+  return b;
+}
+
+int validate_config(const teb_amd_config_t* c) {
+  if (c->footprint_type < TEB_AMD_FOOTPRINT_POINT || c->footprint_type > TEB_AMD_FOOTPRINT_POLYGON)
+    return fail(TEB_AMD_ERR_INVALID_ARG, "unknown footprint_type");
+  if (c->footprint_type == TEB_AMD_FOOTPRINT_LINE && c->footprint_n_vertices != 2)
+    return fail(TEB_AMD_ERR_INVALID_ARG, "line footprint needs exactly 2 vertices");
+  if (c->footprint_type == TEB_AMD_FOOTPRINT_POLYGON &&
+      (c->footprint_n_vertices < 1 || c->footprint_n_vertices > TEB_AMD_MAX_FOOTPRINT_VERTICES))
+    return fail(TEB_AMD_ERR_INVALID_ARG, "polygon footprint needs 1..16 vertices");
+  if (c->jacobian_mode != TEB_AMD_JACOBIAN_ANALYTIC)
+    return fail(TEB_AMD_ERR_UNSUPPORTED, "GPU path implements TEB_AMD_JACOBIAN_ANALYTIC only");
+  if (c->legacy_obstacle_association)
+    return fail(TEB_AMD_ERR_UNSUPPORTED, "legacy_obstacle_association is not implemented on the GPU path yet");
+  return TEB_AMD_OK;
+}
+
+int launch(teb_amd_handle* h, const OptArgs& args) {
+  if (h->B <= 0) return fail(TEB_AMD_ERR_INVALID_ARG, "no TEBs uploaded");
+  SceneDev sc = scene_of(h);
+  BatchDev bt = batch_of(h);
+  HIPCHK(hipMemsetAsync(h->assoc_ovf.p, 0, sizeof(int) * h->max_tebs, h->stream));
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  hipLaunchKernelGGL(teb_optimize_kernel, dim3(h->B), dim3(kThreads), h->lds_bytes, h->stream, h->cfg, sc, bt, args);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  h->timed = true;
+  return TEB_AMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int teb_amd_abi_version(void) { return TEB_AMD_ABI_VERSION; }
+const char* teb_amd_last_error(void) { return g_last_error.c_str(); }
+int teb_amd_sizeof_config(void) { return (int)sizeof(teb_amd_config_t); }
+int teb_amd_sizeof_obstacles(void) { return (int)sizeof(teb_amd_obstacles_t); }
+int teb_amd_sizeof_teb_batch(void) { return (int)sizeof(teb_amd_teb_batch_t); }
+int teb_amd_sizeof_results(void) { return (int)sizeof(teb_amd_results_t); }
+
+void teb_amd_config_default(teb_amd_config_t* c) {   // TebConfig::TebConfig(), reference teb_config.h:245-390
+  std::memset(c, 0, sizeof(*c));
+  c->teb_autosize = 1; c->dt_ref = 0.3; c->dt_hysteresis = 0.1; c->min_samples = 3; c->max_samples = 500;
+  c->exact_arc_length = 0; c->via_points_ordered = 0;
+  c->max_vel_x = 0.4; c->max_vel_x_backwards = 0.2; c->max_vel_y = 0.0; c->max_vel_trans = 0.0; c->max_vel_theta = 0.3;
+  c->acc_lim_x = 0.5; c->acc_lim_y = 0.5; c->acc_lim_theta = 0.5; c->min_turning_radius = 0;
+  c->min_obstacle_dist = 0.5; c->inflation_dist = 0.6; c->dynamic_obstacle_inflation_dist = 0.6;
+  c->include_dynamic_obstacles = 1; c->obstacle_poses_affected = 25; c->legacy_obstacle_association = 0;
+  c->obstacle_association_force_inclusion_factor = 1.5; c->obstacle_association_cutoff_factor = 5;
+  c->obstacle_proximity_ratio_max_vel = 1; c->obstacle_proximity_lower_bound = 0; c->obstacle_proximity_upper_bound = 0.5;
+  c->no_inner_iterations = 5; c->no_outer_iterations = 4; c->optimization_activate = 1; c->penalty_epsilon = 0.05;
+  c->weight_max_vel_x = 2; c->weight_max_vel_y = 2; c->weight_max_vel_theta = 1; c->weight_acc_lim_x = 1;
+  c->weight_acc_lim_y = 1; c->weight_acc_lim_theta = 1; c->weight_kinematics_nh = 1000;
+  c->weight_kinematics_forward_drive = 1; c->weight_kinematics_turning_radius = 1; c->weight_optimaltime = 1;
+  c->weight_shortest_path = 0; c->weight_obstacle = 50; c->weight_inflation = 0.1; c->weight_dynamic_obstacle = 50;
+  c->weight_dynamic_obstacle_inflation = 0.1; c->weight_velocity_obstacle_ratio = 0; c->weight_viapoint = 1;
+  c->weight_prefer_rotdir = 50; c->weight_adapt_factor = 2.0; c->obstacle_cost_exponent = 1.0;
+  c->selection_cost_hysteresis = 1.0; c->selection_prefer_initial_plan = 0.95; c->selection_obst_cost_scale = 100.0;
+  c->selection_viapoint_cost_scale = 1.0; c->selection_alternative_time_cost = 0;
+  c->divergence_detection_enable = 0; c->divergence_detection_max_chi_squared = 10;
+  c->footprint_type = TEB_AMD_FOOTPRINT_POINT;
+  c->jacobian_mode = TEB_AMD_JACOBIAN_ANALYTIC;
+}
+
+int teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_poses, int32_t max_obstacles,
+                   int32_t max_obstacle_vertices, int32_t max_via_points, int32_t device, void* stream,
+                   teb_amd_handle_t** out) {
+  if (!cfg || !out || max_tebs <= 0 || max_poses < 2 || max_obstacles < 0 || max_obstacle_vertices < 0 || max_via_points < 0)
+    return fail(TEB_AMD_ERR_INVALID_ARG, "teb_amd_create: bad arguments");
+  int rc = validate_config(cfg);
+  if (rc) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(TEB_AMD_ERR_NO_DEVICE, "no HIP device visible (libteb_amd has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(TEB_AMD_ERR_INVALID_ARG, "device ordinal out of range");
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(TEB_AMD_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  HIPCHK(hipSetDevice(device));
+  const size_t lds = lds_bytes_for(max_poses);
+  if (max_poses > kThreads * kMaxPoseIter || lds > (size_t)prop.sharedMemPerBlock) {
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "max_poses=%d needs %zu B of LDS per workgroup (device limit %zu B, thread limit %d poses)",
+                  max_poses, lds, (size_t)prop.sharedMemPerBlock, kThreads * kMaxPoseIter);
+    return fail(TEB_AMD_ERR_CAPACITY, buf);
+  }
+  const size_t assoc_bytes = sizeof(int) * (size_t)max_tebs * max_poses * (size_t)(max_obstacles > 0 ? max_obstacles : 1);
+  if (assoc_bytes > ((size_t)64 << 30)) return fail(TEB_AMD_ERR_CAPACITY, "association table would exceed 64 GiB");
+
+  teb_amd_handle* h = new teb_amd_handle();
+  h->device = device;
+  h->cfg = *cfg;
+  h->max_tebs = max_tebs; h->stride = max_poses; h->max_obst = max_obstacles; h->max_verts = max_obstacle_vertices;
+  h->max_via = max_via_points;
+  h->lds_bytes = lds;
+  if (stream) { h->stream = reinterpret_cast<hipStream_t>(stream); h->own_stream = false; }
+  else {
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(TEB_AMD_ERR_HIP, "hipStreamCreate failed"); }
+    h->own_stream = true;
+  }
+  const size_t BS = (size_t)max_tebs * max_poses;
+  const size_t Mo = max_obstacles > 0 ? max_obstacles : 1;
+  bool ok = true;
+  auto A = [&](hipError_t e) { if (e != hipSuccess) ok = false; };
+  A(h->o_type.alloc(Mo)); A(h->o_dyn.alloc(Mo)); A(h->o_voff.alloc(Mo + 1)); A(h->o_static.alloc(Mo)); A(h->o_dynidx.alloc(Mo));
+  A(h->o_ax.alloc(Mo)); A(h->o_ay.alloc(Mo)); A(h->o_bx.alloc(Mo)); A(h->o_by.alloc(Mo)); A(h->o_rad.alloc(Mo));
+  A(h->o_vx.alloc(Mo)); A(h->o_vy.alloc(Mo)); A(h->o_cx.alloc(Mo)); A(h->o_cy.alloc(Mo));
+  A(h->o_pvx.alloc(max_obstacle_vertices)); A(h->o_pvy.alloc(max_obstacle_vertices));
+  A(h->viax.alloc(max_via_points)); A(h->viay.alloc(max_via_points));
+  A(h->n.alloc(max_tebs)); A(h->has_vs.alloc(max_tebs)); A(h->has_vg.alloc(max_tebs)); A(h->rotdir.alloc(max_tebs));
+  A(h->via_en.alloc(max_tebs)); A(h->status.alloc(max_tebs)); A(h->iters.alloc(max_tebs)); A(h->trials.alloc(max_tebs));
+  A(h->assoc_cnt.alloc(BS)); A(h->assoc.alloc(BS * Mo)); A(h->assoc_ovf.alloc(max_tebs));
+  A(h->via_pose.alloc((size_t)max_tebs * (max_via_points > 0 ? max_via_points : 1)));
+  A(h->x.alloc(BS)); A(h->y.alloc(BS)); A(h->th.alloc(BS)); A(h->dt.alloc(BS));
+  A(h->vs.alloc(3 * (size_t)max_tebs)); A(h->vg.alloc(3 * (size_t)max_tebs));
+  A(h->chi2.alloc(max_tebs)); A(h->cost.alloc(max_tebs)); A(h->lambda.alloc(max_tebs));
+  A(h->Hbackup.alloc(BS * 4 * kBand)); A(h->rs_scratch.alloc((size_t)max_tebs * (4 * (size_t)max_poses + 256)));
+  A(h->snap_n.alloc(max_tebs)); A(h->snap_x.alloc(BS)); A(h->snap_y.alloc(BS)); A(h->snap_th.alloc(BS)); A(h->snap_dt.alloc(BS));
+  A(h->dbg_H.alloc((size_t)4 * max_poses * kBand)); A(h->dbg_b.alloc((size_t)4 * max_poses)); A(h->dbg_chi2.alloc(4));
+  A(h->sel_cost.alloc(1)); A(h->sel_idx.alloc(1));
+  if (ok && hipEventCreate(&h->ev0) != hipSuccess) ok = false;
+  if (ok && hipEventCreate(&h->ev1) != hipSuccess) ok = false;
+  if (ok && hipFuncSetAttribute(reinterpret_cast<const void*>(teb_optimize_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) ok = false;
+  if (ok && hipMemset(h->cost.p, 0, sizeof(double) * max_tebs) != hipSuccess) ok = false;
+  if (!ok) { teb_amd_destroy(h); return fail(TEB_AMD_ERR_HIP, "device allocation / kernel attribute setup failed"); }
+  *out = h;
+  return TEB_AMD_OK;
+}
+
+void teb_amd_destroy(teb_amd_handle_t* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  DevBuf<int>* ib[] = {&h->o_type, &h->o_dyn, &h->o_voff, &h->o_static, &h->o_dynidx, &h->n, &h->has_vs, &h->has_vg, &h->rotdir,
+                       &h->via_en, &h->status, &h->iters, &h->trials, &h->assoc_cnt, &h->assoc, &h->assoc_ovf, &h->via_pose,
+                       &h->snap_n, &h->sel_idx};
+  for (auto* q : ib) q->free();
+  DevBuf<double>* db[] = {&h->o_ax, &h->o_ay, &h->o_bx, &h->o_by, &h->o_rad, &h->o_vx, &h->o_vy, &h->o_cx, &h->o_cy, &h->o_pvx,
+                          &h->o_pvy, &h->viax, &h->viay, &h->x, &h->y, &h->th, &h->dt, &h->vs, &h->vg, &h->chi2, &h->cost,
+                          &h->lambda, &h->Hbackup, &h->rs_scratch, &h->snap_x, &h->snap_y, &h->snap_th, &h->snap_dt, &h->dbg_H,
+                          &h->dbg_b, &h->dbg_chi2, &h->sel_cost};
+  for (auto* q : db) q->free();
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int teb_amd_set_config(teb_amd_handle_t* h, const teb_amd_config_t* cfg) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!cfg) return fail(TEB_AMD_ERR_INVALID_ARG, "null config");
+  rc = validate_config(cfg);
+  if (rc) return rc;
+  bool dyn_changed = (cfg->include_dynamic_obstacles != h->cfg.include_dynamic_obstacles);
+  h->cfg = *cfg;
+  if (dyn_changed && h->M > 0) return fail(TEB_AMD_ERR_INVALID_ARG, "include_dynamic_obstacles changed: call teb_amd_set_obstacles again");
+  return TEB_AMD_OK;
+}
+
+int teb_amd_set_obstacles(teb_amd_handle_t* h, const teb_amd_obstacles_t* o) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!o || o->count < 0) return fail(TEB_AMD_ERR_INVALID_ARG, "null obstacle table");
+  const int M = o->count;
+  if (M > h->max_obst) return fail(TEB_AMD_ERR_CAPACITY, "more obstacles than max_obstacles");
+  if (M > 0 && (!o->type || !o->ax || !o->ay)) return fail(TEB_AMD_ERR_INVALID_ARG, "obstacle arrays missing");
+  std::vector<int> type(M), dyn(M), voff(M + 1, 0), st, dy;
+  std::vector<double> ax(M), ay(M), bx(M), by(M), rad(M), vx(M), vy(M), cx(M), cy(M), pvx, pvy;
+  for (int i = 0; i < M; ++i) {
+    type[i] = o->type[i];
+    ax[i] = o->ax[i]; ay[i] = o->ay[i];
+    bx[i] = o->bx ? o->bx[i] : 0; by[i] = o->by ? o->by[i] : 0;
+    rad[i] = o->radius ? o->radius[i] : 0;
+    vx[i] = o->vx ? o->vx[i] : 0; vy[i] = o->vy ? o->vy[i] : 0;
+    dyn[i] = o->dynamic ? (o->dynamic[i] != 0) : 0;
+    voff[i] = (int)pvx.size();
+    switch (type[i]) {
+      case TEB_AMD_OBST_POINT: case TEB_AMD_OBST_CIRCULAR: cx[i] = ax[i]; cy[i] = ay[i]; break;
+      case TEB_AMD_OBST_LINE: case TEB_AMD_OBST_PILL: cx[i] = 0.5 * (ax[i] + bx[i]); cy[i] = 0.5 * (ay[i] + by[i]); break;
+      case TEB_AMD_OBST_POLYGON: {
+        if (!o->vert_offset || !o->vert_x || !o->vert_y) return fail(TEB_AMD_ERR_INVALID_ARG, "polygon obstacle without vertex arrays");
+        int k0 = o->vert_offset[i], k1 = o->vert_offset[i + 1];
+        if (k1 <= k0) return fail(TEB_AMD_ERR_INVALID_ARG, "polygon obstacle without vertices");
+        for (int k = k0; k < k1; ++k) { pvx.push_back(o->vert_x[k]); pvy.push_back(o->vert_y[k]); }
+        polygon_centroid(o->vert_x + k0, o->vert_y + k0, k1 - k0, cx[i], cy[i]);
+        break;
+      }
+      default: return fail(TEB_AMD_ERR_INVALID_ARG, "unknown obstacle type");
+    }
+    // AddEdgesObstacles skips dynamic obstacles iff include_dynamic_obstacles (optimal_planner.cpp:496-497);
+    // AddEdgesDynamicObstacles visits the dynamic ones (:658-659)
+    if (h->cfg.include_dynamic_obstacles && dyn[i]) dy.push_back(i); else st.push_back(i);
+  }
+  voff[M] = (int)pvx.size();
+  if ((int)pvx.size() > h->max_verts) return fail(TEB_AMD_ERR_CAPACITY, "more polygon vertices than max_obstacle_vertices");
+  auto up_i = [&](DevBuf<int>& d, const std::vector<int>& v) { return v.empty() ? hipSuccess : hipMemcpyAsync(d.p, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, h->stream); };
+  auto up_d = [&](DevBuf<double>& d, const std::vector<double>& v) { return v.empty() ? hipSuccess : hipMemcpyAsync(d.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, h->stream); };
+  HIPCHK(up_i(h->o_type, type)); HIPCHK(up_i(h->o_dyn, dyn)); HIPCHK(up_i(h->o_voff, voff)); HIPCHK(up_i(h->o_static, st)); HIPCHK(up_i(h->o_dynidx, dy));
+  HIPCHK(up_d(h->o_ax, ax)); HIPCHK(up_d(h->o_ay, ay)); HIPCHK(up_d(h->o_bx, bx)); HIPCHK(up_d(h->o_by, by)); HIPCHK(up_d(h->o_rad, rad));
+  HIPCHK(up_d(h->o_vx, vx)); HIPCHK(up_d(h->o_vy, vy)); HIPCHK(up_d(h->o_cx, cx)); HIPCHK(up_d(h->o_cy, cy));
+  HIPCHK(up_d(h->o_pvx, pvx)); HIPCHK(up_d(h->o_pvy, pvy));
+  HIPCHK(hipStreamSynchronize(h->stream));   // host vectors go out of scope
+  h->M = M; h->n_static = (int)st.size(); h->n_dyn = (int)dy.size();
+  h->host_type = type;
+  return TEB_AMD_OK;
+}
+
+int teb_amd_set_via_points(teb_amd_handle_t* h, int32_t count, const double* x, const double* y) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (count < 0 || (count > 0 && (!x || !y))) return fail(TEB_AMD_ERR_INVALID_ARG, "bad via-point arrays");
+  if (count > h->max_via) return fail(TEB_AMD_ERR_CAPACITY, "more via-points than max_via_points");
+  if (count > 0) {
+    HIPCHK(hipMemcpyAsync(h->viax.p, x, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->viay.p, y, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  h->nvia = count;
+  return TEB_AMD_OK;
+}
+
+int teb_amd_upload_tebs(teb_amd_handle_t* h, const teb_amd_teb_batch_t* bt) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!bt || bt->count <= 0 || !bt->n || !bt->x || !bt->y || !bt->theta || !bt->dt)
+    return fail(TEB_AMD_ERR_INVALID_ARG, "bad TEB batch");
+  if (bt->count > h->max_tebs) return fail(TEB_AMD_ERR_CAPACITY, "more TEBs than max_tebs");
+  const int B = bt->count;
+  int nmax = 0;
+  for (int b = 0; b < B; ++b) {
+    if (bt->n[b] < 2) return fail(TEB_AMD_ERR_INVALID_ARG, "a TEB needs at least 2 poses");
+    if (bt->n[b] > bt->stride) return fail(TEB_AMD_ERR_INVALID_ARG, "n[b] > stride");
+    nmax = bt->n[b] > nmax ? bt->n[b] : nmax;
+  }
+  if (nmax > h->stride) return fail(TEB_AMD_ERR_CAPACITY, "a TEB has more poses than max_poses");
+  const size_t w = (size_t)(bt->stride < h->stride ? bt->stride : h->stride) * sizeof(double);
+  const size_t sp = (size_t)bt->stride * sizeof(double), dp = (size_t)h->stride * sizeof(double);
+  HIPCHK(hipMemcpy2DAsync(h->x.p, dp, bt->x, sp, w, B, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpy2DAsync(h->y.p, dp, bt->y, sp, w, B, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpy2DAsync(h->th.p, dp, bt->theta, sp, w, B, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpy2DAsync(h->dt.p, dp, bt->dt, sp, w, B, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->n.p, bt->n, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  std::vector<int> hvs(B, 0), hvg(B, 0), rd(B, TEB_AMD_ROT_NONE), ve(B, 1);
+  std::vector<double> vs(3 * (size_t)B, 0.0), vg(3 * (size_t)B, 0.0);
+  for (int b = 0; b < B; ++b) {
+    if (bt->has_vel_start) hvs[b] = bt->has_vel_start[b] != 0;
+    if (bt->has_vel_goal) hvg[b] = bt->has_vel_goal[b] != 0;
+    if (bt->prefer_rotdir) rd[b] = bt->prefer_rotdir[b];
+    if (bt->via_points_enabled) ve[b] = bt->via_points_enabled[b] != 0;
+    for (int q = 0; q < 3; ++q) {
+      if (bt->vel_start) vs[3 * b + q] = bt->vel_start[3 * b + q];
+      if (bt->vel_goal) vg[3 * b + q] = bt->vel_goal[3 * b + q];
+    }
+  }
+  HIPCHK(hipMemcpyAsync(h->has_vs.p, hvs.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->has_vg.p, hvg.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->rotdir.p, rd.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->via_en.p, ve.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->vs.p, vs.data(), 3 * (size_t)B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->vg.p, vg.data(), 3 * (size_t)B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->B = B;
+  return TEB_AMD_OK;
+}
+
+int teb_amd_download_tebs(teb_amd_handle_t* h, teb_amd_teb_batch_t* bt) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!bt || !bt->n || !bt->x || !bt->y || !bt->theta || !bt->dt) return fail(TEB_AMD_ERR_INVALID_ARG, "bad TEB batch");
+  if (bt->count < h->B) return fail(TEB_AMD_ERR_INVALID_ARG, "batch too small for the resident TEBs");
+  const int B = h->B;
+  std::vector<int> n(B);
+  HIPCHK(hipMemcpyAsync(n.data(), h->n.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int b = 0; b < B; ++b) if (n[b] > bt->stride) return fail(TEB_AMD_ERR_CAPACITY, "host batch stride too small for the resized TEB");
+  const size_t w = (size_t)(bt->stride < h->stride ? bt->stride : h->stride) * sizeof(double);
+  const size_t hp = (size_t)bt->stride * sizeof(double), dp = (size_t)h->stride * sizeof(double);
+  HIPCHK(hipMemcpy2DAsync(bt->x, hp, h->x.p, dp, w, B, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpy2DAsync(bt->y, hp, h->y.p, dp, w, B, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpy2DAsync(bt->theta, hp, h->th.p, dp, w, B, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpy2DAsync(bt->dt, hp, h->dt.p, dp, w, B, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int b = 0; b < B; ++b) bt->n[b] = n[b];
+  return TEB_AMD_OK;
+}
+
+int teb_amd_optimize_batch(teb_amd_handle_t* h, int32_t inner, int32_t outer, int32_t compute_cost, double obst_cost_scale,
+                           double viapoint_cost_scale, int32_t alternative_time_cost) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (inner < 0 || outer < 0) return fail(TEB_AMD_ERR_INVALID_ARG, "negative iteration count");
+  OptArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.inner = inner; a.outer = outer; a.compute_cost = compute_cost;
+  a.obst_scale = obst_cost_scale; a.via_scale = viapoint_cost_scale; a.alt_time = alternative_time_cost;
+  return launch(h, a);
+}
+
+int teb_amd_synchronize(teb_amd_handle_t* h) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return TEB_AMD_OK;
+}
+
+int teb_amd_get_results(teb_amd_handle_t* h, teb_amd_results_t* out) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!out) return fail(TEB_AMD_ERR_INVALID_ARG, "null results");
+  const int B = h->B;
+  if (out->status) HIPCHK(hipMemcpyAsync(out->status, h->status.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (out->lm_iterations) HIPCHK(hipMemcpyAsync(out->lm_iterations, h->iters.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (out->lm_trials) HIPCHK(hipMemcpyAsync(out->lm_trials, h->trials.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (out->chi2) HIPCHK(hipMemcpyAsync(out->chi2, h->chi2.p, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (out->cost) HIPCHK(hipMemcpyAsync(out->cost, h->cost.p, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (out->lambda) HIPCHK(hipMemcpyAsync(out->lambda, h->lambda.p, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return TEB_AMD_OK;
+}
+
+int teb_amd_select_best(teb_amd_handle_t* h, int32_t last_best, int32_t initial_plan, int32_t* best, double* best_cost) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!best) return fail(TEB_AMD_ERR_INVALID_ARG, "null output");
+  if (h->B <= 0) return fail(TEB_AMD_ERR_INVALID_ARG, "no TEBs uploaded");
+  if (last_best >= h->B) last_best = -1;
+  if (initial_plan >= h->B) initial_plan = -1;
+  hipLaunchKernelGGL(select_best_kernel, dim3(1), dim3(kThreads), 0, h->stream, h->cost.p, h->B, last_best, initial_plan,
+                     h->cfg.selection_cost_hysteresis, h->cfg.selection_prefer_initial_plan, h->sel_cost.p, h->sel_idx.p);
+  HIPCHK(hipGetLastError());
+  double c; int i;
+  HIPCHK(hipMemcpyAsync(&c, h->sel_cost.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(&i, h->sel_idx.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *best = i;
+  if (best_cost) *best_cost = c;
+  return TEB_AMD_OK;
+}
+
+int teb_amd_device_state(teb_amd_handle_t* h, void** x, void** y, void** theta, void** dt, void** n, int32_t* stride) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (x) *x = h->x.p; if (y) *y = h->y.p; if (theta) *theta = h->th.p; if (dt) *dt = h->dt.p; if (n) *n = h->n.p;
+  if (stride) *stride = h->stride;
+  return TEB_AMD_OK;
+}
+
+int teb_amd_snapshot_state(teb_amd_handle_t* h) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  const size_t BS = (size_t)h->max_tebs * h->stride * sizeof(double);
+  HIPCHK(hipMemcpyAsync(h->snap_x.p, h->x.p, BS, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->snap_y.p, h->y.p, BS, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->snap_th.p, h->th.p, BS, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->snap_dt.p, h->dt.p, BS, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->snap_n.p, h->n.p, h->max_tebs * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+  return TEB_AMD_OK;
+}
+
+int teb_amd_restore_state(teb_amd_handle_t* h) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  const size_t BS = (size_t)h->max_tebs * h->stride * sizeof(double);
+  HIPCHK(hipMemcpyAsync(h->x.p, h->snap_x.p, BS, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->y.p, h->snap_y.p, BS, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->th.p, h->snap_th.p, BS, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->dt.p, h->snap_dt.p, BS, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->n.p, h->snap_n.p, h->max_tebs * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+  return TEB_AMD_OK;
+}
+
+int teb_amd_last_kernel_ms(teb_amd_handle_t* h, float* ms) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!ms || !h->timed) return fail(TEB_AMD_ERR_INVALID_ARG, "no kernel has been launched yet");
+  HIPCHK(hipEventSynchronize(h->ev1));
+  HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return TEB_AMD_OK;
+}
+
+int teb_amd_capacity(teb_amd_handle_t* h, int32_t* lds_bytes, int32_t* max_poses_supported) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (lds_bytes) *lds_bytes = (int32_t)h->lds_bytes;
+  if (max_poses_supported) {
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, h->device));
+    int S = kThreads * kMaxPoseIter;
+    while (S > 2 && lds_bytes_for(S) > (size_t)prop.sharedMemPerBlock) --S;
+    *max_poses_supported = S;
+  }
+  return TEB_AMD_OK;
+}
+
+// ---- test hooks (include/teb_amd_debug.h) -------------------------------------------------------------------
+int teb_amd_debug_linearize(teb_amd_handle_t* h, int32_t b, double weight_multiplier, double* H_dense, double* bvec,
+                            double* chi2, int32_t* assoc_pose, int32_t* assoc_obst, int32_t assoc_cap, int32_t* assoc_count) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (b < 0 || b >= h->B) return fail(TEB_AMD_ERR_INVALID_ARG, "TEB index out of range");
+  // run the kernel in debug mode on TEB b only: temporarily view the batch as starting at b
+  OptArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.inner = 1; a.outer = 1; a.debug_linearize = 1; a.debug_weight_multiplier = weight_multiplier;
+  a.dbg_H = h->dbg_H.p; a.dbg_b = h->dbg_b.p; a.dbg_chi2 = h->dbg_chi2.p;
+  SceneDev sc = scene_of(h);
+  BatchDev bt = batch_of(h);
+  const size_t so = (size_t)b * h->stride;
+  bt.B = 1;
+  bt.n += b; bt.x += so; bt.y += so; bt.th += so; bt.dt += so;
+  bt.has_vs += b; bt.vs += 3 * b; bt.has_vg += b; bt.vg += 3 * b; bt.rotdir += b; bt.via_en += b;
+  bt.status += b; bt.iters += b; bt.trials += b; bt.chi2 += b; bt.cost += b; bt.lambda += b;
+  bt.assoc_cnt += so; bt.assoc += (size_t)b * bt.assoc_cap * h->stride; bt.assoc_overflow += b;
+  bt.via_pose += (size_t)b * bt.via_cap; bt.Hbackup += so * 4 * kBand; bt.rs_scratch += (size_t)b * (4 * (size_t)h->stride + 256);
+  // results of TEB b must not be clobbered by the debug run: save and restore them
+  int sv_i[3]; double sv_d[3];
+  HIPCHK(hipMemcpy(&sv_i[0], h->status.p + b, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&sv_i[1], h->iters.p + b, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&sv_i[2], h->trials.p + b, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&sv_d[0], h->chi2.p + b, sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&sv_d[1], h->cost.p + b, sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&sv_d[2], h->lambda.p + b, sizeof(double), hipMemcpyDeviceToHost));
+  hipLaunchKernelGGL(teb_optimize_kernel, dim3(1), dim3(kThreads), h->lds_bytes, h->stream, h->cfg, sc, bt, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(h->status.p + b, &sv_i[0], sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->iters.p + b, &sv_i[1], sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->trials.p + b, &sv_i[2], sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->chi2.p + b, &sv_d[0], sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->cost.p + b, &sv_d[1], sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->lambda.p + b, &sv_d[2], sizeof(double), hipMemcpyHostToDevice));
+  int n = 0;
+  HIPCHK(hipMemcpy(&n, h->n.p + b, sizeof(int), hipMemcpyDeviceToHost));
+  const int Nt = 4 * n;
+  std::vector<double> Hb((size_t)Nt * kBand), bv(Nt);
+  HIPCHK(hipMemcpy(Hb.data(), h->dbg_H.p, Hb.size() * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(bv.data(), h->dbg_b.p, bv.size() * sizeof(double), hipMemcpyDeviceToHost));
+  if (chi2) HIPCHK(hipMemcpy(chi2, h->dbg_chi2.p, 4 * sizeof(double), hipMemcpyDeviceToHost));
+  if (H_dense) {
+    std::fill(H_dense, H_dense + (size_t)Nt * Nt, 0.0);
+    for (int r = 0; r < Nt; ++r) {
+      bool fr = (r < 3) || (r >= 4 * (n - 1));
+      for (int d = 0; d < kBand && d <= r; ++d) {
+        double v = fr ? 0.0 : Hb[(size_t)r * kBand + d];   // identity rows of fixed variables are exported as zeros
+        H_dense[(size_t)r * Nt + (r - d)] = v;
+        H_dense[(size_t)(r - d) * Nt + r] = v;
+      }
+    }
+  }
+  if (bvec) for (int r = 0; r < Nt; ++r) bvec[r] = bv[r];
+  if (assoc_count) {
+    std::vector<int> cnt(n), lst((size_t)bt.assoc_cap * h->stride);
+    HIPCHK(hipMemcpy(cnt.data(), h->assoc_cnt.p + so, n * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(lst.data(), h->assoc.p + (size_t)b * bt.assoc_cap * h->stride, lst.size() * sizeof(int), hipMemcpyDeviceToHost));
+    int k = 0;
+    for (int i = 1; i < n - 1; ++i)
+      for (int q = 0; q < cnt[i]; ++q) {
+        if (k < assoc_cap) { if (assoc_pose) assoc_pose[k] = i; if (assoc_obst) assoc_obst[k] = lst[(size_t)q * h->stride + i]; }
+        ++k;
+      }
+    *assoc_count = k;
+  }
+  return TEB_AMD_OK;
+}
+
+int teb_amd_debug_distance(teb_amd_handle_t* h, int32_t nq, const int32_t* obst_index, const double* x, const double* y,
+                           const double* theta, const int32_t* spatio_temporal, const double* t, double* dist, double* grad) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (nq <= 0) return fail(TEB_AMD_ERR_INVALID_ARG, "nq <= 0");
+  for (int q = 0; q < nq; ++q) if (obst_index[q] < 0 || obst_index[q] >= h->M) return fail(TEB_AMD_ERR_INVALID_ARG, "obstacle index out of range");
+  DevBuf<int> d_oi, d_st; DevBuf<double> d_x, d_y, d_th, d_t, d_dist, d_grad;
+  HIPCHK(d_oi.alloc(nq)); HIPCHK(d_st.alloc(nq)); HIPCHK(d_x.alloc(nq)); HIPCHK(d_y.alloc(nq)); HIPCHK(d_th.alloc(nq));
+  HIPCHK(d_t.alloc(nq)); HIPCHK(d_dist.alloc(nq)); HIPCHK(d_grad.alloc(3 * (size_t)nq));
+  HIPCHK(hipMemcpy(d_oi.p, obst_index, nq * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_st.p, spatio_temporal, nq * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_x.p, x, nq * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_y.p, y, nq * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_th.p, theta, nq * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_t.p, t, nq * sizeof(double), hipMemcpyHostToDevice));
+  SceneDev sc = scene_of(h);
+  hipLaunchKernelGGL(distance_kernel, dim3((nq + 255) / 256), dim3(256), 0, h->stream, h->cfg, sc, nq, d_oi.p, d_x.p, d_y.p, d_th.p,
+                     d_st.p, d_t.p, d_dist.p, d_grad.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(dist, d_dist.p, nq * sizeof(double), hipMemcpyDeviceToHost));
+  if (grad) HIPCHK(hipMemcpy(grad, d_grad.p, 3 * (size_t)nq * sizeof(double), hipMemcpyDeviceToHost));
+  d_oi.free(); d_st.free(); d_x.free(); d_y.free(); d_th.free(); d_t.free(); d_dist.free(); d_grad.free();
+  return TEB_AMD_OK;
+}
+
+int teb_amd_debug_assoc_overflow(teb_amd_handle_t* h, int32_t* flags) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(flags, h->assoc_ovf.p, h->B * sizeof(int), hipMemcpyDeviceToHost));
+  return TEB_AMD_OK;
+}
+
+}  // extern "C"

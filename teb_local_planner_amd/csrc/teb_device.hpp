@@ -1,0 +1,78 @@
+// teb_device.hpp — device-side data model of the MI355X TEB optimiser (gfx950 only).
+//
+// HBM layout (all fp64 unless noted):
+//   state strips   x,y,theta,dt : [B][stride]  SoA, one contiguous row per candidate TEB (coalesced 8 B/lane)
+//   obstacle table              : SoA columns [M] (type,ax,ay,bx,by,radius,vx,vy,cx,cy,dynamic) + CSR polygon
+//                                 vertices; read-only, shared by all workgroups (L2 resident)
+//   association lists           : int32 [B][assoc_cap][stride]  (entry k of pose i at [(b*cap+k)*stride+i] so
+//                                 that lane i reads entry k coalesced)
+//   H backup                    : [B][4*stride*11] banded normal matrix saved once per LM iteration so a
+//                                 rejected damping trial does not have to re-linearise
+// LDS layout per workgroup (one workgroup = one TEB): see teb_kernel.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/teb_amd.h"
+
+namespace tebamd {
+
+constexpr int kThreads = 256;       // 4 wave64 per workgroup, one workgroup per candidate TEB
+constexpr int kBand = 11;           // diagonal + scalar half-bandwidth 10
+constexpr int kMaxPoseIter = 2;     // poses handled per thread: n <= kThreads * kMaxPoseIter
+
+struct SceneDev {
+  int M;
+  const int* type;
+  const double *ax, *ay, *bx, *by, *rad, *vx, *vy, *cx, *cy;
+  const int* dyn;
+  const int* voff;
+  const double *pvx, *pvy;
+  int n_static;            // obstacles visited by AddEdgesObstacles (all non-dynamic, or all if !include_dynamic)
+  const int* static_idx;
+  int n_dyn;               // obstacles visited by AddEdgesDynamicObstacles
+  const int* dyn_idx;
+  int nvia;
+  const double *viax, *viay;
+};
+
+struct BatchDev {
+  int B, stride;
+  int* n;
+  double *x, *y, *th, *dt;
+  const int* has_vs;
+  const double* vs;
+  const int* has_vg;
+  const double* vg;
+  const int* rotdir;
+  const int* via_en;
+  // results
+  int* status;
+  int* iters;
+  int* trials;
+  double* chi2;
+  double* cost;
+  double* lambda;
+  // scratch
+  int* assoc_cnt;   // [B][stride]
+  int* assoc;       // [B][assoc_cap][stride]
+  int assoc_cap;
+  int* assoc_overflow;  // [B]
+  int* via_pose;    // [B][via_cap]
+  int via_cap;
+  double* Hbackup;  // [B][4*stride*kBand]
+  double* rs_scratch;  // [B][4][stride] autoResize output buffers
+};
+
+struct OptArgs {
+  int inner, outer, compute_cost;
+  double obst_scale, via_scale;
+  int alt_time;
+  int debug_linearize;   // test hook: stop after the first linearisation and dump H, b, chi2 categories
+  double debug_weight_multiplier;
+  double* dbg_H;         // [4*stride*kBand] of TEB 0
+  double* dbg_b;         // [4*stride]
+  double* dbg_chi2;      // [4]
+};
+
+}  // namespace tebamd

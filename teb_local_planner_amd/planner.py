@@ -1,0 +1,294 @@
+"""Host-side mirror of the reference's optimiser interface on top of the C-ABI (libteb_amd.so).
+
+  TebOptimalPlanner.optimizeTEB(...)         <-> reference optimal_planner.h:231-232
+  HomotopyClassPlanner.optimizeAllTEBs(...)  <-> reference src/homotopy_class_planner.cpp:466-493
+  HomotopyClassPlanner.selectBestTeb()       <-> reference src/homotopy_class_planner.cpp:564-667
+
+Same names, argument meaning and error behaviour (bool returns, no exceptions for optimiser failures).
+The library is loaded with ctypes; there is NO CPU fallback: constructing a solver without a gfx950 GPU
+raises TebAmdError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+from .config import TebConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class TebAmdError(RuntimeError):
+    def __init__(self, code, what, msg):
+        super().__init__("%s failed: status %d (%s)" % (what, code, msg))
+        self.code = code
+
+
+def lib():
+    """Loads libteb_amd.so (built in-tree by teb_local_planner_amd.build)."""
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libteb_amd.so")
+        if not os.path.exists(so):
+            raise TebAmdError(-1, "load", "libteb_amd.so missing: run `python -m teb_local_planner_amd.build`")
+        L = C.CDLL(so)
+        vp = C.c_void_p
+        L.teb_amd_last_error.restype = C.c_char_p
+        L.teb_amd_config_default.argtypes = [C.POINTER(_abi.Config)]
+        L.teb_amd_create.argtypes = [C.POINTER(_abi.Config), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int32, vp, C.POINTER(vp)]
+        L.teb_amd_destroy.argtypes = [vp]
+        L.teb_amd_destroy.restype = None
+        L.teb_amd_set_config.argtypes = [vp, C.POINTER(_abi.Config)]
+        L.teb_amd_set_obstacles.argtypes = [vp, C.POINTER(_abi.Obstacles)]
+        L.teb_amd_set_via_points.argtypes = [vp, C.c_int32, _abi.p_f64, _abi.p_f64]
+        L.teb_amd_upload_tebs.argtypes = [vp, C.POINTER(_abi.TebBatch)]
+        L.teb_amd_download_tebs.argtypes = [vp, C.POINTER(_abi.TebBatch)]
+        L.teb_amd_optimize_batch.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32]
+        L.teb_amd_synchronize.argtypes = [vp]
+        L.teb_amd_get_results.argtypes = [vp, C.POINTER(_abi.Results)]
+        L.teb_amd_select_best.argtypes = [vp, C.c_int32, C.c_int32, _abi.p_i32, _abi.p_f64]
+        L.teb_amd_device_state.argtypes = [vp] + [C.POINTER(vp)] * 5 + [_abi.p_i32]
+        L.teb_amd_snapshot_state.argtypes = [vp]
+        L.teb_amd_restore_state.argtypes = [vp]
+        L.teb_amd_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.teb_amd_capacity.argtypes = [vp, _abi.p_i32, _abi.p_i32]
+        L.teb_amd_debug_linearize.argtypes = [vp, C.c_int32, C.c_double, _abi.p_f64, _abi.p_f64, _abi.p_f64,
+                                              _abi.p_i32, _abi.p_i32, C.c_int32, _abi.p_i32]
+        L.teb_amd_debug_distance.argtypes = [vp, C.c_int32, _abi.p_i32, _abi.p_f64, _abi.p_f64, _abi.p_f64,
+                                             _abi.p_i32, _abi.p_f64, _abi.p_f64, _abi.p_f64]
+        L.teb_amd_debug_assoc_overflow.argtypes = [vp, _abi.p_i32]
+        _LIB = L
+    return _LIB
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise TebAmdError(rc, what, lib().teb_amd_last_error().decode())
+
+
+class TebBatchSolver:
+    """Thin RAII wrapper of a teb_amd_handle_t (one per GPU / host thread)."""
+
+    def __init__(self, cfg, max_tebs, max_poses, max_obstacles=0, max_obstacle_vertices=0, max_via_points=0,
+                 device=0, stream=None):
+        self._h = C.c_void_p(None)
+        self.cfg = cfg
+        c = cfg.to_c()
+        _chk(lib().teb_amd_create(C.byref(c), max_tebs, max_poses, max_obstacles, max_obstacle_vertices,
+                                  max_via_points, device, C.c_void_p(stream) if stream else None,
+                                  C.byref(self._h)), "teb_amd_create")
+        self.max_tebs, self.max_poses = max_tebs, max_poses
+        self.count = 0
+
+    def close(self):
+        if self._h:
+            lib().teb_amd_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- scene ---------------------------------------------------------------------------------------
+    def set_config(self, cfg):
+        self.cfg = cfg
+        c = cfg.to_c()
+        _chk(lib().teb_amd_set_config(self._h, C.byref(c)), "teb_amd_set_config")
+
+    def set_obstacles(self, obst):
+        _chk(lib().teb_amd_set_obstacles(self._h, C.byref(obst.freeze())), "teb_amd_set_obstacles")
+
+    def set_via_points(self, via):
+        vx = _abi.f64([v[0] for v in via]) if via else _abi.f64([0.0])
+        vy = _abi.f64([v[1] for v in via]) if via else _abi.f64([0.0])
+        _chk(lib().teb_amd_set_via_points(self._h, len(via), _abi._ptr(vx, C.c_double), _abi._ptr(vy, C.c_double)),
+             "teb_amd_set_via_points")
+
+    # -- state ---------------------------------------------------------------------------------------
+    def upload(self, batch):
+        bs = batch.c_struct()
+        _chk(lib().teb_amd_upload_tebs(self._h, C.byref(bs)), "teb_amd_upload_tebs")
+        self.count = batch.count
+
+    def download(self, batch):
+        bs = batch.c_struct()
+        _chk(lib().teb_amd_download_tebs(self._h, C.byref(bs)), "teb_amd_download_tebs")
+        return batch
+
+    def snapshot(self):
+        _chk(lib().teb_amd_snapshot_state(self._h), "teb_amd_snapshot_state")
+
+    def restore(self):
+        _chk(lib().teb_amd_restore_state(self._h), "teb_amd_restore_state")
+
+    # -- hot path --------------------------------------------------------------------------------------
+    def optimize(self, inner, outer, compute_cost=False, obst_cost_scale=1.0, viapoint_cost_scale=1.0,
+                 alternative_time_cost=False):
+        _chk(lib().teb_amd_optimize_batch(self._h, inner, outer, int(compute_cost), float(obst_cost_scale),
+                                          float(viapoint_cost_scale), int(alternative_time_cost)),
+             "teb_amd_optimize_batch")
+
+    def synchronize(self):
+        _chk(lib().teb_amd_synchronize(self._h), "teb_amd_synchronize")
+
+    def results(self):
+        res = _abi.ResultsHost(self.count)
+        rs = res.c_struct()
+        _chk(lib().teb_amd_get_results(self._h, C.byref(rs)), "teb_amd_get_results")
+        return res
+
+    def select_best(self, last_best=-1, initial_plan=-1):
+        best = C.c_int32(-1)
+        cost = C.c_double(0)
+        _chk(lib().teb_amd_select_best(self._h, last_best, initial_plan, C.byref(best), C.byref(cost)),
+             "teb_amd_select_best")
+        return best.value, cost.value
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        _chk(lib().teb_amd_last_kernel_ms(self._h, C.byref(ms)), "teb_amd_last_kernel_ms")
+        return ms.value
+
+    def capacity(self):
+        a = C.c_int32(0)
+        b = C.c_int32(0)
+        _chk(lib().teb_amd_capacity(self._h, C.byref(a), C.byref(b)), "teb_amd_capacity")
+        return a.value, b.value
+
+    # -- test hooks -----------------------------------------------------------------------------------
+    def debug_linearize(self, b, n, weight_multiplier=1.0, assoc_cap=1 << 16):
+        D = 4 * n
+        H = np.zeros((D, D)); bv = np.zeros(D); chi2 = np.zeros(4)
+        ap = np.zeros(assoc_cap, np.int32); ao = np.zeros(assoc_cap, np.int32)
+        cnt = C.c_int32(0)
+        _chk(lib().teb_amd_debug_linearize(self._h, b, weight_multiplier, _abi._ptr(H, C.c_double),
+                                           _abi._ptr(bv, C.c_double), _abi._ptr(chi2, C.c_double),
+                                           _abi._ptr(ap, C.c_int32), _abi._ptr(ao, C.c_int32), assoc_cap,
+                                           C.byref(cnt)), "teb_amd_debug_linearize")
+        k = min(cnt.value, assoc_cap)
+        return dict(H=H, b=bv, chi2=chi2, assoc_pose=ap[:k].copy(), assoc_obst=ao[:k].copy())
+
+    def debug_distance(self, obst_index, x, y, theta, t=None):
+        oi = _abi.i32(obst_index); x = _abi.f64(x); y = _abi.f64(y); th = _abi.f64(theta)
+        nq = len(oi)
+        st = _abi.i32(np.zeros(nq) if t is None else np.ones(nq))
+        tt = _abi.f64(np.zeros(nq) if t is None else t)
+        d = np.zeros(nq); g = np.zeros((nq, 3))
+        _chk(lib().teb_amd_debug_distance(self._h, nq, _abi._ptr(oi, C.c_int32), _abi._ptr(x, C.c_double),
+                                          _abi._ptr(y, C.c_double), _abi._ptr(th, C.c_double),
+                                          _abi._ptr(st, C.c_int32), _abi._ptr(tt, C.c_double),
+                                          _abi._ptr(d, C.c_double), _abi._ptr(g, C.c_double)),
+             "teb_amd_debug_distance")
+        return d, g
+
+    def debug_overflow_flags(self):
+        f = np.zeros(self.count, np.int32)
+        _chk(lib().teb_amd_debug_assoc_overflow(self._h, _abi._ptr(f, C.c_int32)), "debug_assoc_overflow")
+        return f
+
+
+def make_solver(cfg, obst, via, batch, device=0, stream=None, max_tebs=None, max_poses=None):
+    """Creates a solver sized for the scene, uploads scene + batch."""
+    nverts = len(obst.vert_x)
+    s = TebBatchSolver(cfg, max_tebs or batch.count, max_poses or batch.stride, max(len(obst), 1), max(nverts, 1),
+                       max(len(via), 1), device=device, stream=stream)
+    s.set_obstacles(obst)
+    s.set_via_points(via)
+    s.upload(batch)
+    return s
+
+
+class TebOptimalPlanner:
+    """Single-candidate view (reference include/teb_local_planner/optimal_planner.h:100-696)."""
+
+    def __init__(self, cfg, obstacles=None, via_points=None, max_poses=None, device=0):
+        self.cfg_ = cfg
+        self.obstacles_ = obstacles if obstacles is not None else _abi.ObstacleTable()
+        self.via_points_ = list(via_points or [])
+        self.max_poses = max_poses or min(cfg.trajectory.max_samples + 1, 352)
+        self.teb_ = _abi.TebBatchHost(1, self.max_poses)
+        self.cost_ = float("nan")
+        self.optimized_ = False
+        self.device = device
+        self._solver = None
+        self.last_results = None
+
+    def teb(self):
+        return self.teb_
+
+    def setVelocityStart(self, vx, vy, omega):
+        self.teb_.has_vel_start[0] = 1
+        self.teb_.vel_start[0] = (vx, vy, omega)
+
+    def setVelocityGoal(self, vx, vy, omega):
+        self.teb_.has_vel_goal[0] = 1
+        self.teb_.vel_goal[0] = (vx, vy, omega)
+
+    def setVelocityGoalFree(self):
+        self.teb_.has_vel_goal[0] = 0
+
+    def getCurrentCost(self):
+        return self.cost_
+
+    def isOptimized(self):
+        return self.optimized_
+
+    def optimizeTEB(self, iterations_innerloop, iterations_outerloop, compute_cost_afterwards=False,
+                    obst_cost_scale=1.0, viapoint_cost_scale=1.0, alternative_time_cost=False):
+        if not self.cfg_.optim.optimization_activate:
+            return False
+        self.optimized_ = False
+        if self._solver is None:
+            self._solver = TebBatchSolver(self.cfg_, 1, self.max_poses, max(len(self.obstacles_), 1),
+                                          max(len(self.obstacles_.vert_x), 1), max(len(self.via_points_), 1),
+                                          device=self.device)
+        s = self._solver
+        s.set_config(self.cfg_)
+        s.set_obstacles(self.obstacles_)
+        s.set_via_points(self.via_points_)
+        s.upload(self.teb_)
+        s.optimize(iterations_innerloop, iterations_outerloop, compute_cost_afterwards, obst_cost_scale,
+                   viapoint_cost_scale, alternative_time_cost)
+        res = s.results()
+        s.download(self.teb_)
+        self.last_results = res
+        if res.status[0] != _abi.TEB_OK:
+            return False
+        self.optimized_ = True
+        if compute_cost_afterwards:
+            self.cost_ = float(res.cost[0])
+        return True
+
+
+class HomotopyClassPlanner:
+    """Batch view: owns B candidates resident on one GPU (reference homotopy_class_planner.h)."""
+
+    def __init__(self, cfg, obstacles, via_points, batch, device=0, stream=None):
+        self.cfg_ = cfg
+        self.tebs_ = batch
+        self.solver = make_solver(cfg, obstacles, via_points, batch, device=device, stream=stream)
+        self.best_teb_ = -1
+        self.initial_plan_teb_ = -1
+        self.last_results = None
+
+    def optimizeAllTEBs(self, iter_innerloop, iter_outerloop):
+        h = self.cfg_.hcp
+        self.solver.optimize(iter_innerloop, iter_outerloop, True, h.selection_obst_cost_scale,
+                             h.selection_viapoint_cost_scale, h.selection_alternative_time_cost)
+
+    def selectBestTeb(self):
+        best, _ = self.solver.select_best(self.best_teb_, self.initial_plan_teb_)
+        self.best_teb_ = best
+        return best
+
+    def results(self):
+        self.last_results = self.solver.results()
+        return self.last_results
+
+    def download(self):
+        return self.solver.download(self.tebs_)
