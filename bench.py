@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the TEB hot path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
+
+One "step" = one pass of the hot path over one batch: B x optimizeTEB (4 outer x 5 inner LM iterations,
+association, cost) = HomotopyClassPlanner::optimizeAllTEBs on the resident batch, from the same initial
+state every step (device-to-device restore inside the timed region), with inputs already in HBM.
+Workload at N=1: BASELINE config C4 — 256 candidate TEBs x 200 poses, 500 point obstacles incl. 50 dynamic
+(teb_autosize off so n stays 200). N>1: every rank runs its own 256 candidates (weak scaling),
+no data-path collective; one 16-byte all-gather per step performs the best-trajectory selection.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from teb_local_planner_amd import scenes, planner, _abi  # noqa: E402
+
+# ALGORITHMIC bytes per TEB.LM-iteration (restated in DESIGN.md §Measurement):
+#   64*n (state read+write) + R_obst + 4*E_assoc + 32  + (32*n + R_obst + 4*E_assoc)/inner  [association amortised]
+def alg_bytes_per_unit(n, M, e_assoc, inner):
+    r_obst = 32 * M
+    return 64 * n + r_obst + 4 * e_assoc + 32 + (32 * n + r_obst + 4 * e_assoc) / inner
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tebs", type=int, default=256, help="candidate TEBs per GPU")
+    ap.add_argument("--poses", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=64, help="TEBs in the CPU-oracle sample")
+    ap.add_argument("--latency-reps", type=int, default=20)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    B, n = args.tebs, args.poses
+    # every rank owns its own candidates (different seed -> different bands), the scene is replicated
+    cfg, obst, via, batch = scenes.scene_c4(B=B, n=n, seed=1004 + 7919 * rank)
+    cfg.trajectory.teb_autosize = False
+    inner, outer = cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations
+    hp = planner.HomotopyClassPlanner(cfg, obst, via, batch, device=local_rank)
+    s = hp.solver
+    s.snapshot()
+    sel = torch.zeros(2, dtype=torch.float64, device="cuda")
+    gathered = [torch.zeros(2, dtype=torch.float64, device="cuda") for _ in range(world)] if distributed else None
+
+    def step():
+        s.restore()
+        hp.optimizeAllTEBs(inner, outer)
+        best, cost = s.select_best(-1, -1)          # synchronises the stream (16-byte D2H)
+        if distributed:                             # the path's only exchange: (cost, global index) per rank
+            sel[0] = cost
+            sel[1] = float(rank * B + best)
+            dist.all_gather(gathered, sel)
+            allv = torch.stack(gathered).cpu().numpy()
+            k = np.lexsort((allv[:, 1], allv[:, 0]))[0]   # min cost, ties -> lowest global index
+            return int(allv[k, 1])
+        return best
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(s.last_kernel_ms())        # HIP events on the launch stream
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    res = s.results()
+    units_step = int(res.lm_iterations.sum())
+    tt = torch.tensor([elapsed, float(units_step)], dtype=torch.float64, device="cuda")
+    if distributed:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed_max, units_all = float(tmax[0]), float(tsum[1])
+    else:
+        elapsed_max, units_all = elapsed, float(units_step)
+
+    out = None
+    if rank == 0:
+        value = units_all * args.steps / elapsed_max
+        kms = float(np.mean(kernel_ms))
+        M = len(obst)
+        # association list size for the algorithmic-byte model: measured on TEB 0 of this rank
+        dbg = s.debug_linearize(0, n, 1.0)
+        e_assoc = len(dbg["assoc_pose"])
+        abu = alg_bytes_per_unit(n, M, e_assoc, inner)
+        alg_bytes_launch = abu * units_step
+        achieved = alg_bytes_launch / (kms * 1e-3) / 1e9
+        out = {
+            "metric": "TEB LM iterations/sec (whole node)", "value": value, "unit": "TEB.LM-iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed_max / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C4: %d candidate TEBs/GPU x %d poses, %d point obstacles (%d dynamic), "
+                                   "diff-drive, point footprint, teb_autosize off, 4 outer x 5 inner" %
+                                   (B, n, M, int(np.sum(obst.dynamic))),
+                       "tebs_per_gpu": B, "poses": n, "obstacles": M, "units_per_step_per_gpu": units_step,
+                       "lm_trials_per_step_per_gpu": int(res.lm_trials.sum())},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None,
+                         "kernel": "teb_optimize_kernel", "kernel_ms": kms,
+                         "alg_bytes_per_unit": abu, "alg_bytes_per_launch": alg_bytes_launch},
+        }
+        # ---- p50 plan()-equivalent latency on the 200-pose band: upload -> 4x5 iterations incl. autoResize,
+        #      association, cost -> select -> download (single TEB, config C2, and the C4 batch)
+        lat = {}
+        for name, (c2, o2, v2, b2) in (("c2_single_teb", scenes.scene_c2(stride=256)),
+                                       ("c4_batch", scenes.scene_c4(B=B, n=n, stride=256))):
+            s2 = planner.make_solver(c2, o2, v2, b2)
+            ts = []
+            for _ in range(args.latency_reps):
+                hb = b2.copy()
+                t1 = time.perf_counter()
+                s2.upload(hb)
+                s2.optimize(inner, outer, True, c2.hcp.selection_obst_cost_scale, c2.hcp.selection_viapoint_cost_scale,
+                            c2.hcp.selection_alternative_time_cost)
+                s2.select_best(-1, -1)
+                s2.download(hb)
+                ts.append(time.perf_counter() - t1)
+            lat[name + "_p50_ms"] = 1e3 * float(np.median(ts))
+            s2.close()
+        out["plan_latency"] = lat
+        # ---- CPU baseline: the oracle in the reference-faithful mode (g2o central differences), thread per TEB
+        if not args.no_cpu_baseline:
+            from oracle import oracle_py
+            oracle_py.build()
+            cores = os.cpu_count() or 1
+            ks = min(args.cpu_sample, B)
+            cb = _abi.TebBatchHost(ks, batch.stride)
+            for b in range(ks):
+                cb.set_teb(b, *batch.get_teb(b))
+            cb.has_vel_goal[:] = batch.has_vel_goal[:ks]
+            cfg_cpu = scenes.scene_c4(B=1, n=n)[0]
+            cfg_cpu.trajectory.teb_autosize = False
+            cfg_cpu.jacobian_mode = _abi.JACOBIAN_G2O_NUMERIC
+            t1 = time.perf_counter()
+            _, cres = oracle_py.optimize_batch(cfg_cpu, obst, via, cb, threads=cores)
+            cpu_t = time.perf_counter() - t1
+            out["cpu_baseline"] = {
+                "value": float(cres.lm_iterations.sum()) / cpu_t, "unit": "TEB.LM-iterations/s", "cores": cores,
+                "kind": "port",
+                "sample": "%d of the %d C4 candidates, one optimizeTEB each (4x5), g2o-numeric Jacobians, "
+                          "one std::thread per TEB capped at %d, %.1f s wall" % (ks, B, cores, cpu_t)}
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -42,8 +42,8 @@ def scene_c1(with_velocities=False):
     """test_optim_node scene: src/test_optim_node.cpp:106-117,168 (static variant by default)."""
     cfg = TebConfig()
     obst = _abi.ObstacleTable()
-    vels = [(0.1, 0.2), (-0.1, -0.3), None] if with_velocities else [None, None, None]
-    # note: test_optim_node applies velocities to the first two obstacles (-> dynamic)
+    # test_optim_node.cpp:113-117 gives the first two obstacles a velocity (-> dynamic obstacles)
+    vels = [(0.1, -0.3), (-0.3, -0.2), None] if with_velocities else [None, None, None]
     for (x, y), v in zip([(-3.0, 1.0), (6.0, 2.0), (0.0, 0.1)], vels):
         obst.add_point(x, y, vel=v)
     n = 50
@@ -66,12 +66,12 @@ def _point_obstacles(rng, count, xr, yr, paths, clearance):
     return out
 
 
-def scene_c2(n=200, M=100, seed=1002, stride=None):
+def scene_c2(n=200, M=100, seed=1002, stride=None, length=20.0):
     cfg = TebConfig()
     rng = np.random.default_rng(seed)
-    px, py, th, dt = sine_band(n, 20.0, 0.5, 3.0, cfg.robot.max_vel_x)  # 1.5 periods = 3 half periods
+    px, py, th, dt = sine_band(n, length, 0.5, 3.0, cfg.robot.max_vel_x)  # 1.5 periods = 3 half periods
     obst = _abi.ObstacleTable()
-    for p in _point_obstacles(rng, M, (1.0, 19.0), (-3.0, 3.0), [(px, py)], 0.3):
+    for p in _point_obstacles(rng, M, (1.0, length - 1.0), (-3.0, 3.0), [(px, py)], 0.3):
         obst.add_point(*p)
     batch = _abi.TebBatchHost(1, stride or n)
     batch.set_teb(0, px, py, th, dt)
@@ -109,18 +109,18 @@ def scene_c4(B=256, n=200, M_static=450, M_dyn=50, seed=1004, stride=None):
     return cfg, obst, via, batch
 
 
-def scene_c5(n=300, M=300, seed=1005, stride=None):
+def scene_c5(n=300, M=300, seed=1005, stride=None, length=30.0):
     cfg = TebConfig()
     cfg.robot.min_turning_radius = 1.0
     cfg.optim.weight_kinematics_turning_radius = 1.0
     cfg.robot.max_vel_x_backwards = 0.2
     cfg.robot_model = RobotFootprintModel.polygon([(-0.3, -0.25), (0.9, -0.25), (0.9, 0.25), (-0.3, 0.25)])
     rng = np.random.default_rng(seed)
-    px, py, th, dt = sine_band(n, 30.0, 0.5, 3.0, cfg.robot.max_vel_x)
+    px, py, th, dt = sine_band(n, length, 0.5, 3.0, cfg.robot.max_vel_x)
     obst = _abi.ObstacleTable()
     count = 0
     while count < M:
-        c = (rng.uniform(2.0, 28.0), rng.uniform(-5.0, 5.0))
+        c = (rng.uniform(2.0, length - 2.0), rng.uniform(-5.0, 5.0))
         if _min_dist_to_path(c, px, py) < 0.8 + 0.5:
             continue
         k = int(rng.integers(3, 7))

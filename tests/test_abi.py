@@ -1,0 +1,65 @@
+"""The C-ABI library loads on a CPU-only box, exports every symbol include/*.h declares, and its POD
+layouts match the ctypes mirror. No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from teb_local_planner_amd import _abi, planner
+from teb_local_planner_amd.config import TebConfig
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(teb_amd_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.mark.parametrize("header", ["teb_amd.h", "teb_amd_debug.h"])
+def test_exports_every_declared_symbol(header):
+    L = planner.lib()
+    names = _declared(header)
+    assert len(names) >= 4
+    for n in names:
+        assert hasattr(L, n), "libteb_amd.so does not export %s" % n
+
+
+def test_struct_sizes_match_ctypes_mirror():
+    L = planner.lib()
+    assert L.teb_amd_abi_version() == 1
+    assert L.teb_amd_sizeof_config() == C.sizeof(_abi.Config)
+    assert L.teb_amd_sizeof_obstacles() == C.sizeof(_abi.Obstacles)
+    assert L.teb_amd_sizeof_teb_batch() == C.sizeof(_abi.TebBatch)
+    assert L.teb_amd_sizeof_results() == C.sizeof(_abi.Results)
+
+
+def test_default_config_matches_reference_defaults():
+    """teb_amd_config_default == TebConfig() of the Python mirror == teb_config.h:245-390."""
+    L = planner.lib()
+    c = _abi.Config()
+    L.teb_amd_config_default(C.byref(c))
+    p = TebConfig().to_c()
+    for name, _ in _abi.Config._fields_:
+        a, b = getattr(c, name), getattr(p, name)
+        if hasattr(a, "__len__"):
+            assert list(a) == list(b), name
+        else:
+            assert a == b, (name, a, b)
+    # spot-check against the reference constructor (teb_config.h:321-345)
+    assert c.no_inner_iterations == 5 and c.no_outer_iterations == 4
+    assert c.weight_kinematics_nh == 1000 and c.weight_obstacle == 50 and c.weight_adapt_factor == 2.0
+    assert c.dt_ref == 0.3 and c.dt_hysteresis == 0.1 and c.max_samples == 500
+    assert c.min_obstacle_dist == 0.5 and c.inflation_dist == 0.6 and c.include_dynamic_obstacles == 1
+
+
+def test_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from teb_local_planner_amd import scenes
+    with pytest.raises(planner.TebAmdError) as e:
+        planner.make_solver(*scenes.scene_c1())
+    assert e.value.code == _abi.ERR_NO_DEVICE

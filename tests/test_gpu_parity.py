@@ -1,0 +1,300 @@
+"""Parity of the HIP path (through the C-ABI of libteb_amd.so) against the CPU oracle and the golden
+fixtures. All fp64. Stated tolerances (tightened to what is actually observed):
+
+  T0/T1  one linearisation at the same state:  chi^2 per category rel 1e-12; H, b rel 1e-12 of max|.|
+         (both sides use closed-form Jacobians; only the summation order and libm ulps differ)
+         association lists: bit-exact (integer work)
+  T3     full optimizeTEB (4 x 5 LM iterations incl. autoResize / association / cost):
+         identical pose count, status, LM iteration and trial counts; poses <= 1e-8 m / rad; chi^2 and cost rel 1e-8
+         vs the oracle in the reference-faithful g2o-numeric mode: <= 1e-3 m / rad, cost rel 1e-3 (the reference's own
+         central-difference noise floor, delta = 1e-9)
+  T4     selectBestTeb: same index
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden  # noqa: E402
+
+from teb_local_planner_amd import scenes, planner, _abi  # noqa: E402
+from test_golden_oracle import check_against_golden  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def run_gpu(cfg, obst, via, batch, inner=None, outer=None, compute_cost=True):
+    inner = cfg.optim.no_inner_iterations if inner is None else inner
+    outer = cfg.optim.no_outer_iterations if outer is None else outer
+    s = planner.make_solver(cfg, obst, via, batch)
+    s.optimize(inner, outer, compute_cost, cfg.hcp.selection_obst_cost_scale, cfg.hcp.selection_viapoint_cost_scale,
+               cfg.hcp.selection_alternative_time_cost)
+    res = s.results()
+    out = s.download(batch.copy())
+    best = s.select_best()
+    flags = s.debug_overflow_flags()
+    s.close()
+    assert not flags.any()
+    return out, res, best
+
+
+def assert_full_parity(out, res, ref, rres, pos_tol=1e-8, rtol=1e-8):
+    np.testing.assert_array_equal(out.n, ref.n)
+    np.testing.assert_array_equal(res.status, rres.status)
+    np.testing.assert_array_equal(res.lm_iterations, rres.lm_iterations)
+    np.testing.assert_array_equal(res.lm_trials, rres.lm_trials)
+    np.testing.assert_allclose(res.chi2, rres.chi2, rtol=rtol)
+    np.testing.assert_allclose(res.cost, rres.cost, rtol=rtol)
+    for b in range(out.count):
+        for u, v in zip(out.get_teb(b), ref.get_teb(b)):
+            assert np.abs(u - v).max() <= pos_tol
+
+
+# ---- K10: distances -----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("footprint", ["point", "circular", "two_circles", "line", "polygon"])
+def test_distance_library(oracle, footprint):
+    cfg, obst, via, batch = scenes.scene_small_mixed(footprint=footprint)
+    s = planner.make_solver(cfg, obst, via, batch)
+    rng = np.random.default_rng(11)
+    nq = 400
+    oi = rng.integers(0, len(obst), nq); x = rng.uniform(0, 6, nq); y = rng.uniform(-2, 2, nq)
+    th = rng.uniform(-3.1, 3.1, nq); t = rng.uniform(0, 6, nq)
+    for tt in (None, t):
+        d, g = s.debug_distance(oi, x, y, th, tt)
+        for q in range(nq):
+            do, go = oracle.distance(cfg, obst, int(oi[q]), x[q], y[q], th[q], None if tt is None else tt[q])
+            assert abs(d[q] - do) <= 1e-14 * max(1.0, abs(do))
+            assert np.abs(g[q] - go).max() <= 1e-12
+    s.close()
+
+
+# ---- T0/T1 + association --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("footprint", ["point", "circular", "two_circles", "line", "polygon"])
+def test_linearisation_and_association(oracle, footprint):
+    cfg, obst, via, batch = scenes.scene_small_mixed(footprint=footprint)
+    s = planner.make_solver(cfg, obst, via, batch)
+    for b in range(batch.count):
+        for wm in (1.0, 8.0):
+            G = s.debug_linearize(b, int(batch.n[b]), wm)
+            R = oracle.linearize(cfg, obst, via, batch, b, wm)
+            np.testing.assert_allclose(G["chi2"], R["chi2"], rtol=1e-12, atol=1e-14)
+            assert np.abs(G["H"] - R["H"]).max() <= 1e-12 * np.abs(R["H"]).max()
+            assert np.abs(G["b"] - R["b"]).max() <= 1e-12 * np.abs(R["b"]).max()
+            ap, ao = oracle.associate(cfg, obst, batch, b)
+            np.testing.assert_array_equal(G["assoc_pose"], ap)
+            np.testing.assert_array_equal(G["assoc_obst"], ao)
+    s.close()
+
+
+def _variant(name):
+    cfg, obst, via, batch = scenes.scene_small_mixed(footprint="circular")
+    if name == "carlike":
+        cfg.robot.min_turning_radius = 0.8
+    elif name == "carlike_exact_arc":
+        cfg.robot.min_turning_radius = 0.8
+        cfg.trajectory.exact_arc_length = True
+    elif name == "exact_arc":
+        cfg.trajectory.exact_arc_length = True
+    elif name == "optional_edges":
+        cfg.optim.weight_shortest_path = 0.7
+        cfg.optim.weight_velocity_obstacle_ratio = 3.0
+        cfg.obstacles.obstacle_proximity_lower_bound = 0.1
+        cfg.obstacles.obstacle_proximity_upper_bound = 1.2
+        cfg.obstacles.obstacle_proximity_ratio_max_vel = 0.8
+        cfg.optim.obstacle_cost_exponent = 1.7
+        batch.prefer_rotdir[0] = _abi.ROT_LEFT
+        batch.prefer_rotdir[1] = _abi.ROT_RIGHT
+    elif name == "holonomic":
+        cfg.robot.max_vel_y = 0.3
+        cfg.robot.max_vel_trans = 0.45
+        cfg.robot.acc_lim_y = 0.4
+        rng = np.random.default_rng(3)
+        batch.theta += rng.uniform(-0.4, 0.4, batch.theta.shape)
+        batch.dt *= 0.6
+    elif name == "static_only":
+        cfg.obstacles.include_dynamic_obstacles = False
+    elif name == "no_inflation":
+        cfg.obstacles.inflation_dist = 0.4
+    elif name == "ordered_via_alt_time":
+        cfg.trajectory.via_points_ordered = True
+        cfg.hcp.selection_alternative_time_cost = True
+        batch.via_points_enabled[2] = 0
+    elif name == "divergence_stats":
+        cfg.recovery.divergence_detection_enable = True
+    return cfg, obst, via, batch
+
+
+VARIANTS = ["carlike", "carlike_exact_arc", "exact_arc", "optional_edges", "holonomic", "static_only",
+            "no_inflation", "ordered_via_alt_time", "divergence_stats"]
+
+
+@pytest.mark.parametrize("name", VARIANTS)
+def test_edge_family_variants_linearise_and_optimise(oracle, name):
+    cfg, obst, via, batch = _variant(name)
+    s = planner.make_solver(cfg, obst, via, batch)
+    for b in range(batch.count):
+        G = s.debug_linearize(b, int(batch.n[b]), 2.0)
+        R = oracle.linearize(cfg, obst, via, batch, b, 2.0)
+        np.testing.assert_allclose(G["chi2"], R["chi2"], rtol=1e-12, atol=1e-14)
+        assert np.abs(G["H"] - R["H"]).max() <= 1e-12 * np.abs(R["H"]).max()
+        assert np.abs(G["b"] - R["b"]).max() <= 1e-12 * np.abs(R["b"]).max()
+    s.close()
+    out, res, best = run_gpu(cfg, obst, via, batch)
+    ref, rres = oracle.optimize_batch(cfg, obst, via, batch)
+    assert_full_parity(out, res, ref, rres)
+    assert best[0] == oracle.select_best(cfg, rres.cost)[0]
+
+
+# ---- T3: full optimizeTEB against the golden fixtures and the live oracle ------------------------------------------
+@pytest.mark.parametrize("name", sorted(make_golden.CASES))
+def test_full_optimize_matches_golden(name):
+    cfg, obst, via, batch = make_golden.CASES[name]()
+    out, res, _ = run_gpu(cfg, obst, via, batch)
+    check_against_golden(name, out, res, pos_tol=1e-8, cost_rtol=1e-8)
+
+
+@pytest.mark.parametrize("name", ["c1_test_optim_node", "mixed_polygon", "c2_small"])
+def test_full_optimize_within_reference_noise_of_faithful_oracle(oracle, name):
+    cfg, obst, via, batch = make_golden.CASES[name]()
+    out, res, _ = run_gpu(cfg, obst, via, batch)
+    cfg.jacobian_mode = _abi.JACOBIAN_G2O_NUMERIC
+    ref, rres = oracle.optimize_batch(cfg, obst, via, batch)
+    np.testing.assert_array_equal(out.n, ref.n)
+    np.testing.assert_array_equal(res.status, rres.status)
+    np.testing.assert_allclose(res.cost, rres.cost, rtol=1e-3)
+    for b in range(out.count):
+        for u, v in zip(out.get_teb(b), ref.get_teb(b)):
+            assert np.abs(u - v).max() <= 1e-3
+
+
+def test_iteration_schedules_and_guards(oracle):
+    cfg, obst, via, batch = scenes.scene_small_mixed(footprint="point")
+    for inner, outer in ((1, 1), (3, 2), (5, 1), (0, 1), (2, 0)):
+        out, res, _ = run_gpu(cfg, obst, via, batch, inner, outer)
+        ref, rres = oracle.optimize_batch(cfg, obst, via, batch, inner=inner, outer=outer)
+        assert_full_parity(out, res, ref, rres)
+    # guards of optimizeGraph (optimal_planner.cpp:370-382): too few samples / robot too slow / deactivated
+    for mutate in ("min_samples", "max_vel_x", "deactivate"):
+        cfg, obst, via, batch = scenes.scene_small_mixed(footprint="point")
+        cfg.trajectory.teb_autosize = False
+        if mutate == "min_samples":
+            cfg.trajectory.min_samples = 30
+        elif mutate == "max_vel_x":
+            cfg.robot.max_vel_x = 0.005
+        else:
+            cfg.optim.optimization_activate = False
+        out, res, _ = run_gpu(cfg, obst, via, batch)
+        ref, rres = oracle.optimize_batch(cfg, obst, via, batch)
+        assert (res.status == _abi.TEB_FAILED).all() and (rres.status == _abi.TEB_FAILED).all()
+        np.testing.assert_array_equal(out.x, batch.x)   # state untouched
+
+
+def test_autoresize_on_device_reproduces_sequential_semantics(oracle):
+    """Bands with wildly uneven time differences: splits (recursive), excess shifting, merges, last-interval merge."""
+    cfg, obst, via, _ = scenes.scene_small_mixed(footprint="point", with_dynamic=False)
+    rng = np.random.default_rng(21)
+    B, S = 6, 200
+    batch = _abi.TebBatchHost(B, S)
+    for b in range(B):
+        n = int(rng.integers(5, 40))
+        x = np.sort(rng.uniform(0, 6, n)); y = rng.uniform(-0.5, 0.5, n); th = rng.uniform(-1, 1, n)
+        dt = rng.choice([0.02, 0.1, 0.3, 0.5, 0.9, 2.5], n - 1) * rng.uniform(0.8, 1.2, n - 1)
+        batch.set_teb(b, x, y, th, dt)
+    for fast in (True, False):
+        cfg.obstacles.include_dynamic_obstacles = not fast      # fast_mode = !include_dynamic_obstacles
+        out, res, _ = run_gpu(cfg, obst, via, batch, inner=1, outer=1, compute_cost=False)
+        ref, rres = oracle.optimize_batch(cfg, obst, via, batch, inner=1, outer=1, compute_cost=False)
+        np.testing.assert_array_equal(out.n, ref.n)
+        assert_full_parity(out, res, ref, rres)
+
+
+# ---- T4 + BASELINE configs at full size ------------------------------------------------------------------------------
+def test_c3_batch_selection_matches_oracle(oracle):
+    cfg, obst, via, batch = scenes.scene_c3(B=16, n=150, M=200, stride=192)
+    out, res, best = run_gpu(cfg, obst, via, batch)
+    ref, rres = oracle.optimize_batch(cfg, obst, via, batch, threads=os.cpu_count() or 1)
+    assert_full_parity(out, res, ref, rres, pos_tol=1e-7, rtol=1e-7)
+    assert best[0] == oracle.select_best(cfg, rres.cost)[0]
+    # hysteresis / prefer-initial multipliers
+    s = planner.make_solver(cfg, obst, via, out)
+    s.optimize(1, 1, True, 100.0, 1.0, False)
+    r2 = s.results()
+    for lb, ip in ((3, -1), (-1, 5), (2, 2)):
+        assert s.select_best(lb, ip)[0] == oracle.select_best(cfg, r2.cost, lb, ip)[0]
+    s.close()
+
+
+def test_c4_full_size_properties():
+    """BASELINE config C4 at full size (256 x 200 poses, 450 static + 50 dynamic obstacles): too slow for the
+    oracle, so check size-independent properties: every TEB OK, 20 LM iterations each, chi^2 finite and not worse
+    than the initial one, fixed start/goal untouched, re-running is bit-reproducible, and a sample of TEBs matches
+    the oracle run on exactly those TEBs."""
+    cfg, obst, via, batch = scenes.scene_c4()
+    cfg.trajectory.teb_autosize = False
+    s = planner.make_solver(cfg, obst, via, batch)
+    chi0 = np.array([s.debug_linearize(b, 200, 1.0)["chi2"].sum() for b in (0, 17, 255)])
+    s.optimize(5, 4, True, 100.0, 1.0, False)
+    res = s.results()
+    out = s.download(batch.copy())
+    assert (res.status == _abi.TEB_OK).all()
+    assert (res.lm_iterations == 20).all() and (out.n == 200).all()
+    assert np.isfinite(res.chi2).all() and np.isfinite(res.cost).all()
+    np.testing.assert_array_equal(out.x[:, 0], batch.x[:, 0]); np.testing.assert_array_equal(out.x[:, 199], batch.x[:, 199])
+    np.testing.assert_array_equal(out.theta[:, 0], batch.theta[:, 0])
+    s.upload(batch)
+    s.optimize(5, 4, True, 100.0, 1.0, False)
+    res2 = s.results()
+    out2 = s.download(batch.copy())
+    np.testing.assert_array_equal(out.x, out2.x); np.testing.assert_array_equal(res.cost, res2.cost)   # deterministic
+    s.close()
+    from oracle import oracle_py
+    sub = _abi.TebBatchHost(3, 200)
+    for k, b in enumerate((0, 17, 255)):
+        sub.set_teb(k, *batch.get_teb(b))
+        sub.has_vel_goal[k] = batch.has_vel_goal[b]
+    ref, rres = oracle_py.optimize_batch(cfg, obst, via, sub)
+    for k, b in enumerate((0, 17, 255)):
+        assert res.lm_trials[b] == rres.lm_trials[k]
+        np.testing.assert_allclose(res.cost[b], rres.cost[k], rtol=1e-7)
+        for u, v in zip(out.get_teb(b), ref.get_teb(k)):
+            assert np.abs(u - v).max() <= 1e-7
+
+
+def test_c5_carlike_polygon_full_size(oracle):
+    cfg, obst, via, batch = scenes.scene_c5()
+    out, res, _ = run_gpu(cfg, obst, via, batch)
+    ref, rres = oracle.optimize_batch(cfg, obst, via, batch)
+    assert_full_parity(out, res, ref, rres, pos_tol=1e-7, rtol=1e-7)
+
+
+def test_capacity_errors_are_loud():
+    cfg, obst, via, batch = scenes.scene_c1()
+    with pytest.raises(planner.TebAmdError) as e:
+        planner.TebBatchSolver(cfg, 1, 600, 4, 1, 1)
+    assert e.value.code == _abi.ERR_CAPACITY
+    s = planner.make_solver(cfg, obst, via, batch)
+    big = _abi.ObstacleTable()
+    for k in range(10):
+        big.add_point(k, 0)
+    with pytest.raises(planner.TebAmdError):
+        s.set_obstacles(big)
+    s.close()
+
+
+def test_reference_style_planner_objects(oracle):
+    """TebOptimalPlanner.optimizeTEB / getCurrentCost mirror (optimal_planner.h:231-232, 437)."""
+    cfg, obst, via, batch = scenes.scene_c1()
+    p = planner.TebOptimalPlanner(cfg, obst, via, max_poses=128)
+    p.teb().set_teb(0, *batch.get_teb(0))
+    p.teb().has_vel_goal[0] = 1
+    ok = p.optimizeTEB(cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations, True,
+                       cfg.hcp.selection_obst_cost_scale, cfg.hcp.selection_viapoint_cost_scale, False)
+    assert ok and p.isOptimized()
+    ref, rres = oracle.optimize_batch(cfg, obst, via, batch)
+    assert abs(p.getCurrentCost() - rres.cost[0]) <= 1e-8 * rres.cost[0]
+    assert p.teb().n[0] == ref.n[0]
+    cfg.optim.optimization_activate = False
+    assert p.optimizeTEB(5, 4) is False
