@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--tebs", type=int, default=256, help="candidate TEBs per GPU")
     ap.add_argument("--poses", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=64, help="TEBs in the CPU-oracle sample")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="TEBs in the CPU-oracle sample")
     ap.add_argument("--latency-reps", type=int, default=20)
     args = ap.parse_args()
 
@@ -135,8 +135,8 @@ def main():
         # ---- p50 plan()-equivalent latency on the 200-pose band: upload -> 4x5 iterations incl. autoResize,
         #      association, cost -> select -> download (single TEB, config C2, and the C4 batch)
         lat = {}
-        for name, (c2, o2, v2, b2) in (("c2_single_teb", scenes.scene_c2(stride=256)),
-                                       ("c4_batch", scenes.scene_c4(B=B, n=n, stride=256))):
+        for name, (c2, o2, v2, b2) in (("c2_single_teb", scenes.scene_c2(stride=208)),
+                                       ("c4_batch", scenes.scene_c4(B=B, n=n, stride=max(n, 208)))):
             s2 = planner.make_solver(c2, o2, v2, b2)
             ts = []
             for _ in range(args.latency_reps):

@@ -31,6 +31,11 @@ int teb_amd_debug_distance(teb_amd_handle_t* h, int32_t nq, const int32_t* obst_
                            const double* y, const double* theta, const int32_t* spatio_temporal,
                            const double* t, double* dist, double* grad);
 
+/* phase cycle counters of workgroup 0 of the last optimize_batch (only in a -DTEB_PROFILE build):
+ * [0] autoResize [1] association+via+time stamps [2] linearise [3] H backup [4] damped solve
+ * [5] update+chi2 evaluation [6] accept/reject (+H restore) */
+int teb_amd_debug_profile(teb_amd_handle_t* h, double* cycles8);
+
 /* per-TEB flags of the last launch: bit0 association list overflow, bit1 autoResize capacity overflow */
 int teb_amd_debug_assoc_overflow(teb_amd_handle_t* h, int32_t* flags);
 

@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -114,7 +115,7 @@ __global__ void distance_kernel(const teb_amd_config_t c, const SceneDev sc, int
   int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
   double g[3];
-  dist[q] = footprint_distance(c, sc, oi[q], x[q], y[q], th[q], st[q] != 0, t[q], g);
+  dist[q] = footprint_distance(c, sc, oi[q], x[q], y[q], cos(th[q]), sin(th[q]), st[q] != 0, t[q], g);
   grad[3 * q] = g[0]; grad[3 * q + 1] = g[1]; grad[3 * q + 2] = g[2];
 }
 
@@ -128,6 +129,12 @@ struct teb_amd_handle {
   int max_tebs = 0, stride = 0, max_obst = 0, max_verts = 0, max_via = 0;
   int B = 0, M = 0, nvia = 0, n_static = 0, n_dyn = 0;
   size_t lds_bytes = 0;
+  int solver = 0;
+  size_t hmat_stride = 0;
+  size_t lds_limit = 0;
+  LdsPlan plan;
+  int fast_points = 0;
+  std::vector<int> host_static;
   // scene
   DevBuf<int> o_type, o_dyn, o_voff, o_static, o_dynidx;
   DevBuf<double> o_ax, o_ay, o_bx, o_by, o_rad, o_vx, o_vy, o_cx, o_cy, o_pvx, o_pvy, viax, viay;
@@ -156,6 +163,7 @@ int check_handle(teb_amd_handle* h) {
 SceneDev scene_of(teb_amd_handle* h) {
   SceneDev s;
   s.M = h->M;
+  s.fast_points = h->fast_points;
   s.type = h->o_type.p; s.ax = h->o_ax.p; s.ay = h->o_ay.p; s.bx = h->o_bx.p; s.by = h->o_by.p;
   s.rad = h->o_rad.p; s.vx = h->o_vx.p; s.vy = h->o_vy.p; s.cx = h->o_cx.p; s.cy = h->o_cy.p;
   s.dyn = h->o_dyn.p; s.voff = h->o_voff.p; s.pvx = h->o_pvx.p; s.pvy = h->o_pvy.p;
@@ -175,7 +183,7 @@ BatchDev batch_of(teb_amd_handle* h) {
   b.assoc_cnt = h->assoc_cnt.p; b.assoc = h->assoc.p; b.assoc_cap = h->max_obst > 0 ? h->max_obst : 1;
   b.assoc_overflow = h->assoc_ovf.p;
   b.via_pose = h->via_pose.p; b.via_cap = h->max_via > 0 ? h->max_via : 1;
-  b.Hbackup = h->Hbackup.p; b.rs_scratch = h->rs_scratch.p;
+  b.Hbackup = h->Hbackup.p; b.hmat_stride = h->hmat_stride; b.rs_scratch = h->rs_scratch.p;
   return b;
 }
 
@@ -200,7 +208,10 @@ int launch(teb_amd_handle* h, const OptArgs& args) {
   BatchDev bt = batch_of(h);
   HIPCHK(hipMemsetAsync(h->assoc_ovf.p, 0, sizeof(int) * h->max_tebs, h->stream));
   HIPCHK(hipEventRecord(h->ev0, h->stream));
-  hipLaunchKernelGGL(teb_optimize_kernel, dim3(h->B), dim3(kThreads), h->lds_bytes, h->stream, h->cfg, sc, bt, args);
+  if (h->solver == SOLVER_CR)
+    hipLaunchKernelGGL(teb_optimize_kernel<SOLVER_CR>, dim3(h->B), dim3(kThreads), h->plan.total_bytes, h->stream, h->cfg, sc, bt, args, h->plan);
+  else
+    hipLaunchKernelGGL(teb_optimize_kernel<SOLVER_BAND>, dim3(h->B), dim3(kThreads), h->plan.total_bytes, h->stream, h->cfg, sc, bt, args, h->plan);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   h->timed = true;
@@ -258,11 +269,17 @@ int teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_po
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(TEB_AMD_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
   HIPCHK(hipSetDevice(device));
-  const size_t lds = lds_bytes_for(max_poses);
-  if (max_poses > kThreads * kMaxPoseIter || lds > (size_t)prop.sharedMemPerBlock) {
+  // block cyclic reduction when its block storage fits the LDS, else the sequential band solver
+  int solver = SOLVER_CR;
+  if (const char* env = getenv("TEB_AMD_SOLVER")) solver = (std::strcmp(env, "band") == 0) ? SOLVER_BAND : SOLVER_CR;
+  // the kernel also owns a little static LDS (__syncthreads_or scratch): keep 1 KiB of head-room
+  const size_t lds_limit = (size_t)prop.sharedMemPerBlock - 1024;
+  if (lds_bytes_for(max_poses, SOLVER_CR) > lds_limit) solver = SOLVER_BAND;
+  const size_t lds = lds_bytes_for(max_poses, solver);
+  if (max_poses > kThreads * kMaxPoseIter || lds > lds_limit) {
     char buf[256];
     std::snprintf(buf, sizeof buf, "max_poses=%d needs %zu B of LDS per workgroup (device limit %zu B, thread limit %d poses)",
-                  max_poses, lds, (size_t)prop.sharedMemPerBlock, kThreads * kMaxPoseIter);
+                  max_poses, lds, lds_limit, kThreads * kMaxPoseIter);
     return fail(TEB_AMD_ERR_CAPACITY, buf);
   }
   const size_t assoc_bytes = sizeof(int) * (size_t)max_tebs * max_poses * (size_t)(max_obstacles > 0 ? max_obstacles : 1);
@@ -274,6 +291,10 @@ int teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_po
   h->max_tebs = max_tebs; h->stride = max_poses; h->max_obst = max_obstacles; h->max_verts = max_obstacle_vertices;
   h->max_via = max_via_points;
   h->lds_bytes = lds;
+  h->solver = solver;
+  h->lds_limit = lds_limit;
+  h->plan = make_lds_plan(max_poses, solver, 0);
+  h->hmat_stride = hmat_doubles(max_poses, solver);
   if (stream) { h->stream = reinterpret_cast<hipStream_t>(stream); h->own_stream = false; }
   else {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(TEB_AMD_ERR_HIP, "hipStreamCreate failed"); }
@@ -295,14 +316,15 @@ int teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_po
   A(h->x.alloc(BS)); A(h->y.alloc(BS)); A(h->th.alloc(BS)); A(h->dt.alloc(BS));
   A(h->vs.alloc(3 * (size_t)max_tebs)); A(h->vg.alloc(3 * (size_t)max_tebs));
   A(h->chi2.alloc(max_tebs)); A(h->cost.alloc(max_tebs)); A(h->lambda.alloc(max_tebs));
-  A(h->Hbackup.alloc(BS * 4 * kBand)); A(h->rs_scratch.alloc((size_t)max_tebs * (4 * (size_t)max_poses + 256)));
+  A(h->Hbackup.alloc((size_t)max_tebs * h->hmat_stride)); A(h->rs_scratch.alloc((size_t)max_tebs * (4 * (size_t)max_poses + 256)));
   A(h->snap_n.alloc(max_tebs)); A(h->snap_x.alloc(BS)); A(h->snap_y.alloc(BS)); A(h->snap_th.alloc(BS)); A(h->snap_dt.alloc(BS));
   A(h->dbg_H.alloc((size_t)4 * max_poses * kBand)); A(h->dbg_b.alloc((size_t)4 * max_poses)); A(h->dbg_chi2.alloc(4));
   A(h->sel_cost.alloc(1)); A(h->sel_idx.alloc(1));
   if (ok && hipEventCreate(&h->ev0) != hipSuccess) ok = false;
   if (ok && hipEventCreate(&h->ev1) != hipSuccess) ok = false;
-  if (ok && hipFuncSetAttribute(reinterpret_cast<const void*>(teb_optimize_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) ok = false;
+  if (ok && hipFuncSetAttribute(solver == SOLVER_CR ? reinterpret_cast<const void*>(teb_optimize_kernel<SOLVER_CR>)
+                                                    : reinterpret_cast<const void*>(teb_optimize_kernel<SOLVER_BAND>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit) != hipSuccess) ok = false;
   if (ok && hipMemset(h->cost.p, 0, sizeof(double) * max_tebs) != hipSuccess) ok = false;
   if (!ok) { teb_amd_destroy(h); return fail(TEB_AMD_ERR_HIP, "device allocation / kernel attribute setup failed"); }
   *out = h;
@@ -334,9 +356,11 @@ int teb_amd_set_config(teb_amd_handle_t* h, const teb_amd_config_t* cfg) {
   if (!cfg) return fail(TEB_AMD_ERR_INVALID_ARG, "null config");
   rc = validate_config(cfg);
   if (rc) return rc;
-  bool dyn_changed = (cfg->include_dynamic_obstacles != h->cfg.include_dynamic_obstacles);
+  bool dyn_changed = (cfg->include_dynamic_obstacles != h->cfg.include_dynamic_obstacles) ||
+                     (cfg->footprint_type != h->cfg.footprint_type);
   h->cfg = *cfg;
-  if (dyn_changed && h->M > 0) return fail(TEB_AMD_ERR_INVALID_ARG, "include_dynamic_obstacles changed: call teb_amd_set_obstacles again");
+  if (dyn_changed && h->M > 0)
+    return fail(TEB_AMD_ERR_INVALID_ARG, "include_dynamic_obstacles / footprint_type changed: call teb_amd_set_obstacles again");
   return TEB_AMD_OK;
 }
 
@@ -385,6 +409,14 @@ int teb_amd_set_obstacles(teb_amd_handle_t* h, const teb_amd_obstacles_t* o) {
   HIPCHK(hipStreamSynchronize(h->stream));   // host vectors go out of scope
   h->M = M; h->n_static = (int)st.size(); h->n_dyn = (int)dy.size();
   h->host_type = type;
+  h->host_static = st;
+  // point-like fast path: all obstacles Point/Circular, footprint Point/Circular, and the cache fits the LDS
+  bool pointlike = (h->cfg.footprint_type == TEB_AMD_FOOTPRINT_POINT || h->cfg.footprint_type == TEB_AMD_FOOTPRINT_CIRCULAR);
+  for (int i = 0; i < M && pointlike; ++i) pointlike = (type[i] == TEB_AMD_OBST_POINT || type[i] == TEB_AMD_OBST_CIRCULAR);
+  if (getenv("TEB_AMD_NO_FAST_POINTS")) pointlike = false;
+  LdsPlan with_cache = make_lds_plan(h->stride, h->solver, M);
+  if (pointlike && M > 0 && (size_t)with_cache.total_bytes <= h->lds_limit) { h->fast_points = 1; h->plan = with_cache; }
+  else { h->fast_points = 0; h->plan = make_lds_plan(h->stride, h->solver, 0); }
   return TEB_AMD_OK;
 }
 
@@ -476,6 +508,9 @@ int teb_amd_optimize_batch(teb_amd_handle_t* h, int32_t inner, int32_t outer, in
   std::memset(&a, 0, sizeof a);
   a.inner = inner; a.outer = outer; a.compute_cost = compute_cost;
   a.obst_scale = obst_cost_scale; a.via_scale = viapoint_cost_scale; a.alt_time = alternative_time_cost;
+#ifdef TEB_PROFILE
+  a.dbg_H = h->dbg_H.p;
+#endif
   return launch(h, a);
 }
 
@@ -564,13 +599,14 @@ int teb_amd_last_kernel_ms(teb_amd_handle_t* h, float* ms) {
 int teb_amd_capacity(teb_amd_handle_t* h, int32_t* lds_bytes, int32_t* max_poses_supported) {
   int rc = check_handle(h);
   if (rc) return rc;
-  if (lds_bytes) *lds_bytes = (int32_t)h->lds_bytes;
+  if (lds_bytes) *lds_bytes = (int32_t)h->plan.total_bytes;
   if (max_poses_supported) {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, h->device));
     int S = kThreads * kMaxPoseIter;
-    while (S > 2 && lds_bytes_for(S) > (size_t)prop.sharedMemPerBlock) --S;
+    while (S > 2 && lds_bytes_for(S, SOLVER_BAND) > h->lds_limit) --S;
     *max_poses_supported = S;
+    (void)0;
   }
   return TEB_AMD_OK;
 }
@@ -594,7 +630,7 @@ int teb_amd_debug_linearize(teb_amd_handle_t* h, int32_t b, double weight_multip
   bt.has_vs += b; bt.vs += 3 * b; bt.has_vg += b; bt.vg += 3 * b; bt.rotdir += b; bt.via_en += b;
   bt.status += b; bt.iters += b; bt.trials += b; bt.chi2 += b; bt.cost += b; bt.lambda += b;
   bt.assoc_cnt += so; bt.assoc += (size_t)b * bt.assoc_cap * h->stride; bt.assoc_overflow += b;
-  bt.via_pose += (size_t)b * bt.via_cap; bt.Hbackup += so * 4 * kBand; bt.rs_scratch += (size_t)b * (4 * (size_t)h->stride + 256);
+  bt.via_pose += (size_t)b * bt.via_cap; bt.Hbackup += (size_t)b * h->hmat_stride; bt.rs_scratch += (size_t)b * (4 * (size_t)h->stride + 256);
   // results of TEB b must not be clobbered by the debug run: save and restore them
   int sv_i[3]; double sv_d[3];
   HIPCHK(hipMemcpy(&sv_i[0], h->status.p + b, sizeof(int), hipMemcpyDeviceToHost));
@@ -603,7 +639,10 @@ int teb_amd_debug_linearize(teb_amd_handle_t* h, int32_t b, double weight_multip
   HIPCHK(hipMemcpy(&sv_d[0], h->chi2.p + b, sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(&sv_d[1], h->cost.p + b, sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(&sv_d[2], h->lambda.p + b, sizeof(double), hipMemcpyDeviceToHost));
-  hipLaunchKernelGGL(teb_optimize_kernel, dim3(1), dim3(kThreads), h->lds_bytes, h->stream, h->cfg, sc, bt, a);
+  if (h->solver == SOLVER_CR)
+    hipLaunchKernelGGL(teb_optimize_kernel<SOLVER_CR>, dim3(1), dim3(kThreads), h->plan.total_bytes, h->stream, h->cfg, sc, bt, a, h->plan);
+  else
+    hipLaunchKernelGGL(teb_optimize_kernel<SOLVER_BAND>, dim3(1), dim3(kThreads), h->plan.total_bytes, h->stream, h->cfg, sc, bt, a, h->plan);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipMemcpy(h->status.p + b, &sv_i[0], sizeof(int), hipMemcpyHostToDevice));
@@ -638,7 +677,7 @@ int teb_amd_debug_linearize(teb_amd_handle_t* h, int32_t b, double weight_multip
     int k = 0;
     for (int i = 1; i < n - 1; ++i)
       for (int q = 0; q < cnt[i]; ++q) {
-        if (k < assoc_cap) { if (assoc_pose) assoc_pose[k] = i; if (assoc_obst) assoc_obst[k] = lst[(size_t)q * h->stride + i]; }
+        if (k < assoc_cap) { if (assoc_pose) assoc_pose[k] = i; if (assoc_obst) assoc_obst[k] = h->host_static[lst[(size_t)q * h->stride + i]]; }
         ++k;
       }
     *assoc_count = k;
@@ -670,6 +709,23 @@ int teb_amd_debug_distance(teb_amd_handle_t* h, int32_t nq, const int32_t* obst_
   if (grad) HIPCHK(hipMemcpy(grad, d_grad.p, 3 * (size_t)nq * sizeof(double), hipMemcpyDeviceToHost));
   d_oi.free(); d_st.free(); d_x.free(); d_y.free(); d_th.free(); d_t.free(); d_dist.free(); d_grad.free();
   return TEB_AMD_OK;
+}
+
+int teb_amd_debug_profile(teb_amd_handle_t* h, double* cycles8) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+#ifdef TEB_PROFILE
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(cycles8, h->dbg_H.p, 8 * sizeof(double), hipMemcpyDeviceToHost));
+  long long crp[8];
+  HIPCHK(hipMemcpyFromSymbol(crp, HIP_SYMBOL(tebamd::g_cr_prof), sizeof crp));
+  fprintf(stderr, "[cr_solve cycles, workgroup 0, cumulative] prologue %lld compute %lld barrier0 %lld writes+2 barriers %lld top %lld backsub %lld\n",
+          crp[0], crp[1], crp[2], crp[3], crp[4], crp[5]);
+  return TEB_AMD_OK;
+#else
+  (void)cycles8;
+  return fail(TEB_AMD_ERR_UNSUPPORTED, "library built without -DTEB_PROFILE");
+#endif
 }
 
 int teb_amd_debug_assoc_overflow(teb_amd_handle_t* h, int32_t* flags) {

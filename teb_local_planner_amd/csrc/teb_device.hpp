@@ -21,8 +21,24 @@ constexpr int kThreads = 256;       // 4 wave64 per workgroup, one workgroup per
 constexpr int kBand = 11;           // diagonal + scalar half-bandwidth 10
 constexpr int kMaxPoseIter = 2;     // poses handled per thread: n <= kThreads * kMaxPoseIter
 
+// LDS layout of one workgroup, computed on the host (offsets in doubles from the dynamic-LDS base).
+struct LdsPlan {
+  int S;            // pose capacity
+  int solver;       // SOLVER_BAND / SOLVER_CR
+  int off_state;    // sx sy sth sdt tdyn cs sn : 7*S
+  int off_H;        // normal matrix (band or blocks)
+  int off_b;        // 4S+8
+  int off_dx;       // 4S+8
+  int off_red;      // 64 doubles + 64 ints
+  int off_ob;       // obstacle cache: x y vx vy r, each ob_cap entries (point-like scenes only), or -1
+  int ob_cap;
+  int total_bytes;
+};
+
 struct SceneDev {
   int M;
+  int fast_points;         // 1: every obstacle is Point/Circular, the footprint is Point/Circular and the
+                           //    obstacle cache fits the LDS -> specialised distance path on LDS-resident data
   const int* type;
   const double *ax, *ay, *bx, *by, *rad, *vx, *vy, *cx, *cy;
   const int* dyn;
@@ -60,7 +76,8 @@ struct BatchDev {
   int* assoc_overflow;  // [B]
   int* via_pose;    // [B][via_cap]
   int via_cap;
-  double* Hbackup;  // [B][4*stride*kBand]
+  double* Hbackup;  // [B][hmat_stride]
+  size_t hmat_stride;
   double* rs_scratch;  // [B][4][stride] autoResize output buffers
 };
 

@@ -49,9 +49,9 @@ __device__ __forceinline__ double pen_below(double var, double a, double eps, do
 // v = dist/dt * fast_sigmoid(100 * deltaS.(cos th_a, sin th_a)), omega = normalize(th_b - th_a)/dt.
 // dv[7] = dv/d(xa, ya, tha, xb, yb, thb, dt) when JAC.
 template <bool JAC>
-__device__ __forceinline__ void signed_velocity(const teb_amd_config_t& c, double xa, double ya, double tha, double xb,
-                                                double yb, double thb, double dt, double& v, double& omega,
-                                                double* dv) {
+__device__ __forceinline__ void signed_velocity(const teb_amd_config_t& c, double xa, double ya, double tha, double ca,
+                                                double sa, double xb, double yb, double thb, double dt, double& v,
+                                                double& omega, double* dv) {
   double dx = xb - xa, dy = yb - ya;
   double eucl = sqrt(dx * dx + dy * dy);
   double dist = eucl;
@@ -62,8 +62,7 @@ __device__ __forceinline__ void signed_velocity(const teb_amd_config_t& c, doubl
     dist = fabs(angle_diff * radius);
     arc = true;
   }
-  double ca = cos(tha), sa = sin(tha);
-  double p = dx * ca + dy * sa;
+  double p = dx * ca + dy * sa;   // ca, sa = cos(tha), sin(tha) (per-pose LDS cache)
   double sg = fast_sigmoid(100 * p);
   double vel = dist / dt;
   vel *= sg;
@@ -136,15 +135,16 @@ constexpr unsigned M_POSE2 = 0x700;            // pose i+2
 constexpr unsigned M_SEG = M_POSE0 | M_DT0 | M_POSE1;   // velocity-type edges
 constexpr unsigned M_ALL = 0x7FF;
 
-struct Win {   // thread-local copy of the window state
+struct Win {   // thread-local copy of the window state (+ cached cos/sin of theta_i, theta_{i+1})
   double x0, y0, t0, d0, x1, y1, t1, d1, x2, y2, t2;
+  double c0, s0, c1, s1;
 };
 
 // ---- EdgeVelocity --------------------------------------------------------------------------------------
 template <bool JAC>
 __device__ __forceinline__ void edge_velocity(const teb_amd_config_t& c, const Win& w, Accum& A) {
   double v, om, dv[7];
-  signed_velocity<JAC>(c, w.x0, w.y0, w.t0, w.x1, w.y1, w.t1, w.d0, v, om, dv);
+  signed_velocity<JAC>(c, w.x0, w.y0, w.t0, w.c0, w.s0, w.x1, w.y1, w.t1, w.d0, v, om, dv);
   double sv, sw;
   double e0 = pen_interval2(v, -c.max_vel_x_backwards, c.max_vel_x, c.penalty_epsilon, sv);
   double e1 = pen_interval(om, c.max_vel_theta, c.penalty_epsilon, sw);
@@ -169,7 +169,7 @@ template <bool JAC>
 __device__ __forceinline__ void edge_velocity_holonomic(const teb_amd_config_t& c, const Win& w, Accum& A) {
   double dtv = w.d0;
   double dx = w.x1 - w.x0, dy = w.y1 - w.y0;
-  double c1 = cos(w.t0), s1 = sin(w.t0);
+  double c1 = w.c0, s1 = w.s0;
   double r_dx = c1 * dx + s1 * dy, r_dy = -s1 * dx + c1 * dy;
   double vx = r_dx / dtv, vy = r_dy / dtv;
   double omega = normalize_theta(w.t1 - w.t0) / dtv;
@@ -228,8 +228,8 @@ __device__ __forceinline__ void edge_velocity_holonomic(const teb_amd_config_t& 
 template <bool JAC>
 __device__ __forceinline__ void edge_acceleration(const teb_amd_config_t& c, const Win& w, Accum& A) {
   double v1, o1, v2, o2, d1[7], d2[7];
-  signed_velocity<JAC>(c, w.x0, w.y0, w.t0, w.x1, w.y1, w.t1, w.d0, v1, o1, d1);
-  signed_velocity<JAC>(c, w.x1, w.y1, w.t1, w.x2, w.y2, w.t2, w.d1, v2, o2, d2);
+  signed_velocity<JAC>(c, w.x0, w.y0, w.t0, w.c0, w.s0, w.x1, w.y1, w.t1, w.d0, v1, o1, d1);
+  signed_velocity<JAC>(c, w.x1, w.y1, w.t1, w.c1, w.s1, w.x2, w.y2, w.t2, w.d1, v2, o2, d2);
   double T = w.d0 + w.d1;
   const double acc_lin = (v2 - v1) * 2 / T;
   const double acc_rot = (o2 - o1) * 2 / T;
@@ -266,7 +266,7 @@ __device__ __forceinline__ void edge_acceleration_se(const teb_amd_config_t& c, 
                                                      double vang, Accum& A) {
   double v, om, dv[7];
   double dtv = w.d0;
-  signed_velocity<JAC>(c, w.x0, w.y0, w.t0, w.x1, w.y1, w.t1, dtv, v, om, dv);
+  signed_velocity<JAC>(c, w.x0, w.y0, w.t0, w.c0, w.s0, w.x1, w.y1, w.t1, dtv, v, om, dv);
   double acc_lin, acc_rot;
   if (START) { acc_lin = (v - vlin) / dtv; acc_rot = (om - vang) / dtv; }
   else { acc_lin = (vlin - v) / dtv; acc_rot = (vang - om) / dtv; }
@@ -298,7 +298,7 @@ template <bool JAC>
 __device__ __forceinline__ void edge_acceleration_holonomic(const teb_amd_config_t& c, const Win& w, Accum& A) {
   double dt1 = w.d0, dt2 = w.d1;
   double d1x = w.x1 - w.x0, d1y = w.y1 - w.y0, d2x = w.x2 - w.x1, d2y = w.y2 - w.y1;
-  double c1 = cos(w.t0), s1 = sin(w.t0), c2 = cos(w.t1), s2 = sin(w.t1);
+  double c1 = w.c0, s1 = w.s0, c2 = w.c1, s2 = w.s1;
   double p1_dx = c1 * d1x + s1 * d1y, p1_dy = -s1 * d1x + c1 * d1y;
   double p2_dx = c2 * d2x + s2 * d2y, p2_dy = -s2 * d2x + c2 * d2y;
   double v1x = p1_dx / dt1, v1y = p1_dy / dt1, v2x = p2_dx / dt2, v2y = p2_dy / dt2;
@@ -352,7 +352,7 @@ __device__ __forceinline__ void edge_acceleration_holonomic_se(const teb_amd_con
                                                                const double* vel /* vx, vy, omega */, Accum& A) {
   double dtv = w.d0;
   double dx = w.x1 - w.x0, dy = w.y1 - w.y0;
-  double c1 = cos(w.t0), s1 = sin(w.t0);
+  double c1 = w.c0, s1 = w.s0;
   double pdx = c1 * dx + s1 * dy, pdy = -s1 * dx + c1 * dy;
   double vx = pdx / dtv, vy = pdy / dtv;
   double om = normalize_theta(w.t1 - w.t0) / dtv;
@@ -392,7 +392,7 @@ __device__ __forceinline__ void edge_acceleration_holonomic_se(const teb_amd_con
 template <bool JAC>
 __device__ __forceinline__ double kin_nh(const Win& w, double* r /* cols 0,1,2,4,5,6 */) {
   double dx = w.x1 - w.x0, dy = w.y1 - w.y0;
-  double cos1 = cos(w.t0), cos2 = cos(w.t1), sin1 = sin(w.t0), sin2 = sin(w.t1);
+  double cos1 = w.c0, cos2 = w.c1, sin1 = w.s0, sin2 = w.s1;
   double aux1 = sin1 + sin2, aux2 = cos1 + cos2;
   double val = aux2 * dy - aux1 * dx;
   if (JAC) {
@@ -417,7 +417,7 @@ __device__ __forceinline__ void edge_kinematics_diffdrive(const teb_amd_config_t
   double e0 = kin_nh<JAC>(w, r);
   A.template row<0x077, JAC>(CAT_OTHER, e0, c.weight_kinematics_nh, r);
   double dx = w.x1 - w.x0, dy = w.y1 - w.y0;
-  double cos1 = cos(w.t0), sin1 = sin(w.t0);
+  double cos1 = w.c0, sin1 = w.s0;
   double dd;
   double e1 = pen_below(dx * cos1 + dy * sin1, 0, 0, dd);
   if (JAC) {
@@ -511,7 +511,7 @@ template <bool JAC>
 __device__ __forceinline__ void edge_obstacle(const teb_amd_config_t& c, const SceneDev& sc, int oi, const Win& w,
                                               double w_obst, bool inflated, Accum& A) {
   double gr[3];
-  double dist = footprint_distance(c, sc, oi, w.x0, w.y0, w.t0, false, 0.0, JAC ? gr : nullptr);
+  double dist = footprint_distance(c, sc, oi, w.x0, w.y0, w.c0, w.s0, false, 0.0, JAC ? gr : nullptr);
   double d0;
   double e0 = pen_below(dist, c.min_obstacle_dist, c.penalty_epsilon, d0);
   if (c.obstacle_cost_exponent != 1.0 && c.min_obstacle_dist > 0.0) {
@@ -537,7 +537,7 @@ template <bool JAC>
 __device__ __forceinline__ void edge_dynamic_obstacle(const teb_amd_config_t& c, const SceneDev& sc, int oi,
                                                       const Win& w, double t, Accum& A) {
   double gr[3];
-  double dist = footprint_distance(c, sc, oi, w.x0, w.y0, w.t0, true, t, JAC ? gr : nullptr);
+  double dist = footprint_distance(c, sc, oi, w.x0, w.y0, w.c0, w.s0, true, t, JAC ? gr : nullptr);
   double d0, d1;
   double e0 = pen_below(dist, c.min_obstacle_dist, c.penalty_epsilon, d0);
   double e1 = pen_below(dist, c.dynamic_obstacle_inflation_dist, 0.0, d1);
@@ -561,14 +561,80 @@ __device__ __forceinline__ void edge_via_point(const teb_amd_config_t& c, double
   A.template row<0x003, JAC>(CAT_VIA, nn, c.weight_viapoint, r);
 }
 
+
+// ---- point-like fast path ---------------------------------------------------------------------------------------
+// Point/Circular footprint against Point/Circular obstacles whose (x, y, vx, vy, radius) live in LDS. Same
+// arithmetic (and the same order of operations) as footprint_distance() for these types:
+//   PointObstacle/CircularObstacle::getMinimumDistance / getMinimumSpatioTemporalDistance (obstacles.h:358-397,
+//   502-541) and Point/CircularRobotFootprint (robot_footprint_model.h:160-175, 263-278).
+template <bool GRAD>
+__device__ __forceinline__ double pointlike_distance(const teb_amd_config_t& c, double px, double py, double ox, double oy,
+                                                     double orad, double* grad) {
+  const double vx_ = px - ox, vy_ = py - oy;
+  const double dn = sqrt(vx_ * vx_ + vy_ * vy_);
+  double dist = dn - orad;
+  if (c.footprint_type == TEB_AMD_FOOTPRINT_CIRCULAR) dist = dist - c.footprint_radius;
+  if (GRAD) {
+    if (dn > 0) { grad[0] = vx_ / dn; grad[1] = vy_ / dn; } else { grad[0] = 0; grad[1] = 0; }
+  }
+  return dist;
+}
+
+template <bool JAC>
+__device__ __forceinline__ void edge_obstacle_fast(const teb_amd_config_t& c, double ox, double oy, double orad, const Win& w,
+                                                   double w_obst, bool inflated, Accum& A) {
+  double gr[2];
+  double dist = pointlike_distance<JAC>(c, w.x0, w.y0, ox, oy, orad, gr);
+  double d0;
+  double e0 = pen_below(dist, c.min_obstacle_dist, c.penalty_epsilon, d0);
+  if (c.obstacle_cost_exponent != 1.0 && c.min_obstacle_dist > 0.0) {
+    double lin = e0;
+    e0 = c.min_obstacle_dist * pow(lin / c.min_obstacle_dist, c.obstacle_cost_exponent);
+    if (JAC) {
+      if (lin > 0) d0 *= c.obstacle_cost_exponent * pow(lin / c.min_obstacle_dist, c.obstacle_cost_exponent - 1.0);
+      else d0 = 0;
+    }
+  }
+  double r[11];
+  if (JAC) { r[0] = d0 * gr[0]; r[1] = d0 * gr[1]; }
+  A.template row<0x003, JAC>(CAT_OBST, e0, w_obst, r);
+  if (inflated) {
+    double d1;
+    double e1 = pen_below(dist, c.inflation_dist, 0.0, d1);
+    if (JAC) { r[0] = d1 * gr[0]; r[1] = d1 * gr[1]; }
+    A.template row<0x003, JAC>(CAT_OBST, e1, c.weight_inflation, r);
+  }
+}
+
+// residual rows of EdgeDynamicObstacle given the distance and its gradient (split from the distance so that
+// several obstacles can be in flight at once: the sqrt / divide chains of independent obstacles interleave)
+template <bool JAC>
+__device__ __forceinline__ void dynamic_obstacle_rows(const teb_amd_config_t& c, double dist, const double* gr, Accum& A) {
+  double d0, d1;
+  double e0 = pen_below(dist, c.min_obstacle_dist, c.penalty_epsilon, d0);
+  double e1 = pen_below(dist, c.dynamic_obstacle_inflation_dist, 0.0, d1);
+  double r[11];
+  if (JAC) { r[0] = d0 * gr[0]; r[1] = d0 * gr[1]; }
+  A.template row<0x003, JAC>(CAT_OBST, e0, c.weight_dynamic_obstacle, r);
+  if (JAC) { r[0] = d1 * gr[0]; r[1] = d1 * gr[1]; }
+  A.template row<0x003, JAC>(CAT_OBST, e1, c.weight_dynamic_obstacle_inflation, r);
+}
+
+template <bool JAC>
+__device__ __forceinline__ void edge_dynamic_obstacle_fast(const teb_amd_config_t& c, double ox, double oy, double orad,
+                                                           const Win& w, Accum& A) {
+  double gr[2];
+  double dist = pointlike_distance<JAC>(c, w.x0, w.y0, ox, oy, orad, gr);
+  dynamic_obstacle_rows<JAC>(c, dist, gr, A);
+}
+
 // ---- EdgeVelocityObstacleRatio (pose i, pose i+1, dt_i, obstacle) ------------------------------------------
 template <bool JAC>
-__device__ __forceinline__ void edge_velocity_obstacle_ratio(const teb_amd_config_t& c, const SceneDev& sc, int oi,
+__device__ __forceinline__ void edge_velocity_obstacle_ratio(const teb_amd_config_t& c, double dobs, const double* gr,
                                                              const Win& w, Accum& A) {
+  // dobs, gr: calculateDistance(conf1->pose(), obstacle) and its gradient w.r.t. pose i
   double v, om, dv[7];
-  signed_velocity<JAC>(c, w.x0, w.y0, w.t0, w.x1, w.y1, w.t1, w.d0, v, om, dv);
-  double gr[3];
-  double dobs = footprint_distance(c, sc, oi, w.x0, w.y0, w.t0, false, 0.0, JAC ? gr : nullptr);
+  signed_velocity<JAC>(c, w.x0, w.y0, w.t0, w.c0, w.s0, w.x1, w.y1, w.t1, w.d0, v, om, dv);
   double ratio, dratio;
   if (dobs < c.obstacle_proximity_lower_bound) { ratio = 0; dratio = 0; }
   else if (dobs > c.obstacle_proximity_upper_bound) { ratio = 1; dratio = 0; }

@@ -194,7 +194,8 @@ __device__ inline Wit robot_shape_to_obst(const RobotShape& R, const ObstShape& 
 // footprint x obstacle pair. Returns the distance; if grad != nullptr also d(dist)/d(x,y,theta).
 // ------------------------------------------------------------------------------------------------------
 __device__ inline double footprint_distance(const teb_amd_config_t& c, const SceneDev& sc, int oi, double x, double y,
-                                            double th, bool spatio_temporal, double t, double* grad) {
+                                            double cth, double sth, bool spatio_temporal, double t, double* grad) {
+  // cth, sth = cos(theta), sin(theta) of the pose (orientationUnitVec / transformToWorld)
   const int ty = sc.type[oi];
   ObstShape O;
   O.ox = 0; O.oy = 0;
@@ -222,7 +223,7 @@ __device__ inline double footprint_distance(const teb_amd_config_t& c, const Sce
     dist = w.d - obst_r;
     if (fp == TEB_AMD_FOOTPRINT_CIRCULAR) dist = dist - c.footprint_radius;
   } else if (fp == TEB_AMD_FOOTPRINT_TWO_CIRCLES) {
-    double dx = cos(th), dy = sin(th);
+    double dx = cth, dy = sth;
     Wit wf = robot_point_to_obst(x + c.footprint_front_offset * dx, y + c.footprint_front_offset * dy, O);
     Wit wr = robot_point_to_obst(x - c.footprint_rear_offset * dx, y - c.footprint_rear_offset * dy, O);
     double df = (wf.d - obst_r) - c.footprint_front_radius;
@@ -232,7 +233,7 @@ __device__ inline double footprint_distance(const teb_amd_config_t& c, const Sce
   } else {
     RobotShape R;
     R.k = c.footprint_n_vertices;
-    R.px = x; R.py = y; R.cs = cos(th); R.sn = sin(th);
+    R.px = x; R.py = y; R.cs = cth; R.sn = sth;
     R.bvx = c.footprint_vx; R.bvy = c.footprint_vy;
     w = robot_shape_to_obst(R, O, obst_first);
     dist = w.d - obst_r;

@@ -16,23 +16,66 @@
 
 namespace tebamd {
 
+#ifdef TEB_PROFILE
+#define PROF_DECL long long prof_t0 = 0, prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF_START() prof_t0 = clock64()
+#define PROF_END(k) prof_acc[k] += clock64() - prof_t0
+#else
+#define PROF_DECL
+#define PROF_START()
+#define PROF_END(k)
+#endif
+
+// Two storage formats of the normal matrix (selected per handle by the pose capacity S):
+//   SOLVER_BAND : Hb[4S][11] lower band, solved by the sequential in-LDS LDL^T of wave 0 (any S up to 357)
+//   SOLVER_CR   : block-tridiagonal in 8x8 blocks (two 4-scalar pose groups per block row): D_j (full, symmetric)
+//                 and L_j (coupling to block row j-1), solved by block cyclic reduction with all 256 threads
+//                 (log2(n/2) levels instead of 4n sequential pivots). Needs 664*S bytes of LDS: S <= 245.
+enum { SOLVER_BAND = 0, SOLVER_CR = 1 };
+constexpr int kBlk = 66;   // padded stride (doubles) of one 8x8 block: spreads concurrent eliminations over LDS banks
+
 struct Lds {
-  double *sx, *sy, *sth, *sdt, *tdyn, *Hb, *bv, *dxv, *red;
+  double *sx, *sy, *sth, *sdt, *tdyn, *cs, *sn, *Hb, *bv, *dxv, *red;
+  double *Db, *Lb, *fb;   // SOLVER_CR only (Hb aliases Db)
+  double *obx, *oby, *obvx, *obvy, *obr;   // obstacle cache (static list first, then the dynamic list)
   int* ired;
 };
 
-__host__ __device__ inline size_t lds_bytes_for(int S) {
-  return sizeof(double) * ((size_t)5 * S + (size_t)4 * S * kBand + (size_t)8 * S + 64) + 64 * sizeof(int);
+__host__ __device__ inline int nb_for(int S) { return (4 * S + 7) / 8; }
+__host__ __device__ inline size_t hmat_doubles(int S, int solver) {  // (LDS-resident part)
+  return solver == SOLVER_CR ? (size_t)nb_for(S) * (2 * kBlk + 8) : (size_t)4 * S * kBand;
 }
+// host: lay out the LDS; ob_entries = obstacles to cache (0 = no cache). Returns total bytes.
+__host__ inline LdsPlan make_lds_plan(int S, int solver, int ob_entries) {
+  LdsPlan p;
+  p.S = S; p.solver = solver;
+  int o = 0;
+  p.off_state = o; o += 7 * S;
+  o = (o + 1) & ~1;
+  p.off_H = o; o += (int)hmat_doubles(S, solver);
+  p.off_b = o; o += 4 * S + 8;
+  p.off_dx = o; o += 4 * S + 8;
+  p.off_red = o; o += 64 + 32;
+  p.ob_cap = ob_entries;
+  if (ob_entries > 0) { p.off_ob = o; o += 5 * ob_entries; } else p.off_ob = -1;
+  p.total_bytes = o * (int)sizeof(double);
+  return p;
+}
+__host__ inline size_t lds_bytes_for(int S, int solver) { return (size_t)make_lds_plan(S, solver, 0).total_bytes; }
 
-__device__ __forceinline__ Lds carve(double* base, int S) {
+__device__ __forceinline__ Lds carve(double* base, const LdsPlan& p) {
   Lds l;
-  l.sx = base; l.sy = l.sx + S; l.sth = l.sy + S; l.sdt = l.sth + S; l.tdyn = l.sdt + S;
-  l.Hb = l.tdyn + S;
-  l.bv = l.Hb + (size_t)4 * S * kBand;
-  l.dxv = l.bv + 4 * S;
-  l.red = l.dxv + 4 * S;
+  const int S = p.S;
+  l.sx = base + p.off_state; l.sy = l.sx + S; l.sth = l.sy + S; l.sdt = l.sth + S; l.tdyn = l.sdt + S;
+  l.cs = l.tdyn + S; l.sn = l.cs + S;
+  l.Hb = base + p.off_H;
+  l.Db = l.Hb; l.Lb = l.Db + (size_t)nb_for(S) * kBlk; l.fb = l.Lb + (size_t)nb_for(S) * kBlk;
+  l.bv = base + p.off_b;
+  l.dxv = base + p.off_dx;
+  l.red = base + p.off_red;
   l.ired = reinterpret_cast<int*>(l.red + 64);
+  l.obx = base + (p.off_ob >= 0 ? p.off_ob : 0); l.oby = l.obx + p.ob_cap; l.obvx = l.oby + p.ob_cap;
+  l.obvy = l.obvx + p.ob_cap; l.obr = l.obvy + p.ob_cap;
   return l;
 }
 
@@ -107,21 +150,49 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
   Win w;
   w.x0 = l.sx[i]; w.y0 = l.sy[i]; w.t0 = l.sth[i]; w.d0 = l.sdt[i];
   w.x1 = l.sx[i + 1]; w.y1 = l.sy[i + 1]; w.t1 = l.sth[i + 1];
+  w.c0 = l.cs[i]; w.s0 = l.sn[i]; w.c1 = l.cs[i + 1]; w.s1 = l.sn[i + 1];
   const bool has2 = (i + 2 <= n - 1);
   w.d1 = has2 ? l.sdt[i + 1] : 1.0;
   w.x2 = has2 ? l.sx[i + 2] : 0.0; w.y2 = has2 ? l.sy[i + 2] : 0.0; w.t2 = has2 ? l.sth[i + 2] : 0.0;
   const bool seg_active = (n > 2);   // g2o never activates an edge whose vertices are all fixed (n == 2)
 
   // ---- unary edges of pose i (AddEdgesObstacles :444-548, AddEdgesDynamicObstacles :646-673, AddEdgesViaPoints :675-718)
-  const int cnt = (t.assoc_cnt != nullptr) ? t.assoc_cnt[i] : 0;
+  // association entries are POSITIONS in the static list (sc.static_idx / the LDS obstacle cache)
+  const int cnt = t.assoc_cnt[i];
   if (i >= 1) {
-    for (int k = 0; k < cnt; ++k) {
-      int oi = t.assoc[(size_t)k * t.stride + i];
-      edge_obstacle<JAC>(c, sc, oi, w, t.w_obst, t.inflated, A);
-    }
-    if (c.include_dynamic_obstacles && c.weight_obstacle != 0) {
-      const double ti = l.tdyn[i];
-      for (int k = 0; k < sc.n_dyn; ++k) edge_dynamic_obstacle<JAC>(c, sc, sc.dyn_idx[k], w, ti, A);
+    if (sc.fast_points) {
+      for (int k = 0; k < cnt; ++k) {
+        const int p = t.assoc[(size_t)k * t.stride + i];
+        edge_obstacle_fast<JAC>(c, l.obx[p], l.oby[p], l.obr[p], w, t.w_obst, t.inflated, A);
+      }
+      if (c.include_dynamic_obstacles && c.weight_obstacle != 0) {
+        const double ti = l.tdyn[i];
+        int k = 0;
+        for (; k + 4 <= sc.n_dyn; k += 4) {   // 4 obstacles in flight; rows are still accumulated in list order
+          double dist[4], gr[4][2];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int p = sc.n_static + k + u;
+            // pos_ + t*centroid_velocity_ (obstacles.h:382-385)
+            dist[u] = pointlike_distance<JAC>(c, w.x0, w.y0, l.obx[p] + ti * l.obvx[p], l.oby[p] + ti * l.obvy[p], l.obr[p], gr[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) dynamic_obstacle_rows<JAC>(c, dist[u], gr[u], A);
+        }
+        for (; k < sc.n_dyn; ++k) {
+          const int p = sc.n_static + k;
+          edge_dynamic_obstacle_fast<JAC>(c, l.obx[p] + ti * l.obvx[p], l.oby[p] + ti * l.obvy[p], l.obr[p], w, A);
+        }
+      }
+    } else {
+      for (int k = 0; k < cnt; ++k) {
+        const int oi = sc.static_idx[t.assoc[(size_t)k * t.stride + i]];
+        edge_obstacle<JAC>(c, sc, oi, w, t.w_obst, t.inflated, A);
+      }
+      if (c.include_dynamic_obstacles && c.weight_obstacle != 0) {
+        const double ti = l.tdyn[i];
+        for (int k = 0; k < sc.n_dyn; ++k) edge_dynamic_obstacle<JAC>(c, sc, sc.dyn_idx[k], w, ti, A);
+      }
     }
     if (t.via_en && c.weight_viapoint != 0) {
       for (int v = 0; v < sc.nvia; ++v)
@@ -165,13 +236,18 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
   // ---- AddEdgesVelocityObstacleRatio :999-1021
   if (c.weight_velocity_obstacle_ratio > 0) {
     for (int k = 0; k < cnt; ++k) {
-      int oi = t.assoc[(size_t)k * t.stride + i];
-      edge_velocity_obstacle_ratio<JAC>(c, sc, oi, w, A);
+      const int p = t.assoc[(size_t)k * t.stride + i];
+      double gr[3] = {0, 0, 0};
+      double dobs;
+      if (sc.fast_points) dobs = pointlike_distance<JAC>(c, w.x0, w.y0, l.obx[p], l.oby[p], l.obr[p], gr);
+      else dobs = footprint_distance(c, sc, sc.static_idx[p], w.x0, w.y0, w.c0, w.s0, false, 0.0, JAC ? gr : nullptr);
+      edge_velocity_obstacle_ratio<JAC>(c, dobs, gr, w, A);
     }
   }
 }
 
-// scatter the thread-local window into the LDS band; rows/cols of fixed variables are dropped
+// scatter the thread-local window into the LDS normal matrix; rows/cols of fixed variables are dropped
+template <int SOLVER>
 __device__ __forceinline__ void scatter(const Accum& A, const Lds& l, int i, int n) {
   const int base = 4 * i;
   const int last_pose = 4 * (n - 1);
@@ -186,17 +262,50 @@ __device__ __forceinline__ void scatter(const Accum& A, const Lds& l, int i, int
       int rb = base + b;
       bool fb = (rb < 3) || (rb >= last_pose);
       if (fb) continue;
-      l.Hb[ra * kBand + (a - b)] += A.H[a * (a + 1) / 2 + b];
+      const double v = A.H[a * (a + 1) / 2 + b];
+      if (SOLVER == SOLVER_BAND) {
+        l.Hb[ra * kBand + (a - b)] += v;
+      } else {
+        const int jr = ra >> 3, jc = rb >> 3;   // window spans at most two consecutive block rows
+        if (jr == jc) {
+          l.Db[jr * kBlk + (ra & 7) * 8 + (rb & 7)] += v;
+          if (a != b) l.Db[jr * kBlk + (rb & 7) * 8 + (ra & 7)] += v;
+        } else {
+          l.Lb[jr * kBlk + (ra & 7) * 8 + (rb & 7)] += v;
+        }
+      }
     }
   }
 }
 
+// linear view of the live part of the normal matrix (band: Hb[0, Nt*11); blocks: Db[0, Nb*66) then Lb[0, Nb*66))
+template <int SOLVER>
+__device__ __forceinline__ double* hmat_ptr(const Lds& l, int q, int Nt) {
+  if (SOLVER == SOLVER_BAND) return l.Hb + q;
+  const int half = ((Nt + 7) >> 3) * kBlk;
+  return q < half ? l.Db + q : l.Lb + (q - half);
+}
+
+// address of the diagonal entry of variable r
+template <int SOLVER>
+__device__ __forceinline__ double* diag_ptr(const Lds& l, int r) {
+  return SOLVER == SOLVER_BAND ? &l.Hb[r * kBand] : &l.Db[(r >> 3) * kBlk + (r & 7) * 9];
+}
+
+// per-pose cos/sin cache: every cost term that needs the heading reads these instead of re-evaluating libm
+__device__ __forceinline__ void refresh_trig(const Lds& l, int n) {
+  for (int i = threadIdx.x; i < n; i += kThreads) { const double th = l.sth[i]; l.cs[i] = cos(th); l.sn[i] = sin(th); }
+}
+
 // buildSystem: H = sum J^T Omega J, b = -sum J^T Omega e, and chi^2 per category at the current state.
+template <int SOLVER>
 __device__ inline void linearize(const teb_amd_config_t& c, const SceneDev& sc, const TebCtx& t, const Lds& l,
                                  double* cats /*4, out on all threads*/) {
   const int n = t.n, Nt = 4 * n, tid = threadIdx.x;
-  for (int q = tid; q < Nt * kBand; q += kThreads) l.Hb[q] = 0;
-  for (int q = tid; q < Nt; q += kThreads) l.bv[q] = 0;
+  const int hsz = (SOLVER == SOLVER_BAND) ? Nt * kBand : ((Nt + 7) >> 3) * 2 * kBlk;
+  for (int q = tid; q < hsz; q += kThreads) *hmat_ptr<SOLVER>(l, q, Nt) = 0;
+  for (int q = tid; q < Nt + 8; q += kThreads) l.bv[q] = 0;
+  refresh_trig(l, n);
   __syncthreads();
   Accum A;
   A.clear_chi();
@@ -206,13 +315,16 @@ __device__ inline void linearize(const teb_amd_config_t& c, const SceneDev& sc, 
     A.clear();
     if (active) eval_index<true>(c, sc, t, l, i, A);
     for (int ph = 0; ph < 3; ++ph) {
-      if (active && (i % 3) == ph) scatter(A, l, i, n);
+      if (active && (i % 3) == ph) scatter<SOLVER>(A, l, i, n);
       __syncthreads();
     }
   }
   // fixed variables (pose 0, pose n-1, the non-existing dt_{n-1}) become identity rows
-  if (tid < 3) { l.Hb[tid * kBand] = 1.0; l.bv[tid] = 0; }
-  if (tid >= 4 && tid < 8) { int r = 4 * (n - 1) + (tid - 4); l.Hb[r * kBand] = 1.0; l.bv[r] = 0; }
+  if (tid < 3) { *diag_ptr<SOLVER>(l, tid) = 1.0; l.bv[tid] = 0; }
+  if (tid >= 4 && tid < 8) { int r = 4 * (n - 1) + (tid - 4); *diag_ptr<SOLVER>(l, r) = 1.0; l.bv[r] = 0; }
+  if (SOLVER == SOLVER_CR && tid >= 8 && tid < 12 && (n & 1)) {   // pad the last block row of an odd pose count
+    int r = 4 * n + (tid - 8); *diag_ptr<SOLVER>(l, r) = 1.0;
+  }
   cats[0] = A.chi[0]; cats[1] = A.chi[1]; cats[2] = A.chi[2]; cats[3] = A.chi[3];
   block_sum<4>(cats, l.red);
 }
@@ -220,6 +332,8 @@ __device__ inline void linearize(const teb_amd_config_t& c, const SceneDev& sc, 
 // computeActiveErrors + activeRobustChi2 at the current state
 __device__ inline void evaluate(const teb_amd_config_t& c, const SceneDev& sc, const TebCtx& t, const Lds& l,
                                 double* cats) {
+  refresh_trig(l, t.n);
+  __syncthreads();
   Accum A;   // only chi[] is live when JAC == false
   A.clear_chi();
   for (int i = threadIdx.x; i <= t.n - 2; i += kThreads) eval_index<false>(c, sc, t, l, i, A);
@@ -274,6 +388,233 @@ __device__ inline bool banded_ldlt_solve_wave0(const Lds& l, int Nt, double lamb
     __builtin_amdgcn_wave_barrier();
   }
   return true;
+}
+
+
+// ---- damped solve (K6 v2): block cyclic reduction on the 8x8 block-tridiagonal form -------------------------------
+// (H + lambda I) x = b with H = blocktridiag(L_j, D_j, L_{j+1}^T), j = 0..Nb-1. Level l (stride s = 2^l) eliminates
+// the block rows i = s, 3s, 5s, ... : x_i = P_i (f_i - L_i x_{i-s} - U_i x_{i+s}), P_i = D_i^{-1}, U_i = L_{i+s}^T,
+// and folds the Schur complements into the surviving neighbours
+//     D_{i-s} -= L_i^T P_i L_i     D_{i+s} -= U_i^T P_i U_i     L_{i+s} := -U_i^T P_i L_i     f_{i+-s} -= {L_i,U_i}^T P_i f_i
+// Each elimination is served by 16 lanes (one per right-hand-side column of [L_i | U_i]); every lane factors D_i
+// redundantly in registers (LDL^T, 8 pivots) so no intra-group communication is needed. 16 eliminations run
+// concurrently per workgroup; depth = ceil(log2 Nb) levels instead of 4n sequential pivots.
+// W_L = P L_i, W_U = P U_i and P f_i overwrite the slots of the eliminated row for the back substitution.
+// The result is written to dxv; ired[0] = 0 iff some pivot was <= 0 (matrix not positive definite).
+__device__ __forceinline__ double fast_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+
+struct Ldl8 {   // in-place LDL^T of one 8x8 SPD block: a[r(r+1)/2 + c] holds l_rc (r > c) and 1/d_r on the diagonal
+  double a[36];
+  __device__ __forceinline__ static constexpr int idx(int r, int c) { return r * (r + 1) / 2 + c; }   // r >= c
+  __device__ __forceinline__ void load(const double* Di) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int cc = 0; cc <= r; ++cc) a[idx(r, cc)] = Di[r * 8 + cc];
+  }
+  __device__ __forceinline__ bool factor() {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const double dk = a[idx(k, k)];
+      ok = ok && (dk > 0);
+      const double inv = fast_rcp(dk);
+      a[idx(k, k)] = inv;
+#pragma unroll
+      for (int r = k + 1; r < 8; ++r) {
+        const double ark = a[idx(r, k)];
+        const double lrk = ark * inv;
+#pragma unroll
+        for (int cc = k + 1; cc <= r; ++cc) a[idx(r, cc)] -= lrk * a[idx(cc, k)];   // a[cc][k] still unscaled for cc >= r
+        if (false) (void)ark;
+      }
+#pragma unroll
+      for (int r = k + 1; r < 8; ++r) a[idx(r, k)] *= inv;   // scale the column after all its uses
+    }
+    return ok;
+  }
+  __device__ __forceinline__ void solve3(double* u, double* v, double* w) const {   // three right-hand sides at once
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+#pragma unroll
+      for (int m = 0; m < k; ++m) { const double lk = a[idx(k, m)]; u[k] -= lk * u[m]; v[k] -= lk * v[m]; w[k] -= lk * w[m]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const double di = a[idx(k, k)]; u[k] *= di; v[k] *= di; w[k] *= di; }
+#pragma unroll
+    for (int k = 6; k >= 0; --k) {
+#pragma unroll
+      for (int m = k + 1; m < 8; ++m) { const double lk = a[idx(m, k)]; u[k] -= lk * u[m]; v[k] -= lk * v[m]; w[k] -= lk * w[m]; }
+    }
+  }
+  __device__ __forceinline__ void solve(double* v) const {   // in place
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+#pragma unroll
+      for (int m = 0; m < k; ++m) v[k] -= a[idx(k, m)] * v[m];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] *= a[idx(k, k)];
+#pragma unroll
+    for (int k = 6; k >= 0; --k) {
+#pragma unroll
+      for (int m = k + 1; m < 8; ++m) v[k] -= a[idx(m, k)] * v[m];
+    }
+  }
+};
+
+#ifdef TEB_PROFILE
+__device__ long long g_cr_prof[8];
+#define CRP_DECL long long crp_t0 = clock64(), crp_t1;
+#define CRP(k) do { crp_t1 = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) g_cr_prof[k] += crp_t1 - crp_t0; crp_t0 = crp_t1; } while (0)
+#else
+#define CRP_DECL
+#define CRP(k)
+#endif
+__device__ __noinline__ void cr_solve(const LdsPlan plan, int n, double lambda) {
+  extern __shared__ __attribute__((aligned(16))) double lds_base[];
+  CRP_DECL
+  const Lds l = carve(lds_base, plan);
+  const int tid = threadIdx.x;
+  const int Nt = 4 * n, Nb = (Nt + 7) >> 3;
+  double* __restrict__ D = l.Db;
+  double* __restrict__ L = l.Lb;
+  double* __restrict__ f = l.fb;
+  for (int q = tid; q < Nb * 8; q += kThreads) {
+    f[q] = (q < Nt) ? l.bv[q] : 0.0;
+    D[(q >> 3) * kBlk + (q & 7) * 9] += lambda;
+  }
+  if (tid == 0) l.ired[0] = 1;
+  __syncthreads();
+  CRP(0);
+  // 8 lanes per elimination: lane c owns column c of L_i, of U_i and (redundantly) f_i; 32 eliminations per round
+  const int grp = tid >> 3, c = tid & 7;
+  bool ok = true;
+  for (int s = 1; s < Nb; s <<= 1) {
+    const int E = (Nb - 1 - s) / (2 * s) + 1;
+    for (int e0 = 0; e0 < E; e0 += kThreads / 8) {
+      const int e = e0 + grp;
+      const bool act = e < E;
+      const int i = s * (2 * e + 1);
+      const bool hasU = act && (i + s < Nb);
+      double wL[8], wU[8], wf[8], o1[8], o2[8], o3[8];
+      double s1 = 0, s2 = 0;
+      if (act) {
+        const double* Di = D + i * kBlk;
+        const double* Li = L + i * kBlk;
+        const double* Lp = L + (i + s) * kBlk;   // U_i^T, valid iff hasU
+        Ldl8 F;
+        F.load(Di);
+        ok = F.factor() && ok;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          wL[k] = Li[k * 8 + c];                    // column c of L_i
+          wU[k] = hasU ? Lp[c * 8 + k] : 0.0;       // column c of U_i = row c of L_{i+s}
+          wf[k] = f[i * 8 + k];
+        }
+        F.solve3(wL, wU, wf);                       // three independent chains, interleaved
+#pragma unroll
+        for (int aa = 0; aa < 8; ++aa) { o1[aa] = 0; o2[aa] = 0; o3[aa] = 0; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+          for (int aa = 0; aa < 8; ++aa) o1[aa] += Li[k * 8 + aa] * wL[k];   // (L_i^T W_L)[aa][c]
+          s1 += Li[k * 8 + c] * wf[k];                                         // (L_i^T P f_i)[c]
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (hasU) {
+#pragma unroll
+          for (int aa = 0; aa < 8; ++aa) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const double lp = Lp[aa * 8 + k];
+              o2[aa] -= lp * wL[k];                                            // -(L_{i+s} W_L)[aa][c]
+              o3[aa] += lp * wU[k];                                            //  (L_{i+s} W_U)[aa][c]
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) s2 += Lp[c * 8 + k] * wf[k];            // (L_{i+s} P f_i)[c]
+        }
+      }
+      CRP(1);
+      __syncthreads();   // every read of this round is done
+      CRP(2);
+      if (act) {
+        double* Dm = D + (i - s) * kBlk;
+        double* Di = D + i * kBlk;
+        double* Li = L + i * kBlk;
+#pragma unroll
+        for (int aa = 0; aa < 8; ++aa) Dm[aa * 8 + c] -= o1[aa];
+        if (hasU) {
+          double* Lp = L + (i + s) * kBlk;
+#pragma unroll
+          for (int aa = 0; aa < 8; ++aa) Lp[aa * 8 + c] = o2[aa];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { Di[k * 8 + c] = wL[k]; Li[k * 8 + c] = wU[k]; }   // W_L, W_U
+        f[(i - s) * 8 + c] -= s1;
+        f[i * 8 + c] = wf[c];                                                            // P f_i
+      }
+      __syncthreads();
+      if (hasU) {
+        double* Dp = D + (i + s) * kBlk;
+#pragma unroll
+        for (int aa = 0; aa < 8; ++aa) Dp[aa * 8 + c] -= o3[aa];
+        f[(i + s) * 8 + c] -= s2;
+      }
+      __syncthreads();
+      CRP(3);
+    }
+  }
+  // the last surviving block row: x_0 = D_0^{-1} f_0
+  if (tid < 8) {
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = f[k];
+    Ldl8 F;
+    F.load(D);
+    ok = F.factor() && ok;
+    F.solve(v);
+    double mine = v[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) mine = (tid == k) ? v[k] : mine;
+    f[tid] = mine;
+  }
+  if (!ok) l.ired[0] = 0;
+  __syncthreads();
+  CRP(4);
+  // back substitution, coarsest level first
+  int stop = 1;
+  while (stop * 2 < Nb) stop *= 2;
+  for (int s = stop; s >= 1; s >>= 1) {
+    const int E = (Nb - 1 - s) / (2 * s) + 1;
+    for (int u = tid; u < E * 8; u += kThreads) {
+      const int e = u >> 3, r = u & 7;
+      const int i = s * (2 * e + 1);
+      double acc = f[i * 8 + r], acc2 = 0;
+      const double* WL = D + i * kBlk + r * 8;
+      const double* xm = f + (i - s) * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc -= WL[k] * xm[k];
+      if (i + s < Nb) {
+        const double* WU = L + i * kBlk + r * 8;
+        const double* xp = f + (i + s) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc2 -= WU[k] * xp[k];
+      }
+      f[i * 8 + r] = acc + acc2;
+    }
+    __syncthreads();
+  }
+  for (int q = tid; q < Nt; q += kThreads) l.dxv[q] = f[q];
+  __syncthreads();
+  CRP(5);
 }
 
 // ---- TimedElasticBand::autoResize (src/timed_elastic_band.cpp:227-286) -------------------------------------
@@ -392,25 +733,48 @@ __device__ inline void associate(const teb_amd_config_t& c, const SceneDev& sc, 
   for (int i = threadIdx.x; i < n; i += kThreads) {
     int cnt = 0;
     if (i >= first_vertex && i < n - 1) {
-      const double x = l.sx[i], y = l.sy[i], th = l.sth[i];
-      const double ox_ = cos(th), oy_ = sin(th);
+      const double x = l.sx[i], y = l.sy[i];
+      const double ox_ = l.cs[i], oy_ = l.sn[i];   // orientationUnitVec
       double left_min = 1.7976931348623157e308, right_min = 1.7976931348623157e308;
       int left = -1, right = -1;
       const double force = c.min_obstacle_dist * c.obstacle_association_force_inclusion_factor;
       const double cutoff = c.min_obstacle_dist * c.obstacle_association_cutoff_factor;
-      for (int k = 0; k < sc.n_static; ++k) {
-        const int oi = sc.static_idx[k];
-        double dist = footprint_distance(c, sc, oi, x, y, th, false, 0.0, nullptr);
+      int k0 = 0;
+      auto visit = [&](int k, double dist, double ccx, double ccy) {
         if (dist < force) {
-          if (cnt < cap) assoc[(size_t)cnt * stride + i] = oi; else *overflow = 1;
+          if (cnt < cap) assoc[(size_t)cnt * stride + i] = k; else *overflow = 1;
           ++cnt;
-          continue;
+          return;
         }
-        if (dist > cutoff) continue;
+        if (dist > cutoff) return;
         // cross2d(pose_orient, centroid - position) > 0 -> left (misc.h:119-123)
-        double vx_ = sc.cx[oi] - x, vy_ = sc.cy[oi] - y;
-        if (ox_ * vy_ - vx_ * oy_ > 0) { if (dist < left_min) { left_min = dist; left = oi; } }
-        else { if (dist < right_min) { right_min = dist; right = oi; } }
+        double vx_ = ccx - x, vy_ = ccy - y;
+        if (ox_ * vy_ - vx_ * oy_ > 0) { if (dist < left_min) { left_min = dist; left = k; } }
+        else { if (dist < right_min) { right_min = dist; right = k; } }
+      };
+      if (sc.fast_points) {
+        for (; k0 + 4 <= sc.n_static; k0 += 4) {   // 4 distances in flight, decisions in list order
+          double dist[4], ccx[4], ccy[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            ccx[u] = l.obx[k0 + u]; ccy[u] = l.oby[k0 + u];
+            dist[u] = pointlike_distance<false>(c, x, y, ccx[u], ccy[u], l.obr[k0 + u], nullptr);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) visit(k0 + u, dist[u], ccx[u], ccy[u]);
+        }
+      }
+      for (int k = k0; k < sc.n_static; ++k) {
+        double dist, ccx, ccy;
+        if (sc.fast_points) {
+          ccx = l.obx[k]; ccy = l.oby[k];
+          dist = pointlike_distance<false>(c, x, y, ccx, ccy, l.obr[k], nullptr);
+        } else {
+          const int oi = sc.static_idx[k];
+          dist = footprint_distance(c, sc, oi, x, y, ox_, oy_, false, 0.0, nullptr);
+          ccx = sc.cx[oi]; ccy = sc.cy[oi];
+        }
+        visit(k, dist, ccx, ccy);
       }
       if (left >= 0) { if (cnt < cap) assoc[(size_t)cnt * stride + i] = left; else *overflow = 1; ++cnt; }
       if (right >= 0) { if (cnt < cap) assoc[(size_t)cnt * stride + i] = right; else *overflow = 1; ++cnt; }
@@ -421,11 +785,21 @@ __device__ inline void associate(const teb_amd_config_t& c, const SceneDev& sc, 
 }
 
 // =================================================================================================================
+template <int SOLVER>
 __global__ void __launch_bounds__(kThreads)
-teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev bt, const OptArgs args) {
+teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev bt, const OptArgs args,
+                    const LdsPlan plan) {
   extern __shared__ __attribute__((aligned(16))) double lds_base[];
   const int b = blockIdx.x, tid = threadIdx.x, S = bt.stride;
-  const Lds l = carve(lds_base, S);
+  const Lds l = carve(lds_base, plan);
+  if (sc.fast_points) {   // stage the point-like obstacle table once: static list first, then the dynamic list
+    const int tot = sc.n_static + sc.n_dyn;
+    for (int k = tid; k < tot; k += kThreads) {
+      const int oi = (k < sc.n_static) ? sc.static_idx[k] : sc.dyn_idx[k - sc.n_static];
+      l.obx[k] = sc.ax[oi]; l.oby[k] = sc.ay[oi]; l.obvx[k] = sc.vx[oi]; l.obvy[k] = sc.vy[oi];
+      l.obr[k] = (sc.type[oi] == TEB_AMD_OBST_CIRCULAR) ? sc.rad[oi] : 0.0;
+    }
+  }
   int n = bt.n[b];
   const size_t so = (size_t)b * S;
 
@@ -446,7 +820,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   int* assoc = bt.assoc + (size_t)b * bt.assoc_cap * S;
   int* via_pose = bt.via_pose + (size_t)b * bt.via_cap;
   t.assoc_cnt = assoc_cnt; t.assoc = assoc; t.via_pose = via_pose;
-  double* Hbk = bt.Hbackup + (size_t)b * 4 * S * kBand;
+  double* Hbk = bt.Hbackup + (size_t)b * bt.hmat_stride;
   double* rs = bt.rs_scratch + (size_t)b * (4 * (size_t)S + 256);
 
   int status = TEB_AMD_TEB_OK, iters = 0, trials = 0;
@@ -455,6 +829,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   double weight_multiplier = args.debug_linearize ? args.debug_weight_multiplier : 1.0;
   const bool fast_mode = !c.include_dynamic_obstacles;
   bool done = false;
+  PROF_DECL
 
   if (!c.optimization_activate) { status = TEB_AMD_TEB_FAILED; done = true; }
 
@@ -462,7 +837,9 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     // ---- K1: autoResize
     if (c.teb_autosize && !args.debug_linearize) {
       int ovf = 0;
+      PROF_START();
       n = autoresize(c, l, n, rs, S, fast_mode, &ovf);
+      PROF_END(0);
       if (ovf) { status = TEB_AMD_TEB_FAILED; if (tid == 0) bt.assoc_overflow[b] |= 2; break; }
     }
     t.n = n;
@@ -470,6 +847,9 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     if (c.max_vel_x < 0.01 || n < 2 || n < c.min_samples) { status = TEB_AMD_TEB_FAILED; break; }
     // ---- buildGraph side data: association (K2), dynamic-obstacle time stamps, via-point attachment
     t.w_obst = c.weight_obstacle * weight_multiplier;
+    PROF_START();
+    refresh_trig(l, n);
+    __syncthreads();
     const bool obst_edges = !(c.weight_obstacle == 0 || weight_multiplier == 0) && !c.legacy_obstacle_association;
     if (obst_edges) {
       int ovf = 0;
@@ -508,6 +888,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     }
     __threadfence_block();
     __syncthreads();
+    PROF_END(1);
 
     // ---- optimize(): Levenberg-Marquardt
     if (args.inner <= 0 && !args.debug_linearize) { status = TEB_AMD_TEB_FAILED; break; }   // optimize(0) returns 0
@@ -515,12 +896,23 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     bool lm_ok = true;
     for (int it = 0; it < args.inner && lm_ok; ++it) {
       double cats[4];
-      linearize(c, sc, t, l, cats);
+      PROF_START();
+      linearize<SOLVER>(c, sc, t, l, cats);
+      PROF_END(2);
       double currentChi = ((cats[0] + cats[1]) + cats[2]) + cats[3];
       if (args.debug_linearize) {
         if (b == 0) {
           const int Nt = 4 * n;
-          for (int q = tid; q < Nt * kBand; q += kThreads) args.dbg_H[q] = l.Hb[q];
+          for (int q = tid; q < Nt * kBand; q += kThreads) {   // always exported in band form
+            const int r = q / kBand, d = q % kBand, cc = r - d;
+            double v = 0;
+            if (cc >= 0) {
+              if (SOLVER == SOLVER_BAND) v = l.Hb[q];
+              else if ((r >> 3) == (cc >> 3)) v = l.Db[(r >> 3) * kBlk + (r & 7) * 8 + (cc & 7)];
+              else if ((r >> 3) == (cc >> 3) + 1) v = l.Lb[(r >> 3) * kBlk + (r & 7) * 8 + (cc & 7)];
+            }
+            args.dbg_H[q] = v;
+          }
           for (int q = tid; q < Nt; q += kThreads) args.dbg_b[q] = l.bv[q];
           if (tid < 4) args.dbg_chi2[tid] = cats[tid];
         }
@@ -531,20 +923,30 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       if (it == 0) {   // computeLambdaInit: tau * max |H_ii| over the free variables
         double m = 0;
         for (int r = tid; r < Nt; r += kThreads)
-          if (r >= 3 && r < 4 * (n - 1)) m = fmax(m, fabs(l.Hb[r * kBand]));
+          if (r >= 3 && r < 4 * (n - 1)) m = fmax(m, fabs(*diag_ptr<SOLVER>(l, r)));
         lambda = 1e-5 * block_max(m, l.red);
         ni = 2;
       }
-      for (int q = tid; q < Nt * kBand; q += kThreads) Hbk[q] = l.Hb[q];   // saved for rejected trials
+      PROF_START();
+      const int hsz = (SOLVER == SOLVER_BAND) ? Nt * kBand : ((Nt + 7) >> 3) * 2 * kBlk;
+      for (int q = tid; q < hsz; q += kThreads) Hbk[q] = *hmat_ptr<SOLVER>(l, q, Nt);   // saved for rejected trials
+      PROF_END(3);
       double rho = 0;
       int qmax = 0;
       do {
         // --- damped solve
-        if (tid < 64) {
-          bool ok = banded_ldlt_solve_wave0(l, Nt, lambda);
-          if (tid == 0) l.ired[0] = ok ? 1 : 0;
+        PROF_START();
+        if (SOLVER == SOLVER_BAND) {
+          if (tid < 64) {
+            bool ok = banded_ldlt_solve_wave0(l, Nt, lambda);
+            if (tid == 0) l.ired[0] = ok ? 1 : 0;
+          }
+          __syncthreads();
+        } else {
+          cr_solve(plan, n, lambda);
         }
-        __syncthreads();
+        PROF_END(4);
+        PROF_START();
         const bool ok2 = l.ired[0] != 0;
         if (!ok2) { for (int r = tid; r < Nt; r += kThreads) l.dxv[r] = l.bv[r]; __syncthreads(); }
         // --- push + oplus (vertex_pose.h:195-198, vertex_timediff.h:113-116)
@@ -574,6 +976,8 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
         double tempChi = ((tc[0] + tc[1]) + tc[2]) + tc[3];
         double scv[1] = {sc_part};
         block_sum<1>(scv, l.red);
+        PROF_END(5);
+        PROF_START();
         if (!ok2) tempChi = 1.7976931348623157e308;
         rho = (currentChi - tempChi);
         double scale = scv[0] + 1e-3;
@@ -597,9 +1001,10 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
           }
           if (!isfinite(lambda)) { ++qmax; __syncthreads(); break; }
           if (rho < 0 && qmax + 1 < 10)   // another trial follows: bring back the un-factored H
-            for (int q = tid; q < Nt * kBand; q += kThreads) l.Hb[q] = Hbk[q];
+            for (int q = tid; q < hsz; q += kThreads) *hmat_ptr<SOLVER>(l, q, Nt) = Hbk[q];
         }
         __syncthreads();
+        PROF_END(6);
         qmax++;
       } while (rho < 0 && qmax < 10);
       ++iters;
@@ -640,6 +1045,9 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     if (!(isfinite(x) && isfinite(y) && isfinite(th) && isfinite(d))) nonfinite = 1;
   }
   nonfinite = __syncthreads_or(nonfinite);
+#ifdef TEB_PROFILE
+  if (tid == 0 && b == 0 && args.dbg_H) for (int q = 0; q < 8; ++q) args.dbg_H[q] = (double)prof_acc[q];
+#endif
   if (tid == 0) {
     if (nonfinite) status = TEB_AMD_TEB_NONFINITE;
     bt.n[b] = n;

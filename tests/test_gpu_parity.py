@@ -264,7 +264,7 @@ def test_c4_full_size_properties():
 
 
 def test_c5_carlike_polygon_full_size(oracle):
-    cfg, obst, via, batch = scenes.scene_c5()
+    cfg, obst, via, batch = scenes.scene_c5(stride=320)
     out, res, _ = run_gpu(cfg, obst, via, batch)
     ref, rres = oracle.optimize_batch(cfg, obst, via, batch)
     assert_full_parity(out, res, ref, rres, pos_tol=1e-7, rtol=1e-7)
@@ -298,3 +298,62 @@ def test_reference_style_planner_objects(oracle):
     assert p.teb().n[0] == ref.n[0]
     cfg.optim.optimization_activate = False
     assert p.optimizeTEB(5, 4) is False
+
+
+@pytest.mark.parametrize("solver", ["band", "cr"])
+def test_both_damped_solvers_match_the_oracle(oracle, solver, monkeypatch):
+    """K6 v1 (sequential banded LDL^T) and K6 v2 (block cyclic reduction) solve the same damped system:
+    identical accept/reject decisions, trajectories within 1e-8. Even and odd pose counts (block padding)."""
+    monkeypatch.setenv("TEB_AMD_SOLVER", solver)
+    for n0 in (24, 25):
+        cfg, obst, via, batch = scenes.scene_small_mixed(footprint="polygon", n=n0)
+        for autosize in (True, False):
+            cfg.trajectory.teb_autosize = autosize
+            out, res, best = run_gpu(cfg, obst, via, batch)
+            ref, rres = oracle.optimize_batch(cfg, obst, via, batch)
+            assert_full_parity(out, res, ref, rres)
+
+
+def test_solver_fails_like_cholesky_on_indefinite_system(oracle):
+    """Negative weights make H indefinite: CSparse's cholesky (and both GPU solvers) must report failure,
+    the LM loop then rejects every trial and terminates after 10 of them."""
+    cfg, obst, via, batch = scenes.scene_small_mixed(footprint="point", with_dynamic=False)
+    cfg.trajectory.teb_autosize = False
+    cfg.optim.weight_kinematics_nh = -1000.0
+    out, res, _ = run_gpu(cfg, obst, via, batch, inner=2, outer=1)
+    ref, rres = oracle.optimize_batch(cfg, obst, via, batch, inner=2, outer=1)
+    assert (rres.lm_trials > rres.lm_iterations).all()      # there were failed factorisations / rejected trials
+    assert_full_parity(out, res, ref, rres, pos_tol=1e-7, rtol=1e-7)
+
+
+@pytest.mark.parametrize("fast", [True, False])
+@pytest.mark.parametrize("footprint", ["point", "circular"])
+def test_pointlike_fast_path_equals_generic_path(oracle, fast, footprint, monkeypatch):
+    """Point/Circular obstacles + Point/Circular footprint take the LDS-resident specialised distance path;
+    TEB_AMD_NO_FAST_POINTS forces the generic one. Both must match the oracle (incl. the velocity-obstacle-ratio edge)."""
+    if not fast:
+        monkeypatch.setenv("TEB_AMD_NO_FAST_POINTS", "1")
+    cfg, obst0, via, batch = scenes.scene_small_mixed(footprint=footprint, stride=192)
+    obst = _abi.ObstacleTable()
+    rng = np.random.default_rng(4)
+    for k in range(30):
+        p = (rng.uniform(0.5, 5.5), rng.uniform(-1.5, 1.5))
+        vel = (rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2)) if k % 5 == 0 else None
+        if k % 3 == 0:
+            obst.add_circle(p[0], p[1], rng.uniform(0.05, 0.3), vel=vel)
+        else:
+            obst.add_point(p[0], p[1], vel=vel)
+    cfg.optim.weight_velocity_obstacle_ratio = 2.0
+    s = planner.make_solver(cfg, obst, via, batch)
+    for b in range(batch.count):
+        G = s.debug_linearize(b, int(batch.n[b]), 2.0)
+        R = oracle.linearize(cfg, obst, via, batch, b, 2.0)
+        np.testing.assert_allclose(G["chi2"], R["chi2"], rtol=1e-12, atol=1e-14)
+        assert np.abs(G["H"] - R["H"]).max() <= 1e-12 * np.abs(R["H"]).max()
+        ap, ao = oracle.associate(cfg, obst, batch, b)
+        np.testing.assert_array_equal(G["assoc_pose"], ap)
+        np.testing.assert_array_equal(G["assoc_obst"], ao)
+    s.close()
+    out, res, best = run_gpu(cfg, obst, via, batch)
+    ref, rres = oracle.optimize_batch(cfg, obst, via, batch)
+    assert_full_parity(out, res, ref, rres)

@@ -8,7 +8,7 @@ from oracle import oracle_py as O
 
 def cmp_scene(name, cfg, obst, via, batch, full=True):
     print("=== %s: B=%d n=%s M=%d" % (name, batch.count, batch.n[:4], len(obst)))
-    s = planner.make_solver(cfg, obst, via, batch, max_poses=max(batch.stride, 128))
+    s = planner.make_solver(cfg, obst, via, batch, max_poses=batch.stride)
     print("capacity", s.capacity())
     # distances
     rng = np.random.default_rng(0)
@@ -67,6 +67,6 @@ if __name__ == "__main__":
     if "c1" in which:
         cmp_scene("c1", *scenes.scene_c1())
     if "c2" in which:
-        cmp_scene("c2", *scenes.scene_c2(stride=256))
+        cmp_scene("c2", *scenes.scene_c2(stride=208))
     if "c5" in which:
         cmp_scene("c5", *scenes.scene_c5(n=120, M=80, stride=200))
