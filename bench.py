@@ -21,7 +21,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from teb_local_planner_amd import scenes, planner, _abi  # noqa: E402
+from teb_local_planner_amd import scenes, planner, parallel, _abi  # noqa: E402
 
 # ALGORITHMIC bytes per TEB.LM-iteration (restated in DESIGN.md §Measurement):
 #   64*n (state read+write) + R_obst + 4*E_assoc + 32  + (32*n + R_obst + 4*E_assoc)/inner  [association amortised]
@@ -64,20 +64,12 @@ def main():
     hp = planner.HomotopyClassPlanner(cfg, obst, via, batch, device=local_rank)
     s = hp.solver
     s.snapshot()
-    sel = torch.zeros(2, dtype=torch.float64, device="cuda")
-    gathered = [torch.zeros(2, dtype=torch.float64, device="cuda") for _ in range(world)] if distributed else None
-
     def step():
         s.restore()
         hp.optimizeAllTEBs(inner, outer)
-        best, cost = s.select_best(-1, -1)          # synchronises the stream (16-byte D2H)
-        if distributed:                             # the path's only exchange: (cost, global index) per rank
-            sel[0] = cost
-            sel[1] = float(rank * B + best)
-            dist.all_gather(gathered, sel)
-            allv = torch.stack(gathered).cpu().numpy()
-            k = np.lexsort((allv[:, 1], allv[:, 0]))[0]   # min cost, ties -> lowest global index
-            return int(allv[k, 1])
+        best, cost = s.select_best(-1, -1)          # K9 on the resident costs; synchronises the stream (16-byte D2H)
+        if distributed:                             # the path's only exchange: one (cost, global index) record per rank
+            return parallel.select_best_distributed(cost, rank * B + best, device="cuda")[1]
         return best
 
     for _ in range(args.warmup):
@@ -117,6 +109,21 @@ def main():
         abu = alg_bytes_per_unit(n, M, e_assoc, inner)
         alg_bytes_launch = abu * units_step
         achieved = alg_bytes_launch / (kms * 1e-3) / 1e9
+        # HBM-side traffic per launch from the committed rocprofv3 PMC passes of THIS command (FETCH_SIZE / WRITE_SIZE in
+        # separate runs, scaled by the factors calibrated on a known 1 GiB stream; profiles/rocprof_*_summary.json)
+        traffic, traffic_src = None, None
+        try:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "rocprof_r*_summary.json")))
+            if cands and B == 256 and n == 200:
+                pj = json.load(open(cands[-1]))
+                cal = pj.get("calibration", {})
+                fr = cal.get("FETCH_SIZE_bytes_per_counted_KB", 2048.0)
+                fw = cal.get("WRITE_SIZE_bytes_per_counted_KB", 1024.0)
+                traffic = pj["FETCH_SIZE_KB_per_launch"] * fr + pj["WRITE_SIZE_KB_per_launch"] * fw
+                traffic_src = os.path.basename(cands[-1])
+        except Exception:
+            traffic = None
         out = {
             "metric": "TEB LM iterations/sec (whole node)", "value": value, "unit": "TEB.LM-iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -128,15 +135,16 @@ def main():
                        "tebs_per_gpu": B, "poses": n, "obstacles": M, "units_per_step_per_gpu": units_step,
                        "lm_trials_per_step_per_gpu": int(res.lm_trials.sum())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src,
                          "kernel": "teb_optimize_kernel", "kernel_ms": kms,
                          "alg_bytes_per_unit": abu, "alg_bytes_per_launch": alg_bytes_launch},
         }
         # ---- p50 plan()-equivalent latency on the 200-pose band: upload -> 4x5 iterations incl. autoResize,
         #      association, cost -> select -> download (single TEB, config C2, and the C4 batch)
         lat = {}
-        for name, (c2, o2, v2, b2) in (("c2_single_teb", scenes.scene_c2(stride=208)),
-                                       ("c4_batch", scenes.scene_c4(B=B, n=n, stride=max(n, 208)))):
+        for name, (c2, o2, v2, b2) in ((("c2_single_teb", scenes.scene_c2(stride=208)),
+                                        ("c4_batch", scenes.scene_c4(B=B, n=n, stride=max(n, 208)))) if args.latency_reps > 0 else ()):
             s2 = planner.make_solver(c2, o2, v2, b2)
             ts = []
             for _ in range(args.latency_reps):

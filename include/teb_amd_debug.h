@@ -36,6 +36,10 @@ int teb_amd_debug_distance(teb_amd_handle_t* h, int32_t nq, const int32_t* obst_
  * [5] update+chi2 evaluation [6] accept/reject (+H restore) */
 int teb_amd_debug_profile(teb_amd_handle_t* h, double* cycles8);
 
+/* Streams n_doubles fp64 values global->global (8 B per lane, coalesced; reads and writes n_doubles*8 bytes each)
+ * `repeats` times: a known byte count to calibrate rocprofv3 FETCH_SIZE / WRITE_SIZE against. */
+int teb_amd_debug_stream(teb_amd_handle_t* h, int64_t n_doubles, int32_t repeats);
+
 /* per-TEB flags of the last launch: bit0 association list overflow, bit1 autoResize capacity overflow */
 int teb_amd_debug_assoc_overflow(teb_amd_handle_t* h, int32_t* flags);
 

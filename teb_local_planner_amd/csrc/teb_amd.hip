@@ -108,6 +108,12 @@ __global__ void select_best_kernel(const double* cost, int count, int last_best,
   if (threadIdx.x == 0) { *out_cost = sv[0]; *out_idx = si[0]; }
 }
 
+// debug: known-byte-count stream with the kernel's own global access pattern (8 B per lane, coalesced) used to
+// calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE on gfx950 (MI355X_MICROARCH.md, HBM section)
+__global__ void stream_kernel(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i] + 1.0;
+}
+
 // debug: footprint_distance for a list of queries
 __global__ void distance_kernel(const teb_amd_config_t c, const SceneDev sc, int nq, const int* oi, const double* x,
                                 const double* y, const double* th, const int* st, const double* t, double* dist,
@@ -726,6 +732,22 @@ int teb_amd_debug_profile(teb_amd_handle_t* h, double* cycles8) {
   (void)cycles8;
   return fail(TEB_AMD_ERR_UNSUPPORTED, "library built without -DTEB_PROFILE");
 #endif
+}
+
+int teb_amd_debug_stream(teb_amd_handle_t* h, int64_t n_doubles, int32_t repeats) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (n_doubles <= 0 || repeats <= 0) return fail(TEB_AMD_ERR_INVALID_ARG, "bad stream size");
+  DevBuf<double> a, b;
+  HIPCHK(a.alloc((size_t)n_doubles)); HIPCHK(b.alloc((size_t)n_doubles));
+  HIPCHK(hipMemsetAsync(a.p, 0, sizeof(double) * (size_t)n_doubles, h->stream));
+  for (int r = 0; r < repeats; ++r) {
+    hipLaunchKernelGGL(stream_kernel, dim3(2048), dim3(256), 0, h->stream, a.p, b.p, (size_t)n_doubles);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  a.free(); b.free();
+  return TEB_AMD_OK;
 }
 
 int teb_amd_debug_assoc_overflow(teb_amd_handle_t* h, int32_t* flags) {

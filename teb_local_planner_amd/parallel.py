@@ -1,0 +1,60 @@
+"""Multi-GPU sharding of the candidate batch and the path's only exchange step.
+
+The candidate TEBs of HomotopyClassPlanner are independent units (reference
+src/homotopy_class_planner.cpp:468 "independend of each other"): rank r owns a contiguous block of the B
+candidates, the obstacle table / config are replicated, state strips never move between GPUs, and there is NO
+data-path collective. Per plan() there is exactly one exchange: selectBestTeb
+(src/homotopy_class_planner.cpp:564-667) = argmin of the (already hysteresis-scaled) costs with the lowest
+index winning ties (strict '<' at :610). Each rank contributes its local winner as a 16-byte record
+(cost f64, global index as f64) to an all-gather (RCCL over xGMI when the backend is "nccl", gloo in the CPU
+tests); every rank then takes the lexicographic minimum, so all ranks agree without a second collective.
+"""
+import numpy as np
+
+
+def shard_range(total, rank, world):
+    """Contiguous block partition: the first (total % world) ranks get one extra candidate."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def local_best(costs, offset=0, last_best=-1, initial_plan=-1, hysteresis=1.0, prefer_initial=1.0):
+    """selectBestTeb restricted to this rank's candidates; indices are GLOBAL (offset + local).
+    Returns (cost, global_index) with cost = +inf and index = -1 when the rank owns nothing."""
+    best_c, best_i = np.finfo(np.float64).max, -1
+    for k, c in enumerate(np.asarray(costs, dtype=np.float64)):
+        g = offset + k
+        if g == last_best:
+            c = c * hysteresis
+        elif g == initial_plan:
+            c = c * prefer_initial
+        if c < best_c:
+            best_c, best_i = c, g
+    return best_c, best_i
+
+
+def pick_global(records):
+    """records: iterable of (cost, global_index). Lowest cost wins, ties -> lowest index; -1 entries ignored."""
+    best_c, best_i = np.finfo(np.float64).max, -1
+    for c, i in records:
+        i = int(i)
+        if i < 0:
+            continue
+        if c < best_c or (c == best_c and (best_i < 0 or i < best_i)):
+            best_c, best_i = float(c), i
+    return best_c, best_i
+
+
+def select_best_distributed(cost, global_index, group=None, device=None):
+    """All-gather of one (cost, index) record per rank; returns the same (cost, index) on every rank.
+
+    Works with any initialised torch.distributed backend: "nccl" (= RCCL on ROCm; pass device="cuda") or "gloo"."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rec = torch.tensor([float(cost), float(global_index)], dtype=torch.float64, device=device)
+    out = [torch.empty_like(rec) for _ in range(world)]
+    dist.all_gather(out, rec, group=group)
+    allv = torch.stack(out).cpu().numpy()
+    return pick_global((allv[k, 0], allv[k, 1]) for k in range(world))

@@ -60,6 +60,8 @@ def lib():
         L.teb_amd_debug_distance.argtypes = [vp, C.c_int32, _abi.p_i32, _abi.p_f64, _abi.p_f64, _abi.p_f64,
                                              _abi.p_i32, _abi.p_f64, _abi.p_f64, _abi.p_f64]
         L.teb_amd_debug_assoc_overflow.argtypes = [vp, _abi.p_i32]
+        L.teb_amd_debug_stream.argtypes = [vp, C.c_int64, C.c_int32]
+        L.teb_amd_debug_profile.argtypes = [vp, _abi.p_f64]
         _LIB = L
     return _LIB
 
@@ -185,6 +187,9 @@ class TebBatchSolver:
                                           _abi._ptr(d, C.c_double), _abi._ptr(g, C.c_double)),
              "teb_amd_debug_distance")
         return d, g
+
+    def debug_stream(self, n_doubles, repeats=1):
+        _chk(lib().teb_amd_debug_stream(self._h, int(n_doubles), int(repeats)), "teb_amd_debug_stream")
 
     def debug_overflow_flags(self):
         f = np.zeros(self.count, np.int32)

@@ -1,0 +1,119 @@
+"""N > 1 path on CPU: two gloo ranks shard a candidate batch, optimise their shards with the ORACLE standing in
+for the GPU kernel (the exchange step is what is under test), and agree on the same best trajectory as a
+single-process selectBestTeb over the whole batch — including ties and hysteresis / prefer-initial multipliers."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from teb_local_planner_amd import parallel, scenes, _abi  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if case == "oracle_shards":
+            from oracle import oracle_py
+            cfg, obst, via, batch = scenes.scene_small_mixed(B=6, stride=192)
+            lo, hi = parallel.shard_range(batch.count, rank, world)
+            sub = _abi.TebBatchHost(hi - lo, batch.stride)
+            for k, b in enumerate(range(lo, hi)):
+                sub.set_teb(k, *batch.get_teb(b))
+                sub.has_vel_goal[k] = batch.has_vel_goal[b]
+                sub.has_vel_start[k] = batch.has_vel_start[b]
+                sub.vel_start[k] = batch.vel_start[b]
+            _, res = oracle_py.optimize_batch(cfg, obst, via, sub)
+            c, i = parallel.local_best(res.cost, offset=lo)
+            gc, gi = parallel.select_best_distributed(c, i)
+            q.put((rank, gc, gi, res.cost.tolist(), lo))
+        else:
+            res = []
+            for cs in case:
+                costs = np.array(cs["costs"], dtype=np.float64)
+                lo, hi = parallel.shard_range(len(costs), rank, world)
+                c, i = parallel.local_best(costs[lo:hi], offset=lo, last_best=cs["last_best"],
+                                           initial_plan=cs["initial_plan"], hysteresis=cs["hyst"],
+                                           prefer_initial=cs["prefer"])
+                res.append(parallel.select_best_distributed(c, i))
+            q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, case):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(outs)
+
+
+def test_shard_range_partitions_exactly():
+    for total in (0, 1, 7, 256, 257):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_selection_matches_single_process(world):
+    from teb_local_planner_amd.config import TebConfig
+    from oracle import oracle_py
+    cases = [
+        dict(costs=[5.0, 3.0, 9.0, 3.0, 7.0], last_best=-1, initial_plan=-1, hyst=1.0, prefer=1.0),   # tie across ranks
+        dict(costs=[5.0, 3.0, 9.0, 3.0, 7.0], last_best=4, initial_plan=-1, hyst=0.4, prefer=1.0),    # hysteresis wins
+        dict(costs=[5.0, 3.0, 9.0, 3.0, 7.0], last_best=-1, initial_plan=2, hyst=1.0, prefer=0.3),    # prefer-initial wins
+        dict(costs=[4.0], last_best=-1, initial_plan=-1, hyst=1.0, prefer=1.0),                        # some ranks own nothing
+    ]
+    outs = _run(world, cases)
+    for k, case in enumerate(cases):
+        cfg = TebConfig()
+        cfg.hcp.selection_cost_hysteresis = case["hyst"]
+        cfg.hcp.selection_prefer_initial_plan = case["prefer"]
+        ref_i, ref_c = oracle_py.select_best(cfg, case["costs"], case["last_best"], case["initial_plan"])
+        for rank, res in outs:
+            gc, gi = res[k]
+            assert gi == ref_i and gc == ref_c, (case, rank, gc, gi, ref_c, ref_i)
+
+
+def test_two_ranks_optimise_shards_and_agree():
+    outs = _run(2, "oracle_shards")
+    from oracle import oracle_py
+    cfg, obst, via, batch = scenes.scene_small_mixed(B=6, stride=192)
+    _, res = oracle_py.optimize_batch(cfg, obst, via, batch)
+    ref_i, ref_c = oracle_py.select_best(cfg, res.cost)
+    allc = {}
+    for rank, gc, gi, costs, lo in outs:
+        assert gi == ref_i and gc == ref_c
+        for k, c in enumerate(costs):
+            allc[lo + k] = c
+    np.testing.assert_array_equal(np.array([allc[k] for k in range(6)]), res.cost)   # sharding does not change results
