@@ -49,6 +49,10 @@ def lib():
             C.POINTER(_abi.Config), C.POINTER(_abi.Obstacles), C.c_int32, _abi.p_f64, _abi.p_f64,
             C.POINTER(_abi.TebBatch), C.c_int32, C.c_double, _abi.p_f64, _abi.p_f64, _abi.p_f64,
             _abi.p_i32, _abi.p_i32]
+        _LIB.teb_oracle_edges.restype = C.c_int
+        _LIB.teb_oracle_edges.argtypes = [
+            C.POINTER(_abi.Config), C.POINTER(_abi.Obstacles), C.c_int32, _abi.p_f64, _abi.p_f64,
+            C.POINTER(_abi.TebBatch), C.c_int32, C.c_double, _abi.p_i32, _abi.p_f64, C.c_int32, _abi.p_i32]
         _LIB.teb_oracle_associate.restype = C.c_int
         _LIB.teb_oracle_associate.argtypes = [
             C.POINTER(_abi.Config), C.POINTER(_abi.Obstacles), C.POINTER(_abi.TebBatch), C.c_int32,
@@ -131,6 +135,20 @@ def linearize(cfg, obst, via, batch, b=0, weight_multiplier=1.0):
                                       _abi._ptr(H, C.c_double), _abi._ptr(bv, C.c_double),
                                       _abi._ptr(chi2, C.c_double), C.byref(ne), C.byref(nr)), "linearize")
     return dict(H=H, b=bv, chi2=chi2, n_edges=ne.value, n_rows=nr.value)
+
+
+def edges(cfg, obst, via, batch, b=0, weight_multiplier=1.0, cap=1 << 16):
+    """The oracle's hyper-graph of TEB b: (irec [E,16] int32, drec [E,56] float64), see teb_oracle.h."""
+    c = cfg.to_c()
+    ir = np.zeros((cap, 16), np.int32); dr = np.zeros((cap, 56))
+    cnt = C.c_int32(0)
+    vx, vy = _via_arrays(via)
+    bs = batch.c_struct()
+    _check(lib().teb_oracle_edges(C.byref(c), C.byref(obst.freeze()), len(via), _abi._ptr(vx, C.c_double),
+                                  _abi._ptr(vy, C.c_double), C.byref(bs), b, weight_multiplier,
+                                  _abi._ptr(ir, C.c_int32), _abi._ptr(dr, C.c_double), cap, C.byref(cnt)), "edges")
+    k = min(cnt.value, cap)
+    return ir[:k].copy(), dr[:k].copy()
 
 
 def associate(cfg, obst, batch, b=0, cap=1 << 16):

@@ -1,0 +1,87 @@
+"""ctypes wrapper of oracle/_ref/libteb_ref.so — the reference's own classes behind a C interface (TEST INFRASTRUCTURE).
+
+libteb_ref.so is built by `make -C oracle/ref_shim` from /root/reference's headers and src/{obstacles,timed_elastic_band}.cpp
+against stand-in Eigen/g2o/ROS/Boost headers; it exists only where /root/reference exists (or as a prebuilt file)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from teb_local_planner_amd import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(_HERE, "_ref", "libteb_ref.so")
+_LIB = None
+
+
+def available():
+    return os.path.exists(SO) or os.path.isdir("/root/reference")
+
+
+def build():
+    if os.path.isdir("/root/reference"):
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "ref_shim")])
+    return SO
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO):
+            build()
+        _LIB = C.CDLL(SO)
+    return _LIB
+
+
+def config_default():
+    c = _abi.Config()
+    assert lib().ref_config_default(C.byref(c)) == 0
+    return c
+
+
+def eval_edges(cfg, obst, via, batch, b, irec, drec):
+    """Evaluates the edge records with the REFERENCE edge classes; returns (err [E,3], jac [E,3,11], jac_valid [E])."""
+    c = cfg.to_c()
+    x, y, th, dt = batch.get_teb(b)
+    n = len(x)
+    dtp = np.zeros(n); dtp[:n - 1] = dt
+    E = len(irec)
+    err = np.zeros((E, 3)); jac = np.zeros((E, 33)); jv = np.zeros(E, np.int32)
+    vx = _abi.f64([v[0] for v in via]) if via else _abi.f64([0.0])
+    vy = _abi.f64([v[1] for v in via]) if via else _abi.f64([0.0])
+    ir = np.ascontiguousarray(irec, np.int32); dr = np.ascontiguousarray(drec, np.float64)
+    vs = _abi.f64(batch.vel_start[b]); vg = _abi.f64(batch.vel_goal[b])
+    P = lambda a: _abi._ptr(a, C.c_double)
+    rc = lib().ref_eval_edges(C.byref(c), C.byref(obst.freeze()), len(via), P(vx), P(vy), n, P(_abi.f64(x)), P(_abi.f64(y)),
+                              P(_abi.f64(th)), P(dtp), P(vs), P(vg), E, _abi._ptr(ir, C.c_int32), P(dr), P(err), P(jac),
+                              _abi._ptr(jv, C.c_int32))
+    assert rc == 0
+    return err, jac.reshape(E, 3, 11), jv
+
+
+def distance(cfg, obst, oi, x, y, th, t=None):
+    c = cfg.to_c()
+    oi = _abi.i32(oi); x = _abi.f64(x); y = _abi.f64(y); th = _abi.f64(th)
+    nq = len(oi)
+    st = _abi.i32(np.zeros(nq) if t is None else np.ones(nq)); tt = _abi.f64(np.zeros(nq) if t is None else t)
+    d = np.zeros(nq); cx = np.zeros(nq); cy = np.zeros(nq)
+    P = lambda a: _abi._ptr(a, C.c_double)
+    rc = lib().ref_distance(C.byref(c), C.byref(obst.freeze()), nq, _abi._ptr(oi, C.c_int32), P(x), P(y), P(th),
+                            _abi._ptr(st, C.c_int32), P(tt), P(d), P(cx), P(cy))
+    assert rc == 0
+    return d, cx, cy
+
+
+def autoresize(x, y, theta, dt, dt_ref, dt_hysteresis, min_samples, max_samples, fast_mode, cap=4096):
+    n = len(x)
+    X = np.zeros(cap); Y = np.zeros(cap); T = np.zeros(cap); D = np.zeros(cap)
+    X[:n] = x; Y[:n] = y; T[:n] = theta; D[:n - 1] = dt
+    nn = C.c_int32(n)
+    P = lambda a: _abi._ptr(a, C.c_double)
+    lib().ref_autoresize.argtypes = [_abi.p_f64] * 4 + [_abi.p_i32, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
+    rc = lib().ref_autoresize(P(X), P(Y), P(T), P(D), C.byref(nn), cap, dt_ref, dt_hysteresis, min_samples, max_samples,
+                              int(fast_mode))
+    assert rc == 0, rc
+    n = nn.value
+    return X[:n].copy(), Y[:n].copy(), T[:n].copy(), D[:n - 1].copy()

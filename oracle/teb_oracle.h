@@ -57,6 +57,19 @@ int teb_oracle_linearize(const teb_amd_config_t* cfg, const teb_amd_obstacles_t*
                          const teb_amd_teb_batch_t* batch, int32_t b, double weight_multiplier,
                          double* H_dense, double* bvec, double* chi2, int32_t* n_edges, int32_t* n_rows);
 
+/* Test hook: the hyper-graph of TEB b in insertion order (buildGraph with the given weight_multiplier), one record
+ * per edge, 16 int32 and 56 doubles:
+ *   irec: [type, np, pose0, pose1, pose2, nd, dt0, dt1, dim, obst, via, 0...]   (type = EType of teb_oracle.cpp:
+ *         0 obstacle, 1 inflated obstacle, 2 dynamic obstacle, 3 via-point, 4 velocity, 5 velocity holonomic, 6 acceleration,
+ *         7 acc. start, 8 acc. goal, 9 acc. holonomic, 10 acc. holonomic start, 11 acc. holonomic goal, 12 time-optimal,
+ *         13 shortest path, 14 kinematics diff-drive, 15 kinematics car-like, 16 prefer-rotdir, 17 velocity-obstacle-ratio)
+ *   drec: [err0..2, info0..2, t, dir, J(3x11 row-major, columns pose0 xyz, pose1 xyz, pose2 xyz, dt0, dt1) in the
+ *          configured jacobian_mode, 15 spare]
+ * Returns the number of edges in *count (records beyond cap are not written). */
+int teb_oracle_edges(const teb_amd_config_t* cfg, const teb_amd_obstacles_t* obst, int32_t n_via, const double* via_x,
+                     const double* via_y, const teb_amd_teb_batch_t* batch, int32_t b, double weight_multiplier,
+                     int32_t* irec, double* drec, int32_t cap, int32_t* count);
+
 /* Test hook: obstacle association of TEB b (AddEdgesObstacles, src/optimal_planner.cpp:444-548, or the
  * legacy variant :551-643). assoc_pose/assoc_obst receive up to cap (pose, obstacle) pairs in edge
  * insertion order; returns the pair count in *count. */
