@@ -200,9 +200,11 @@ typedef struct teb_amd_teb_batch {
   double*  y;
   double*  theta;
   double*  dt;         /* [B*stride]; dt[b*stride+i] connects pose i and i+1 */
-  const int32_t* has_vel_start;   /* [B]  or NULL (= all 0) */
+  const int32_t* has_vel_start;   /* [B]  or NULL (= all 1: TebOptimalPlanner::initialize() fixes the start velocity,
+                                   *      at zero until setVelocityStart, src/optimal_planner.cpp:94-97; 0 = free start
+                                   *      velocity is an extension, the reference cannot express it) */
   const double*  vel_start;       /* [B*3] (vx, vy, omega) or NULL */
-  const int32_t* has_vel_goal;    /* [B]  or NULL (= all 0) */
+  const int32_t* has_vel_goal;    /* [B]  or NULL (= all 1, src/optimal_planner.cpp:99-102); 0 = setVelocityGoalFree() */
   const double*  vel_goal;        /* [B*3] or NULL */
   const int32_t* prefer_rotdir;   /* [B]  TEB_AMD_ROT_* or NULL (= none) */
   const int32_t* via_points_enabled; /* [B] or NULL (= all 1) */

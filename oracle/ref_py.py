@@ -85,3 +85,62 @@ def autoresize(x, y, theta, dt, dt_ref, dt_hysteresis, min_samples, max_samples,
     assert rc == 0, rc
     n = nn.value
     return X[:n].copy(), Y[:n].copy(), T[:n].copy(), D[:n - 1].copy()
+
+
+def _via_xy(via):
+    vx = _abi.f64([v[0] for v in via]) if via else _abi.f64([0.0])
+    vy = _abi.f64([v[1] for v in via]) if via else _abi.f64([0.0])
+    return vx, vy
+
+
+def _teb_flags(batch, b):
+    hs = int(batch.has_vel_start[b]); hg = int(batch.has_vel_goal[b])
+    rot = int(batch.prefer_rotdir[b]); ve = int(batch.via_points_enabled[b])
+    return hs, _abi.f64(batch.vel_start[b]), hg, _abi.f64(batch.vel_goal[b]), rot, ve
+
+
+def optimize_teb(cfg, obst, via, batch, b=0, inner=None, outer=None, compute_cost=True, obst_cost_scale=None,
+                 viapoint_cost_scale=None, alternative_time_cost=None, cap=4096):
+    """The reference's TebOptimalPlanner::optimizeTEB (src/optimal_planner.cpp, compiled in place) on TEB b.
+    Returns dict(success, x, y, theta, dt, cost). The LM iteration inside is the stand-in of shim_g2o.h."""
+    c = cfg.to_c()
+    x, y, th, dt = batch.get_teb(b)
+    n = len(x)
+    X = np.zeros(cap); Y = np.zeros(cap); T = np.zeros(cap); D = np.zeros(cap)
+    X[:n] = x; Y[:n] = y; T[:n] = th; D[:n - 1] = dt
+    nn = C.c_int32(n)
+    vx, vy = _via_xy(via)
+    hs, vs, hg, vg, rot, ve = _teb_flags(batch, b)
+    inner = cfg.optim.no_inner_iterations if inner is None else inner
+    outer = cfg.optim.no_outer_iterations if outer is None else outer
+    osc = cfg.hcp.selection_obst_cost_scale if obst_cost_scale is None else obst_cost_scale
+    vsc = cfg.hcp.selection_viapoint_cost_scale if viapoint_cost_scale is None else viapoint_cost_scale
+    atc = cfg.hcp.selection_alternative_time_cost if alternative_time_cost is None else alternative_time_cost
+    ok = C.c_int32(0); cost = C.c_double(0)
+    P = lambda a: _abi._ptr(a, C.c_double)
+    rc = lib().ref_optimize_teb(C.byref(c), C.byref(obst.freeze()), len(via), P(vx), P(vy), C.byref(nn), cap, P(X), P(Y),
+                                P(T), P(D), hs, P(vs), hg, P(vg), rot, ve, int(inner), int(outer), int(compute_cost),
+                                C.c_double(osc), C.c_double(vsc), int(atc), C.byref(ok), C.byref(cost))
+    assert rc == 0, rc
+    n = nn.value
+    return dict(success=bool(ok.value), x=X[:n].copy(), y=Y[:n].copy(), theta=T[:n].copy(), dt=D[:n - 1].copy(),
+                cost=cost.value)
+
+
+def build_graph(cfg, obst, via, batch, b=0, weight_multiplier=1.0, cap=1 << 16):
+    """The hyper-graph the reference's buildGraph creates for TEB b: (irec [E,8], drec [E,48]), see ref_driver.cpp."""
+    c = cfg.to_c()
+    x, y, th, dt = batch.get_teb(b)
+    n = len(x)
+    dtp = np.zeros(n); dtp[:n - 1] = dt
+    vx, vy = _via_xy(via)
+    hs, vs, hg, vg, rot, ve = _teb_flags(batch, b)
+    ir = np.zeros((cap, 8), np.int32); dr = np.zeros((cap, 48))
+    cnt = C.c_int32(0)
+    P = lambda a: _abi._ptr(a, C.c_double)
+    rc = lib().ref_build_graph(C.byref(c), C.byref(obst.freeze()), len(via), P(vx), P(vy), n, P(_abi.f64(x)),
+                               P(_abi.f64(y)), P(_abi.f64(th)), P(dtp), hs, P(vs), hg, P(vg), rot, ve,
+                               C.c_double(weight_multiplier), _abi._ptr(ir, C.c_int32), P(dr), cap, C.byref(cnt))
+    assert rc == 0, rc
+    k = min(cnt.value, cap)
+    return ir[:k].copy(), dr[:k].copy()

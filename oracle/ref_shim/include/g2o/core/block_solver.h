@@ -1,0 +1,1 @@
+#include "../../../shim_g2o.h"

@@ -1,0 +1,1 @@
+#include "../../shim_ros.h"

@@ -3,9 +3,12 @@
 // What is reference code here: every computeError(), penalties.h, misc.h, pose_se2.h, distance_calculations.h,
 // obstacles.h + src/obstacles.cpp, robot_footprint_model.h, TimedElasticBand::autoResize (src/timed_elastic_band.cpp),
 // EdgeKinematicsDiffDrive::linearizeOplus / EdgeTimeOptimal::linearizeOplus, TebConfig's constructor defaults.
+// + src/optimal_planner.cpp (buildGraph / AddEdges* / optimizeGraph / computeCurrentCost / optimizeTEB) driven through the
+// recording SparseOptimizer stand-in of shim_g2o.h (the LM iteration itself is restated there, libg2o being absent).
 // What is NOT (external, absent): libg2o, Eigen, ROS, Boost -> ./shim_*.h.
 #include <teb_local_planner/teb_config.h>
 #include <teb_local_planner/timed_elastic_band.h>
+#include <teb_local_planner/optimal_planner.h>
 #include <teb_local_planner/g2o_types/edge_velocity.h>
 #include <teb_local_planner/g2o_types/edge_acceleration.h>
 #include <teb_local_planner/g2o_types/edge_kinematics.h>
@@ -41,6 +44,27 @@ void to_ref_config(const teb_amd_config_t& a, TebConfig& c) {
   c.obstacles.obstacle_proximity_lower_bound = a.obstacle_proximity_lower_bound;
   c.obstacles.obstacle_proximity_upper_bound = a.obstacle_proximity_upper_bound;
   c.optim.penalty_epsilon = a.penalty_epsilon; c.optim.obstacle_cost_exponent = a.obstacle_cost_exponent;
+  c.obstacles.obstacle_poses_affected = a.obstacle_poses_affected;
+  c.obstacles.legacy_obstacle_association = a.legacy_obstacle_association;
+  c.obstacles.obstacle_association_force_inclusion_factor = a.obstacle_association_force_inclusion_factor;
+  c.obstacles.obstacle_association_cutoff_factor = a.obstacle_association_cutoff_factor;
+  c.optim.no_inner_iterations = a.no_inner_iterations; c.optim.no_outer_iterations = a.no_outer_iterations;
+  c.optim.optimization_activate = a.optimization_activate; c.optim.optimization_verbose = false;
+  c.optim.weight_max_vel_x = a.weight_max_vel_x; c.optim.weight_max_vel_y = a.weight_max_vel_y;
+  c.optim.weight_max_vel_theta = a.weight_max_vel_theta; c.optim.weight_acc_lim_x = a.weight_acc_lim_x;
+  c.optim.weight_acc_lim_y = a.weight_acc_lim_y; c.optim.weight_acc_lim_theta = a.weight_acc_lim_theta;
+  c.optim.weight_kinematics_nh = a.weight_kinematics_nh; c.optim.weight_kinematics_forward_drive = a.weight_kinematics_forward_drive;
+  c.optim.weight_kinematics_turning_radius = a.weight_kinematics_turning_radius; c.optim.weight_optimaltime = a.weight_optimaltime;
+  c.optim.weight_shortest_path = a.weight_shortest_path; c.optim.weight_obstacle = a.weight_obstacle;
+  c.optim.weight_inflation = a.weight_inflation; c.optim.weight_dynamic_obstacle = a.weight_dynamic_obstacle;
+  c.optim.weight_dynamic_obstacle_inflation = a.weight_dynamic_obstacle_inflation;
+  c.optim.weight_velocity_obstacle_ratio = a.weight_velocity_obstacle_ratio; c.optim.weight_viapoint = a.weight_viapoint;
+  c.optim.weight_prefer_rotdir = a.weight_prefer_rotdir; c.optim.weight_adapt_factor = a.weight_adapt_factor;
+  c.hcp.selection_cost_hysteresis = a.selection_cost_hysteresis; c.hcp.selection_prefer_initial_plan = a.selection_prefer_initial_plan;
+  c.hcp.selection_obst_cost_scale = a.selection_obst_cost_scale; c.hcp.selection_viapoint_cost_scale = a.selection_viapoint_cost_scale;
+  c.hcp.selection_alternative_time_cost = a.selection_alternative_time_cost;
+  c.recovery.divergence_detection_enable = a.divergence_detection_enable;
+  c.recovery.divergence_detection_max_chi_squared = a.divergence_detection_max_chi_squared;
   switch (a.footprint_type) {
     case TEB_AMD_FOOTPRINT_POINT: c.robot_model = boost::make_shared<PointRobotFootprint>(); break;
     case TEB_AMD_FOOTPRINT_CIRCULAR: c.robot_model = boost::make_shared<CircularRobotFootprint>(a.footprint_radius); break;
@@ -82,9 +106,126 @@ void to_ref_obstacles(const teb_amd_obstacles_t* o, ObstContainer& out) {
   }
 }
 
+// TebOptimalPlanner with its protected graph builders exposed (the class is the reference's; nothing is overridden)
+struct PlannerProbe : public TebOptimalPlanner {
+  using TebOptimalPlanner::TebOptimalPlanner;
+  using TebOptimalPlanner::buildGraph;
+  using TebOptimalPlanner::clearGraph;
+};
+
+int edge_type_code(g2o::OptimizableGraph::Edge* e) {   // EType numbering of teb_oracle.h (teb_oracle_edges)
+  if (dynamic_cast<EdgeInflatedObstacle*>(e)) return 1;
+  if (dynamic_cast<EdgeObstacle*>(e)) return 0;
+  if (dynamic_cast<EdgeDynamicObstacle*>(e)) return 2;
+  if (dynamic_cast<EdgeViaPoint*>(e)) return 3;
+  if (dynamic_cast<EdgeVelocityHolonomic*>(e)) return 5;
+  if (dynamic_cast<EdgeVelocity*>(e)) return 4;
+  if (dynamic_cast<EdgeAccelerationHolonomicStart*>(e)) return 10;
+  if (dynamic_cast<EdgeAccelerationHolonomicGoal*>(e)) return 11;
+  if (dynamic_cast<EdgeAccelerationHolonomic*>(e)) return 9;
+  if (dynamic_cast<EdgeAccelerationStart*>(e)) return 7;
+  if (dynamic_cast<EdgeAccelerationGoal*>(e)) return 8;
+  if (dynamic_cast<EdgeAcceleration*>(e)) return 6;
+  if (dynamic_cast<EdgeTimeOptimal*>(e)) return 12;
+  if (dynamic_cast<EdgeShortestPath*>(e)) return 13;
+  if (dynamic_cast<EdgeKinematicsDiffDrive*>(e)) return 14;
+  if (dynamic_cast<EdgeKinematicsCarlike*>(e)) return 15;
+  if (dynamic_cast<EdgePreferRotDir*>(e)) return 16;
+  if (dynamic_cast<EdgeVelocityObstacleRatio*>(e)) return 17;
+  return -1;
+}
+
+void fill_planner(PlannerProbe& pl, int n, const double* x, const double* y, const double* th, const double* dt,
+                  int has_vs, const double* vs, int has_vg, const double* vg, int rotdir) {
+  TimedElasticBand& teb = pl.teb();
+  teb.addPose(x[0], y[0], th[0], true);
+  for (int i = 1; i < n; ++i) teb.addPoseAndTimeDiff(x[i], y[i], th[i], dt[i - 1]);
+  teb.setPoseVertexFixed(n - 1, true);
+  if (has_vs) { geometry_msgs::Twist t; t.linear.x = vs[0]; t.linear.y = vs[1]; t.angular.z = vs[2]; pl.setVelocityStart(t); }
+  if (has_vg) { geometry_msgs::Twist t; t.linear.x = vg[0]; t.linear.y = vg[1]; t.angular.z = vg[2]; pl.setVelocityGoal(t); }
+  else pl.setVelocityGoalFree();
+  pl.setPreferredTurningDir(rotdir == TEB_AMD_ROT_LEFT ? RotType::left : rotdir == TEB_AMD_ROT_RIGHT ? RotType::right : RotType::none);
+}
+
 }  // namespace
 
 extern "C" {
+
+// TebOptimalPlanner::optimizeTEB of the reference (src/optimal_planner.cpp:183-233) on one strip. Arrays have capacity cap.
+// out: success flag, n, state, cost (getCurrentCost()).
+int ref_optimize_teb(const teb_amd_config_t* acfg, const teb_amd_obstacles_t* o, int n_via, const double* via_x,
+                     const double* via_y, int32_t* n_io, int cap, double* x, double* y, double* th, double* dt, int has_vs,
+                     const double* vs, int has_vg, const double* vg, int rotdir, int via_enabled, int inner, int outer,
+                     int compute_cost, double obst_cost_scale, double viapoint_cost_scale, int alternative_time_cost,
+                     int32_t* success, double* cost) {
+  TebConfig cfg;
+  to_ref_config(*acfg, cfg);
+  ObstContainer obst;
+  to_ref_obstacles(o, obst);
+  ViaPointContainer via;
+  for (int i = 0; i < n_via; ++i) via.push_back(Eigen::Vector2d(via_x[i], via_y[i]));
+  PlannerProbe pl(cfg, &obst, TebVisualizationPtr(), via_enabled ? &via : nullptr);
+  fill_planner(pl, *n_io, x, y, th, dt, has_vs, vs, has_vg, vg, rotdir);
+  const bool ok = pl.optimizeTEB(inner, outer, compute_cost != 0, obst_cost_scale, viapoint_cost_scale, alternative_time_cost != 0);
+  *success = ok ? 1 : 0;
+  *cost = pl.getCurrentCost();
+  const TimedElasticBand& teb = pl.teb();
+  const int n = teb.sizePoses();
+  if (n > cap) return 4;
+  *n_io = n;
+  for (int i = 0; i < n; ++i) { x[i] = teb.Pose(i).x(); y[i] = teb.Pose(i).y(); th[i] = teb.Pose(i).theta(); }
+  for (int i = 0; i < teb.sizeTimeDiffs(); ++i) dt[i] = teb.TimeDiff(i);
+  return 0;
+}
+
+// The hyper-graph TebOptimalPlanner::buildGraph (src/optimal_planner.cpp:323-366) creates for one strip, in insertion order,
+// errors computed at the given state. Per edge: irec[8] = {type, dim, n_vertices, v0, v1, v2, v3, v4} with vertex codes
+// 2*i for pose i and 2*i+1 for time difference i (the ids AddTEBVertices assigns, :423-441); drec[48] = {err0..2, info0..2, J(3 x 14 row-major: up to 3 pose
+// vertices x 3 columns, then up to 2 time-difference vertices, then 3 spare) = what e->linearizeOplus() leaves (the reference's
+// two analytic Jacobians, else the central differences of shim_g2o.h over the reference's computeError)}.
+int ref_build_graph(const teb_amd_config_t* acfg, const teb_amd_obstacles_t* o, int n_via, const double* via_x,
+                    const double* via_y, int n, const double* x, const double* y, const double* th, const double* dt,
+                    int has_vs, const double* vs, int has_vg, const double* vg, int rotdir, int via_enabled,
+                    double weight_multiplier, int32_t* irec, double* drec, int cap, int32_t* count) {
+  TebConfig cfg;
+  to_ref_config(*acfg, cfg);
+  ObstContainer obst;
+  to_ref_obstacles(o, obst);
+  ViaPointContainer via;
+  for (int i = 0; i < n_via; ++i) via.push_back(Eigen::Vector2d(via_x[i], via_y[i]));
+  PlannerProbe pl(cfg, &obst, TebVisualizationPtr(), via_enabled ? &via : nullptr);
+  fill_planner(pl, n, x, y, th, dt, has_vs, vs, has_vg, vg, rotdir);
+  if (!pl.buildGraph(weight_multiplier)) return 1;
+  pl.optimizer()->initializeOptimization();
+  pl.optimizer()->computeActiveErrors();
+  int k = 0;
+  for (g2o::OptimizableGraph::Edge* e : pl.optimizer()->activeEdges()) {
+    if (k < cap) {
+      int32_t* ir = irec + (size_t)k * 8;
+      double* dr = drec + (size_t)k * 48;
+      for (int q = 0; q < 48; ++q) dr[q] = 0;
+      ir[0] = edge_type_code(e); ir[1] = e->dimension(); ir[2] = e->nVertices();
+      for (int q = 0; q < 5; ++q) ir[3 + q] = q < e->nVertices() ? e->vertexAt(q)->id() : -1;
+      for (int q = 0; q < 3; ++q) { dr[q] = q < e->dimension() ? e->errorAt(q) : 0.0; dr[3 + q] = q < e->dimension() ? e->infoAt(q, q) : 0.0; }
+      e->linearizeOplus();
+      int np = 0, nd = 0;
+      for (int v = 0; v < e->nVertices(); ++v) {
+        g2o::OptimizableGraph::Vertex* vv = e->vertexAt(v);
+        const bool is_pose = vv->dimension() == 3;
+        const int col0 = is_pose ? 3 * np : 9 + nd;
+        if (!vv->fixed())
+          for (int r = 0; r < e->dimension(); ++r)
+            for (int cc = 0; cc < vv->dimension(); ++cc) dr[6 + r * 14 + col0 + cc] = e->jacAt(v, r, cc);
+        if (is_pose) ++np; else ++nd;
+      }
+    }
+    ++k;
+  }
+  *count = k;
+  pl.clearGraph();
+  return 0;
+}
+
 
 // TebConfig() constructor defaults of the reference (teb_config.h:245-390), flattened like teb_amd_config_default
 int ref_config_default(teb_amd_config_t* a) {

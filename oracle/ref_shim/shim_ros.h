@@ -31,7 +31,7 @@
 namespace ros {
 class NodeHandle {};
 struct Time { double t = 0; static Time now() { return Time(); } double toSec() const { return t; } };
-struct Duration { double d = 0; explicit Duration(double x = 0) : d(x) {} double toSec() const { return d; } };
+struct Duration { double d = 0; explicit Duration(double x = 0) : d(x) {} double toSec() const { return d; } Duration& fromSec(double x) { d = x; return *this; } };
 }  // namespace ros
 
 namespace boost {
@@ -40,6 +40,9 @@ template <typename T, typename... A> shared_ptr<T> make_shared(A&&... a) { retur
 template <typename T, typename U> shared_ptr<T> dynamic_pointer_cast(const shared_ptr<U>& p) { return std::dynamic_pointer_cast<T>(p); }
 template <typename T, typename U> shared_ptr<T> static_pointer_cast(const shared_ptr<U>& p) { return std::static_pointer_cast<T>(p); }
 using mutex = std::mutex;
+using once_flag = std::once_flag;
+template <typename F> void call_once(F f, once_flag& fl) { std::call_once(fl, f); }
+#define BOOST_ONCE_INIT {}
 template <typename T> struct is_pointer : std::is_pointer<T> {};
 template <typename C, typename T = void> struct disable_if : std::enable_if<!C::value, T> {};
 template <typename C, typename T = void> struct enable_if : std::enable_if<C::value, T> {};
@@ -120,6 +123,24 @@ struct Marker {
 };
 }  // namespace visualization_msgs
 
+namespace geometry_msgs {
+struct TwistStamped { std_msgs::Header header; Twist twist; };
+struct Accel { Vector3 linear, angular; };
+}  // namespace geometry_msgs
+namespace nav_msgs {
+struct Path { std_msgs::Header header; std::vector<geometry_msgs::PoseStamped> poses; };
+struct Odometry { std_msgs::Header header; };
+}  // namespace nav_msgs
+namespace base_local_planner {
+class CostmapModel {
+ public:
+  virtual ~CostmapModel() {}
+  virtual double footprintCost(double, double, double, const std::vector<geometry_msgs::Point>&, double = 0.0, double = 0.0) { return 0.0; }
+};
+}  // namespace base_local_planner
+
 namespace teb_local_planner {
 class TebLocalPlannerReconfigureConfig {};
+struct TrajectoryPointMsg { geometry_msgs::Pose pose; geometry_msgs::Twist velocity; geometry_msgs::Twist acceleration; ros::Duration time_from_start; };
+struct TrajectoryMsg { std_msgs::Header header; std::vector<TrajectoryPointMsg> trajectory; };
 }

@@ -15,7 +15,8 @@
  *   Base{Unary,Binary,Multi}Edge::linearizeOplus (central differences, delta=1e-9),
  *   constructQuadraticForm, BlockSolver + LinearSolverCSparse (exact sparse Cholesky).
  * g2o is not vendored in /root/reference; its published algorithm is restated here from the upstream
- * sources of that API generation. PARITY UNPINNED at that boundary.
+ * sources of that API generation. PARITY UNPINNED inside that library; everything of the reference's
+ * own code is pinned bit-for-bit by tests/test_reference_pinning.py (oracle/_ref).
  *
  * Jacobian modes: TEB_AMD_JACOBIAN_G2O_NUMERIC = what the reference really does ("faithful");
  *                 TEB_AMD_JACOBIAN_ANALYTIC    = closed forms with the one-sided conventions of
@@ -1696,8 +1697,8 @@ void teb_from_batch(const teb_amd_teb_batch_t* bt, int b, Teb& t) {
   t.y.assign(bt->y + o, bt->y + o + n);
   t.th.assign(bt->theta + o, bt->theta + o + n);
   t.dt.assign(bt->dt + o, bt->dt + o + std::max(0, n - 1));
-  t.has_vs = bt->has_vel_start && bt->has_vel_start[b];
-  t.has_vg = bt->has_vel_goal && bt->has_vel_goal[b];
+  t.has_vs = !bt->has_vel_start || bt->has_vel_start[b];
+  t.has_vg = !bt->has_vel_goal || bt->has_vel_goal[b];
   for (int k = 0; k < 3; ++k) {
     t.vs[k] = (bt->vel_start) ? bt->vel_start[3 * b + k] : 0.0;
     t.vg[k] = (bt->vel_goal) ? bt->vel_goal[3 * b + k] : 0.0;

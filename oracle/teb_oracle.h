@@ -5,9 +5,10 @@
  * (TebOptimalPlanner::optimizeTEB and its g2o/CSparse back end). Only tests/, __graft_entry__.smoke()
  * and bench.py's cpu_baseline leg may load libteb_oracle.so; libteb_amd.so never links or calls it.
  *
- * PARITY UNPINNED for the optimiser as a whole: the reference ships no golden vectors for this path
- * (test/teb_basics.cpp only pins autoResize post-conditions) and libg2o / SuiteSparse are not present
- * in /root/reference. See oracle/README.md for what IS pinned (oracle/_ref).
+ * PINNED bit-for-bit against the reference's own sources compiled in place (oracle/_ref/libteb_ref.so: every edge
+ * class, geometry, autoResize, src/optimal_planner.cpp's buildGraph / optimizeTEB / computeCurrentCost) by
+ * tests/test_reference_pinning.py and the committed tests/golden/ref_*.npz. PARITY UNPINNED only inside the external
+ * libg2o (LM iteration, central differences, linear solver: absent from /root/reference, restated). See DESIGN.md section 5.
  */
 #ifndef TEB_ORACLE_H_
 #define TEB_ORACLE_H_

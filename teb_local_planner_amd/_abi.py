@@ -169,8 +169,9 @@ class TebBatchHost:
         B, S = self.count, self.stride
         self.n = np.zeros(B, np.int32)
         self.x = np.zeros((B, S)); self.y = np.zeros((B, S)); self.theta = np.zeros((B, S)); self.dt = np.zeros((B, S))
-        self.has_vel_start = np.zeros(B, np.int32); self.vel_start = np.zeros((B, 3))
-        self.has_vel_goal = np.zeros(B, np.int32); self.vel_goal = np.zeros((B, 3))
+        # TebOptimalPlanner::initialize(): start and goal velocity fixed, at zero (src/optimal_planner.cpp:94-102)
+        self.has_vel_start = np.ones(B, np.int32); self.vel_start = np.zeros((B, 3))
+        self.has_vel_goal = np.ones(B, np.int32); self.vel_goal = np.zeros((B, 3))
         self.prefer_rotdir = np.full(B, ROT_NONE, np.int32)
         self.via_points_enabled = np.ones(B, np.int32)
 

@@ -461,7 +461,7 @@ int teb_amd_upload_tebs(teb_amd_handle_t* h, const teb_amd_teb_batch_t* bt) {
   HIPCHK(hipMemcpy2DAsync(h->th.p, dp, bt->theta, sp, w, B, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpy2DAsync(h->dt.p, dp, bt->dt, sp, w, B, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->n.p, bt->n, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  std::vector<int> hvs(B, 0), hvg(B, 0), rd(B, TEB_AMD_ROT_NONE), ve(B, 1);
+  std::vector<int> hvs(B, 1), hvg(B, 1), rd(B, TEB_AMD_ROT_NONE), ve(B, 1);
   std::vector<double> vs(3 * (size_t)B, 0.0), vg(3 * (size_t)B, 0.0);
   for (int b = 0; b < B; ++b) {
     if (bt->has_vel_start) hvs[b] = bt->has_vel_start[b] != 0;
