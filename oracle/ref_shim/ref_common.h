@@ -1,0 +1,146 @@
+// ref_common.h — conversions from the C-ABI PODs to the REFERENCE's own objects, shared by ref_driver.cpp and backend_check.cpp.
+// TEST INFRASTRUCTURE (oracle/_ref build only).
+#pragma once
+#include <teb_local_planner/teb_config.h>
+#include <teb_local_planner/timed_elastic_band.h>
+#include <teb_local_planner/optimal_planner.h>
+#include <teb_local_planner/g2o_types/edge_velocity.h>
+#include <teb_local_planner/g2o_types/edge_acceleration.h>
+#include <teb_local_planner/g2o_types/edge_kinematics.h>
+#include <teb_local_planner/g2o_types/edge_obstacle.h>
+#include <teb_local_planner/g2o_types/edge_dynamic_obstacle.h>
+#include <teb_local_planner/g2o_types/edge_time_optimal.h>
+#include <teb_local_planner/g2o_types/edge_via_point.h>
+#include <teb_local_planner/g2o_types/edge_shortest_path.h>
+#include <teb_local_planner/g2o_types/edge_prefer_rotdir.h>
+#include <teb_local_planner/g2o_types/edge_velocity_obstacle_ratio.h>
+
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "../../include/teb_amd.h"
+
+using namespace teb_local_planner;
+
+namespace refshim {
+
+inline void to_ref_config(const teb_amd_config_t& a, TebConfig& c) {
+  c.trajectory.teb_autosize = a.teb_autosize; c.trajectory.dt_ref = a.dt_ref; c.trajectory.dt_hysteresis = a.dt_hysteresis;
+  c.trajectory.min_samples = a.min_samples; c.trajectory.max_samples = a.max_samples;
+  c.trajectory.exact_arc_length = a.exact_arc_length; c.trajectory.via_points_ordered = a.via_points_ordered;
+  c.robot.max_vel_x = a.max_vel_x; c.robot.max_vel_x_backwards = a.max_vel_x_backwards; c.robot.max_vel_y = a.max_vel_y;
+  c.robot.max_vel_trans = a.max_vel_trans; c.robot.max_vel_theta = a.max_vel_theta; c.robot.acc_lim_x = a.acc_lim_x;
+  c.robot.acc_lim_y = a.acc_lim_y; c.robot.acc_lim_theta = a.acc_lim_theta; c.robot.min_turning_radius = a.min_turning_radius;
+  c.obstacles.min_obstacle_dist = a.min_obstacle_dist; c.obstacles.inflation_dist = a.inflation_dist;
+  c.obstacles.dynamic_obstacle_inflation_dist = a.dynamic_obstacle_inflation_dist;
+  c.obstacles.include_dynamic_obstacles = a.include_dynamic_obstacles;
+  c.obstacles.obstacle_proximity_ratio_max_vel = a.obstacle_proximity_ratio_max_vel;
+  c.obstacles.obstacle_proximity_lower_bound = a.obstacle_proximity_lower_bound;
+  c.obstacles.obstacle_proximity_upper_bound = a.obstacle_proximity_upper_bound;
+  c.optim.penalty_epsilon = a.penalty_epsilon; c.optim.obstacle_cost_exponent = a.obstacle_cost_exponent;
+  c.obstacles.obstacle_poses_affected = a.obstacle_poses_affected;
+  c.obstacles.legacy_obstacle_association = a.legacy_obstacle_association;
+  c.obstacles.obstacle_association_force_inclusion_factor = a.obstacle_association_force_inclusion_factor;
+  c.obstacles.obstacle_association_cutoff_factor = a.obstacle_association_cutoff_factor;
+  c.optim.no_inner_iterations = a.no_inner_iterations; c.optim.no_outer_iterations = a.no_outer_iterations;
+  c.optim.optimization_activate = a.optimization_activate; c.optim.optimization_verbose = false;
+  c.optim.weight_max_vel_x = a.weight_max_vel_x; c.optim.weight_max_vel_y = a.weight_max_vel_y;
+  c.optim.weight_max_vel_theta = a.weight_max_vel_theta; c.optim.weight_acc_lim_x = a.weight_acc_lim_x;
+  c.optim.weight_acc_lim_y = a.weight_acc_lim_y; c.optim.weight_acc_lim_theta = a.weight_acc_lim_theta;
+  c.optim.weight_kinematics_nh = a.weight_kinematics_nh; c.optim.weight_kinematics_forward_drive = a.weight_kinematics_forward_drive;
+  c.optim.weight_kinematics_turning_radius = a.weight_kinematics_turning_radius; c.optim.weight_optimaltime = a.weight_optimaltime;
+  c.optim.weight_shortest_path = a.weight_shortest_path; c.optim.weight_obstacle = a.weight_obstacle;
+  c.optim.weight_inflation = a.weight_inflation; c.optim.weight_dynamic_obstacle = a.weight_dynamic_obstacle;
+  c.optim.weight_dynamic_obstacle_inflation = a.weight_dynamic_obstacle_inflation;
+  c.optim.weight_velocity_obstacle_ratio = a.weight_velocity_obstacle_ratio; c.optim.weight_viapoint = a.weight_viapoint;
+  c.optim.weight_prefer_rotdir = a.weight_prefer_rotdir; c.optim.weight_adapt_factor = a.weight_adapt_factor;
+  c.hcp.selection_cost_hysteresis = a.selection_cost_hysteresis; c.hcp.selection_prefer_initial_plan = a.selection_prefer_initial_plan;
+  c.hcp.selection_obst_cost_scale = a.selection_obst_cost_scale; c.hcp.selection_viapoint_cost_scale = a.selection_viapoint_cost_scale;
+  c.hcp.selection_alternative_time_cost = a.selection_alternative_time_cost;
+  c.recovery.divergence_detection_enable = a.divergence_detection_enable;
+  c.recovery.divergence_detection_max_chi_squared = a.divergence_detection_max_chi_squared;
+  switch (a.footprint_type) {
+    case TEB_AMD_FOOTPRINT_POINT: c.robot_model = boost::make_shared<PointRobotFootprint>(); break;
+    case TEB_AMD_FOOTPRINT_CIRCULAR: c.robot_model = boost::make_shared<CircularRobotFootprint>(a.footprint_radius); break;
+    case TEB_AMD_FOOTPRINT_TWO_CIRCLES:
+      c.robot_model = boost::make_shared<TwoCirclesRobotFootprint>(a.footprint_front_offset, a.footprint_front_radius,
+                                                                  a.footprint_rear_offset, a.footprint_rear_radius);
+      break;
+    case TEB_AMD_FOOTPRINT_LINE:
+      c.robot_model = boost::make_shared<LineRobotFootprint>(Eigen::Vector2d(a.footprint_vx[0], a.footprint_vy[0]),
+                                                            Eigen::Vector2d(a.footprint_vx[1], a.footprint_vy[1]), 0.0);
+      break;
+    default: {
+      Point2dContainer v;
+      for (int i = 0; i < a.footprint_n_vertices; ++i) v.push_back(Eigen::Vector2d(a.footprint_vx[i], a.footprint_vy[i]));
+      c.robot_model = boost::make_shared<PolygonRobotFootprint>(v);
+    }
+  }
+}
+
+inline void to_ref_obstacles(const teb_amd_obstacles_t* o, ObstContainer& out) {
+  out.clear();
+  if (!o) return;
+  for (int i = 0; i < o->count; ++i) {
+    ObstaclePtr p;
+    switch (o->type[i]) {
+      case TEB_AMD_OBST_POINT: p = boost::make_shared<PointObstacle>(o->ax[i], o->ay[i]); break;
+      case TEB_AMD_OBST_CIRCULAR: p = boost::make_shared<CircularObstacle>(o->ax[i], o->ay[i], o->radius[i]); break;
+      case TEB_AMD_OBST_LINE: p = boost::make_shared<LineObstacle>(o->ax[i], o->ay[i], o->bx[i], o->by[i]); break;
+      case TEB_AMD_OBST_PILL: p = boost::make_shared<PillObstacle>(o->ax[i], o->ay[i], o->bx[i], o->by[i], o->radius[i]); break;
+      default: {
+        auto q = boost::make_shared<PolygonObstacle>();
+        for (int k = o->vert_offset[i]; k < o->vert_offset[i + 1]; ++k) q->pushBackVertex(o->vert_x[k], o->vert_y[k]);
+        q->finalizePolygon();
+        p = q;
+      }
+    }
+    if (o->dynamic && o->dynamic[i]) p->setCentroidVelocity(Eigen::Vector2d(o->vx[i], o->vy[i]));
+    out.push_back(p);
+  }
+}
+
+// TebOptimalPlanner with its protected graph builders exposed (the class is the reference's; nothing is overridden)
+struct PlannerProbe : public TebOptimalPlanner {
+  using TebOptimalPlanner::TebOptimalPlanner;
+  using TebOptimalPlanner::buildGraph;
+  using TebOptimalPlanner::clearGraph;
+};
+
+inline int edge_type_code(g2o::OptimizableGraph::Edge* e) {   // EType numbering of teb_oracle.h (teb_oracle_edges)
+  if (dynamic_cast<EdgeInflatedObstacle*>(e)) return 1;
+  if (dynamic_cast<EdgeObstacle*>(e)) return 0;
+  if (dynamic_cast<EdgeDynamicObstacle*>(e)) return 2;
+  if (dynamic_cast<EdgeViaPoint*>(e)) return 3;
+  if (dynamic_cast<EdgeVelocityHolonomic*>(e)) return 5;
+  if (dynamic_cast<EdgeVelocity*>(e)) return 4;
+  if (dynamic_cast<EdgeAccelerationHolonomicStart*>(e)) return 10;
+  if (dynamic_cast<EdgeAccelerationHolonomicGoal*>(e)) return 11;
+  if (dynamic_cast<EdgeAccelerationHolonomic*>(e)) return 9;
+  if (dynamic_cast<EdgeAccelerationStart*>(e)) return 7;
+  if (dynamic_cast<EdgeAccelerationGoal*>(e)) return 8;
+  if (dynamic_cast<EdgeAcceleration*>(e)) return 6;
+  if (dynamic_cast<EdgeTimeOptimal*>(e)) return 12;
+  if (dynamic_cast<EdgeShortestPath*>(e)) return 13;
+  if (dynamic_cast<EdgeKinematicsDiffDrive*>(e)) return 14;
+  if (dynamic_cast<EdgeKinematicsCarlike*>(e)) return 15;
+  if (dynamic_cast<EdgePreferRotDir*>(e)) return 16;
+  if (dynamic_cast<EdgeVelocityObstacleRatio*>(e)) return 17;
+  return -1;
+}
+
+inline void fill_planner(TebOptimalPlanner& pl, int n, const double* x, const double* y, const double* th, const double* dt,
+                  int has_vs, const double* vs, int has_vg, const double* vg, int rotdir) {
+  TimedElasticBand& teb = pl.teb();
+  teb.addPose(x[0], y[0], th[0], true);
+  for (int i = 1; i < n; ++i) teb.addPoseAndTimeDiff(x[i], y[i], th[i], dt[i - 1]);
+  teb.setPoseVertexFixed(n - 1, true);
+  if (has_vs) { geometry_msgs::Twist t; t.linear.x = vs[0]; t.linear.y = vs[1]; t.angular.z = vs[2]; pl.setVelocityStart(t); }
+  if (has_vg) { geometry_msgs::Twist t; t.linear.x = vg[0]; t.linear.y = vg[1]; t.angular.z = vg[2]; pl.setVelocityGoal(t); }
+  else pl.setVelocityGoalFree();
+  pl.setPreferredTurningDir(rotdir == TEB_AMD_ROT_LEFT ? RotType::left : rotdir == TEB_AMD_ROT_RIGHT ? RotType::right : RotType::none);
+}
+
+}  // namespace refshim
+

@@ -145,7 +145,7 @@ struct teb_amd_handle {
   DevBuf<int> o_type, o_dyn, o_voff, o_static, o_dynidx;
   DevBuf<double> o_ax, o_ay, o_bx, o_by, o_rad, o_vx, o_vy, o_cx, o_cy, o_pvx, o_pvy, viax, viay;
   // batch
-  DevBuf<int> n, has_vs, has_vg, rotdir, via_en, status, iters, trials, assoc_cnt, assoc, assoc_ovf, via_pose;
+  DevBuf<int> n, has_vs, has_vg, rotdir, via_en, status, iters, trials, assoc_cnt, assoc, assoc_ovf, via_pose, legacy_idx;
   DevBuf<double> x, y, th, dt, vs, vg, chi2, cost, lambda, Hbackup, rs_scratch;
   // snapshot
   DevBuf<int> snap_n;
@@ -187,7 +187,7 @@ BatchDev batch_of(teb_amd_handle* h) {
   b.status = h->status.p; b.iters = h->iters.p; b.trials = h->trials.p;
   b.chi2 = h->chi2.p; b.cost = h->cost.p; b.lambda = h->lambda.p;
   b.assoc_cnt = h->assoc_cnt.p; b.assoc = h->assoc.p; b.assoc_cap = h->max_obst > 0 ? h->max_obst : 1;
-  b.assoc_overflow = h->assoc_ovf.p;
+  b.assoc_overflow = h->assoc_ovf.p; b.legacy_idx = h->legacy_idx.p;
   b.via_pose = h->via_pose.p; b.via_cap = h->max_via > 0 ? h->max_via : 1;
   b.Hbackup = h->Hbackup.p; b.hmat_stride = h->hmat_stride; b.rs_scratch = h->rs_scratch.p;
   return b;
@@ -201,11 +201,22 @@ int validate_config(const teb_amd_config_t* c) {
   if (c->footprint_type == TEB_AMD_FOOTPRINT_POLYGON &&
       (c->footprint_n_vertices < 1 || c->footprint_n_vertices > TEB_AMD_MAX_FOOTPRINT_VERTICES))
     return fail(TEB_AMD_ERR_INVALID_ARG, "polygon footprint needs 1..16 vertices");
-  if (c->jacobian_mode != TEB_AMD_JACOBIAN_ANALYTIC)
-    return fail(TEB_AMD_ERR_UNSUPPORTED, "GPU path implements TEB_AMD_JACOBIAN_ANALYTIC only");
-  if (c->legacy_obstacle_association)
-    return fail(TEB_AMD_ERR_UNSUPPORTED, "legacy_obstacle_association is not implemented on the GPU path yet");
+  if (c->jacobian_mode != TEB_AMD_JACOBIAN_ANALYTIC && c->jacobian_mode != TEB_AMD_JACOBIAN_G2O_NUMERIC)
+    return fail(TEB_AMD_ERR_INVALID_ARG, "jacobian_mode must be TEB_AMD_JACOBIAN_ANALYTIC or TEB_AMD_JACOBIAN_G2O_NUMERIC");
   return TEB_AMD_OK;
+}
+
+typedef void (*opt_kernel_t)(const teb_amd_config_t, const SceneDev, const BatchDev, const OptArgs, const LdsPlan);
+opt_kernel_t opt_kernel(int solver, int jmode) {
+  if (jmode == TEB_AMD_JACOBIAN_G2O_NUMERIC)
+    return solver == SOLVER_CR ? teb_optimize_kernel<SOLVER_CR, TEB_AMD_JACOBIAN_G2O_NUMERIC>
+                               : teb_optimize_kernel<SOLVER_BAND, TEB_AMD_JACOBIAN_G2O_NUMERIC>;
+  return solver == SOLVER_CR ? teb_optimize_kernel<SOLVER_CR, TEB_AMD_JACOBIAN_ANALYTIC>
+                             : teb_optimize_kernel<SOLVER_BAND, TEB_AMD_JACOBIAN_ANALYTIC>;
+}
+void launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const BatchDev& bt, const OptArgs& a) {
+  hipLaunchKernelGGL(opt_kernel(h->solver, h->cfg.jacobian_mode), dim3(grid), dim3(kThreads), h->plan.total_bytes, h->stream,
+                     h->cfg, sc, bt, a, h->plan);
 }
 
 int launch(teb_amd_handle* h, const OptArgs& args) {
@@ -214,10 +225,7 @@ int launch(teb_amd_handle* h, const OptArgs& args) {
   BatchDev bt = batch_of(h);
   HIPCHK(hipMemsetAsync(h->assoc_ovf.p, 0, sizeof(int) * h->max_tebs, h->stream));
   HIPCHK(hipEventRecord(h->ev0, h->stream));
-  if (h->solver == SOLVER_CR)
-    hipLaunchKernelGGL(teb_optimize_kernel<SOLVER_CR>, dim3(h->B), dim3(kThreads), h->plan.total_bytes, h->stream, h->cfg, sc, bt, args, h->plan);
-  else
-    hipLaunchKernelGGL(teb_optimize_kernel<SOLVER_BAND>, dim3(h->B), dim3(kThreads), h->plan.total_bytes, h->stream, h->cfg, sc, bt, args, h->plan);
+  launch_opt(h, h->B, sc, bt, args);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   h->timed = true;
@@ -317,7 +325,7 @@ int teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_po
   A(h->viax.alloc(max_via_points)); A(h->viay.alloc(max_via_points));
   A(h->n.alloc(max_tebs)); A(h->has_vs.alloc(max_tebs)); A(h->has_vg.alloc(max_tebs)); A(h->rotdir.alloc(max_tebs));
   A(h->via_en.alloc(max_tebs)); A(h->status.alloc(max_tebs)); A(h->iters.alloc(max_tebs)); A(h->trials.alloc(max_tebs));
-  A(h->assoc_cnt.alloc(BS)); A(h->assoc.alloc(BS * Mo)); A(h->assoc_ovf.alloc(max_tebs));
+  A(h->assoc_cnt.alloc(BS)); A(h->assoc.alloc(BS * Mo)); A(h->assoc_ovf.alloc(max_tebs)); A(h->legacy_idx.alloc((size_t)max_tebs * Mo));
   A(h->via_pose.alloc((size_t)max_tebs * (max_via_points > 0 ? max_via_points : 1)));
   A(h->x.alloc(BS)); A(h->y.alloc(BS)); A(h->th.alloc(BS)); A(h->dt.alloc(BS));
   A(h->vs.alloc(3 * (size_t)max_tebs)); A(h->vg.alloc(3 * (size_t)max_tebs));
@@ -328,9 +336,9 @@ int teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_po
   A(h->sel_cost.alloc(1)); A(h->sel_idx.alloc(1));
   if (ok && hipEventCreate(&h->ev0) != hipSuccess) ok = false;
   if (ok && hipEventCreate(&h->ev1) != hipSuccess) ok = false;
-  if (ok && hipFuncSetAttribute(solver == SOLVER_CR ? reinterpret_cast<const void*>(teb_optimize_kernel<SOLVER_CR>)
-                                                    : reinterpret_cast<const void*>(teb_optimize_kernel<SOLVER_BAND>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit) != hipSuccess) ok = false;
+  for (int jm : {TEB_AMD_JACOBIAN_ANALYTIC, TEB_AMD_JACOBIAN_G2O_NUMERIC})
+    if (ok && hipFuncSetAttribute(reinterpret_cast<const void*>(opt_kernel(solver, jm)),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit) != hipSuccess) ok = false;
   if (ok && hipMemset(h->cost.p, 0, sizeof(double) * max_tebs) != hipSuccess) ok = false;
   if (!ok) { teb_amd_destroy(h); return fail(TEB_AMD_ERR_HIP, "device allocation / kernel attribute setup failed"); }
   *out = h;
@@ -342,7 +350,7 @@ void teb_amd_destroy(teb_amd_handle_t* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   DevBuf<int>* ib[] = {&h->o_type, &h->o_dyn, &h->o_voff, &h->o_static, &h->o_dynidx, &h->n, &h->has_vs, &h->has_vg, &h->rotdir,
-                       &h->via_en, &h->status, &h->iters, &h->trials, &h->assoc_cnt, &h->assoc, &h->assoc_ovf, &h->via_pose,
+                       &h->via_en, &h->status, &h->iters, &h->trials, &h->assoc_cnt, &h->assoc, &h->assoc_ovf, &h->via_pose, &h->legacy_idx,
                        &h->snap_n, &h->sel_idx};
   for (auto* q : ib) q->free();
   DevBuf<double>* db[] = {&h->o_ax, &h->o_ay, &h->o_bx, &h->o_by, &h->o_rad, &h->o_vx, &h->o_vy, &h->o_cx, &h->o_cy, &h->o_pvx,
@@ -645,10 +653,7 @@ int teb_amd_debug_linearize(teb_amd_handle_t* h, int32_t b, double weight_multip
   HIPCHK(hipMemcpy(&sv_d[0], h->chi2.p + b, sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(&sv_d[1], h->cost.p + b, sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(&sv_d[2], h->lambda.p + b, sizeof(double), hipMemcpyDeviceToHost));
-  if (h->solver == SOLVER_CR)
-    hipLaunchKernelGGL(teb_optimize_kernel<SOLVER_CR>, dim3(1), dim3(kThreads), h->plan.total_bytes, h->stream, h->cfg, sc, bt, a, h->plan);
-  else
-    hipLaunchKernelGGL(teb_optimize_kernel<SOLVER_BAND>, dim3(1), dim3(kThreads), h->plan.total_bytes, h->stream, h->cfg, sc, bt, a, h->plan);
+  launch_opt(h, 1, sc, bt, a);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipMemcpy(h->status.p + b, &sv_i[0], sizeof(int), hipMemcpyHostToDevice));
@@ -683,8 +688,11 @@ int teb_amd_debug_linearize(teb_amd_handle_t* h, int32_t b, double weight_multip
     int k = 0;
     for (int i = 1; i < n - 1; ++i)
       for (int q = 0; q < cnt[i]; ++q) {
-        if (k < assoc_cap) { if (assoc_pose) assoc_pose[k] = i; if (assoc_obst) assoc_obst[k] = h->host_static[lst[(size_t)q * h->stride + i]]; }
-        ++k;
+        const int ent = lst[(size_t)q * h->stride + i];
+        for (int rep = (ent & kAssocTriple) ? 3 : 1; rep > 0; --rep) {
+          if (k < assoc_cap) { if (assoc_pose) assoc_pose[k] = i; if (assoc_obst) assoc_obst[k] = h->host_static[ent & kAssocMask]; }
+          ++k;
+        }
       }
     *assoc_count = k;
   }

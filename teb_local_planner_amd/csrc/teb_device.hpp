@@ -52,6 +52,9 @@ struct SceneDev {
   const double *viax, *viay;
 };
 
+constexpr int kAssocTriple = 1 << 30;   // legacy association adds the edge at the closest pose three times (:583-641)
+constexpr int kAssocMask = kAssocTriple - 1;
+
 struct BatchDev {
   int B, stride;
   int* n;
@@ -71,9 +74,10 @@ struct BatchDev {
   double* lambda;
   // scratch
   int* assoc_cnt;   // [B][stride]
-  int* assoc;       // [B][assoc_cap][stride]
+  int* assoc;       // [B][assoc_cap][stride]; entry = position in the static list, | kAssocTriple for 3 identical edges
   int assoc_cap;
   int* assoc_overflow;  // [B]
+  int* legacy_idx;  // [B][assoc_cap] closest pose per static obstacle (legacy association only)
   int* via_pose;    // [B][via_cap]
   int via_cap;
   double* Hbackup;  // [B][hmat_stride]

@@ -140,9 +140,76 @@ struct Win {   // thread-local copy of the window state (+ cached cos/sin of the
   double c0, s0, c1, s1;
 };
 
+// ---- g2o numeric differentiation (TEB_AMD_JACOBIAN_G2O_NUMERIC) ----------------------------------------------------
+// Base{Unary,Binary,Multi}Edge::linearizeOplus of libg2o: per vertex dimension d, push; oplus(+delta e_d); computeError;
+// pop; push; oplus(-delta e_d); computeError; pop; column = (1 / (2 delta)) * (e+ - e-), delta = 1e-9.
+// RowRec stands in for Accum while an edge is only evaluated: it records the residual rows in order.
+struct RowRec {
+  double e[3], wgt[3];
+  int n;
+  __device__ __forceinline__ RowRec() : n(0) {}
+  template <unsigned MASK, bool JAC>
+  __device__ __forceinline__ void row(int, double e_, double w_, const double*) {
+    e[n] = e_; wgt[n] = w_; ++n;
+  }
+};
+
+// VertexPose::oplusImpl / VertexTimeDiff::oplusImpl on window column Q (x += d, y += d, theta = normalize_theta(theta + d),
+// dt += d; vertex_pose.h:195-198, vertex_timediff.h:113-116); the cached cos/sin follow theta.
+template <int Q>
+__device__ __forceinline__ Win oplus_column(const Win& w, double d) {
+  Win p = w;
+  if (Q == 0) p.x0 += d;
+  if (Q == 1) p.y0 += d;
+  if (Q == 2) { p.t0 = normalize_theta(p.t0 + d); p.c0 = cos(p.t0); p.s0 = sin(p.t0); }
+  if (Q == 3) p.d0 += d;
+  if (Q == 4) p.x1 += d;
+  if (Q == 5) p.y1 += d;
+  if (Q == 6) { p.t1 = normalize_theta(p.t1 + d); p.c1 = cos(p.t1); p.s1 = sin(p.t1); }
+  if (Q == 7) p.d1 += d;
+  if (Q == 8) p.x2 += d;
+  if (Q == 9) p.y2 += d;
+  if (Q == 10) p.t2 = normalize_theta(p.t2 + d);
+  return p;
+}
+
+template <unsigned VMASK, int Q, class F>
+__device__ __forceinline__ void numeric_column(const Win& w, F& f, double (*J)[11]) {
+  if ((VMASK >> Q) & 1u) {
+    const double delta = 1e-9;
+    const double scalar = 1.0 / (2 * delta);
+    RowRec ep, em;
+    f(oplus_column<Q>(w, delta), ep);
+    f(oplus_column<Q>(w, -delta), em);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (k < ep.n) J[k][Q] = scalar * (ep.e[k] - em.e[k]);
+  }
+}
+
+// One edge in numeric mode: f(window, accumulator) evaluates the edge's residual rows (error only). VMASK = the window
+// columns of the edge's vertices, CAT its cost category. The rows then enter the accumulator exactly like analytic rows.
+template <unsigned VMASK, int CAT, class F>
+__device__ __forceinline__ void numeric_edge(const Win& w, Accum& A, F f) {
+  RowRec base;
+  f(w, base);
+  double J[3][11];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int q = 0; q < 11; ++q) J[k][q] = 0;
+  numeric_column<VMASK, 0>(w, f, J); numeric_column<VMASK, 1>(w, f, J); numeric_column<VMASK, 2>(w, f, J);
+  numeric_column<VMASK, 3>(w, f, J); numeric_column<VMASK, 4>(w, f, J); numeric_column<VMASK, 5>(w, f, J);
+  numeric_column<VMASK, 6>(w, f, J); numeric_column<VMASK, 7>(w, f, J); numeric_column<VMASK, 8>(w, f, J);
+  numeric_column<VMASK, 9>(w, f, J); numeric_column<VMASK, 10>(w, f, J);
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (k < base.n) A.template row<VMASK, true>(CAT, base.e[k], base.wgt[k], J[k]);
+}
+
 // ---- EdgeVelocity --------------------------------------------------------------------------------------
-template <bool JAC>
-__device__ __forceinline__ void edge_velocity(const teb_amd_config_t& c, const Win& w, Accum& A) {
+template <bool JAC, class ACC>
+__device__ __forceinline__ void edge_velocity(const teb_amd_config_t& c, const Win& w, ACC& A) {
   double v, om, dv[7];
   signed_velocity<JAC>(c, w.x0, w.y0, w.t0, w.c0, w.s0, w.x1, w.y1, w.t1, w.d0, v, om, dv);
   double sv, sw;
@@ -165,8 +232,8 @@ __device__ __forceinline__ void edge_velocity(const teb_amd_config_t& c, const W
 }
 
 // ---- EdgeVelocityHolonomic -----------------------------------------------------------------------------
-template <bool JAC>
-__device__ __forceinline__ void edge_velocity_holonomic(const teb_amd_config_t& c, const Win& w, Accum& A) {
+template <bool JAC, class ACC>
+__device__ __forceinline__ void edge_velocity_holonomic(const teb_amd_config_t& c, const Win& w, ACC& A) {
   double dtv = w.d0;
   double dx = w.x1 - w.x0, dy = w.y1 - w.y0;
   double c1 = w.c0, s1 = w.s0;
@@ -225,8 +292,8 @@ __device__ __forceinline__ void edge_velocity_holonomic(const teb_amd_config_t& 
 }
 
 // ---- EdgeAcceleration (poses i, i+1, i+2; dt_i, dt_{i+1}) -------------------------------------------------
-template <bool JAC>
-__device__ __forceinline__ void edge_acceleration(const teb_amd_config_t& c, const Win& w, Accum& A) {
+template <bool JAC, class ACC>
+__device__ __forceinline__ void edge_acceleration(const teb_amd_config_t& c, const Win& w, ACC& A) {
   double v1, o1, v2, o2, d1[7], d2[7];
   signed_velocity<JAC>(c, w.x0, w.y0, w.t0, w.c0, w.s0, w.x1, w.y1, w.t1, w.d0, v1, o1, d1);
   signed_velocity<JAC>(c, w.x1, w.y1, w.t1, w.c1, w.s1, w.x2, w.y2, w.t2, w.d1, v2, o2, d2);
@@ -261,9 +328,9 @@ __device__ __forceinline__ void edge_acceleration(const teb_amd_config_t& c, con
 }
 
 // ---- EdgeAccelerationStart / Goal: segment (pose a = window pose 0, pose b = window pose 1, dt0) ---------
-template <bool JAC, bool START>
+template <bool JAC, bool START, class ACC>
 __device__ __forceinline__ void edge_acceleration_se(const teb_amd_config_t& c, const Win& w, double vlin,
-                                                     double vang, Accum& A) {
+                                                     double vang, ACC& A) {
   double v, om, dv[7];
   double dtv = w.d0;
   signed_velocity<JAC>(c, w.x0, w.y0, w.t0, w.c0, w.s0, w.x1, w.y1, w.t1, dtv, v, om, dv);
@@ -294,8 +361,8 @@ __device__ __forceinline__ void edge_acceleration_se(const teb_amd_config_t& c, 
 }
 
 // ---- holonomic accelerations -----------------------------------------------------------------------------
-template <bool JAC>
-__device__ __forceinline__ void edge_acceleration_holonomic(const teb_amd_config_t& c, const Win& w, Accum& A) {
+template <bool JAC, class ACC>
+__device__ __forceinline__ void edge_acceleration_holonomic(const teb_amd_config_t& c, const Win& w, ACC& A) {
   double dt1 = w.d0, dt2 = w.d1;
   double d1x = w.x1 - w.x0, d1y = w.y1 - w.y0, d2x = w.x2 - w.x1, d2y = w.y2 - w.y1;
   double c1 = w.c0, s1 = w.s0, c2 = w.c1, s2 = w.s1;
@@ -347,9 +414,9 @@ __device__ __forceinline__ void edge_acceleration_holonomic(const teb_amd_config
   }
 }
 
-template <bool JAC, bool START>
+template <bool JAC, bool START, class ACC>
 __device__ __forceinline__ void edge_acceleration_holonomic_se(const teb_amd_config_t& c, const Win& w,
-                                                               const double* vel /* vx, vy, omega */, Accum& A) {
+                                                               const double* vel /* vx, vy, omega */, ACC& A) {
   double dtv = w.d0;
   double dx = w.x1 - w.x0, dy = w.y1 - w.y0;
   double c1 = w.c0, s1 = w.s0;
@@ -407,8 +474,8 @@ __device__ __forceinline__ double kin_nh(const Win& w, double* r /* cols 0,1,2,4
   return fabs(val);
 }
 
-template <bool JAC>
-__device__ __forceinline__ void edge_kinematics_diffdrive(const teb_amd_config_t& c, const Win& w, Accum& A) {
+template <bool JAC, class ACC>
+__device__ __forceinline__ void edge_kinematics_diffdrive(const teb_amd_config_t& c, const Win& w, ACC& A) {
   double r[11];
   if (JAC) {
 #pragma unroll
@@ -427,8 +494,8 @@ __device__ __forceinline__ void edge_kinematics_diffdrive(const teb_amd_config_t
   A.template row<0x037, JAC>(CAT_OTHER, e1, c.weight_kinematics_forward_drive, r);
 }
 
-template <bool JAC>
-__device__ __forceinline__ void edge_kinematics_carlike(const teb_amd_config_t& c, const Win& w, Accum& A) {
+template <bool JAC, class ACC>
+__device__ __forceinline__ void edge_kinematics_carlike(const teb_amd_config_t& c, const Win& w, ACC& A) {
   double r[11];
   if (JAC) {
 #pragma unroll
@@ -468,8 +535,8 @@ __device__ __forceinline__ void edge_kinematics_carlike(const teb_amd_config_t& 
 }
 
 // ---- EdgeShortestPath / EdgePreferRotDir / EdgeTimeOptimal ------------------------------------------------
-template <bool JAC>
-__device__ __forceinline__ void edge_shortest_path(const teb_amd_config_t& c, const Win& w, Accum& A) {
+template <bool JAC, class ACC>
+__device__ __forceinline__ void edge_shortest_path(const teb_amd_config_t& c, const Win& w, ACC& A) {
   double dx = w.x1 - w.x0, dy = w.y1 - w.y0;
   double nn = sqrt(dx * dx + dy * dy);
   double r[11];
@@ -481,8 +548,8 @@ __device__ __forceinline__ void edge_shortest_path(const teb_amd_config_t& c, co
   A.template row<0x033, JAC>(CAT_OTHER, nn, c.weight_shortest_path, r);
 }
 
-template <bool JAC>
-__device__ __forceinline__ void edge_prefer_rotdir(const teb_amd_config_t& c, const Win& w, double dir, Accum& A) {
+template <bool JAC, class ACC>
+__device__ __forceinline__ void edge_prefer_rotdir(const teb_amd_config_t& c, const Win& w, double dir, ACC& A) {
   double dev;
   double e = pen_below(dir * normalize_theta(w.t1 - w.t0), 0, 0, dev);
   double r[11];
@@ -494,8 +561,8 @@ __device__ __forceinline__ void edge_prefer_rotdir(const teb_amd_config_t& c, co
   A.template row<0x044, JAC>(CAT_OTHER, e, c.weight_prefer_rotdir, r);
 }
 
-template <bool JAC>
-__device__ __forceinline__ void edge_time_optimal(const teb_amd_config_t& c, const Win& w, Accum& A) {
+template <bool JAC, class ACC>
+__device__ __forceinline__ void edge_time_optimal(const teb_amd_config_t& c, const Win& w, ACC& A) {
   double r[11];
   if (JAC) {
 #pragma unroll
@@ -507,9 +574,9 @@ __device__ __forceinline__ void edge_time_optimal(const teb_amd_config_t& c, con
 
 // ---- unary pose edges (pose i = window pose 0) --------------------------------------------------------------
 // EdgeObstacle / EdgeInflatedObstacle (static, weight_obstacle * multiplier) and EdgeDynamicObstacle
-template <bool JAC>
+template <bool JAC, class ACC>
 __device__ __forceinline__ void edge_obstacle(const teb_amd_config_t& c, const SceneDev& sc, int oi, const Win& w,
-                                              double w_obst, bool inflated, Accum& A) {
+                                              double w_obst, bool inflated, ACC& A) {
   double gr[3];
   double dist = footprint_distance(c, sc, oi, w.x0, w.y0, w.c0, w.s0, false, 0.0, JAC ? gr : nullptr);
   double d0;
@@ -533,9 +600,9 @@ __device__ __forceinline__ void edge_obstacle(const teb_amd_config_t& c, const S
   }
 }
 
-template <bool JAC>
+template <bool JAC, class ACC>
 __device__ __forceinline__ void edge_dynamic_obstacle(const teb_amd_config_t& c, const SceneDev& sc, int oi,
-                                                      const Win& w, double t, Accum& A) {
+                                                      const Win& w, double t, ACC& A) {
   double gr[3];
   double dist = footprint_distance(c, sc, oi, w.x0, w.y0, w.c0, w.s0, true, t, JAC ? gr : nullptr);
   double d0, d1;
@@ -548,9 +615,9 @@ __device__ __forceinline__ void edge_dynamic_obstacle(const teb_amd_config_t& c,
   A.template row<M_POSE0, JAC>(CAT_OBST, e1, c.weight_dynamic_obstacle_inflation, r);
 }
 
-template <bool JAC>
+template <bool JAC, class ACC>
 __device__ __forceinline__ void edge_via_point(const teb_amd_config_t& c, double vx, double vy, const Win& w,
-                                               Accum& A) {
+                                               ACC& A) {
   double dx = w.x0 - vx, dy = w.y0 - vy;
   double nn = sqrt(dx * dx + dy * dy);
   double r[11];
@@ -580,9 +647,9 @@ __device__ __forceinline__ double pointlike_distance(const teb_amd_config_t& c, 
   return dist;
 }
 
-template <bool JAC>
+template <bool JAC, class ACC>
 __device__ __forceinline__ void edge_obstacle_fast(const teb_amd_config_t& c, double ox, double oy, double orad, const Win& w,
-                                                   double w_obst, bool inflated, Accum& A) {
+                                                   double w_obst, bool inflated, ACC& A) {
   double gr[2];
   double dist = pointlike_distance<JAC>(c, w.x0, w.y0, ox, oy, orad, gr);
   double d0;
@@ -608,8 +675,8 @@ __device__ __forceinline__ void edge_obstacle_fast(const teb_amd_config_t& c, do
 
 // residual rows of EdgeDynamicObstacle given the distance and its gradient (split from the distance so that
 // several obstacles can be in flight at once: the sqrt / divide chains of independent obstacles interleave)
-template <bool JAC>
-__device__ __forceinline__ void dynamic_obstacle_rows(const teb_amd_config_t& c, double dist, const double* gr, Accum& A) {
+template <bool JAC, class ACC>
+__device__ __forceinline__ void dynamic_obstacle_rows(const teb_amd_config_t& c, double dist, const double* gr, ACC& A) {
   double d0, d1;
   double e0 = pen_below(dist, c.min_obstacle_dist, c.penalty_epsilon, d0);
   double e1 = pen_below(dist, c.dynamic_obstacle_inflation_dist, 0.0, d1);
@@ -620,18 +687,18 @@ __device__ __forceinline__ void dynamic_obstacle_rows(const teb_amd_config_t& c,
   A.template row<0x003, JAC>(CAT_OBST, e1, c.weight_dynamic_obstacle_inflation, r);
 }
 
-template <bool JAC>
+template <bool JAC, class ACC>
 __device__ __forceinline__ void edge_dynamic_obstacle_fast(const teb_amd_config_t& c, double ox, double oy, double orad,
-                                                           const Win& w, Accum& A) {
+                                                           const Win& w, ACC& A) {
   double gr[2];
   double dist = pointlike_distance<JAC>(c, w.x0, w.y0, ox, oy, orad, gr);
   dynamic_obstacle_rows<JAC>(c, dist, gr, A);
 }
 
 // ---- EdgeVelocityObstacleRatio (pose i, pose i+1, dt_i, obstacle) ------------------------------------------
-template <bool JAC>
+template <bool JAC, class ACC>
 __device__ __forceinline__ void edge_velocity_obstacle_ratio(const teb_amd_config_t& c, double dobs, const double* gr,
-                                                             const Win& w, Accum& A) {
+                                                             const Win& w, ACC& A) {
   // dobs, gr: calculateDistance(conf1->pose(), obstacle) and its gradient w.r.t. pose i
   double v, om, dv[7];
   signed_velocity<JAC>(c, w.x0, w.y0, w.t0, w.c0, w.s0, w.x1, w.y1, w.t1, w.d0, v, om, dv);

@@ -143,9 +143,23 @@ struct TebCtx {
 
 // All cost terms whose first vertex is pose i / timediff i (0 <= i <= n-2). JAC=true also accumulates
 // J^T Omega J and J^T Omega e into the thread-local window accumulator.
-template <bool JAC>
+// Edge dispatch of eval_index: MODE 0 = residuals only (computeActiveErrors), 1 = closed-form Jacobians,
+// 2 = g2o central differences over the residual code (the two edges the reference linearises analytically -
+// EdgeKinematicsDiffDrive edge_kinematics.h:112-149, EdgeTimeOptimal edge_time_optimal.h:93-99 - stay analytic).
+// Inside CALL the window is W, the accumulator ACC_ and the Jacobian switch J_.
+#define TEB_EDGE(VMASK, CAT, ...)                                                                                   \
+  do {                                                                                                                \
+    if constexpr (MODE == 2) {                                                                                        \
+      numeric_edge<VMASK, CAT>(w, A, [&](const Win& W, RowRec& ACC_) { constexpr bool J_ = false; __VA_ARGS__; });          \
+    } else {                                                                                                          \
+      const Win& W = w; Accum& ACC_ = A; constexpr bool J_ = (MODE == 1); __VA_ARGS__;                                    \
+    }                                                                                                                 \
+  } while (0)
+
+template <int MODE>
 __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const SceneDev& sc, const TebCtx& t,
                                            const Lds& l, int i, Accum& A) {
+  constexpr bool JAC = (MODE == 1);
   const int n = t.n;
   Win w;
   w.x0 = l.sx[i]; w.y0 = l.sy[i]; w.t0 = l.sth[i]; w.d0 = l.sdt[i];
@@ -161,90 +175,120 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
   const int cnt = t.assoc_cnt[i];
   if (i >= 1) {
     if (sc.fast_points) {
-      for (int k = 0; k < cnt; ++k) {
-        const int p = t.assoc[(size_t)k * t.stride + i];
-        edge_obstacle_fast<JAC>(c, l.obx[p], l.oby[p], l.obr[p], w, t.w_obst, t.inflated, A);
+      if (!c.legacy_obstacle_association) {
+        for (int k = 0; k < cnt; ++k) {
+          const int p = t.assoc[(size_t)k * t.stride + i];
+          const double ox = l.obx[p], oy = l.oby[p], orad = l.obr[p];
+          TEB_EDGE(M_POSE0, CAT_OBST, edge_obstacle_fast<J_>(c, ox, oy, orad, W, t.w_obst, t.inflated, ACC_));
+        }
+      } else {   // legacy lists carry the triple edge at the closest pose as one flagged entry
+        for (int k = 0; k < cnt; ++k) {
+          const int ent = t.assoc[(size_t)k * t.stride + i];
+          const int p = ent & kAssocMask;
+          const double ox = l.obx[p], oy = l.oby[p], orad = l.obr[p];
+#pragma unroll 1
+          for (int rep = (ent & kAssocTriple) ? 3 : 1; rep > 0; --rep)
+            TEB_EDGE(M_POSE0, CAT_OBST, edge_obstacle_fast<J_>(c, ox, oy, orad, W, t.w_obst, t.inflated, ACC_));
+        }
       }
       if (c.include_dynamic_obstacles && c.weight_obstacle != 0) {
         const double ti = l.tdyn[i];
         int k = 0;
-        for (; k + 4 <= sc.n_dyn; k += 4) {   // 4 obstacles in flight; rows are still accumulated in list order
-          double dist[4], gr[4][2];
+        if constexpr (MODE != 2) {
+          for (; k + 4 <= sc.n_dyn; k += 4) {   // 4 obstacles in flight; rows are still accumulated in list order
+            double dist[4], gr[4][2];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int p = sc.n_static + k + u;
-            // pos_ + t*centroid_velocity_ (obstacles.h:382-385)
-            dist[u] = pointlike_distance<JAC>(c, w.x0, w.y0, l.obx[p] + ti * l.obvx[p], l.oby[p] + ti * l.obvy[p], l.obr[p], gr[u]);
+            for (int u = 0; u < 4; ++u) {
+              const int p = sc.n_static + k + u;
+              // pos_ + t*centroid_velocity_ (obstacles.h:382-385)
+              dist[u] = pointlike_distance<JAC>(c, w.x0, w.y0, l.obx[p] + ti * l.obvx[p], l.oby[p] + ti * l.obvy[p], l.obr[p], gr[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dynamic_obstacle_rows<JAC>(c, dist[u], gr[u], A);
           }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) dynamic_obstacle_rows<JAC>(c, dist[u], gr[u], A);
         }
         for (; k < sc.n_dyn; ++k) {
           const int p = sc.n_static + k;
-          edge_dynamic_obstacle_fast<JAC>(c, l.obx[p] + ti * l.obvx[p], l.oby[p] + ti * l.obvy[p], l.obr[p], w, A);
+          const double ox = l.obx[p] + ti * l.obvx[p], oy = l.oby[p] + ti * l.obvy[p], orad = l.obr[p];
+          TEB_EDGE(M_POSE0, CAT_OBST, edge_dynamic_obstacle_fast<J_>(c, ox, oy, orad, W, ACC_));
         }
       }
     } else {
       for (int k = 0; k < cnt; ++k) {
-        const int oi = sc.static_idx[t.assoc[(size_t)k * t.stride + i]];
-        edge_obstacle<JAC>(c, sc, oi, w, t.w_obst, t.inflated, A);
+        const int ent = t.assoc[(size_t)k * t.stride + i];
+        const int oi = sc.static_idx[ent & kAssocMask];
+#pragma unroll 1
+        for (int rep = (ent & kAssocTriple) ? 3 : 1; rep > 0; --rep)
+          TEB_EDGE(M_POSE0, CAT_OBST, edge_obstacle<J_>(c, sc, oi, W, t.w_obst, t.inflated, ACC_));
       }
       if (c.include_dynamic_obstacles && c.weight_obstacle != 0) {
         const double ti = l.tdyn[i];
-        for (int k = 0; k < sc.n_dyn; ++k) edge_dynamic_obstacle<JAC>(c, sc, sc.dyn_idx[k], w, ti, A);
+        for (int k = 0; k < sc.n_dyn; ++k) {
+          const int oi = sc.dyn_idx[k];
+          TEB_EDGE(M_POSE0, CAT_OBST, edge_dynamic_obstacle<J_>(c, sc, oi, W, ti, ACC_));
+        }
       }
     }
     if (t.via_en && c.weight_viapoint != 0) {
       for (int v = 0; v < sc.nvia; ++v)
-        if (t.via_pose[v] == i) edge_via_point<JAC>(c, sc.viax[v], sc.viay[v], w, A);
+        if (t.via_pose[v] == i) {
+          const double vx = sc.viax[v], vy = sc.viay[v];
+          TEB_EDGE(M_POSE0, CAT_VIA, edge_via_point<J_>(c, vx, vy, W, ACC_));
+        }
     }
   }
   // ---- AddEdgesVelocity :720-769
   if (c.max_vel_y == 0) {
-    if (!(c.weight_max_vel_x == 0 && c.weight_max_vel_theta == 0)) edge_velocity<JAC>(c, w, A);
+    if (!(c.weight_max_vel_x == 0 && c.weight_max_vel_theta == 0)) TEB_EDGE(M_SEG, CAT_OTHER, edge_velocity<J_>(c, W, ACC_));
   } else {
     if (!(c.weight_max_vel_x == 0 && c.weight_max_vel_y == 0 && c.weight_max_vel_theta == 0))
-      edge_velocity_holonomic<JAC>(c, w, A);
+      TEB_EDGE(M_SEG, CAT_OTHER, edge_velocity_holonomic<J_>(c, W, ACC_));
   }
   // ---- AddEdgesAcceleration :771-873
   if (!(c.weight_acc_lim_x == 0 && c.weight_acc_lim_theta == 0)) {
     const bool nonholo = (c.max_vel_y == 0 || c.acc_lim_y == 0);
     if (nonholo) {
-      if (i == 0 && t.has_vs) edge_acceleration_se<JAC, true>(c, w, t.vs[0], t.vs[2], A);
-      if (has2) edge_acceleration<JAC>(c, w, A);
-      if (i == n - 2 && t.has_vg) edge_acceleration_se<JAC, false>(c, w, t.vg[0], t.vg[2], A);
+      if (i == 0 && t.has_vs) TEB_EDGE(M_SEG, CAT_OTHER, (edge_acceleration_se<J_, true>(c, W, t.vs[0], t.vs[2], ACC_)));
+      if (has2) TEB_EDGE(M_ALL, CAT_OTHER, edge_acceleration<J_>(c, W, ACC_));
+      if (i == n - 2 && t.has_vg) TEB_EDGE(M_SEG, CAT_OTHER, (edge_acceleration_se<J_, false>(c, W, t.vg[0], t.vg[2], ACC_)));
     } else {
-      if (i == 0 && t.has_vs) edge_acceleration_holonomic_se<JAC, true>(c, w, t.vs, A);
-      if (has2) edge_acceleration_holonomic<JAC>(c, w, A);
-      if (i == n - 2 && t.has_vg) edge_acceleration_holonomic_se<JAC, false>(c, w, t.vg, A);
+      if (i == 0 && t.has_vs) TEB_EDGE(M_SEG, CAT_OTHER, (edge_acceleration_holonomic_se<J_, true>(c, W, t.vs, ACC_)));
+      if (has2) TEB_EDGE(M_ALL, CAT_OTHER, edge_acceleration_holonomic<J_>(c, W, ACC_));
+      if (i == n - 2 && t.has_vg) TEB_EDGE(M_SEG, CAT_OTHER, (edge_acceleration_holonomic_se<J_, false>(c, W, t.vg, ACC_)));
     }
   }
-  // ---- AddEdgesTimeOptimal :877-893, AddEdgesShortestPath :895-912
-  if (c.weight_optimaltime != 0) edge_time_optimal<JAC>(c, w, A);
-  if (c.weight_shortest_path != 0 && seg_active) edge_shortest_path<JAC>(c, w, A);
-  // ---- kinematics :355-358, 916-958
+  // ---- AddEdgesTimeOptimal :877-893 (analytic in the reference), AddEdgesShortestPath :895-912
+  if (c.weight_optimaltime != 0) edge_time_optimal<MODE != 0>(c, w, A);
+  if (c.weight_shortest_path != 0 && seg_active) TEB_EDGE(M_POSE0 | M_POSE1, CAT_OTHER, edge_shortest_path<J_>(c, W, ACC_));
+  // ---- kinematics :355-358, 916-958 (diff-drive: analytic in the reference)
   if (seg_active) {
     if (c.min_turning_radius == 0 || c.weight_kinematics_turning_radius == 0) {
-      if (!(c.weight_kinematics_nh == 0 && c.weight_kinematics_forward_drive == 0)) edge_kinematics_diffdrive<JAC>(c, w, A);
+      if (!(c.weight_kinematics_nh == 0 && c.weight_kinematics_forward_drive == 0)) edge_kinematics_diffdrive<MODE != 0>(c, w, A);
     } else {
-      if (!(c.weight_kinematics_nh == 0 && c.weight_kinematics_turning_radius == 0)) edge_kinematics_carlike<JAC>(c, w, A);
+      if (!(c.weight_kinematics_nh == 0 && c.weight_kinematics_turning_radius == 0))
+        TEB_EDGE(M_POSE0 | M_POSE1, CAT_OTHER, edge_kinematics_carlike<J_>(c, W, ACC_));
     }
   }
   // ---- AddEdgesPreferRotDir :961-997
-  if (i < 3 && seg_active && c.weight_prefer_rotdir != 0 && (t.rotdir == TEB_AMD_ROT_LEFT || t.rotdir == TEB_AMD_ROT_RIGHT))
-    edge_prefer_rotdir<JAC>(c, w, t.rotdir == TEB_AMD_ROT_LEFT ? 1.0 : -1.0, A);
+  if (i < 3 && seg_active && c.weight_prefer_rotdir != 0 && (t.rotdir == TEB_AMD_ROT_LEFT || t.rotdir == TEB_AMD_ROT_RIGHT)) {
+    const double dir = t.rotdir == TEB_AMD_ROT_LEFT ? 1.0 : -1.0;
+    TEB_EDGE(M_POSE0 | M_POSE1, CAT_OTHER, edge_prefer_rotdir<J_>(c, W, dir, ACC_));
+  }
   // ---- AddEdgesVelocityObstacleRatio :999-1021
-  if (c.weight_velocity_obstacle_ratio > 0) {
+  if (c.weight_velocity_obstacle_ratio > 0 && !c.legacy_obstacle_association) {   // obstacles_per_vertex_ stays empty in legacy mode
     for (int k = 0; k < cnt; ++k) {
       const int p = t.assoc[(size_t)k * t.stride + i];
-      double gr[3] = {0, 0, 0};
-      double dobs;
-      if (sc.fast_points) dobs = pointlike_distance<JAC>(c, w.x0, w.y0, l.obx[p], l.oby[p], l.obr[p], gr);
-      else dobs = footprint_distance(c, sc, sc.static_idx[p], w.x0, w.y0, w.c0, w.s0, false, 0.0, JAC ? gr : nullptr);
-      edge_velocity_obstacle_ratio<JAC>(c, dobs, gr, w, A);
+      TEB_EDGE(M_SEG, CAT_OTHER, {
+        double gr[3] = {0, 0, 0};
+        double dobs;
+        if (sc.fast_points) dobs = pointlike_distance<J_>(c, W.x0, W.y0, l.obx[p], l.oby[p], l.obr[p], gr);
+        else dobs = footprint_distance(c, sc, sc.static_idx[p], W.x0, W.y0, W.c0, W.s0, false, 0.0, J_ ? gr : nullptr);
+        edge_velocity_obstacle_ratio<J_>(c, dobs, gr, W, ACC_);
+      });
     }
   }
 }
+#undef TEB_EDGE
 
 // scatter the thread-local window into the LDS normal matrix; rows/cols of fixed variables are dropped
 template <int SOLVER>
@@ -298,7 +342,7 @@ __device__ __forceinline__ void refresh_trig(const Lds& l, int n) {
 }
 
 // buildSystem: H = sum J^T Omega J, b = -sum J^T Omega e, and chi^2 per category at the current state.
-template <int SOLVER>
+template <int SOLVER, int JMODE>
 __device__ inline void linearize(const teb_amd_config_t& c, const SceneDev& sc, const TebCtx& t, const Lds& l,
                                  double* cats /*4, out on all threads*/) {
   const int n = t.n, Nt = 4 * n, tid = threadIdx.x;
@@ -313,7 +357,7 @@ __device__ inline void linearize(const teb_amd_config_t& c, const SceneDev& sc, 
     const int i = k0 + tid;
     const bool active = i <= n - 2;
     A.clear();
-    if (active) eval_index<true>(c, sc, t, l, i, A);
+    if (active) eval_index<JMODE == TEB_AMD_JACOBIAN_G2O_NUMERIC ? 2 : 1>(c, sc, t, l, i, A);
     for (int ph = 0; ph < 3; ++ph) {
       if (active && (i % 3) == ph) scatter<SOLVER>(A, l, i, n);
       __syncthreads();
@@ -336,7 +380,7 @@ __device__ inline void evaluate(const teb_amd_config_t& c, const SceneDev& sc, c
   __syncthreads();
   Accum A;   // only chi[] is live when JAC == false
   A.clear_chi();
-  for (int i = threadIdx.x; i <= t.n - 2; i += kThreads) eval_index<false>(c, sc, t, l, i, A);
+  for (int i = threadIdx.x; i <= t.n - 2; i += kThreads) eval_index<0>(c, sc, t, l, i, A);
   cats[0] = A.chi[0]; cats[1] = A.chi[1]; cats[2] = A.chi[2]; cats[3] = A.chi[3];
   block_sum<4>(cats, l.red);
 }
@@ -784,8 +828,85 @@ __device__ inline void associate(const teb_amd_config_t& c, const SceneDev& sc, 
   }
 }
 
+// ---- legacy association, AddEdgesObstaclesLegacy (src/optimal_planner.cpp:551-643) ---------------------------------------
+// Per static obstacle: index = findClosestTrajectoryPose(obstacle) (src/timed_elastic_band.cpp:455-552; n/2 for all when
+// obstacle_poses_affected >= n); skipped unless 1 < index <= n-2; one edge at index, then for nb = 0 .. floor(poses_affected/2)-1
+// edges at index+nb and index-nb (so the closest pose carries the edge three times when poses_affected >= 2).
+// Phase A: one thread per obstacle finds its pose; phase B: one thread per pose collects its obstacles in list order.
+__device__ inline void associate_legacy(const teb_amd_config_t& c, const SceneDev& sc, const Lds& l, int n, int* assoc_cnt,
+                                        int* assoc, int cap, int stride, int* overflow, int* idx) {
+  const double kMax = 1.7976931348623157e308;
+  for (int k = threadIdx.x; k < sc.n_static; k += kThreads) {
+    int index;
+    if (c.obstacle_poses_affected >= n) index = n / 2;
+    else {
+      const int oi = sc.static_idx[k];
+      const int ty = sc.type[oi];
+      const int v0 = sc.voff[oi], nv = sc.voff[oi + 1] - v0;
+      double best = kMax;
+      index = -1;
+      if (ty == TEB_AMD_OBST_LINE || (ty == TEB_AMD_OBST_POLYGON && nv == 2)) {
+        double ax, ay, bx, by;
+        if (ty == TEB_AMD_OBST_LINE) { ax = sc.ax[oi]; ay = sc.ay[oi]; bx = sc.bx[oi]; by = sc.by[oi]; }
+        else { ax = sc.pvx[v0]; ay = sc.pvy[v0]; bx = sc.pvx[v0 + 1]; by = sc.pvy[v0 + 1]; }
+        for (int i = 0; i < n; ++i) {
+          double cx, cy;
+          const double d = point_segment(l.sx[i], l.sy[i], ax, ay, bx, by, cx, cy);
+          if (d < best) { best = d; index = i; }
+        }
+      } else if (ty == TEB_AMD_OBST_POLYGON && nv > 2) {
+        for (int i = 0; i < n; ++i) {
+          const double px = l.sx[i], py = l.sy[i];
+          double dp = kMax, cx, cy;
+          for (int j = 0; j < nv - 1; ++j) {
+            const double d = point_segment(px, py, sc.pvx[v0 + j], sc.pvy[v0 + j], sc.pvx[v0 + j + 1], sc.pvy[v0 + j + 1], cx, cy);
+            if (d < dp) dp = d;   // std::min(dp, d)
+          }
+          const double dc = point_segment(px, py, sc.pvx[v0 + nv - 1], sc.pvy[v0 + nv - 1], sc.pvx[v0], sc.pvy[v0], cx, cy);
+          if (dc < dp) dp = dc;
+          if (dp < best) { best = dp; index = i; }
+        }
+      } else if (ty == TEB_AMD_OBST_POLYGON && nv == 0) {
+        index = 0;
+      } else {   // point-like reference: the point itself, a one-vertex polygon, else the centroid (circle, pill)
+        double qx, qy;
+        if (ty == TEB_AMD_OBST_POINT) { qx = sc.ax[oi]; qy = sc.ay[oi]; }
+        else if (ty == TEB_AMD_OBST_POLYGON) { qx = sc.pvx[v0]; qy = sc.pvy[v0]; }
+        else { qx = sc.cx[oi]; qy = sc.cy[oi]; }
+        for (int i = 0; i < n; ++i) {   // squared distance, strict '<' (timed_elastic_band.cpp:455-478)
+          const double ddx = qx - l.sx[i], ddy = qy - l.sy[i];
+          const double d2 = ddx * ddx + ddy * ddy;
+          if (d2 < best) { best = d2; index = i; }
+        }
+      }
+    }
+    idx[k] = index;
+  }
+  __threadfence_block();
+  __syncthreads();
+  const int half = c.obstacle_poses_affected / 2;   // floor(int / int), :583
+  for (int i = threadIdx.x; i < n; i += kThreads) {
+    int cnt = 0;
+    if (i >= 1 && i <= n - 2) {
+      for (int k = 0; k < sc.n_static; ++k) {
+        const int index = idx[k];
+        if (index <= 1 || index > n - 2) continue;
+        int ent = -1;
+        if (i == index) ent = half >= 1 ? (k | kAssocTriple) : k;
+        else if ((i > index ? i - index : index - i) < half) ent = k;
+        if (ent >= 0) {
+          if (cnt < cap) assoc[(size_t)cnt * stride + i] = ent; else *overflow = 1;
+          ++cnt;
+        }
+      }
+      if (cnt > cap) cnt = cap;
+    }
+    assoc_cnt[i] = cnt;
+  }
+}
+
 // =================================================================================================================
-template <int SOLVER>
+template <int SOLVER, int JMODE>
 __global__ void __launch_bounds__(kThreads)
 teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev bt, const OptArgs args,
                     const LdsPlan plan) {
@@ -850,10 +971,13 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     PROF_START();
     refresh_trig(l, n);
     __syncthreads();
-    const bool obst_edges = !(c.weight_obstacle == 0 || weight_multiplier == 0) && !c.legacy_obstacle_association;
+    const bool obst_edges = !(c.weight_obstacle == 0 || weight_multiplier == 0);
     if (obst_edges) {
       int ovf = 0;
-      associate(c, sc, l, n, assoc_cnt, assoc, bt.assoc_cap, S, &ovf);
+      if (c.legacy_obstacle_association)
+        associate_legacy(c, sc, l, n, assoc_cnt, assoc, bt.assoc_cap, S, &ovf, bt.legacy_idx + (size_t)b * bt.assoc_cap);
+      else
+        associate(c, sc, l, n, assoc_cnt, assoc, bt.assoc_cap, S, &ovf);
       if (ovf && tid < kThreads) bt.assoc_overflow[b] |= 1;
     } else {
       for (int i = tid; i < n; i += kThreads) assoc_cnt[i] = 0;
@@ -897,7 +1021,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     for (int it = 0; it < args.inner && lm_ok; ++it) {
       double cats[4];
       PROF_START();
-      linearize<SOLVER>(c, sc, t, l, cats);
+      linearize<SOLVER, JMODE>(c, sc, t, l, cats);
       PROF_END(2);
       double currentChi = ((cats[0] + cats[1]) + cats[2]) + cats[3];
       if (args.debug_linearize) {

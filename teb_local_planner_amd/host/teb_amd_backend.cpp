@@ -1,0 +1,312 @@
+// teb_amd_backend.cpp — see teb_amd_backend.h. Host C++ above the C-ABI, written against the reference's classes.
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <limits>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <sstream>
+#include <stack>
+#include <string>
+#include <vector>
+
+// The five footprint classes keep their parameters private and offer no getters (robot_footprint_model.h:227, 306, 424,
+// 592, 768). A maintainer adds four one-line getters there; this out-of-tree build reads the members directly instead.
+#ifndef TEB_AMD_BACKEND_HAVE_FOOTPRINT_GETTERS
+#define private public
+#include <teb_local_planner/robot_footprint_model.h>
+#undef private
+#endif
+
+#include "teb_amd_backend.h"
+
+namespace teb_local_planner {
+
+namespace {
+int g_jacobian_mode = TEB_AMD_JACOBIAN_ANALYTIC;
+}
+
+void setAmdJacobianMode(int mode) { g_jacobian_mode = mode; }
+
+bool toAmdFootprint(const BaseRobotFootprintModel& model, teb_amd_config_t& a)
+{
+  a.footprint_radius = 0; a.footprint_front_offset = a.footprint_front_radius = 0;
+  a.footprint_rear_offset = a.footprint_rear_radius = 0; a.footprint_n_vertices = 0;
+  if (dynamic_cast<const PointRobotFootprint*>(&model)) { a.footprint_type = TEB_AMD_FOOTPRINT_POINT; return true; }
+  if (const CircularRobotFootprint* m = dynamic_cast<const CircularRobotFootprint*>(&model))
+  {
+    a.footprint_type = TEB_AMD_FOOTPRINT_CIRCULAR;
+    a.footprint_radius = m->radius_;
+    return true;
+  }
+  if (const TwoCirclesRobotFootprint* m = dynamic_cast<const TwoCirclesRobotFootprint*>(&model))
+  {
+    a.footprint_type = TEB_AMD_FOOTPRINT_TWO_CIRCLES;
+    a.footprint_front_offset = m->front_offset_; a.footprint_front_radius = m->front_radius_;
+    a.footprint_rear_offset = m->rear_offset_;   a.footprint_rear_radius = m->rear_radius_;
+    return true;
+  }
+  if (const LineRobotFootprint* m = dynamic_cast<const LineRobotFootprint*>(&model))
+  {
+    a.footprint_type = TEB_AMD_FOOTPRINT_LINE;
+    a.footprint_n_vertices = 2;
+    a.footprint_vx[0] = m->line_start_.x(); a.footprint_vy[0] = m->line_start_.y();
+    a.footprint_vx[1] = m->line_end_.x();   a.footprint_vy[1] = m->line_end_.y();
+    return true;
+  }
+  if (const PolygonRobotFootprint* m = dynamic_cast<const PolygonRobotFootprint*>(&model))
+  {
+    if ((int)m->vertices_.size() > TEB_AMD_MAX_FOOTPRINT_VERTICES) return false;
+    a.footprint_type = TEB_AMD_FOOTPRINT_POLYGON;
+    a.footprint_n_vertices = (int32_t)m->vertices_.size();
+    for (int i = 0; i < a.footprint_n_vertices; ++i) { a.footprint_vx[i] = m->vertices_[i].x(); a.footprint_vy[i] = m->vertices_[i].y(); }
+    return true;
+  }
+  return false;
+}
+
+void toAmdConfig(const TebConfig& c, teb_amd_config_t& a)
+{
+  teb_amd_config_default(&a);
+  a.teb_autosize = c.trajectory.teb_autosize ? 1 : 0;   a.dt_ref = c.trajectory.dt_ref;
+  a.dt_hysteresis = c.trajectory.dt_hysteresis;          a.min_samples = c.trajectory.min_samples;
+  a.max_samples = c.trajectory.max_samples;              a.exact_arc_length = c.trajectory.exact_arc_length;
+  a.via_points_ordered = c.trajectory.via_points_ordered;
+  a.max_vel_x = c.robot.max_vel_x;                       a.max_vel_x_backwards = c.robot.max_vel_x_backwards;
+  a.max_vel_y = c.robot.max_vel_y;                       a.max_vel_trans = c.robot.max_vel_trans;
+  a.max_vel_theta = c.robot.max_vel_theta;               a.acc_lim_x = c.robot.acc_lim_x;
+  a.acc_lim_y = c.robot.acc_lim_y;                       a.acc_lim_theta = c.robot.acc_lim_theta;
+  a.min_turning_radius = c.robot.min_turning_radius;
+  a.min_obstacle_dist = c.obstacles.min_obstacle_dist;   a.inflation_dist = c.obstacles.inflation_dist;
+  a.dynamic_obstacle_inflation_dist = c.obstacles.dynamic_obstacle_inflation_dist;
+  a.include_dynamic_obstacles = c.obstacles.include_dynamic_obstacles;
+  a.obstacle_poses_affected = c.obstacles.obstacle_poses_affected;
+  a.legacy_obstacle_association = c.obstacles.legacy_obstacle_association;
+  a.obstacle_association_force_inclusion_factor = c.obstacles.obstacle_association_force_inclusion_factor;
+  a.obstacle_association_cutoff_factor = c.obstacles.obstacle_association_cutoff_factor;
+  a.obstacle_proximity_ratio_max_vel = c.obstacles.obstacle_proximity_ratio_max_vel;
+  a.obstacle_proximity_lower_bound = c.obstacles.obstacle_proximity_lower_bound;
+  a.obstacle_proximity_upper_bound = c.obstacles.obstacle_proximity_upper_bound;
+  a.no_inner_iterations = c.optim.no_inner_iterations;   a.no_outer_iterations = c.optim.no_outer_iterations;
+  a.optimization_activate = c.optim.optimization_activate; a.penalty_epsilon = c.optim.penalty_epsilon;
+  a.weight_max_vel_x = c.optim.weight_max_vel_x;         a.weight_max_vel_y = c.optim.weight_max_vel_y;
+  a.weight_max_vel_theta = c.optim.weight_max_vel_theta; a.weight_acc_lim_x = c.optim.weight_acc_lim_x;
+  a.weight_acc_lim_y = c.optim.weight_acc_lim_y;         a.weight_acc_lim_theta = c.optim.weight_acc_lim_theta;
+  a.weight_kinematics_nh = c.optim.weight_kinematics_nh;
+  a.weight_kinematics_forward_drive = c.optim.weight_kinematics_forward_drive;
+  a.weight_kinematics_turning_radius = c.optim.weight_kinematics_turning_radius;
+  a.weight_optimaltime = c.optim.weight_optimaltime;     a.weight_shortest_path = c.optim.weight_shortest_path;
+  a.weight_obstacle = c.optim.weight_obstacle;           a.weight_inflation = c.optim.weight_inflation;
+  a.weight_dynamic_obstacle = c.optim.weight_dynamic_obstacle;
+  a.weight_dynamic_obstacle_inflation = c.optim.weight_dynamic_obstacle_inflation;
+  a.weight_velocity_obstacle_ratio = c.optim.weight_velocity_obstacle_ratio;
+  a.weight_viapoint = c.optim.weight_viapoint;           a.weight_prefer_rotdir = c.optim.weight_prefer_rotdir;
+  a.weight_adapt_factor = c.optim.weight_adapt_factor;   a.obstacle_cost_exponent = c.optim.obstacle_cost_exponent;
+  a.selection_cost_hysteresis = c.hcp.selection_cost_hysteresis;
+  a.selection_prefer_initial_plan = c.hcp.selection_prefer_initial_plan;
+  a.selection_obst_cost_scale = c.hcp.selection_obst_cost_scale;
+  a.selection_viapoint_cost_scale = c.hcp.selection_viapoint_cost_scale;
+  a.selection_alternative_time_cost = c.hcp.selection_alternative_time_cost;
+  a.divergence_detection_enable = c.recovery.divergence_detection_enable;
+  a.divergence_detection_max_chi_squared = c.recovery.divergence_detection_max_chi_squared;
+  a.jacobian_mode = g_jacobian_mode;
+  if (!c.robot_model || !toAmdFootprint(*c.robot_model, a))
+    ROS_ERROR("toAmdConfig(): unknown robot footprint model, falling back to the point footprint");
+}
+
+void AmdObstacleTable::assign(const ObstContainer* obstacles)
+{
+  type.clear(); dynamic.clear(); vert_offset.assign(1, 0);
+  ax.clear(); ay.clear(); bx.clear(); by.clear(); radius.clear(); vx.clear(); vy.clear(); vert_x.clear(); vert_y.clear();
+  if (!obstacles) return;
+  for (const ObstaclePtr& p : *obstacles)
+  {
+    double x0 = 0, y0 = 0, x1 = 0, y1 = 0, r = 0;
+    int32_t t;
+    if (const PointObstacle* q = dynamic_cast<const PointObstacle*>(p.get())) { t = TEB_AMD_OBST_POINT; x0 = q->x(); y0 = q->y(); }
+    else if (const CircularObstacle* q = dynamic_cast<const CircularObstacle*>(p.get())) { t = TEB_AMD_OBST_CIRCULAR; x0 = q->x(); y0 = q->y(); r = q->radius(); }
+    else if (const LineObstacle* q = dynamic_cast<const LineObstacle*>(p.get()))
+    { t = TEB_AMD_OBST_LINE; x0 = q->start().x(); y0 = q->start().y(); x1 = q->end().x(); y1 = q->end().y(); }
+    else if (const PillObstacle* q = dynamic_cast<const PillObstacle*>(p.get()))
+    {
+      t = TEB_AMD_OBST_PILL; x0 = q->start().x(); y0 = q->start().y(); x1 = q->end().x(); y1 = q->end().y();
+      r = -q->getMinimumDistance(q->start());   // no radius getter: distance of the start point is 0 - radius_ (obstacles.h:800-803)
+    }
+    else if (const PolygonObstacle* q = dynamic_cast<const PolygonObstacle*>(p.get()))
+    {
+      t = TEB_AMD_OBST_POLYGON;
+      for (const Eigen::Vector2d& v : q->vertices()) { vert_x.push_back(v.x()); vert_y.push_back(v.y()); }
+    }
+    else { ROS_ERROR("AmdObstacleTable: unknown obstacle class skipped"); continue; }
+    type.push_back(t); ax.push_back(x0); ay.push_back(y0); bx.push_back(x1); by.push_back(y1); radius.push_back(r);
+    vx.push_back(p->getCentroidVelocity().x()); vy.push_back(p->getCentroidVelocity().y());
+    dynamic.push_back(p->isDynamic() ? 1 : 0);
+    vert_offset.push_back((int32_t)vert_x.size());
+  }
+}
+
+teb_amd_obstacles_t AmdObstacleTable::view() const
+{
+  teb_amd_obstacles_t o;
+  std::memset(&o, 0, sizeof(o));
+  o.count = (int32_t)type.size();
+  o.type = type.data(); o.ax = ax.data(); o.ay = ay.data(); o.bx = bx.data(); o.by = by.data(); o.radius = radius.data();
+  o.vx = vx.data(); o.vy = vy.data(); o.dynamic = dynamic.data();
+  o.vert_offset = vert_offset.data(); o.vert_x = vert_x.data(); o.vert_y = vert_y.data();
+  return o;
+}
+
+// ---- TebOptimalPlannerAmd --------------------------------------------------------------------------------------------
+
+TebOptimalPlannerAmd::TebOptimalPlannerAmd(const TebConfig& cfg, ObstContainer* obstacles, TebVisualizationPtr visual,
+                                           const ViaPointContainer* via_points)
+    : TebOptimalPlanner(cfg, obstacles, visual, via_points)
+{
+}
+
+bool TebOptimalPlannerAmd::optimizeTEB(int iterations_innerloop, int iterations_outerloop, bool compute_cost_afterwards,
+                                       double obst_cost_scale, double viapoint_cost_scale, bool alternative_time_cost)
+{
+  if (cfg_->optim.optimization_activate == false) return false;   // src/optimal_planner.cpp:186-187
+  AmdObstacleTable probe;
+  probe.assign(obstacles_);
+  const int need_poses = std::max(teb_.sizePoses(), std::min(cfg_->trajectory.max_samples + 1, 343));
+  if (!single_ || teb_.sizePoses() > single_->maxPoses())
+    single_.reset(new TebAmdBatch(*cfg_, 1, need_poses, std::max<int>(1, (int)probe.type.size()), std::max(1, probe.vertices()),
+                                  std::max<int>(1, via_points_ ? (int)via_points_->size() : 0)));
+  std::vector<TebOptimalPlannerAmd*> one(1, this);
+  return single_->optimizeAllTEBs(one, iterations_innerloop, iterations_outerloop, compute_cost_afterwards, obst_cost_scale,
+                                  viapoint_cost_scale, alternative_time_cost) == 1;
+}
+
+// ---- TebAmdBatch -------------------------------------------------------------------------------------------------
+
+TebAmdBatch::TebAmdBatch(const TebConfig& cfg, int max_tebs, int max_poses, int max_obstacles, int max_obstacle_vertices,
+                         int max_via_points, int device)
+    : max_tebs_(max_tebs), max_poses_(max_poses)
+{
+  teb_amd_config_t a;
+  toAmdConfig(cfg, a);
+  check(teb_amd_create(&a, max_tebs, max_poses, max_obstacles, max_obstacle_vertices, max_via_points, device, NULL, &h_),
+        "teb_amd_create");
+}
+
+TebAmdBatch::~TebAmdBatch() { if (h_) teb_amd_destroy(h_); }
+
+bool TebAmdBatch::check(int rc, const char* what)
+{
+  if (rc == TEB_AMD_OK) return true;
+  std::ostringstream s;
+  s << what << " failed (" << rc << "): " << teb_amd_last_error();
+  error_ = s.str();
+  ROS_ERROR("TebAmdBatch: %s", error_.c_str());   // no CPU fallback: the caller sees optimizeTEB() == false
+  return false;
+}
+
+float TebAmdBatch::lastKernelMs() const
+{
+  float ms = 0;
+  if (h_) teb_amd_last_kernel_ms(h_, &ms);
+  return ms;
+}
+
+int TebAmdBatch::optimizeAllTEBs(const std::vector<TebOptimalPlannerAmd*>& tebs, int iter_innerloop, int iter_outerloop,
+                                 bool compute_cost_afterwards, double obst_cost_scale, double viapoint_cost_scale,
+                                 bool alternative_time_cost)
+{
+  const int B = (int)tebs.size(), S = max_poses_;
+  if (!h_ || B == 0) return 0;
+  if (B > max_tebs_) { check(TEB_AMD_ERR_CAPACITY, "optimizeAllTEBs (more candidates than max_tebs)"); return 0; }
+  TebOptimalPlannerAmd& first = *tebs.front();
+  if (first.cfg_->optim.optimization_activate == false) return 0;
+
+  // scene: TebConfig (dynamic_reconfigure may have changed it), obstacles, via-points
+  teb_amd_config_t a;
+  toAmdConfig(*first.cfg_, a);
+  AmdObstacleTable table;
+  table.assign(first.obstacles_);
+  teb_amd_obstacles_t ov = table.view();
+  std::vector<double> viax, viay;
+  if (first.via_points_)
+    for (const Eigen::Vector2d& v : *first.via_points_) { viax.push_back(v.x()); viay.push_back(v.y()); }
+  // set_obstacles before set_config would be rejected when include_dynamic_obstacles / footprint changed: config first, then scene
+  int rc = teb_amd_set_config(h_, &a);
+  if (rc != TEB_AMD_OK && rc != TEB_AMD_ERR_INVALID_ARG) { check(rc, "teb_amd_set_config"); return 0; }
+  if (!check(teb_amd_set_obstacles(h_, &ov), "teb_amd_set_obstacles")) return 0;
+  if (!check(teb_amd_set_via_points(h_, (int32_t)viax.size(), viax.data(), viay.data()), "teb_amd_set_via_points")) return 0;
+
+  // bands: TimedElasticBand -> SoA strips
+  std::vector<int32_t> n(B), hvs(B), hvg(B), rot(B), via(B);
+  std::vector<double> x((size_t)B * S, 0.0), y((size_t)B * S, 0.0), th((size_t)B * S, 0.0), dt((size_t)B * S, 0.0), vs(3 * (size_t)B), vg(3 * (size_t)B);
+  for (int b = 0; b < B; ++b)
+  {
+    TebOptimalPlannerAmd& p = *tebs[b];
+    p.optimized_ = false;
+    const TimedElasticBand& t = p.teb_;
+    if (t.sizePoses() > S) { check(TEB_AMD_ERR_CAPACITY, "optimizeAllTEBs (band longer than max_poses)"); return 0; }
+    n[b] = t.sizePoses();
+    for (int i = 0; i < t.sizePoses(); ++i) { x[(size_t)b * S + i] = t.Pose(i).x(); y[(size_t)b * S + i] = t.Pose(i).y(); th[(size_t)b * S + i] = t.Pose(i).theta(); }
+    for (int i = 0; i < t.sizeTimeDiffs(); ++i) dt[(size_t)b * S + i] = t.TimeDiff(i);
+    hvs[b] = p.vel_start_.first; hvg[b] = p.vel_goal_.first;
+    vs[3 * b] = p.vel_start_.second.linear.x; vs[3 * b + 1] = p.vel_start_.second.linear.y; vs[3 * b + 2] = p.vel_start_.second.angular.z;
+    vg[3 * b] = p.vel_goal_.second.linear.x;  vg[3 * b + 1] = p.vel_goal_.second.linear.y;  vg[3 * b + 2] = p.vel_goal_.second.angular.z;
+    rot[b] = p.prefer_rotdir_ == RotType::left ? TEB_AMD_ROT_LEFT : (p.prefer_rotdir_ == RotType::right ? TEB_AMD_ROT_RIGHT : TEB_AMD_ROT_NONE);
+    via[b] = p.via_points_ != NULL;
+  }
+  teb_amd_teb_batch_t batch;
+  std::memset(&batch, 0, sizeof(batch));
+  batch.count = B; batch.stride = S; batch.n = n.data(); batch.x = x.data(); batch.y = y.data(); batch.theta = th.data(); batch.dt = dt.data();
+  batch.has_vel_start = hvs.data(); batch.vel_start = vs.data(); batch.has_vel_goal = hvg.data(); batch.vel_goal = vg.data();
+  batch.prefer_rotdir = rot.data(); batch.via_points_enabled = via.data();
+  if (!check(teb_amd_upload_tebs(h_, &batch), "teb_amd_upload_tebs")) return 0;
+
+  // the whole outer x inner loop of every candidate: one launch
+  if (!check(teb_amd_optimize_batch(h_, iter_innerloop, iter_outerloop, compute_cost_afterwards ? 1 : 0, obst_cost_scale,
+                                    viapoint_cost_scale, alternative_time_cost ? 1 : 0), "teb_amd_optimize_batch")) return 0;
+  std::vector<int32_t> status(B), iters(B), trials(B);
+  std::vector<double> chi2(B), cost(B), lambda(B);
+  teb_amd_results_t res = { status.data(), iters.data(), trials.data(), chi2.data(), cost.data(), lambda.data() };
+  if (!check(teb_amd_get_results(h_, &res), "teb_amd_get_results")) return 0;
+  if (!check(teb_amd_download_tebs(h_, &batch), "teb_amd_download_tebs")) return 0;
+
+  // write back: bands (autoResize may have changed the pose count), cost_, optimized_
+  int ok = 0;
+  for (int b = 0; b < B; ++b)
+  {
+    TebOptimalPlannerAmd& p = *tebs[b];
+    TimedElasticBand& t = p.teb_;
+    const size_t o = (size_t)b * S;
+    if (n[b] == t.sizePoses())
+    {
+      for (int i = 0; i < n[b]; ++i) { t.Pose(i).x() = x[o + i]; t.Pose(i).y() = y[o + i]; t.Pose(i).theta() = th[o + i]; }
+      for (int i = 0; i < n[b] - 1; ++i) t.TimeDiff(i) = dt[o + i];
+    }
+    else
+    {
+      t.clearTimedElasticBand();
+      t.addPose(x[o], y[o], th[o], true);                       // start pose is fixed
+      for (int i = 1; i < n[b]; ++i) t.addPoseAndTimeDiff(x[o + i], y[o + i], th[o + i], dt[o + i - 1]);
+      t.setPoseVertexFixed(n[b] - 1, true);                     // goal pose is fixed
+    }
+    p.lm_iterations_ = iters[b]; p.lm_trials_ = trials[b];
+    if (compute_cost_afterwards && status[b] == TEB_AMD_TEB_OK) p.cost_ = cost[b];   // computeCurrentCost ran in the last outer iteration
+    if (status[b] == TEB_AMD_TEB_OK) { p.optimized_ = true; ++ok; }
+  }
+  return ok;
+}
+
+int TebAmdBatch::selectBestTeb(int last_best, int initial_plan, double* best_cost)
+{
+  int32_t best = -1;
+  double bc = 0;
+  if (!h_ || !check(teb_amd_select_best(h_, last_best, initial_plan, &best, &bc), "teb_amd_select_best")) return -1;
+  if (best_cost) *best_cost = bc;
+  return best;
+}
+
+} // namespace teb_local_planner

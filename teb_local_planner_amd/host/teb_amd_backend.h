@@ -1,0 +1,113 @@
+// teb_amd_backend.h — host side of the drop-in, written against the REFERENCE's own classes.
+//
+// This is the translation unit a teb_local_planner maintainer adds: adapters from TebConfig /
+// ObstContainer / ViaPointContainer / TimedElasticBand to the C-ABI of libteb_amd.so (include/teb_amd.h), a
+// TebOptimalPlanner subclass whose optimizeTEB() runs on the MI355X, and the batched replacement of
+// HomotopyClassPlanner::optimizeAllTEBs / selectBestTeb. Same method names, argument meaning and return values as
+//   TebOptimalPlanner::optimizeTEB                 include/teb_local_planner/optimal_planner.h:231, src/optimal_planner.cpp:183-233
+//   HomotopyClassPlanner::optimizeAllTEBs          src/homotopy_class_planner.cpp:466-493
+//   HomotopyClassPlanner::selectBestTeb (arg-min)  src/homotopy_class_planner.cpp:564-667
+// It needs the reference's headers to compile, so in this repository it is built only where /root/reference exists
+// (oracle/ref_shim/Makefile -> oracle/_ref/libteb_backend_check.so) and exercised by tests/test_reference_backend.py.
+#ifndef TEB_AMD_BACKEND_H_
+#define TEB_AMD_BACKEND_H_
+
+#include <teb_amd.h>
+
+#include <teb_local_planner/optimal_planner.h>
+
+#include <string>
+#include <vector>
+
+namespace teb_local_planner {
+
+//! TebConfig (teb_config.h:62-430) -> flat teb_amd_config_t; robot_model is flattened by toAmdFootprint.
+void toAmdConfig(const TebConfig& cfg, teb_amd_config_t& out);
+
+//! One of the five footprint classes (robot_footprint_model.h:134-770) -> footprint_* fields. Returns false for an unknown class.
+bool toAmdFootprint(const BaseRobotFootprintModel& model, teb_amd_config_t& out);
+
+//! ObstContainer (obstacles.h:262) as the SoA table of the C-ABI; owns the arrays the view points into.
+struct AmdObstacleTable
+{
+  std::vector<int32_t> type, dynamic, vert_offset;
+  std::vector<double> ax, ay, bx, by, radius, vx, vy, vert_x, vert_y;
+  void assign(const ObstContainer* obstacles);
+  teb_amd_obstacles_t view() const;
+  int vertices() const { return (int)vert_x.size(); }
+};
+
+//! Extension of the C-ABI that TebConfig has no field for (TEB_AMD_JACOBIAN_*); process-wide, default analytic.
+void setAmdJacobianMode(int mode);
+
+class TebAmdBatch;
+
+/**
+ * TebOptimalPlanner whose optimizeTEB() is executed by libteb_amd.so. Everything else (plan(), velocity extraction,
+ * feasibility check, visualisation) is inherited unchanged; the g2o optimizer_ member is simply never used.
+ */
+class TebOptimalPlannerAmd : public TebOptimalPlanner
+{
+public:
+  TebOptimalPlannerAmd(const TebConfig& cfg, ObstContainer* obstacles = NULL,
+                       TebVisualizationPtr visual = TebVisualizationPtr(), const ViaPointContainer* via_points = NULL);
+
+  //! Same contract as TebOptimalPlanner::optimizeTEB (optimal_planner.h:204-232).
+  bool optimizeTEB(int iterations_innerloop, int iterations_outerloop, bool compute_cost_afterwards = false,
+                   double obst_cost_scale = 1.0, double viapoint_cost_scale = 1.0, bool alternative_time_cost = false);
+
+  //! Statistics of the last run (not available from g2o in the reference): LM iterations / damped-solve trials.
+  int lastLmIterations() const { return lm_iterations_; }
+  int lastLmTrials() const { return lm_trials_; }
+
+private:
+  friend class TebAmdBatch;
+  boost::shared_ptr<TebAmdBatch> single_;   //!< lazily created batch of one
+  int lm_iterations_ = 0, lm_trials_ = 0;
+};
+typedef boost::shared_ptr<TebOptimalPlannerAmd> TebOptimalPlannerAmdPtr;
+
+/**
+ * One libteb_amd.so handle = device buffers for up to max_tebs candidates. optimizeAllTEBs() packs the candidates'
+ * bands into one batch, runs ONE kernel launch for the whole outer x inner loop of every candidate and writes bands,
+ * cost and the optimized flag back into the planner objects.
+ */
+class TebAmdBatch
+{
+public:
+  TebAmdBatch(const TebConfig& cfg, int max_tebs, int max_poses, int max_obstacles, int max_obstacle_vertices,
+              int max_via_points, int device = 0);
+  ~TebAmdBatch();
+  TebAmdBatch(const TebAmdBatch&) = delete;
+  TebAmdBatch& operator=(const TebAmdBatch&) = delete;
+
+  /**
+   * Replaces the body of HomotopyClassPlanner::optimizeAllTEBs. All candidates share cfg / obstacles / via-points of
+   * the first one (as in the reference, where they are constructed from the same pointers, homotopy_class_planner.cpp:434-449).
+   * Cost parameters as passed by the reference: cfg.hcp.selection_obst_cost_scale, selection_viapoint_cost_scale,
+   * selection_alternative_time_cost. Returns the number of candidates whose optimizeTEB "returned true".
+   */
+  int optimizeAllTEBs(const std::vector<TebOptimalPlannerAmd*>& tebs, int iter_innerloop, int iter_outerloop,
+                      bool compute_cost_afterwards, double obst_cost_scale, double viapoint_cost_scale,
+                      bool alternative_time_cost);
+
+  /**
+   * The arg-min of selectBestTeb over the costs of the last optimizeAllTEBs (strict '<', hysteresis on last_best,
+   * selection_prefer_initial_plan on initial_plan; -1 = none). Returns the index into the vector passed to optimizeAllTEBs, -1 if empty.
+   */
+  int selectBestTeb(int last_best, int initial_plan, double* best_cost = NULL);
+
+  int maxPoses() const { return max_poses_; }
+  const std::string& lastError() const { return error_; }
+  float lastKernelMs() const;
+
+private:
+  bool check(int rc, const char* what);
+  teb_amd_handle_t* h_ = NULL;
+  int max_tebs_, max_poses_;
+  std::string error_;
+};
+
+} // namespace teb_local_planner
+
+#endif

@@ -1,0 +1,133 @@
+"""The reference-side binding of INTEGRATION.md, compiled and run: teb_local_planner_amd/host/teb_amd_backend.cpp (TebOptimalPlannerAmd,
+TebAmdBatch, TebConfig / ObstContainer adapters) built against the REFERENCE's own classes and linked to libteb_amd.so
+(oracle/_ref/libteb_backend_check.so, built where /root/reference exists; the binary travels to the GPU box).
+
+Each case hands the SAME reference objects (TebConfig, ObstContainer, ViaPointContainer, TimedElasticBand) to
+  (1) the reference's TebOptimalPlanner::optimizeTEB — its own src/optimal_planner.cpp on the CPU (LM stand-in of shim_g2o.h), and
+  (2) TebOptimalPlannerAmd::optimizeTEB / TebAmdBatch::optimizeAllTEBs + selectBestTeb — the MI355X through the C-ABI,
+and compares what ends up in the planners' TimedElasticBand / getCurrentCost() / isOptimized().
+Tolerances: g2o-numeric Jacobian mode <= 1e-3 (observed ~1e-6, see tests/test_gpu_parity.py); analytic mode <= 1e-3 m / rad.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_ref_golden as RG  # noqa: E402
+
+from teb_local_planner_amd import _abi  # noqa: E402
+
+SO = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "libteb_backend_check.so")
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    if not os.path.exists(SO):
+        pytest.skip("oracle/_ref/libteb_backend_check.so not built (needs /root/reference at build time)")
+    return C.CDLL(SO)
+
+
+def run(cfg, obst, via, batch, jacobian_mode, mode, run_reference=True, last_best=-1, initial_plan=-1, inner=None, outer=None):
+    L = _lib()
+    c = cfg.to_c()
+    B, S = batch.count, batch.stride
+    vx = _abi.f64([v[0] for v in via]) if via else _abi.f64([0.0])
+    vy = _abi.f64([v[1] for v in via]) if via else _abi.f64([0.0])
+    P = lambda a: _abi._ptr(a, C.c_double)
+    I = lambda a: _abi._ptr(a, C.c_int32)
+    out = {}
+    for side in ("ref", "amd"):
+        for k in ("x", "y", "th", "dt"):
+            out[side + "_" + k] = np.zeros((B, S))
+        out[side + "_n"] = np.zeros(B, np.int32); out[side + "_cost"] = np.zeros(B); out[side + "_ok"] = np.zeros(B, np.int32)
+    best = C.c_int32(-1); best_cost = C.c_double(0); rt = C.c_int32(0)
+    bs = batch.c_struct()
+    inner = cfg.optim.no_inner_iterations if inner is None else inner
+    outer = cfg.optim.no_outer_iterations if outer is None else outer
+    args = [C.byref(c), C.byref(obst.freeze()), len(via), P(vx), P(vy), C.byref(bs), int(inner), int(outer), 1,
+            C.c_double(cfg.hcp.selection_obst_cost_scale), C.c_double(cfg.hcp.selection_viapoint_cost_scale),
+            int(cfg.hcp.selection_alternative_time_cost), int(jacobian_mode), int(mode), int(run_reference), int(last_best),
+            int(initial_plan)]
+    for side in ("ref", "amd"):
+        args += [P(out[side + "_x"]), P(out[side + "_y"]), P(out[side + "_th"]), P(out[side + "_dt"]), I(out[side + "_n"]),
+                 P(out[side + "_cost"]), I(out[side + "_ok"])]
+    args += [C.byref(best), C.byref(best_cost), C.byref(rt)]
+    rc = L.backend_check_run(*args)
+    assert rc == 0, rc
+    out["best"] = best.value; out["best_cost"] = best_cost.value; out["roundtrip_ok"] = rt.value
+    return out
+
+
+def compare(out, B, tol):
+    worst = 0.0
+    for b in range(B):
+        n = int(out["ref_n"][b])
+        assert int(out["amd_n"][b]) == n
+        assert out["amd_ok"][b] == out["ref_ok"][b]
+        for k in ("x", "y", "th"):
+            worst = max(worst, np.abs(out["amd_" + k][b, :n] - out["ref_" + k][b, :n]).max())
+        worst = max(worst, np.abs(out["amd_dt"][b, :n - 1] - out["ref_dt"][b, :n - 1]).max())
+        assert abs(out["amd_cost"][b] - out["ref_cost"][b]) <= tol * max(1.0, abs(out["ref_cost"][b]))
+    assert worst <= tol, worst
+    return worst
+
+
+CASES = ["edges_point", "edges_two_circles", "edges_line", "edges_polygon_carlike_arc", "edges_optional", "edges_holonomic",
+         "c1", "c1_velocities", "c3_small", "legacy_association"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_batch_backend_on_reference_objects_numeric_mode(name):
+    cfg, obst, via, batch = RG.PLANNER_CASES[name]()
+    out = run(cfg, obst, via, batch, _abi.JACOBIAN_G2O_NUMERIC, mode=0)
+    assert out["roundtrip_ok"] == 1          # TebConfig / ObstContainer adapters reproduce the inputs exactly
+    w = compare(out, batch.count, 1e-3)
+    # selectBestTeb on the device-resident costs == strict '<' arg-min over the reference planners' costs
+    assert out["best"] == int(np.argmin(out["ref_cost"]))
+    print("backend (numeric) vs reference objects, %s: %.3g" % (name, w))
+
+
+@pytest.mark.parametrize("name", ["edges_point", "c1", "edges_polygon_carlike_arc"])
+def test_batch_backend_on_reference_objects_analytic_mode(name):
+    cfg, obst, via, batch = RG.PLANNER_CASES[name]()
+    out = run(cfg, obst, via, batch, _abi.JACOBIAN_ANALYTIC, mode=0)
+    compare(out, batch.count, 1e-3)
+
+
+@pytest.mark.parametrize("name", ["edges_point", "c1_velocities"])
+def test_single_planner_optimizeTEB_override(name):
+    """TebOptimalPlannerAmd::optimizeTEB (one lazily created handle per planner) instead of the batch entry point."""
+    cfg, obst, via, batch = RG.PLANNER_CASES[name]()
+    out = run(cfg, obst, via, batch, _abi.JACOBIAN_G2O_NUMERIC, mode=1)
+    compare(out, batch.count, 1e-3)
+
+
+def test_backend_error_behaviour_matches_reference():
+    """optimization_activate = false and a too-short band: optimizeTEB returns false on both sides, bands untouched."""
+    cfg, obst, via, batch = RG.PLANNER_CASES["edges_point"]()
+    cfg.optim.optimization_activate = False
+    out = run(cfg, obst, via, batch, _abi.JACOBIAN_ANALYTIC, mode=1)
+    assert not out["amd_ok"].any() and not out["ref_ok"].any()
+    for b in range(batch.count):
+        n = int(batch.n[b])
+        np.testing.assert_array_equal(out["amd_x"][b, :n], batch.x[b, :n])
+    cfg, obst, via, batch = RG.PLANNER_CASES["edges_point"]()
+    cfg.trajectory.teb_autosize = False
+    cfg.trajectory.min_samples = 30
+    out = run(cfg, obst, via, batch, _abi.JACOBIAN_ANALYTIC, mode=0)
+    assert not out["amd_ok"].any() and not out["ref_ok"].any()
+
+
+def test_selection_hysteresis_through_backend():
+    cfg, obst, via, batch = RG.PLANNER_CASES["c3_small"]()
+    out = run(cfg, obst, via, batch, _abi.JACOBIAN_ANALYTIC, mode=0)
+    costs = out["amd_cost"].copy()
+    order = np.argsort(costs)
+    runner_up = int(order[1])
+    cfg.hcp.selection_cost_hysteresis = float(0.5 * costs[order[0]] / costs[runner_up])   # makes the runner-up win when it was last best
+    out2 = run(cfg, obst, via, batch, _abi.JACOBIAN_ANALYTIC, mode=0, run_reference=False, last_best=runner_up)
+    assert out2["best"] == runner_up
