@@ -172,14 +172,17 @@ def main():
             cfg_cpu = scenes.scene_c4(B=1, n=n)[0]
             cfg_cpu.trajectory.teb_autosize = False
             cfg_cpu.jacobian_mode = _abi.JACOBIAN_G2O_NUMERIC
-            t1 = time.perf_counter()
-            _, cres = oracle_py.optimize_batch(cfg_cpu, obst, via, cb, threads=cores)
-            cpu_t = time.perf_counter() - t1
+            cpu_t = float("inf")
+            for _rep in range(3):   # best of 3: 256 threads on a shared host are noisy
+                t1 = time.perf_counter()
+                _, cres = oracle_py.optimize_batch(cfg_cpu, obst, via, cb, threads=cores)
+                cpu_t = min(cpu_t, time.perf_counter() - t1)
             out["cpu_baseline"] = {
                 "value": float(cres.lm_iterations.sum()) / cpu_t, "unit": "TEB.LM-iterations/s", "cores": cores,
                 "kind": "port",
                 "sample": "%d of the %d C4 candidates, one optimizeTEB each (4x5), g2o-numeric Jacobians, "
-                          "one std::thread per TEB capped at %d, %.1f s wall" % (ks, B, cores, cpu_t)}
+                          "one std::thread per TEB capped at %d, best of 3 runs, %.1f s wall; the port is bit-identical to the "
+                          "reference's src/optimal_planner.cpp on the pinned bands (tests/test_reference_pinning.py)" % (ks, B, cores, cpu_t)}
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

@@ -6,8 +6,8 @@ fixtures. All fp64. Stated tolerances (tightened to what is actu
          association lists: bit-exact (integer work)
   T3     full optimizeTEB (4 x 5 LM iterations incl. autoResize / association / cost):
          identical pose count, status, LM iteration and trial counts; poses <= 1e-8 m / rad; chi^2 and cost rel 1e-8
-         vs the oracle in the reference-faithful g2o-numeric mode: <= 1e-3 m / rad, cost rel 1e-3 (the reference's own
-         central-difference noise floor, delta = 1e-9)
+         vs the vectors of the reference's own code (either Jacobian mode): per-band tolerance of tests/sensitivity.py,
+         2e-5 m / rad / s on bands that damp the reference's central-difference noise (delta = 1e-9)
   T4     selectBestTeb: same index
 """
 import os
@@ -384,28 +384,34 @@ def test_numeric_mode_linearisation_matches_oracle(oracle, name):
     s.close()
 
 
+@pytest.mark.parametrize("mode", ["analytic", "g2o_numeric"])
 @pytest.mark.parametrize("name", NUMERIC_CASES)
-def test_numeric_mode_optimizeTEB_matches_reference_code(name):
-    """GPU (g2o-numeric Jacobians) against the vectors produced by the REFERENCE's own src/optimal_planner.cpp
-    (tests/golden/ref_opt_*.npz, see tests/test_reference_pinning.py): same pose count and success flag; poses and time
-    differences <= 1e-3 m / rad / s, cost rel 1e-3 after the full 4 x 5 iterations. Observed: ~1e-6 on well-conditioned bands, up
-    to 7e-4 on a band that starts inside an obstacle (cost ~3e4), where 20 LM iterations amplify the 1e-7 Jacobian noise."""
+def test_optimizeTEB_matches_reference_code(oracle, name, mode):
+    """GPU (either Jacobian mode) against the vectors produced by the REFERENCE's own src/optimal_planner.cpp
+    (tests/golden/ref_opt_*.npz, see tests/test_reference_pinning.py) after the full 4 x 5 iterations: same pose count and
+    success flag; poses, time differences and cost within the per-band tolerance of tests/sensitivity.py - 2e-5 for bands that
+    damp the reference's own 1e-7 linearisation noise (observed 1e-8 .. 4e-6 in both modes), looser only where the CPU oracle's
+    two Jacobian modes themselves drift apart (bands in collision), skipped where even their pose counts differ."""
+    import sensitivity
     g = np.load(os.path.join(HERE, "golden", "ref_opt_%s.npz" % name))
     cfg, obst, via, batch = RG.PLANNER_CASES[name]()
-    cfg.jacobian_mode = _abi.JACOBIAN_G2O_NUMERIC
+    tols = sensitivity.band_tolerances(oracle, cfg, obst, via, batch)
+    cfg.jacobian_mode = _abi.JACOBIAN_G2O_NUMERIC if mode == "g2o_numeric" else _abi.JACOBIAN_ANALYTIC
     out, res, _ = run_gpu(cfg, obst, via, batch)
-    worst = 0.0
+    checked = 0
     for b in range(min(batch.count, RG.MAX_TEBS)):
+        assert bool(g["success"][b]) == (res.status[b] == _abi.TEB_OK)
+        if tols[b] is None:
+            continue
         n = int(g["n"][b])
         assert int(out.n[b]) == n
-        assert bool(g["success"][b]) == (res.status[b] == _abi.TEB_OK)
         x, y, th, dt = out.get_teb(b)
         d = max(np.abs(x - g["state"][b, 0, :n]).max(), np.abs(y - g["state"][b, 1, :n]).max(),
                 np.abs(th - g["state"][b, 2, :n]).max(), np.abs(dt - g["state"][b, 3, :n - 1]).max())
-        worst = max(worst, d)
-        assert d <= 1e-3, (name, b, d)
-        assert abs(res.cost[b] - g["cost"][b]) <= 1e-3 * abs(g["cost"][b]), (name, b, res.cost[b], g["cost"][b])
-    print("numeric-mode deviation from the reference code, %s: %.3g" % (name, worst))
+        assert d <= tols[b], (name, b, d, tols[b])
+        assert abs(res.cost[b] - g["cost"][b]) <= tols[b] * abs(g["cost"][b]), (name, b, res.cost[b], g["cost"][b])
+        checked += 1
+    assert checked >= 1
 
 
 # ---- legacy obstacle association (AddEdgesObstaclesLegacy) on the device ---------------------------------------------------
