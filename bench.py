@@ -111,7 +111,7 @@ def main():
         achieved = alg_bytes_launch / (kms * 1e-3) / 1e9
         # HBM-side traffic per launch from the committed rocprofv3 PMC passes of THIS command (FETCH_SIZE / WRITE_SIZE in
         # separate runs, scaled by the factors calibrated on a known 1 GiB stream; profiles/rocprof_*_summary.json)
-        traffic, traffic_src = None, None
+        traffic, traffic_src, fp64 = None, None, None
         try:
             import glob
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "rocprof_r*_summary.json")))
@@ -122,6 +122,12 @@ def main():
                 fw = cal.get("WRITE_SIZE_bytes_per_counted_KB", 1024.0)
                 traffic = pj["FETCH_SIZE_KB_per_launch"] * fr + pj["WRITE_SIZE_KB_per_launch"] * fw
                 traffic_src = os.path.basename(cands[-1])
+                if pj.get("fp64_flop_per_launch"):   # PMC pass SQ_INSTS_VALU_*_F64 of this command (instruction counts x 64 lanes)
+                    fp64 = {"flop_per_launch": pj["fp64_flop_per_launch"], "achieved": pj["fp64_flop_per_launch"] / (kms * 1e-3) / 1e12,
+                            "peak": 78.6, "unit": "TFLOP/s", "source": traffic_src,
+                            "note": "vector fp64 (no MFMA on this path); peak = AMD spec, half the 157.3 TFLOP/s fp32 vector rate; "
+                                    "the build uses -ffp-contract=off, so mul+add pairs issue as two instructions (ceiling ~39 TFLOP/s)"}
+                    fp64["frac"] = fp64["achieved"] / fp64["peak"]
         except Exception:
             traffic = None
         out = {
@@ -140,6 +146,8 @@ def main():
                          "kernel": "teb_optimize_kernel", "kernel_ms": kms,
                          "alg_bytes_per_unit": abu, "alg_bytes_per_launch": alg_bytes_launch},
         }
+        if fp64:
+            out["roofline"]["valu_fp64"] = fp64
         # ---- p50 plan()-equivalent latency on the 200-pose band: upload -> 4x5 iterations incl. autoResize,
         #      association, cost -> select -> download (single TEB, config C2, and the C4 batch)
         lat = {}

@@ -60,6 +60,22 @@ def main():
                                   "'%%teb_optimize%%' and grid_size_x=%d group by counter_name" % grid):
             lines.append("%-24s %.6g" % (cn, avg))
             summary[cn] = avg
+    db = os.path.join(SRC, "pmc_f64", "f64_results.db")
+    if os.path.exists(db):
+        lines.append("")
+        lines.append("# rocprofv3 --pmc SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 --kernel-trace (separate pass): wave-level instruction counts,")
+        lines.append("# mean per full launch; fp64 FLOP/launch = (ADD + MUL + TRANS + 2 FMA) x 64 lanes (upper bound: ignores the exec mask)")
+        f64 = {}
+        for cn, cnt, avg in q(db, "select counter_name, count(*), avg(value) from counters_collection where kernel_name like "
+                                  "'%%teb_optimize%%' and grid_size_x=%d group by counter_name" % grid):
+            lines.append("%-28s %.6g" % (cn, avg))
+            summary[cn] = avg
+            f64[cn] = avg
+        if len(f64) == 4:
+            flop = 64.0 * (f64["SQ_INSTS_VALU_ADD_F64"] + f64["SQ_INSTS_VALU_MUL_F64"] + f64["SQ_INSTS_VALU_TRANS_F64"]
+                           + 2.0 * f64["SQ_INSTS_VALU_FMA_F64"])
+            summary["fp64_flop_per_launch"] = flop
+            lines.append("fp64_flop_per_launch %.6g  (%.3f TFLOP/s at the traced average duration)" % (flop, flop / (summary["avg_ms"] * 1e-3) / 1e12))
     cal = os.path.join(SRC, "calib.json")
     if os.path.exists(cal):
         summary["calibration"] = json.load(open(cal))

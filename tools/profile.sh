@@ -12,6 +12,7 @@ rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/bench_tra
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o fetch -- $CMD > $OUT/bench_fetch.json 2> $OUT/fetch.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o write -- $CMD > $OUT/bench_write.json 2> $OUT/write.log
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace -d $OUT/pmc_sq -o sq -- $CMD > $OUT/bench_sq.json 2> $OUT/sq.log
+rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 --kernel-trace -d $OUT/pmc_f64 -o f64 -- $CMD > $OUT/bench_f64.json 2> $OUT/f64.log
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/cal_fetch -o calf -- python $ROOT/tools/calib_stream.py > /dev/null 2> $OUT/calf.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/cal_write -o calw -- python $ROOT/tools/calib_stream.py > /dev/null 2> $OUT/calw.log
 cd $ROOT
@@ -32,7 +33,7 @@ for f in $(find $OUT/trace -name "*kernel_stats.csv"); do echo "== $f"; head -20
 python - <<'PY'
 import csv, glob, os, collections
 out = os.path.join(os.getcwd(), "gpurun_out", "prof")
-for tag in ("fetch", "write", "sq"):
+for tag in ("fetch", "write", "sq", "f64"):
     for f in glob.glob(os.path.join(out, "pmc_" + tag, "**", "*counter_collection.csv"), recursive=True):
         agg = collections.defaultdict(lambda: [0.0, 0])
         with open(f) as fh:
