@@ -177,3 +177,70 @@ def centroid(obst, index):
     cx = C.c_double(0); cy = C.c_double(0)
     _check(lib().teb_oracle_centroid(C.byref(obst.freeze()), index, C.byref(cx), C.byref(cy)), "centroid")
     return cx.value, cy.value
+
+
+# ---- SURVEY section 8(f) rows f1 / f2 ------------------------------------------------------------------------------------
+def _band_buffers(cap):
+    return np.zeros(cap), np.zeros(cap), np.zeros(cap), np.zeros(cap), C.c_int32(0)
+
+
+def _band_result(X, Y, T, D, nn):
+    n = nn.value
+    return X[:n].copy(), Y[:n].copy(), T[:n].copy(), D[:max(n - 1, 0)].copy()
+
+
+_P = lambda a: _abi._ptr(a, C.c_double)
+
+
+def init_trajectory_line(start, goal, diststep, max_vel_x, min_samples, guess_backwards_motion, cap=4096):
+    X, Y, T, D, nn = _band_buffers(cap)
+    s = _abi.f64(start); g = _abi.f64(goal)
+    _check(lib().teb_oracle_init_trajectory_line(_P(s), _P(g), C.c_double(diststep), C.c_double(max_vel_x), int(min_samples),
+                                                 int(guess_backwards_motion), _P(X), _P(Y), _P(T), _P(D), C.byref(nn), cap),
+           "init_trajectory_line")
+    return _band_result(X, Y, T, D, nn)
+
+
+def init_trajectory_plan(px, py, pyaw, max_vel_x, max_vel_theta, estimate_orient, min_samples, guess_backwards_motion, cap=4096):
+    X, Y, T, D, nn = _band_buffers(cap)
+    px = _abi.f64(px); py = _abi.f64(py); pyaw = _abi.f64(pyaw)
+    _check(lib().teb_oracle_init_trajectory_plan(len(px), _P(px), _P(py), _P(pyaw), C.c_double(max_vel_x), C.c_double(max_vel_theta),
+                                                 int(estimate_orient), int(min_samples), int(guess_backwards_motion), _P(X), _P(Y),
+                                                 _P(T), _P(D), C.byref(nn), cap), "init_trajectory_plan")
+    return _band_result(X, Y, T, D, nn)
+
+
+def init_trajectory_path(px, py, max_vel_x, max_vel_theta, max_acc_x, start_orient, goal_orient, min_samples,
+                         guess_backwards_motion, cap=4096):
+    """max_acc_x / start_orient / goal_orient: None = boost::none."""
+    X, Y, T, D, nn = _band_buffers(cap)
+    px = _abi.f64(px); py = _abi.f64(py)
+    opt = lambda v: (int(v is not None), C.c_double(0.0 if v is None else v))
+    a, so, go = opt(max_acc_x), opt(start_orient), opt(goal_orient)
+    _check(lib().teb_oracle_init_trajectory_path(len(px), _P(px), _P(py), C.c_double(max_vel_x), C.c_double(max_vel_theta), a[0], a[1],
+                                                 so[0], so[1], go[0], go[1], int(min_samples), int(guess_backwards_motion), _P(X), _P(Y),
+                                                 _P(T), _P(D), C.byref(nn), cap), "init_trajectory_path")
+    return _band_result(X, Y, T, D, nn)
+
+
+def update_and_prune(x, y, theta, dt, new_start, new_goal, min_samples):
+    n = len(x)
+    X = _abi.f64(x).copy(); Y = _abi.f64(y).copy(); T = _abi.f64(theta).copy(); D = np.zeros(n); D[:n - 1] = dt
+    nn = C.c_int32(n)
+    s = None if new_start is None else _abi.f64(new_start); g = None if new_goal is None else _abi.f64(new_goal)
+    _check(lib().teb_oracle_update_and_prune(_P(X), _P(Y), _P(T), _P(D), C.byref(nn), None if s is None else _P(s),
+                                             None if g is None else _P(g), int(min_samples)), "update_and_prune")
+    return _band_result(X, Y, T, D, nn)
+
+
+def consumers(cfg, batch, b, look_ahead_poses=1, prevent_look_ahead_poses_near_goal=0):
+    """getVelocityCommand / getVelocityProfile / getFullTrajectory on TEB b: dict(cmd [3], ok, profile [n+1,3], trajectory [n,7])."""
+    c = cfg.to_c()
+    bs = batch.c_struct()
+    n = int(batch.n[b])
+    cmd = np.zeros(3); ok = C.c_int32(0); prof = np.zeros((n + 1, 3)); traj = np.zeros((n, 7))
+    _check(lib().teb_oracle_velocity_command(C.byref(c), C.byref(bs), b, int(look_ahead_poses), int(prevent_look_ahead_poses_near_goal),
+                                             _P(cmd), C.byref(ok)), "velocity_command")
+    _check(lib().teb_oracle_velocity_profile(C.byref(c), C.byref(bs), b, _P(prof)), "velocity_profile")
+    _check(lib().teb_oracle_full_trajectory(C.byref(c), C.byref(bs), b, _P(traj)), "full_trajectory")
+    return dict(cmd=cmd, ok=bool(ok.value), profile=prof, trajectory=traj)

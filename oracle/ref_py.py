@@ -144,3 +144,70 @@ def build_graph(cfg, obst, via, batch, b=0, weight_multiplier=1.0, cap=1 << 16):
     assert rc == 0, rc
     k = min(cnt.value, cap)
     return ir[:k].copy(), dr[:k].copy()
+
+
+# ---- SURVEY section 8(f) rows f1 / f2 on the reference's own TimedElasticBand / TebOptimalPlanner -------------------------
+_P = lambda a: _abi._ptr(a, C.c_double)
+
+
+def _bufs(cap):
+    return np.zeros(cap), np.zeros(cap), np.zeros(cap), np.zeros(cap), C.c_int32(0)
+
+
+def _res(X, Y, T, D, nn):
+    n = nn.value
+    return X[:n].copy(), Y[:n].copy(), T[:n].copy(), D[:max(n - 1, 0)].copy()
+
+
+def init_trajectory_line(start, goal, diststep, max_vel_x, min_samples, guess_backwards_motion, cap=4096):
+    X, Y, T, D, nn = _bufs(cap)
+    s = _abi.f64(start); g = _abi.f64(goal)
+    assert lib().ref_init_trajectory_line(_P(s), _P(g), C.c_double(diststep), C.c_double(max_vel_x), int(min_samples),
+                                          int(guess_backwards_motion), _P(X), _P(Y), _P(T), _P(D), C.byref(nn), cap) == 0
+    return _res(X, Y, T, D, nn)
+
+
+def init_trajectory_plan(px, py, pyaw, max_vel_x, max_vel_theta, estimate_orient, min_samples, guess_backwards_motion, cap=4096):
+    """Returns (band, yaw_seen): the plan travels as quaternions (geometry_msgs::PoseStamped); yaw_seen = tf::getYaw of them."""
+    X, Y, T, D, nn = _bufs(cap)
+    px = _abi.f64(px); py = _abi.f64(py); pyaw = _abi.f64(pyaw)
+    seen = np.zeros(len(px))
+    assert lib().ref_init_trajectory_plan(len(px), _P(px), _P(py), _P(pyaw), C.c_double(max_vel_x), C.c_double(max_vel_theta),
+                                          int(estimate_orient), int(min_samples), int(guess_backwards_motion), _P(seen), _P(X), _P(Y),
+                                          _P(T), _P(D), C.byref(nn), cap) == 0
+    return _res(X, Y, T, D, nn), seen
+
+
+def init_trajectory_path(px, py, max_vel_x, max_vel_theta, max_acc_x, start_orient, goal_orient, min_samples,
+                         guess_backwards_motion, cap=4096):
+    X, Y, T, D, nn = _bufs(cap)
+    px = _abi.f64(px); py = _abi.f64(py)
+    opt = lambda v: (int(v is not None), C.c_double(0.0 if v is None else v))
+    a, so, go = opt(max_acc_x), opt(start_orient), opt(goal_orient)
+    assert lib().ref_init_trajectory_path(len(px), _P(px), _P(py), C.c_double(max_vel_x), C.c_double(max_vel_theta), a[0], a[1], so[0],
+                                          so[1], go[0], go[1], int(min_samples), int(guess_backwards_motion), _P(X), _P(Y), _P(T),
+                                          _P(D), C.byref(nn), cap) == 0
+    return _res(X, Y, T, D, nn)
+
+
+def update_and_prune(x, y, theta, dt, new_start, new_goal, min_samples):
+    n = len(x)
+    X = _abi.f64(x).copy(); Y = _abi.f64(y).copy(); T = _abi.f64(theta).copy(); D = np.zeros(n); D[:n - 1] = dt
+    nn = C.c_int32(n)
+    s = None if new_start is None else _abi.f64(new_start); g = None if new_goal is None else _abi.f64(new_goal)
+    assert lib().ref_update_and_prune(_P(X), _P(Y), _P(T), _P(D), C.byref(nn), None if s is None else _P(s),
+                                      None if g is None else _P(g), int(min_samples)) == 0
+    return _res(X, Y, T, D, nn)
+
+
+def consumers(cfg, batch, b, look_ahead_poses=1, prevent_look_ahead_poses_near_goal=0):
+    c = cfg.to_c()
+    x, y, th, dt = batch.get_teb(b)
+    n = len(x)
+    dtp = np.zeros(n); dtp[:n - 1] = dt
+    cmd = np.zeros(3); ok = C.c_int32(0); prof = np.zeros((n + 1, 3)); traj = np.zeros((n, 7))
+    vs = _abi.f64(batch.vel_start[b]); vg = _abi.f64(batch.vel_goal[b])
+    assert lib().ref_consumers(C.byref(c), n, _P(_abi.f64(x)), _P(_abi.f64(y)), _P(_abi.f64(th)), _P(dtp), int(batch.has_vel_start[b]),
+                               _P(vs), int(batch.has_vel_goal[b]), _P(vg), int(look_ahead_poses), int(prevent_look_ahead_poses_near_goal),
+                               _P(cmd), C.byref(ok), _P(prof), _P(traj)) == 0
+    return dict(cmd=cmd, ok=bool(ok.value), profile=prof, trajectory=traj)

@@ -240,4 +240,99 @@ int ref_scalar_helpers(int nq, const double* v, const double* a, const double* b
   return 0;
 }
 
+// ---- SURVEY section 8(f) rows f1 / f2, executed by the reference's own TimedElasticBand / TebOptimalPlanner ---------------------
+namespace {
+int band_out(const TimedElasticBand& teb, double* x, double* y, double* th, double* dt, int32_t* n, int cap) {
+  const int k = teb.sizePoses();
+  if (k > cap) return 4;
+  *n = k;
+  for (int i = 0; i < k; ++i) { x[i] = teb.Pose(i).x(); y[i] = teb.Pose(i).y(); th[i] = teb.Pose(i).theta(); }
+  for (int i = 0; i < teb.sizeTimeDiffs(); ++i) dt[i] = teb.TimeDiff(i);
+  return 0;
+}
+void band_in(TimedElasticBand& teb, int n, const double* x, const double* y, const double* th, const double* dt) {
+  teb.addPose(x[0], y[0], th[0], true);
+  for (int i = 1; i < n; ++i) teb.addPoseAndTimeDiff(x[i], y[i], th[i], dt[i - 1]);
+  teb.setPoseVertexFixed(n - 1, true);
+}
+}  // namespace
+
+// TimedElasticBand::initTrajectoryToGoal(start, goal, diststep, ...) src/timed_elastic_band.cpp:325-377
+int ref_init_trajectory_line(const double* start, const double* goal, double diststep, double max_vel_x, int min_samples, int guess_backwards,
+                             double* x, double* y, double* th, double* dt, int32_t* n, int cap) {
+  TimedElasticBand teb;
+  if (!teb.initTrajectoryToGoal(PoseSE2(start[0], start[1], start[2]), PoseSE2(goal[0], goal[1], goal[2]), diststep, max_vel_x, min_samples,
+                                guess_backwards != 0)) return 1;
+  return band_out(teb, x, y, th, dt, n, cap);
+}
+
+// initTrajectoryToGoal(plan (PoseStamped), ...) :380-452. yaw_seen[np] = tf::getYaw of the quaternions the plan was given as.
+int ref_init_trajectory_plan(int np, const double* px, const double* py, const double* pyaw, double max_vel_x, double max_vel_theta,
+                             int estimate_orient, int min_samples, int guess_backwards, double* yaw_seen, double* x, double* y, double* th,
+                             double* dt, int32_t* n, int cap) {
+  std::vector<geometry_msgs::PoseStamped> plan(np);
+  for (int i = 0; i < np; ++i) {
+    plan[i].pose.position.x = px[i]; plan[i].pose.position.y = py[i];
+    plan[i].pose.orientation = tf::createQuaternionMsgFromYaw(pyaw[i]);
+    yaw_seen[i] = tf::getYaw(plan[i].pose.orientation);
+  }
+  TimedElasticBand teb;
+  if (!teb.initTrajectoryToGoal(plan, max_vel_x, max_vel_theta, estimate_orient != 0, min_samples, guess_backwards != 0)) return 1;
+  return band_out(teb, x, y, th, dt, n, cap);
+}
+
+// template initTrajectoryToGoal(path_start, path_end, fun_position, ...) timed_elastic_band.hpp:46-183
+int ref_init_trajectory_path(int np, const double* px, const double* py, double max_vel_x, double max_vel_theta, int has_max_acc_x,
+                             double max_acc_x, int has_start_orient, double start_orient, int has_goal_orient, double goal_orient,
+                             int min_samples, int guess_backwards, double* x, double* y, double* th, double* dt, int32_t* n, int cap) {
+  std::vector<Eigen::Vector2d> path;
+  for (int i = 0; i < np; ++i) path.push_back(Eigen::Vector2d(px[i], py[i]));
+  TimedElasticBand teb;
+  auto fun = [](const Eigen::Vector2d& p) -> const Eigen::Vector2d& { return p; };
+  boost::optional<double> acc = has_max_acc_x ? boost::optional<double>(max_acc_x) : boost::optional<double>(boost::none);
+  boost::optional<double> so = has_start_orient ? boost::optional<double>(start_orient) : boost::optional<double>(boost::none);
+  boost::optional<double> go = has_goal_orient ? boost::optional<double>(goal_orient) : boost::optional<double>(boost::none);
+  if (!teb.initTrajectoryToGoal(path.begin(), path.end(), fun, max_vel_x, max_vel_theta, acc, boost::optional<double>(boost::none), so, go,
+                                min_samples, guess_backwards != 0)) return 1;
+  return band_out(teb, x, y, th, dt, n, cap);
+}
+
+// TimedElasticBand::updateAndPruneTEB :555-597
+int ref_update_and_prune(double* x, double* y, double* th, double* dt, int32_t* n, const double* new_start, const double* new_goal,
+                         int min_samples) {
+  TimedElasticBand teb;
+  band_in(teb, *n, x, y, th, dt);
+  PoseSE2 s, g;
+  if (new_start) s = PoseSE2(new_start[0], new_start[1], new_start[2]);
+  if (new_goal) g = PoseSE2(new_goal[0], new_goal[1], new_goal[2]);
+  teb.updateAndPruneTEB(new_start ? boost::optional<const PoseSE2&>(s) : boost::optional<const PoseSE2&>(boost::none),
+                        new_goal ? boost::optional<const PoseSE2&>(g) : boost::optional<const PoseSE2&>(boost::none), min_samples);
+  return band_out(teb, x, y, th, dt, n, *n);
+}
+
+// getVelocityCommand / getVelocityProfile / getFullTrajectory of the reference, src/optimal_planner.cpp:1135-1247
+int ref_consumers(const teb_amd_config_t* acfg, int n, const double* x, const double* y, const double* th, const double* dt, int has_vs,
+                  const double* vs, int has_vg, const double* vg, int look_ahead_poses, int prevent_look_ahead_poses_near_goal,
+                  double* cmd /*3*/, int32_t* cmd_ok, double* profile /*(n+1)*3*/, double* traj /*n*7*/) {
+  TebConfig cfg;
+  to_ref_config(*acfg, cfg);
+  cfg.trajectory.prevent_look_ahead_poses_near_goal = prevent_look_ahead_poses_near_goal;
+  PlannerProbe pl(cfg, nullptr, TebVisualizationPtr(), nullptr);
+  fill_planner(pl, n, x, y, th, dt, has_vs, vs, has_vg, vg, TEB_AMD_ROT_NONE);
+  if (!has_vg) {   // fill_planner called setVelocityGoalFree(); the stored twist stays zero
+  }
+  *cmd_ok = pl.getVelocityCommand(cmd[0], cmd[1], cmd[2], look_ahead_poses) ? 1 : 0;
+  std::vector<geometry_msgs::Twist> prof;
+  pl.getVelocityProfile(prof);
+  for (size_t i = 0; i < prof.size(); ++i) { profile[3 * i] = prof[i].linear.x; profile[3 * i + 1] = prof[i].linear.y; profile[3 * i + 2] = prof[i].angular.z; }
+  std::vector<TrajectoryPointMsg> tr;
+  pl.getFullTrajectory(tr);
+  for (size_t i = 0; i < tr.size(); ++i) {
+    double* o = traj + 7 * i;
+    o[0] = tr[i].pose.position.x; o[1] = tr[i].pose.position.y; o[2] = tf::getYaw(tr[i].pose.orientation);
+    o[3] = tr[i].velocity.linear.x; o[4] = tr[i].velocity.linear.y; o[5] = tr[i].velocity.angular.z; o[6] = tr[i].time_from_start.toSec();
+  }
+  return 0;
+}
+
 }  // extern "C"

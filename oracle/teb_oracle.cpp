@@ -1814,6 +1814,314 @@ int teb_oracle_autoresize(double* x, double* y, double* theta, double* dt, int32
   return TEB_AMD_OK;
 }
 
+// ================================================================================================================
+// the producers and consumers either side of optimizeTEB.
+// ================================================================================================================
+namespace {
+
+// estimateDeltaT, src/timed_elastic_band.cpp:52-65
+double estimate_delta_t(double sx, double sy, double sth, double ex, double ey, double eth, double max_vel_x, double max_vel_theta) {
+  double dt_constant_motion = 0.1;
+  if (max_vel_x > 0) {
+    double trans_dist = norm(V2{ex, ey} - V2{sx, sy});
+    dt_constant_motion = trans_dist / max_vel_x;
+  }
+  if (max_vel_theta > 0) {
+    double rot_dist = std::abs(normalize_theta(eth - sth));
+    dt_constant_motion = std::max(dt_constant_motion, rot_dist / max_vel_theta);
+  }
+  return dt_constant_motion;
+}
+
+void push_pose(Teb& t, double x, double y, double th) { t.x.push_back(x); t.y.push_back(y); t.th.push_back(th); }
+void push_pose_dt(Teb& t, double x, double y, double th, double dt) { push_pose(t, x, y, th); t.dt.push_back(dt); }
+
+// PoseSE2::average(BackPose(), goal), pose_se2.h:266-269
+void back_goal_average(const Teb& t, double gx, double gy, double gth, double& ax, double& ay, double& ath) {
+  ax = (t.x.back() + gx) / 2; ay = (t.y.back() + gy) / 2;
+  ath = average_angle(t.th.back(), gth);
+}
+
+// TimedElasticBand::initTrajectoryToGoal(start, goal, diststep, max_vel_x, min_samples, guess_backwards_motion), :325-377
+bool init_trajectory_line(Teb& t, const double* start, const double* goal, double diststep, double max_vel_x, int min_samples,
+                          bool guess_backwards_motion) {
+  if (t.n() != 0 || !t.dt.empty()) return false;   // isInit()
+  push_pose(t, start[0], start[1], start[2]);
+  double timestep = 0.1;
+  if (diststep != 0) {
+    V2 point_to_goal = V2{goal[0], goal[1]} - V2{start[0], start[1]};
+    double dir_to_goal = std::atan2(point_to_goal.y, point_to_goal.x);
+    double dx = diststep * std::cos(dir_to_goal);
+    double dy = diststep * std::sin(dir_to_goal);
+    double orient_init = dir_to_goal;
+    if (guess_backwards_motion && dot(point_to_goal, V2{std::cos(start[2]), std::sin(start[2])}) < 0)
+      orient_init = normalize_theta(orient_init + M_PI);
+    double dist_to_goal = norm(point_to_goal);
+    double no_steps_d = dist_to_goal / std::abs(diststep);
+    unsigned int no_steps = (unsigned int)std::floor(no_steps_d);
+    if (max_vel_x > 0) timestep = diststep / max_vel_x;
+    for (unsigned int i = 1; i <= no_steps; i++) {
+      if (i == no_steps && no_steps_d == (float)no_steps) break;
+      push_pose_dt(t, start[0] + i * dx, start[1] + i * dy, orient_init, timestep);
+    }
+  }
+  if (t.n() < min_samples - 1) {
+    while (t.n() < min_samples - 1) {
+      double ax, ay, ath;
+      back_goal_average(t, goal[0], goal[1], goal[2], ax, ay, ath);
+      if (max_vel_x > 0) timestep = norm(V2{ax, ay} - V2{t.x.back(), t.y.back()}) / max_vel_x;
+      push_pose_dt(t, ax, ay, ath, timestep);
+    }
+  }
+  if (max_vel_x > 0) timestep = norm(V2{goal[0], goal[1]} - V2{t.x.back(), t.y.back()}) / max_vel_x;
+  push_pose_dt(t, goal[0], goal[1], goal[2], timestep);
+  return true;
+}
+
+// initTrajectoryToGoal(plan, max_vel_x, max_vel_theta, estimate_orient, min_samples, guess_backwards_motion), :380-452
+// plan given as positions + yaw (tf::getYaw of the pose orientation is taken by the caller)
+bool init_trajectory_plan(Teb& t, int np, const double* px, const double* py, const double* pyaw, double max_vel_x,
+                          double max_vel_theta, bool estimate_orient, int min_samples, bool guess_backwards_motion) {
+  if (t.n() != 0 || !t.dt.empty()) return false;
+  const double sx = px[0], sy = py[0], sth = pyaw[0];
+  const double gx = px[np - 1], gy = py[np - 1], gth = pyaw[np - 1];
+  push_pose(t, sx, sy, sth);
+  bool backwards = false;
+  if (guess_backwards_motion && dot(V2{gx, gy} - V2{sx, sy}, V2{std::cos(sth), std::sin(sth)}) < 0) backwards = true;
+  for (int i = 1; i < np - 1; ++i) {
+    double yaw;
+    if (estimate_orient) {
+      double dx = px[i + 1] - px[i];
+      double dy = py[i + 1] - py[i];
+      yaw = std::atan2(dy, dx);
+      if (backwards) yaw = normalize_theta(yaw + M_PI);
+    } else {
+      yaw = pyaw[i];
+    }
+    double dt = estimate_delta_t(t.x.back(), t.y.back(), t.th.back(), px[i], py[i], yaw, max_vel_x, max_vel_theta);
+    push_pose_dt(t, px[i], py[i], yaw, dt);
+  }
+  if (t.n() < min_samples - 1) {
+    while (t.n() < min_samples - 1) {
+      double ax, ay, ath;
+      back_goal_average(t, gx, gy, gth, ax, ay, ath);
+      double dt = estimate_delta_t(t.x.back(), t.y.back(), t.th.back(), ax, ay, ath, max_vel_x, max_vel_theta);
+      push_pose_dt(t, ax, ay, ath, dt);
+    }
+  }
+  double dt = estimate_delta_t(t.x.back(), t.y.back(), t.th.back(), gx, gy, gth, max_vel_x, max_vel_theta);
+  push_pose_dt(t, gx, gy, gth, dt);
+  return true;
+}
+
+// template initTrajectoryToGoal(path_start, path_end, fun_position, ...), timed_elastic_band.hpp:46-183 (positions only)
+bool init_trajectory_path(Teb& t, int np, const double* px, const double* py, double max_vel_x, double max_vel_theta,
+                          bool has_max_acc_x, double max_acc_x, bool has_start_orient, double start_orientation,
+                          bool has_goal_orient, double goal_orientation, int min_samples, bool guess_backwards_motion) {
+  (void)max_vel_theta;
+  V2 start_position{px[0], py[0]}, goal_position{px[np - 1], py[np - 1]};
+  bool backwards = false;
+  double start_orient, goal_orient;
+  if (has_start_orient) {
+    start_orient = start_orientation;
+    if (guess_backwards_motion && dot(goal_position - start_position, V2{std::cos(start_orient), std::sin(start_orient)}) < 0)
+      backwards = true;
+  } else {
+    V2 start2goal = goal_position - start_position;
+    start_orient = std::atan2(start2goal.y, start2goal.x);
+  }
+  double timestep = 1;
+  goal_orient = has_goal_orient ? goal_orientation : start_orient;
+  if (t.n() != 0 || !t.dt.empty()) return false;
+  push_pose(t, start_position.x, start_position.y, start_orient);
+  int idx = 0;
+  for (int k = 1; k < np - 1; ++k) {
+    V2 curr_point{px[k], py[k]};
+    V2 diff_last = curr_point - V2{t.x[idx], t.y[idx]};
+    double diff_norm = norm(diff_last);
+    double timestep_vel = diff_norm / max_vel_x;
+    double timestep_acc;
+    if (has_max_acc_x) {
+      timestep_acc = std::sqrt(2 * diff_norm / max_acc_x);
+      if (timestep_vel < timestep_acc && has_max_acc_x) timestep = timestep_acc;
+      else timestep = timestep_vel;
+    } else timestep = timestep_vel;
+    if (timestep <= 0) timestep = 0.2;
+    double yaw = std::atan2(diff_last.y, diff_last.x);
+    if (backwards) yaw = normalize_theta(yaw + M_PI);
+    push_pose_dt(t, curr_point.x, curr_point.y, yaw, timestep);
+    ++idx;
+  }
+  V2 diff = goal_position - V2{t.x[idx], t.y[idx]};
+  double diff_norm = norm(diff);
+  double timestep_vel = diff_norm / max_vel_x;
+  if (has_max_acc_x) {
+    double timestep_acc = std::sqrt(2 * diff_norm / max_acc_x);
+    if (timestep_vel < timestep_acc) timestep = timestep_acc;
+    else timestep = timestep_vel;
+  } else timestep = timestep_vel;
+  if (t.n() < min_samples - 1) {
+    while (t.n() < min_samples - 1) {
+      timestep /= 2;
+      double ax, ay, ath;
+      back_goal_average(t, goal_position.x, goal_position.y, goal_orient, ax, ay, ath);
+      push_pose_dt(t, ax, ay, ath, timestep);
+    }
+  }
+  push_pose_dt(t, goal_position.x, goal_position.y, goal_orient, timestep);
+  return true;
+}
+
+// TimedElasticBand::updateAndPruneTEB, src/timed_elastic_band.cpp:555-597
+void update_and_prune(Teb& t, bool has_start, const double* ns, bool has_goal, const double* ng, int min_samples) {
+  if (has_start && t.n() > 0) {
+    V2 p{ns[0], ns[1]};
+    double dist_cache = norm(p - V2{t.x[0], t.y[0]});
+    double dist;
+    int lookahead = std::min<int>(t.n() - min_samples, 10);
+    int nearest_idx = 0;
+    for (int i = 1; i <= lookahead; ++i) {
+      dist = norm(p - V2{t.x[i], t.y[i]});
+      if (dist < dist_cache) { dist_cache = dist; nearest_idx = i; }
+      else break;
+    }
+    if (nearest_idx > 0) {   // deletePoses(1, nearest_idx); deleteTimeDiffs(1, nearest_idx)
+      t.x.erase(t.x.begin() + 1, t.x.begin() + 1 + nearest_idx);
+      t.y.erase(t.y.begin() + 1, t.y.begin() + 1 + nearest_idx);
+      t.th.erase(t.th.begin() + 1, t.th.begin() + 1 + nearest_idx);
+      t.dt.erase(t.dt.begin() + 1, t.dt.begin() + 1 + nearest_idx);
+    }
+    t.x[0] = ns[0]; t.y[0] = ns[1]; t.th[0] = ns[2];
+  }
+  if (has_goal && t.n() > 0) { t.x.back() = ng[0]; t.y.back() = ng[1]; t.th.back() = ng[2]; }
+}
+
+// TebOptimalPlanner::extractVelocity, src/optimal_planner.cpp:1097-1133
+void extract_velocity(const teb_amd_config_t& c, double x1, double y1, double th1, double x2, double y2, double th2, double dt,
+                      double& vx, double& vy, double& omega) {
+  if (dt == 0) { vx = 0; vy = 0; omega = 0; return; }
+  V2 deltaS = V2{x2, y2} - V2{x1, y1};
+  if (c.max_vel_y == 0) {
+    V2 conf1dir{std::cos(th1), std::sin(th1)};
+    double dir = dot(deltaS, conf1dir);
+    vx = sign(dir) * norm(deltaS) / dt;   // (double) g2o::sign(dir)
+    vy = 0;
+  } else {
+    double cos_theta1 = std::cos(th1);
+    double sin_theta1 = std::sin(th1);
+    double p1_dx = cos_theta1 * deltaS.x + sin_theta1 * deltaS.y;
+    double p1_dy = -sin_theta1 * deltaS.x + cos_theta1 * deltaS.y;
+    vx = p1_dx / dt;
+    vy = p1_dy / dt;
+  }
+  double orientdiff = normalize_theta(th2 - th1);
+  omega = orientdiff / dt;
+}
+
+int teb_out(const Teb& t, double* x, double* y, double* th, double* dt, int32_t* n, int cap) {
+  if (t.n() > cap) return TEB_AMD_ERR_CAPACITY;
+  *n = t.n();
+  std::copy(t.x.begin(), t.x.end(), x); std::copy(t.y.begin(), t.y.end(), y);
+  std::copy(t.th.begin(), t.th.end(), th); std::copy(t.dt.begin(), t.dt.end(), dt);
+  return TEB_AMD_OK;
+}
+
+}  // namespace
+
+int teb_oracle_init_trajectory_line(const double* start, const double* goal, double diststep, double max_vel_x, int32_t min_samples,
+                                    int32_t guess_backwards_motion, double* x, double* y, double* th, double* dt, int32_t* n,
+                                    int32_t cap) {
+  Teb t;
+  if (!init_trajectory_line(t, start, goal, diststep, max_vel_x, min_samples, guess_backwards_motion != 0)) return TEB_AMD_ERR_INVALID_ARG;
+  return teb_out(t, x, y, th, dt, n, cap);
+}
+
+int teb_oracle_init_trajectory_plan(int32_t np, const double* px, const double* py, const double* pyaw, double max_vel_x,
+                                    double max_vel_theta, int32_t estimate_orient, int32_t min_samples,
+                                    int32_t guess_backwards_motion, double* x, double* y, double* th, double* dt, int32_t* n,
+                                    int32_t cap) {
+  if (np < 1) return TEB_AMD_ERR_INVALID_ARG;
+  Teb t;
+  if (!init_trajectory_plan(t, np, px, py, pyaw, max_vel_x, max_vel_theta, estimate_orient != 0, min_samples, guess_backwards_motion != 0))
+    return TEB_AMD_ERR_INVALID_ARG;
+  return teb_out(t, x, y, th, dt, n, cap);
+}
+
+int teb_oracle_init_trajectory_path(int32_t np, const double* px, const double* py, double max_vel_x, double max_vel_theta,
+                                    int32_t has_max_acc_x, double max_acc_x, int32_t has_start_orient, double start_orient,
+                                    int32_t has_goal_orient, double goal_orient, int32_t min_samples,
+                                    int32_t guess_backwards_motion, double* x, double* y, double* th, double* dt, int32_t* n,
+                                    int32_t cap) {
+  if (np < 1) return TEB_AMD_ERR_INVALID_ARG;
+  Teb t;
+  if (!init_trajectory_path(t, np, px, py, max_vel_x, max_vel_theta, has_max_acc_x != 0, max_acc_x, has_start_orient != 0, start_orient,
+                            has_goal_orient != 0, goal_orient, min_samples, guess_backwards_motion != 0))
+    return TEB_AMD_ERR_INVALID_ARG;
+  return teb_out(t, x, y, th, dt, n, cap);
+}
+
+int teb_oracle_update_and_prune(double* x, double* y, double* th, double* dt, int32_t* n, const double* new_start,
+                                const double* new_goal, int32_t min_samples) {
+  Teb t;
+  t.x.assign(x, x + *n); t.y.assign(y, y + *n); t.th.assign(th, th + *n); t.dt.assign(dt, dt + std::max(0, *n - 1));
+  update_and_prune(t, new_start != nullptr, new_start, new_goal != nullptr, new_goal, min_samples);
+  return teb_out(t, x, y, th, dt, n, *n);
+}
+
+int teb_oracle_velocity_command(const teb_amd_config_t* cfg, const teb_amd_teb_batch_t* batch, int32_t b, int32_t look_ahead_poses,
+                                int32_t prevent_look_ahead_poses_near_goal, double* v, int32_t* ok) {
+  Teb t;
+  teb_from_batch(batch, b, t);
+  v[0] = v[1] = v[2] = 0; *ok = 0;
+  if (t.n() < 2) return TEB_AMD_OK;                                   // :1137-1144
+  look_ahead_poses = std::max(1, std::min(look_ahead_poses, t.n() - 1 - prevent_look_ahead_poses_near_goal));
+  double dt = 0.0;
+  for (int counter = 0; counter < look_ahead_poses; ++counter) {
+    dt += t.dt[counter];
+    if (dt >= cfg->dt_ref * look_ahead_poses) { look_ahead_poses = counter + 1; break; }
+  }
+  if (dt <= 0) return TEB_AMD_OK;                                     // :1156-1163
+  extract_velocity(*cfg, t.x[0], t.y[0], t.th[0], t.x[look_ahead_poses], t.y[look_ahead_poses], t.th[look_ahead_poses], dt, v[0], v[1], v[2]);
+  *ok = 1;
+  return TEB_AMD_OK;
+}
+
+// getVelocityProfile :1170-1196 -> out[(n+1)*3] = (linear.x, linear.y, angular.z)
+int teb_oracle_velocity_profile(const teb_amd_config_t* cfg, const teb_amd_teb_batch_t* batch, int32_t b, double* out) {
+  Teb t;
+  teb_from_batch(batch, b, t);
+  const int n = t.n();
+  for (int k = 0; k < 3; ++k) { out[k] = t.vs[k]; }
+  for (int i = 1; i < n; ++i)
+    extract_velocity(*cfg, t.x[i - 1], t.y[i - 1], t.th[i - 1], t.x[i], t.y[i], t.th[i], t.dt[i - 1], out[3 * i], out[3 * i + 1], out[3 * i + 2]);
+  for (int k = 0; k < 3; ++k) out[3 * n + k] = t.vg[k];
+  return TEB_AMD_OK;
+}
+
+// getFullTrajectory :1198-1247 -> out[n*7] = (x, y, theta, vx, vy, omega, time_from_start)
+int teb_oracle_full_trajectory(const teb_amd_config_t* cfg, const teb_amd_teb_batch_t* batch, int32_t b, double* out) {
+  Teb t;
+  teb_from_batch(batch, b, t);
+  const int n = t.n();
+  if (n == 0) return TEB_AMD_OK;
+  double curr_time = 0;
+  auto put = [&](int i, double vx, double vy, double om, double tt) {
+    double* o = out + 7 * i;
+    o[0] = t.x[i]; o[1] = t.y[i]; o[2] = t.th[i]; o[3] = vx; o[4] = vy; o[5] = om; o[6] = tt;
+  };
+  put(0, t.vs[0], t.vs[1], t.vs[2], curr_time);
+  curr_time += t.dt[0];
+  for (int i = 1; i < n - 1; ++i) {
+    double vel1_x, vel1_y, vel2_x, vel2_y, omega1, omega2;
+    extract_velocity(*cfg, t.x[i - 1], t.y[i - 1], t.th[i - 1], t.x[i], t.y[i], t.th[i], t.dt[i - 1], vel1_x, vel1_y, omega1);
+    extract_velocity(*cfg, t.x[i], t.y[i], t.th[i], t.x[i + 1], t.y[i + 1], t.th[i + 1], t.dt[i], vel2_x, vel2_y, omega2);
+    put(i, 0.5 * (vel1_x + vel2_x), 0.5 * (vel1_y + vel2_y), 0.5 * (omega1 + omega2), curr_time);
+    curr_time += t.dt[i];
+  }
+  put(n - 1, t.vg[0], t.vg[1], t.vg[2], curr_time);
+  return TEB_AMD_OK;
+}
+
 int teb_oracle_linearize(const teb_amd_config_t* cfg, const teb_amd_obstacles_t* obst, int32_t n_via,
                          const double* via_x, const double* via_y, const teb_amd_teb_batch_t* batch, int32_t b,
                          double weight_multiplier, double* H_dense, double* bvec, double* chi2, int32_t* n_edges,

@@ -88,6 +88,36 @@ int teb_oracle_distance(const teb_amd_config_t* cfg, const teb_amd_obstacles_t* 
 /* Polygon centroid as PolygonObstacle::calcCentroid (src/obstacles.cpp:56-121), and the centroid of any obstacle. */
 int teb_oracle_centroid(const teb_amd_obstacles_t* obst, int32_t obst_index, double* cx, double* cy);
 
+/* ---- SURVEY section 8(f) rows f1 (producers of the state strip) and f2 (consumers of the optimised strip) ---------------- */
+/* TimedElasticBand::initTrajectoryToGoal(start, goal, diststep, max_vel_x, min_samples, guess_backwards_motion),
+ * src/timed_elastic_band.cpp:325-377. start/goal = (x, y, theta). Output arrays have capacity cap. */
+int teb_oracle_init_trajectory_line(const double* start, const double* goal, double diststep, double max_vel_x, int32_t min_samples,
+                                    int32_t guess_backwards_motion, double* x, double* y, double* th, double* dt, int32_t* n,
+                                    int32_t cap);
+/* initTrajectoryToGoal(plan, max_vel_x, max_vel_theta, estimate_orient, min_samples, guess_backwards_motion), :380-452;
+ * the plan as positions + yaw (the caller applies tf::getYaw). */
+int teb_oracle_init_trajectory_plan(int32_t np, const double* px, const double* py, const double* pyaw, double max_vel_x,
+                                    double max_vel_theta, int32_t estimate_orient, int32_t min_samples,
+                                    int32_t guess_backwards_motion, double* x, double* y, double* th, double* dt, int32_t* n,
+                                    int32_t cap);
+/* template initTrajectoryToGoal(path_start, path_end, fun_position, ...), timed_elastic_band.hpp:46-183 (what
+ * HomotopyClassPlanner::addAndInitNewTeb feeds with graph vertices). */
+int teb_oracle_init_trajectory_path(int32_t np, const double* px, const double* py, double max_vel_x, double max_vel_theta,
+                                    int32_t has_max_acc_x, double max_acc_x, int32_t has_start_orient, double start_orient,
+                                    int32_t has_goal_orient, double goal_orient, int32_t min_samples,
+                                    int32_t guess_backwards_motion, double* x, double* y, double* th, double* dt, int32_t* n,
+                                    int32_t cap);
+/* TimedElasticBand::updateAndPruneTEB (src/timed_elastic_band.cpp:555-597) in place; new_start / new_goal may be NULL. */
+int teb_oracle_update_and_prune(double* x, double* y, double* th, double* dt, int32_t* n, const double* new_start,
+                                const double* new_goal, int32_t min_samples);
+/* TebOptimalPlanner::getVelocityCommand (src/optimal_planner.cpp:1135-1168): v = (vx, vy, omega), *ok = return value. */
+int teb_oracle_velocity_command(const teb_amd_config_t* cfg, const teb_amd_teb_batch_t* batch, int32_t b, int32_t look_ahead_poses,
+                                int32_t prevent_look_ahead_poses_near_goal, double* v, int32_t* ok);
+/* getVelocityProfile (:1170-1196): out[(n+1)*3] = (linear.x, linear.y, angular.z). */
+int teb_oracle_velocity_profile(const teb_amd_config_t* cfg, const teb_amd_teb_batch_t* batch, int32_t b, double* out);
+/* getFullTrajectory (:1198-1247): out[n*7] = (x, y, theta, vx, vy, omega, time_from_start). */
+int teb_oracle_full_trajectory(const teb_amd_config_t* cfg, const teb_amd_teb_batch_t* batch, int32_t b, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,7 +30,7 @@ def lib():
     """Loads libteb_amd.so (built in-tree by teb_local_planner_amd.build)."""
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "libteb_amd.so")
+        so = os.environ.get("TEB_AMD_LIB") or os.path.join(_HERE, "libteb_amd.so")   # TEB_AMD_LIB: kernel experiments (tools/)
         if not os.path.exists(so):
             raise TebAmdError(-1, "load", "libteb_amd.so missing: run `python -m teb_local_planner_amd.build`")
         L = C.CDLL(so)

@@ -206,3 +206,56 @@ def test_reference_default_start_and_goal_velocity_are_fixed_at_zero(oracle):
     if r is not None:
         rir, _ = r.build_graph(cfg, obst, via, batch, 0, 1.0)
         assert (rir[:, 0] == 7).sum() == 1 and (rir[:, 0] == 8).sum() == 1
+
+
+# ---- producers and consumers of the strip, pinned on the reference's TimedElasticBand / planner ------
+
+def _same_band(a, b):
+    assert len(a[0]) == len(b[0])
+    for u, v in zip(a, b):
+        np.testing.assert_array_equal(u, v)
+
+
+def test_f1_initTrajectoryToGoal_line_matches_reference(oracle):
+    ref, src = _ref_results("f1_init_line")
+    for k, c in enumerate(G.init_line_cases()):
+        _same_band(oracle.init_trajectory_line(*c), G.unpack(ref, k))
+
+
+def test_f1_initTrajectoryToGoal_plan_matches_reference(oracle):
+    ref, src = _ref_results("f1_init_plan")
+    o = 0
+    for k, c in enumerate(G.init_plan_cases()):
+        seen = ref["yaw_seen"][o:o + len(c[0])]; o += len(c[0])   # the plan reaches the reference as quaternions
+        np.testing.assert_allclose(seen, c[2], rtol=0, atol=1e-15)
+        _same_band(oracle.init_trajectory_plan(c[0], c[1], seen, *c[3:]), G.unpack(ref, k))
+
+
+def test_f1_initTrajectoryToGoal_path_template_matches_reference(oracle):
+    ref, src = _ref_results("f1_init_path")
+    for k, c in enumerate(G.init_path_cases()):
+        _same_band(oracle.init_trajectory_path(*c), G.unpack(ref, k))
+
+
+def test_f1_updateAndPruneTEB_matches_reference(oracle):
+    ref, src = _ref_results("f1_prune")
+    pruned = 0
+    for k, c in enumerate(G.prune_cases()):
+        out = oracle.update_and_prune(*c)
+        _same_band(out, G.unpack(ref, k))
+        pruned += len(out[0]) < len(c[0])
+    assert pruned >= 5
+
+
+def test_f2_velocity_command_profile_and_trajectory_match_reference(oracle):
+    ref, src = _ref_results("f2_consumers")
+    po = to = 0
+    for k, c in enumerate(G.consumer_cases()):
+        r = oracle.consumers(*c)
+        n = int(c[1].n[c[2]])
+        assert r["ok"] == bool(ref["ok"][k])
+        np.testing.assert_array_equal(r["cmd"], ref["cmd"][k])
+        np.testing.assert_array_equal(r["profile"], ref["profile"][po:po + n + 1]); po += n + 1
+        t = ref["trajectory"][to:to + n]; to += n
+        np.testing.assert_array_equal(r["trajectory"][:, [0, 1, 3, 4, 5, 6]], t[:, [0, 1, 3, 4, 5, 6]])
+        np.testing.assert_allclose(r["trajectory"][:, 2], t[:, 2], rtol=0, atol=1e-15)   # yaw went through a quaternion in the reference
