@@ -275,6 +275,51 @@ int  teb_amd_device_state(teb_amd_handle_t* h, void** x, void** y, void** theta,
 /* Snapshot / restore the resident strips device-to-device (used to re-run identical work per step). */
 int  teb_amd_snapshot_state(teb_amd_handle_t* h);
 int  teb_amd_restore_state(teb_amd_handle_t* h);
+/*
+ * ---- Producers and consumers of the DEVICE-RESIDENT strips --------------------------------
+ * With these a planning tick is: update_and_prune (or init_trajectory_*) -> set_obstacles -> optimize_batch -> select_best ->
+ * get_velocity_command, without uploading or downloading the bands.
+ *
+ * f1 — TimedElasticBand::initTrajectoryToGoal, the three overloads, writing slot b (0 <= b < max_tebs; slots >= the current
+ * batch size extend it, with the TebOptimalPlanner::initialize() defaults: start / goal velocity fixed at zero, no preferred turning
+ * direction, via-points enabled). Poses are (x, y, theta). TEB_AMD_ERR_CAPACITY when the band would exceed max_poses.
+ */
+/* initTrajectoryToGoal(start, goal, diststep, max_vel_x, min_samples, guess_backwards_motion), src/timed_elastic_band.cpp:325-377 */
+int  teb_amd_init_trajectory_line(teb_amd_handle_t* h, int32_t b, const double* start, const double* goal, double diststep,
+                                  double max_vel_x, int32_t min_samples, int32_t guess_backwards_motion);
+/* initTrajectoryToGoal(plan, max_vel_x, max_vel_theta, estimate_orient, min_samples, guess_backwards_motion), :380-452; the plan
+ * (std::vector<geometry_msgs::PoseStamped>) as n_plan positions + yaw (tf::getYaw of each orientation) */
+int  teb_amd_init_trajectory_plan(teb_amd_handle_t* h, int32_t b, int32_t n_plan, const double* plan_x, const double* plan_y,
+                                  const double* plan_yaw, double max_vel_x, double max_vel_theta, int32_t estimate_orient,
+                                  int32_t min_samples, int32_t guess_backwards_motion);
+/* template initTrajectoryToGoal(path_start, path_end, fun_position, max_vel_x, max_vel_theta, max_acc_x, max_acc_theta,
+ * start_orientation, goal_orientation, min_samples, guess_backwards_motion), timed_elastic_band.hpp:46-183 (the overload
+ * HomotopyClassPlanner feeds with graph vertices). Optional arguments: NULL = boost::none. */
+int  teb_amd_init_trajectory_path(teb_amd_handle_t* h, int32_t b, int32_t n_path, const double* path_x, const double* path_y,
+                                  double max_vel_x, double max_vel_theta, const double* max_acc_x, const double* start_orientation,
+                                  const double* goal_orientation, int32_t min_samples, int32_t guess_backwards_motion);
+/* TimedElasticBand::updateAndPruneTEB(new_start, new_goal, min_samples), src/timed_elastic_band.cpp:555-597, on band b or on every
+ * band of the batch (b = -1: HomotopyClassPlanner::updateAllTEBs, src/homotopy_class_planner.cpp:539-562). NULL = boost::none. */
+int  teb_amd_update_and_prune(teb_amd_handle_t* h, int32_t b, const double* new_start, const double* new_goal, int32_t min_samples);
+/* setVelocityStart / setVelocityGoal / setVelocityGoalFree (optimal_planner.h:247-260) on band b or all (b = -1);
+ * fixed = 0 frees the velocity (the stored twist is kept), v = (linear.x, linear.y, angular.z) or NULL to keep the stored twist. */
+int  teb_amd_set_velocity_start(teb_amd_handle_t* h, int32_t b, int32_t fixed, const double* v);
+int  teb_amd_set_velocity_goal(teb_amd_handle_t* h, int32_t b, int32_t fixed, const double* v);
+/* current pose counts of the batch (after init / prune / optimise), n [count] */
+int  teb_amd_get_pose_counts(teb_amd_handle_t* h, int32_t* n, int32_t* count);
+/*
+ * f2 — consumers of the optimised strip of band b, computed on the device for the whole batch in one launch and cached until the
+ * bands change: TebOptimalPlanner::getVelocityCommand (src/optimal_planner.cpp:1135-1168; *ok = its return value; uses
+ * trajectory.prevent_look_ahead_poses_near_goal, passed here because teb_amd_config_t does not carry it), getVelocityProfile
+ * (:1170-1196, out [(n+1)*3] = linear.x, linear.y, angular.z), getFullTrajectory (:1198-1247, out [n*7] = x, y, theta,
+ * linear.x, linear.y, angular.z, time_from_start) and hasDiverged (:1023-1039).
+ */
+int  teb_amd_get_velocity_command(teb_amd_handle_t* h, int32_t b, int32_t look_ahead_poses,
+                                  int32_t prevent_look_ahead_poses_near_goal, double* vx, double* vy, double* omega, int32_t* ok);
+int  teb_amd_get_velocity_profile(teb_amd_handle_t* h, int32_t b, double* out, int32_t capacity_rows, int32_t* rows);
+int  teb_amd_get_full_trajectory(teb_amd_handle_t* h, int32_t b, double* out, int32_t capacity_rows, int32_t* rows);
+int  teb_amd_has_diverged(teb_amd_handle_t* h, int32_t b, int32_t* diverged);
+
 /* Duration [ms] of the last optimize_batch kernel, measured with HIP events on the launch stream. */
 int  teb_amd_last_kernel_ms(teb_amd_handle_t* h, float* ms);
 /* LDS bytes per workgroup and the largest pose count this build can optimise. */

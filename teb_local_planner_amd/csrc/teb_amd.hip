@@ -13,6 +13,7 @@
 #include "../../include/teb_amd.h"
 #include "../../include/teb_amd_debug.h"
 #include "teb_kernel.hpp"
+#include "teb_strip.hpp"
 
 using namespace tebamd;
 
@@ -152,7 +153,11 @@ struct teb_amd_handle {
   DevBuf<double> snap_x, snap_y, snap_th, snap_dt;
   // debug / select
   DevBuf<double> dbg_H, dbg_b, dbg_chi2, sel_cost;
-  DevBuf<int> sel_idx;
+  DevBuf<int> sel_idx, err_flag;
+  // strip producers / consumers (f1, f2)
+  DevBuf<double> stage_x, stage_y, stage_yaw, out_cmd, out_prof, out_traj;
+  bool consumers_valid = false;
+  int consumers_la = 0, consumers_prevent = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   std::vector<int> host_type;
@@ -226,6 +231,7 @@ int launch(teb_amd_handle* h, const OptArgs& args) {
   HIPCHK(hipMemsetAsync(h->assoc_ovf.p, 0, sizeof(int) * h->max_tebs, h->stream));
   HIPCHK(hipEventRecord(h->ev0, h->stream));
   launch_opt(h, h->B, sc, bt, args);
+  h->consumers_valid = false;
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   h->timed = true;
@@ -333,13 +339,18 @@ int teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_po
   A(h->Hbackup.alloc((size_t)max_tebs * h->hmat_stride)); A(h->rs_scratch.alloc((size_t)max_tebs * (4 * (size_t)max_poses + 256)));
   A(h->snap_n.alloc(max_tebs)); A(h->snap_x.alloc(BS)); A(h->snap_y.alloc(BS)); A(h->snap_th.alloc(BS)); A(h->snap_dt.alloc(BS));
   A(h->dbg_H.alloc((size_t)4 * max_poses * kBand)); A(h->dbg_b.alloc((size_t)4 * max_poses)); A(h->dbg_chi2.alloc(4));
-  A(h->sel_cost.alloc(1)); A(h->sel_idx.alloc(1));
+  A(h->sel_cost.alloc(1)); A(h->sel_idx.alloc(1)); A(h->err_flag.alloc(1));
+  A(h->stage_x.alloc((size_t)max_poses + 2)); A(h->stage_y.alloc((size_t)max_poses + 2)); A(h->stage_yaw.alloc((size_t)max_poses + 2));
+  A(h->out_cmd.alloc(4 * (size_t)max_tebs)); A(h->out_prof.alloc((size_t)max_tebs * (max_poses + 1) * 3)); A(h->out_traj.alloc(BS * 7));
   if (ok && hipEventCreate(&h->ev0) != hipSuccess) ok = false;
   if (ok && hipEventCreate(&h->ev1) != hipSuccess) ok = false;
   for (int jm : {TEB_AMD_JACOBIAN_ANALYTIC, TEB_AMD_JACOBIAN_G2O_NUMERIC})
     if (ok && hipFuncSetAttribute(reinterpret_cast<const void*>(opt_kernel(solver, jm)),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit) != hipSuccess) ok = false;
   if (ok && hipMemset(h->cost.p, 0, sizeof(double) * max_tebs) != hipSuccess) ok = false;
+  if (ok && hipMemset(h->chi2.p, 0, sizeof(double) * max_tebs) != hipSuccess) ok = false;
+  if (ok && hipMemset(h->iters.p, 0, sizeof(int) * max_tebs) != hipSuccess) ok = false;   // hasDiverged: "no statistics yet"
+  if (ok && hipMemset(h->status.p, 0, sizeof(int) * max_tebs) != hipSuccess) ok = false;
   if (!ok) { teb_amd_destroy(h); return fail(TEB_AMD_ERR_HIP, "device allocation / kernel attribute setup failed"); }
   *out = h;
   return TEB_AMD_OK;
@@ -351,12 +362,12 @@ void teb_amd_destroy(teb_amd_handle_t* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   DevBuf<int>* ib[] = {&h->o_type, &h->o_dyn, &h->o_voff, &h->o_static, &h->o_dynidx, &h->n, &h->has_vs, &h->has_vg, &h->rotdir,
                        &h->via_en, &h->status, &h->iters, &h->trials, &h->assoc_cnt, &h->assoc, &h->assoc_ovf, &h->via_pose, &h->legacy_idx,
-                       &h->snap_n, &h->sel_idx};
+                       &h->snap_n, &h->sel_idx, &h->err_flag};
   for (auto* q : ib) q->free();
   DevBuf<double>* db[] = {&h->o_ax, &h->o_ay, &h->o_bx, &h->o_by, &h->o_rad, &h->o_vx, &h->o_vy, &h->o_cx, &h->o_cy, &h->o_pvx,
                           &h->o_pvy, &h->viax, &h->viay, &h->x, &h->y, &h->th, &h->dt, &h->vs, &h->vg, &h->chi2, &h->cost,
                           &h->lambda, &h->Hbackup, &h->rs_scratch, &h->snap_x, &h->snap_y, &h->snap_th, &h->snap_dt, &h->dbg_H,
-                          &h->dbg_b, &h->dbg_chi2, &h->sel_cost};
+                          &h->dbg_b, &h->dbg_chi2, &h->sel_cost, &h->stage_x, &h->stage_y, &h->stage_yaw, &h->out_cmd, &h->out_prof, &h->out_traj};
   for (auto* q : db) q->free();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -489,6 +500,7 @@ int teb_amd_upload_tebs(teb_amd_handle_t* h, const teb_amd_teb_batch_t* bt) {
   HIPCHK(hipMemcpyAsync(h->vg.p, vg.data(), 3 * (size_t)B * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->B = B;
+  h->consumers_valid = false;
   return TEB_AMD_OK;
 }
 
@@ -569,6 +581,227 @@ int teb_amd_select_best(teb_amd_handle_t* h, int32_t last_best, int32_t initial_
   return TEB_AMD_OK;
 }
 
+// ---- f1 / f2: producers and consumers of the device-resident strips (kernels in teb_strip.hpp) ---------------------------------
+namespace {
+
+// slots >= B join the batch with the defaults of TebOptimalPlanner::initialize() (src/optimal_planner.cpp:86-104)
+int extend_batch(teb_amd_handle* h, int b) {
+  if (b < 0 || b >= h->max_tebs) return fail(TEB_AMD_ERR_INVALID_ARG, "TEB slot out of range");
+  for (int k = h->B; k <= b; ++k) {
+    const int one = 1, none = TEB_AMD_ROT_NONE, two = 2;
+    const double z3[3] = {0, 0, 0};
+    HIPCHK(hipMemcpyAsync(h->has_vs.p + k, &one, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->has_vg.p + k, &one, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->rotdir.p + k, &none, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->via_en.p + k, &one, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->vs.p + 3 * k, z3, sizeof(z3), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->vg.p + 3 * k, z3, sizeof(z3), hipMemcpyHostToDevice, h->stream));
+    if (k < b) {   // a skipped slot becomes the trivial two-pose band at the origin so that the batch stays well-formed
+      const double zz[2] = {0, 0}, dd[2] = {0.1, 0};
+      const size_t o = (size_t)k * h->stride;
+      HIPCHK(hipMemcpyAsync(h->x.p + o, zz, sizeof(zz), hipMemcpyHostToDevice, h->stream));
+      HIPCHK(hipMemcpyAsync(h->y.p + o, zz, sizeof(zz), hipMemcpyHostToDevice, h->stream));
+      HIPCHK(hipMemcpyAsync(h->th.p + o, zz, sizeof(zz), hipMemcpyHostToDevice, h->stream));
+      HIPCHK(hipMemcpyAsync(h->dt.p + o, dd, sizeof(dd), hipMemcpyHostToDevice, h->stream));
+      HIPCHK(hipMemcpyAsync(h->n.p + k, &two, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));   // the small host temporaries above
+  }
+  if (b >= h->B) h->B = b + 1;
+  return TEB_AMD_OK;
+}
+
+int finish_init(teb_amd_handle* h) {
+  HIPCHK(hipGetLastError());
+  int err = 0;
+  HIPCHK(hipMemcpyAsync(&err, h->err_flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->consumers_valid = false;
+  if (err) return fail(TEB_AMD_ERR_CAPACITY, "initTrajectoryToGoal: the band needs more poses than max_poses");
+  return TEB_AMD_OK;
+}
+
+int stage(teb_amd_handle* h, int n, const double* px, const double* py, const double* pyaw) {
+  if (n < 1 || !px || !py) return fail(TEB_AMD_ERR_INVALID_ARG, "empty plan / path");
+  if (n > h->stride + 1) return fail(TEB_AMD_ERR_CAPACITY, "plan / path longer than max_poses + 1");
+  HIPCHK(hipMemcpyAsync(h->stage_x.p, px, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->stage_y.p, py, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (pyaw) HIPCHK(hipMemcpyAsync(h->stage_yaw.p, pyaw, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemsetAsync(h->err_flag.p, 0, sizeof(int), h->stream));
+  return TEB_AMD_OK;
+}
+
+int run_consumers(teb_amd_handle* h, int look_ahead, int prevent) {
+  if (h->B <= 0) return fail(TEB_AMD_ERR_INVALID_ARG, "no TEBs on the device");
+  if (h->consumers_valid && h->consumers_la == look_ahead && h->consumers_prevent == prevent) return TEB_AMD_OK;
+  hipLaunchKernelGGL(consumers_kernel, dim3(h->B), dim3(kThreads), 0, h->stream, h->cfg, batch_of(h), look_ahead, prevent,
+                     h->out_cmd.p, h->out_prof.p, h->out_traj.p);
+  HIPCHK(hipGetLastError());
+  h->consumers_valid = true; h->consumers_la = look_ahead; h->consumers_prevent = prevent;
+  return TEB_AMD_OK;
+}
+
+int band_n(teb_amd_handle* h, int b, int* n) {
+  if (b < 0 || b >= h->B) return fail(TEB_AMD_ERR_INVALID_ARG, "TEB index out of range");
+  HIPCHK(hipMemcpyAsync(n, h->n.p + b, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return TEB_AMD_OK;
+}
+
+}  // namespace
+
+int teb_amd_init_trajectory_line(teb_amd_handle_t* h, int32_t b, const double* start, const double* goal, double diststep,
+                                 double max_vel_x, int32_t min_samples, int32_t guess_backwards_motion) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!start || !goal) return fail(TEB_AMD_ERR_INVALID_ARG, "null start / goal");
+  if ((rc = extend_batch(h, b))) return rc;
+  HIPCHK(hipMemsetAsync(h->err_flag.p, 0, sizeof(int), h->stream));
+  hipLaunchKernelGGL(init_line_kernel, dim3(1), dim3(kThreads), 0, h->stream, batch_of(h), b, start[0], start[1], start[2], goal[0],
+                     goal[1], goal[2], diststep, max_vel_x, min_samples, guess_backwards_motion, h->err_flag.p);
+  return finish_init(h);
+}
+
+int teb_amd_init_trajectory_plan(teb_amd_handle_t* h, int32_t b, int32_t n_plan, const double* plan_x, const double* plan_y,
+                                 const double* plan_yaw, double max_vel_x, double max_vel_theta, int32_t estimate_orient,
+                                 int32_t min_samples, int32_t guess_backwards_motion) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!plan_yaw) return fail(TEB_AMD_ERR_INVALID_ARG, "null plan_yaw");
+  if ((rc = extend_batch(h, b))) return rc;
+  if ((rc = stage(h, n_plan, plan_x, plan_y, plan_yaw))) return rc;
+  hipLaunchKernelGGL(init_plan_kernel, dim3(1), dim3(kThreads), 0, h->stream, batch_of(h), b, n_plan, h->stage_x.p, h->stage_y.p,
+                     h->stage_yaw.p, max_vel_x, max_vel_theta, estimate_orient, min_samples, guess_backwards_motion, h->err_flag.p);
+  return finish_init(h);
+}
+
+int teb_amd_init_trajectory_path(teb_amd_handle_t* h, int32_t b, int32_t n_path, const double* path_x, const double* path_y,
+                                 double max_vel_x, double max_vel_theta, const double* max_acc_x, const double* start_orientation,
+                                 const double* goal_orientation, int32_t min_samples, int32_t guess_backwards_motion) {
+  (void)max_vel_theta;   // unused by the reference too (its angular time step code is commented out, timed_elastic_band.hpp:118-140)
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if ((rc = extend_batch(h, b))) return rc;
+  if ((rc = stage(h, n_path, path_x, path_y, nullptr))) return rc;
+  hipLaunchKernelGGL(init_path_kernel, dim3(1), dim3(kThreads), 0, h->stream, batch_of(h), b, n_path, h->stage_x.p, h->stage_y.p,
+                     max_vel_x, max_acc_x ? 1 : 0, max_acc_x ? *max_acc_x : 0.0, start_orientation ? 1 : 0,
+                     start_orientation ? *start_orientation : 0.0, goal_orientation ? 1 : 0, goal_orientation ? *goal_orientation : 0.0,
+                     min_samples, guess_backwards_motion, h->err_flag.p);
+  return finish_init(h);
+}
+
+int teb_amd_update_and_prune(teb_amd_handle_t* h, int32_t b, const double* new_start, const double* new_goal, int32_t min_samples) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (h->B <= 0) return fail(TEB_AMD_ERR_INVALID_ARG, "no TEBs on the device");
+  if (b >= h->B || b < -1) return fail(TEB_AMD_ERR_INVALID_ARG, "TEB index out of range");
+  const double z[3] = {0, 0, 0};
+  const double* s = new_start ? new_start : z;
+  const double* g = new_goal ? new_goal : z;
+  hipLaunchKernelGGL(prune_kernel, dim3(b < 0 ? h->B : 1), dim3(kThreads), 4 * (size_t)h->stride * sizeof(double), h->stream,
+                     batch_of(h), b < 0 ? 0 : b, new_start ? 1 : 0, s[0], s[1], s[2], new_goal ? 1 : 0, g[0], g[1], g[2], min_samples);
+  HIPCHK(hipGetLastError());
+  h->consumers_valid = false;
+  return TEB_AMD_OK;
+}
+
+namespace {
+int set_velocity(teb_amd_handle* h, DevBuf<int>& flag, DevBuf<double>& vel, int b, int fixed, const double* v) {
+  if (h->B <= 0) return fail(TEB_AMD_ERR_INVALID_ARG, "no TEBs on the device");
+  if (b >= h->B || b < -1) return fail(TEB_AMD_ERR_INVALID_ARG, "TEB index out of range");
+  const int b0 = b < 0 ? 0 : b, b1 = b < 0 ? h->B : b + 1;
+  std::vector<int> f(b1 - b0, fixed ? 1 : 0);
+  HIPCHK(hipMemcpyAsync(flag.p + b0, f.data(), f.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  std::vector<double> vv;
+  if (v) {
+    for (int k = b0; k < b1; ++k) { vv.push_back(v[0]); vv.push_back(v[1]); vv.push_back(v[2]); }
+    HIPCHK(hipMemcpyAsync(vel.p + 3 * b0, vv.data(), vv.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->consumers_valid = false;
+  return TEB_AMD_OK;
+}
+}  // namespace
+
+int teb_amd_set_velocity_start(teb_amd_handle_t* h, int32_t b, int32_t fixed, const double* v) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  return set_velocity(h, h->has_vs, h->vs, b, fixed, v);
+}
+
+int teb_amd_set_velocity_goal(teb_amd_handle_t* h, int32_t b, int32_t fixed, const double* v) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  return set_velocity(h, h->has_vg, h->vg, b, fixed, v);
+}
+
+int teb_amd_get_pose_counts(teb_amd_handle_t* h, int32_t* n, int32_t* count) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (count) *count = h->B;
+  if (n && h->B > 0) {
+    HIPCHK(hipMemcpyAsync(n, h->n.p, h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return TEB_AMD_OK;
+}
+
+int teb_amd_get_velocity_command(teb_amd_handle_t* h, int32_t b, int32_t look_ahead_poses, int32_t prevent_look_ahead_poses_near_goal,
+                                 double* vx, double* vy, double* omega, int32_t* ok) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (b < 0 || b >= h->B) return fail(TEB_AMD_ERR_INVALID_ARG, "TEB index out of range");
+  if ((rc = run_consumers(h, look_ahead_poses, prevent_look_ahead_poses_near_goal))) return rc;
+  double c[4];
+  HIPCHK(hipMemcpyAsync(c, h->out_cmd.p + 4 * (size_t)b, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (vx) *vx = c[0]; if (vy) *vy = c[1]; if (omega) *omega = c[2]; if (ok) *ok = c[3] != 0;
+  return TEB_AMD_OK;
+}
+
+int teb_amd_get_velocity_profile(teb_amd_handle_t* h, int32_t b, double* out, int32_t capacity_rows, int32_t* rows) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  int n = 0;
+  if ((rc = band_n(h, b, &n))) return rc;
+  if (rows) *rows = n + 1;
+  if (!out) return TEB_AMD_OK;
+  if (capacity_rows < n + 1) return fail(TEB_AMD_ERR_CAPACITY, "velocity profile needs n+1 rows");
+  if ((rc = run_consumers(h, h->consumers_valid ? h->consumers_la : 1, h->consumers_valid ? h->consumers_prevent : 0))) return rc;
+  HIPCHK(hipMemcpyAsync(out, h->out_prof.p + (size_t)b * (h->stride + 1) * 3, (size_t)(n + 1) * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return TEB_AMD_OK;
+}
+
+int teb_amd_get_full_trajectory(teb_amd_handle_t* h, int32_t b, double* out, int32_t capacity_rows, int32_t* rows) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  int n = 0;
+  if ((rc = band_n(h, b, &n))) return rc;
+  if (rows) *rows = n;
+  if (!out) return TEB_AMD_OK;
+  if (capacity_rows < n) return fail(TEB_AMD_ERR_CAPACITY, "trajectory needs n rows");
+  if ((rc = run_consumers(h, h->consumers_valid ? h->consumers_la : 1, h->consumers_valid ? h->consumers_prevent : 0))) return rc;
+  HIPCHK(hipMemcpyAsync(out, h->out_traj.p + (size_t)b * h->stride * 7, (size_t)n * 7 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return TEB_AMD_OK;
+}
+
+int teb_amd_has_diverged(teb_amd_handle_t* h, int32_t b, int32_t* diverged) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (b < 0 || b >= h->B || !diverged) return fail(TEB_AMD_ERR_INVALID_ARG, "TEB index out of range");
+  *diverged = 0;
+  if (!h->cfg.divergence_detection_enable) return TEB_AMD_OK;            // :1026-1027
+  double chi2 = 0; int iters = 0;
+  HIPCHK(hipMemcpyAsync(&chi2, h->chi2.p + b, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(&iters, h->iters.p + b, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (iters <= 0) return TEB_AMD_OK;                                      // no statistics yet, :1031-1033
+  *diverged = chi2 > h->cfg.divergence_detection_max_chi_squared;
+  return TEB_AMD_OK;
+}
+
 int teb_amd_device_state(teb_amd_handle_t* h, void** x, void** y, void** theta, void** dt, void** n, int32_t* stride) {
   int rc = check_handle(h);
   if (rc) return rc;
@@ -598,6 +831,7 @@ int teb_amd_restore_state(teb_amd_handle_t* h) {
   HIPCHK(hipMemcpyAsync(h->th.p, h->snap_th.p, BS, hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->dt.p, h->snap_dt.p, BS, hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->n.p, h->snap_n.p, h->max_tebs * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+  h->consumers_valid = false;
   return TEB_AMD_OK;
 }
 

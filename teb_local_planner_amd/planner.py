@@ -62,6 +62,20 @@ def lib():
         L.teb_amd_debug_assoc_overflow.argtypes = [vp, _abi.p_i32]
         L.teb_amd_debug_stream.argtypes = [vp, C.c_int64, C.c_int32]
         L.teb_amd_debug_profile.argtypes = [vp, _abi.p_f64]
+        # producers / consumers of the device-resident strips
+        d, i32 = C.c_double, C.c_int32
+        L.teb_amd_init_trajectory_line.argtypes = [vp, i32, _abi.p_f64, _abi.p_f64, d, d, i32, i32]
+        L.teb_amd_init_trajectory_plan.argtypes = [vp, i32, i32, _abi.p_f64, _abi.p_f64, _abi.p_f64, d, d, i32, i32, i32]
+        L.teb_amd_init_trajectory_path.argtypes = [vp, i32, i32, _abi.p_f64, _abi.p_f64, d, d, _abi.p_f64, _abi.p_f64, _abi.p_f64,
+                                                   i32, i32]
+        L.teb_amd_update_and_prune.argtypes = [vp, i32, _abi.p_f64, _abi.p_f64, i32]
+        L.teb_amd_set_velocity_start.argtypes = [vp, i32, i32, _abi.p_f64]
+        L.teb_amd_set_velocity_goal.argtypes = [vp, i32, i32, _abi.p_f64]
+        L.teb_amd_get_pose_counts.argtypes = [vp, _abi.p_i32, _abi.p_i32]
+        L.teb_amd_get_velocity_command.argtypes = [vp, i32, i32, i32, _abi.p_f64, _abi.p_f64, _abi.p_f64, _abi.p_i32]
+        L.teb_amd_get_velocity_profile.argtypes = [vp, i32, _abi.p_f64, i32, _abi.p_i32]
+        L.teb_amd_get_full_trajectory.argtypes = [vp, i32, _abi.p_f64, i32, _abi.p_i32]
+        L.teb_amd_has_diverged.argtypes = [vp, i32, _abi.p_i32]
         _LIB = L
     return _LIB
 
@@ -161,6 +175,87 @@ class TebBatchSolver:
         b = C.c_int32(0)
         _chk(lib().teb_amd_capacity(self._h, C.byref(a), C.byref(b)), "teb_amd_capacity")
         return a.value, b.value
+
+    # -- producers / consumers of the device-resident strips ----------------------
+    @staticmethod
+    def _opt3(v):
+        return None if v is None else _abi._ptr(_abi.f64(v), C.c_double)
+
+    @staticmethod
+    def _opt1(v):
+        return None if v is None else _abi._ptr(_abi.f64([v]), C.c_double)
+
+    def _sync_count(self):
+        c = C.c_int32(0)
+        _chk(lib().teb_amd_get_pose_counts(self._h, None, C.byref(c)), "teb_amd_get_pose_counts")
+        self.count = c.value
+
+    def init_trajectory_line(self, b, start, goal, diststep, max_vel_x, min_samples, guess_backwards_motion=False):
+        _chk(lib().teb_amd_init_trajectory_line(self._h, b, self._opt3(start), self._opt3(goal), diststep, max_vel_x, min_samples,
+                                                int(guess_backwards_motion)), "teb_amd_init_trajectory_line")
+        self._sync_count()
+
+    def init_trajectory_plan(self, b, px, py, pyaw, max_vel_x, max_vel_theta, estimate_orient, min_samples,
+                             guess_backwards_motion=False):
+        px = _abi.f64(px); py = _abi.f64(py); pyaw = _abi.f64(pyaw)
+        P = lambda a: _abi._ptr(a, C.c_double)
+        _chk(lib().teb_amd_init_trajectory_plan(self._h, b, len(px), P(px), P(py), P(pyaw), max_vel_x, max_vel_theta,
+                                                int(estimate_orient), min_samples, int(guess_backwards_motion)),
+             "teb_amd_init_trajectory_plan")
+        self._sync_count()
+
+    def init_trajectory_path(self, b, px, py, max_vel_x, max_vel_theta, max_acc_x=None, start_orientation=None,
+                             goal_orientation=None, min_samples=3, guess_backwards_motion=False):
+        px = _abi.f64(px); py = _abi.f64(py)
+        P = lambda a: _abi._ptr(a, C.c_double)
+        _chk(lib().teb_amd_init_trajectory_path(self._h, b, len(px), P(px), P(py), max_vel_x, max_vel_theta, self._opt1(max_acc_x),
+                                                self._opt1(start_orientation), self._opt1(goal_orientation), min_samples,
+                                                int(guess_backwards_motion)), "teb_amd_init_trajectory_path")
+        self._sync_count()
+
+    def update_and_prune(self, new_start=None, new_goal=None, min_samples=3, b=-1):
+        _chk(lib().teb_amd_update_and_prune(self._h, b, self._opt3(new_start), self._opt3(new_goal), min_samples),
+             "teb_amd_update_and_prune")
+
+    def set_velocity_start(self, v, fixed=True, b=-1):
+        _chk(lib().teb_amd_set_velocity_start(self._h, b, int(fixed), self._opt3(v)), "teb_amd_set_velocity_start")
+
+    def set_velocity_goal(self, v=None, fixed=True, b=-1):
+        _chk(lib().teb_amd_set_velocity_goal(self._h, b, int(fixed), self._opt3(v)), "teb_amd_set_velocity_goal")
+
+    def pose_counts(self):
+        self._sync_count()
+        n = np.zeros(max(self.count, 1), np.int32)
+        c = C.c_int32(0)
+        _chk(lib().teb_amd_get_pose_counts(self._h, _abi._ptr(n, C.c_int32), C.byref(c)), "teb_amd_get_pose_counts")
+        return n[:c.value].copy()
+
+    def velocity_command(self, b, look_ahead_poses=1, prevent_look_ahead_poses_near_goal=0):
+        vx = C.c_double(0); vy = C.c_double(0); om = C.c_double(0); ok = C.c_int32(0)
+        _chk(lib().teb_amd_get_velocity_command(self._h, b, look_ahead_poses, prevent_look_ahead_poses_near_goal, C.byref(vx),
+                                                C.byref(vy), C.byref(om), C.byref(ok)), "teb_amd_get_velocity_command")
+        return bool(ok.value), np.array([vx.value, vy.value, om.value])
+
+    def velocity_profile(self, b):
+        rows = C.c_int32(0)
+        _chk(lib().teb_amd_get_velocity_profile(self._h, b, None, 0, C.byref(rows)), "teb_amd_get_velocity_profile")
+        out = np.zeros((rows.value, 3))
+        _chk(lib().teb_amd_get_velocity_profile(self._h, b, _abi._ptr(out, C.c_double), rows.value, C.byref(rows)),
+             "teb_amd_get_velocity_profile")
+        return out
+
+    def full_trajectory(self, b):
+        rows = C.c_int32(0)
+        _chk(lib().teb_amd_get_full_trajectory(self._h, b, None, 0, C.byref(rows)), "teb_amd_get_full_trajectory")
+        out = np.zeros((rows.value, 7))
+        _chk(lib().teb_amd_get_full_trajectory(self._h, b, _abi._ptr(out, C.c_double), rows.value, C.byref(rows)),
+             "teb_amd_get_full_trajectory")
+        return out
+
+    def has_diverged(self, b):
+        d = C.c_int32(0)
+        _chk(lib().teb_amd_has_diverged(self._h, b, C.byref(d)), "teb_amd_has_diverged")
+        return bool(d.value)
 
     # -- test hooks -----------------------------------------------------------------------------------
     def debug_linearize(self, b, n, weight_multiplier=1.0, assoc_cap=1 << 16):

@@ -1,0 +1,198 @@
+"""SURVEY section 8(f) rows f1 / f2 on the device-resident strips, through the C-ABI: the three initTrajectoryToGoal overloads,
+updateAndPruneTEB, setVelocity*, getVelocityCommand / getVelocityProfile / getFullTrajectory, hasDiverged.
+
+Checked against the CPU oracle (itself pinned bit-for-bit on the reference's TimedElasticBand / TebOptimalPlanner,
+tests/test_reference_pinning.py) and against the vectors produced by the reference code (tests/golden/ref_f1_*.npz, ref_f2_*.npz).
+Tolerances: pose counts, time differences built from sqrt / divide only, and pruning are bit-exact (IEEE-exact operations on both
+sides); anything that passes through sin / cos / atan2 differs by device-vs-host libm ulps: 1e-12."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_ref_golden as RG  # noqa: E402
+
+from teb_local_planner_amd import scenes, planner, _abi  # noqa: E402
+from teb_local_planner_amd.config import TebConfig  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def _solver(cfg=None, max_tebs=4, max_poses=128):
+    return planner.TebBatchSolver(cfg or TebConfig(), max_tebs, max_poses, 16, 16, 4)
+
+
+def _band(s, b, stride=128):
+    out = _abi.TebBatchHost(s.count, stride)
+    s.download(out)
+    return out.get_teb(b)
+
+
+def _close(a, b, tol=TOL):
+    assert len(a[0]) == len(b[0]), (len(a[0]), len(b[0]))
+    for u, v in zip(a, b):
+        assert np.abs(np.asarray(u) - np.asarray(v)).max(initial=0.0) <= tol
+
+
+def test_init_line_on_device(oracle):
+    g = np.load(os.path.join(HERE, "golden", "ref_f1_init_line.npz"))
+    s = _solver()
+    for k, c in enumerate(RG.init_line_cases()):
+        s.init_trajectory_line(0, *c)
+        got = _band(s, 0)
+        _close(got, oracle.init_trajectory_line(*c))
+        _close(got, RG.unpack(g, k))
+    s.close()
+
+
+def test_init_plan_on_device(oracle):
+    g = np.load(os.path.join(HERE, "golden", "ref_f1_init_plan.npz"))
+    s = _solver()
+    for k, c in enumerate(RG.init_plan_cases()):
+        s.init_trajectory_plan(1, *c)          # slot 1: slot 0 is created as the trivial band
+        got = _band(s, 1)
+        _close(got, oracle.init_trajectory_plan(*c))
+        _close(got, RG.unpack(g, k), 1e-11)   # the reference saw the yaw through a quaternion
+    assert s.count == 2 and s.pose_counts()[0] == 2
+    s.close()
+
+
+def test_init_path_on_device(oracle):
+    g = np.load(os.path.join(HERE, "golden", "ref_f1_init_path.npz"))
+    s = _solver()
+    for k, c in enumerate(RG.init_path_cases()):
+        px, py, mvx, mvt, acc, so, go, ms, gb = c
+        s.init_trajectory_path(0, px, py, mvx, mvt, acc, so, go, ms, gb)
+        got = _band(s, 0)
+        _close(got, oracle.init_trajectory_path(*c))
+        _close(got, RG.unpack(g, k))
+    s.close()
+
+
+def test_init_capacity_error():
+    s = _solver(max_poses=16)
+    with pytest.raises(planner.TebAmdError) as e:
+        s.init_trajectory_line(0, [0, 0, 0], [10, 0, 0], 0.1, 0.4, 3)
+    assert e.value.code == _abi.ERR_CAPACITY
+    px = np.linspace(0, 5, 40)
+    with pytest.raises(planner.TebAmdError):
+        s.init_trajectory_path(0, px, 0 * px, 0.4, 0.3)
+    s.close()
+
+
+def test_update_and_prune_on_device_is_bit_exact(oracle):
+    g = np.load(os.path.join(HERE, "golden", "ref_f1_prune.npz"))
+    cfg, obst, via, batch = scenes.scene_small_mixed()
+    s = planner.make_solver(cfg, obst, via, batch)
+    for k, c in enumerate(RG.prune_cases()):
+        s.upload(batch)
+        x, y, th, dt, ns, ng, ms = c
+        b = k % 3                                   # prune_cases() takes band k % 3 of this scene
+        s.update_and_prune(ns, ng, ms, b=b)
+        got = _band(s, b, batch.stride)
+        ref = RG.unpack(g, k)
+        assert len(got[0]) == len(ref[0])
+        for u, v in zip(got, ref):
+            np.testing.assert_array_equal(u, v)
+    # b = -1: every band of the batch (HomotopyClassPlanner::updateAllTEBs)
+    s.upload(batch)
+    ns = [float(batch.x[0, 3]), float(batch.y[0, 3]), 0.0]
+    s.update_and_prune(ns, None, 3)
+    for b in range(batch.count):
+        want = oracle.update_and_prune(*batch.get_teb(b), ns, None, 3)
+        for u, v in zip(_band(s, b, batch.stride), want):
+            np.testing.assert_array_equal(u, v)
+    s.close()
+
+
+@pytest.mark.parametrize("holonomic", [False, True])
+def test_consumers_on_device(oracle, holonomic):
+    cfg, obst, via, batch = scenes.scene_small_mixed()
+    if holonomic:
+        cfg.robot.max_vel_y = 0.3
+    batch.vel_start[:] = (0.1, 0.02, -0.05)
+    batch.vel_goal[:] = (0.05, 0.0, 0.01)
+    s = planner.make_solver(cfg, obst, via, batch)
+    for b in range(batch.count):
+        for la, prevent in ((1, 0), (3, 2), (100, 2)):
+            want = oracle.consumers(cfg, batch, b, la, prevent)
+            ok, cmd = s.velocity_command(b, la, prevent)
+            assert ok == want["ok"]
+            assert np.abs(cmd - want["cmd"]).max() <= TOL
+            assert np.abs(s.velocity_profile(b) - want["profile"]).max() <= TOL
+            tr = s.full_trajectory(b)
+            assert np.abs(tr - want["trajectory"]).max() <= TOL
+            np.testing.assert_array_equal(tr[:, 6], want["trajectory"][:, 6])   # running time sums: same order, exact
+    s.close()
+
+
+def test_consumers_against_reference_vectors():
+    g = np.load(os.path.join(HERE, "golden", "ref_f2_consumers.npz"))
+    po = to = 0
+    for k, (cfg, batch, b, la, prevent) in enumerate(RG.consumer_cases()):
+        n = int(batch.n[b])
+        s = planner.TebBatchSolver(cfg, batch.count, batch.stride, 1, 1, 1)
+        s.upload(batch)
+        ok, cmd = s.velocity_command(b, la, prevent)
+        assert ok == bool(g["ok"][k]) and np.abs(cmd - g["cmd"][k]).max() <= TOL
+        assert np.abs(s.velocity_profile(b) - g["profile"][po:po + n + 1]).max() <= TOL
+        assert np.abs(s.full_trajectory(b) - g["trajectory"][to:to + n]).max() <= TOL
+        po += n + 1; to += n
+        s.close()
+
+
+def test_device_resident_tick_sequence(oracle):
+    """plan() of the reference, tick after tick, without moving the bands across PCIe: init -> optimise -> command ->
+    (robot moves) -> updateAndPrune + new start velocity -> optimise -> command. Same sequence on the CPU oracle."""
+    cfg, obst, via, _ = scenes.scene_small_mixed(footprint="point")
+    S = 160
+    s = planner.TebBatchSolver(cfg, 1, S, len(obst), max(len(obst.vert_x), 1), max(len(via), 1))
+    s.set_obstacles(obst); s.set_via_points(via)
+    start, goal = [0.0, 0.0, 0.0], [6.0, 0.3, 0.0]
+    s.init_trajectory_line(0, start, goal, 0, cfg.robot.max_vel_x, cfg.trajectory.min_samples, False)
+    ox, oy, oth, odt = oracle.init_trajectory_line(start, goal, 0, cfg.robot.max_vel_x, cfg.trajectory.min_samples, False)
+    host = _abi.TebBatchHost(1, S)
+    host.set_teb(0, ox, oy, oth, odt)
+    inner, outer = cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations
+    vel = None
+    for tick in range(3):
+        s.optimize(inner, outer, True)
+        host, res = oracle.optimize_batch(cfg, obst, via, host, compute_cost=True)
+        got = _band(s, 0, S)
+        want = host.get_teb(0)
+        assert len(got[0]) == len(want[0])
+        for u, v in zip(got, want):
+            assert np.abs(u - v).max() <= 1e-7
+        ok, cmd = s.velocity_command(0, 1, 0)
+        wc = oracle.consumers(cfg, host, 0, 1, 0)
+        assert ok and wc["ok"] and np.abs(cmd - wc["cmd"]).max() <= 1e-7
+        assert not s.has_diverged(0)
+        # the robot has moved to the second pose of the band; next tick warm-starts there with the commanded velocity
+        new_start = [float(want[0][1]), float(want[1][1]), float(want[2][1])]
+        vel = wc["cmd"]
+        s.update_and_prune(new_start, goal, cfg.trajectory.min_samples)
+        s.set_velocity_start(cmd)
+        px, py, pth, pdt = oracle.update_and_prune(*want, new_start, goal, cfg.trajectory.min_samples)
+        host = _abi.TebBatchHost(1, S)
+        host.set_teb(0, px, py, pth, pdt)
+        host.vel_start[0] = vel
+    s.close()
+
+
+def test_has_diverged_follows_last_chi2():
+    cfg, obst, via, batch = scenes.scene_small_mixed()
+    cfg.recovery.divergence_detection_enable = True
+    cfg.recovery.divergence_detection_max_chi_squared = 1e-6
+    s = planner.make_solver(cfg, obst, via, batch)
+    assert not s.has_diverged(0)                      # no statistics before the first optimisation
+    s.optimize(cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations, True)
+    res = s.results()
+    assert all(s.has_diverged(b) == (res.chi2[b] > 1e-6) for b in range(batch.count)) and s.has_diverged(0)
+    cfg.recovery.divergence_detection_enable = False
+    s.set_config(cfg)
+    assert not s.has_diverged(0)
+    s.close()
