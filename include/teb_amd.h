@@ -320,6 +320,24 @@ int  teb_amd_get_velocity_profile(teb_amd_handle_t* h, int32_t b, double* out, i
 int  teb_amd_get_full_trajectory(teb_amd_handle_t* h, int32_t b, double* out, int32_t capacity_rows, int32_t* rows);
 int  teb_amd_has_diverged(teb_amd_handle_t* h, int32_t b, int32_t* diverged);
 
+/*
+ * f3 (arithmetic core) — equivalence classes of the device-resident bands, as HomotopyClassPlanner::calculateEquivalenceClass
+ * (homotopy_class_planner.hpp:46-62) computes them for every candidate in renewAndAnalyzeOldTebs: HSignature3d
+ * (h_signature.h:281-347; one value per obstacle) when cfg.include_dynamic_obstacles, else HSignature (h_signature.h:96-188; one
+ * complex value). One launch for the whole batch. prescaler = hcp.h_signature_prescaler. values (may be NULL): 3-D [B*M] in
+ * obstacle-table order, 2-D [B*2] = (re, im). *width receives M or 2.
+ */
+int  teb_amd_compute_h_signatures(teb_amd_handle_t* h, double prescaler, double* values, int32_t* width);
+/*
+ * The class list of renewAndAnalyzeOldTebs / addEquivalenceClassIfNew / hasEquivalenceClass (src/homotopy_class_planner.cpp:178-254)
+ * over the signatures of the last teb_amd_compute_h_signatures call: bands are visited in order, with the last best band first
+ * (best >= 0; std::iter_swap with the first band); keep[b] = 1 iff band b opens a new class or is one of at most
+ * max_number_plans_in_current_class bands in the best band's class; valid[b] = isValid(), reasonable[b] = isReasonable()
+ * (h_signature.h:190-226, 349-409). threshold = hcp.h_signature_threshold. Output arrays [B], any may be NULL.
+ */
+int  teb_amd_filter_equivalence_classes(teb_amd_handle_t* h, double threshold, int32_t best, int32_t max_number_plans_in_current_class,
+                                        int32_t* keep, int32_t* valid, int32_t* reasonable);
+
 /* Duration [ms] of the last optimize_batch kernel, measured with HIP events on the launch stream. */
 int  teb_amd_last_kernel_ms(teb_amd_handle_t* h, float* ms);
 /* LDS bytes per workgroup and the largest pose count this build can optimise. */

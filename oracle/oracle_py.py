@@ -244,3 +244,33 @@ def consumers(cfg, batch, b, look_ahead_poses=1, prevent_look_ahead_poses_near_g
     _check(lib().teb_oracle_velocity_profile(C.byref(c), C.byref(bs), b, _P(prof)), "velocity_profile")
     _check(lib().teb_oracle_full_trajectory(C.byref(c), C.byref(bs), b, _P(traj)), "full_trajectory")
     return dict(cmd=cmd, ok=bool(ok.value), profile=prof, trajectory=traj)
+
+
+# ---- row f3 (arithmetic core): H-signatures and equivalence classes ------------------------------------------------------------
+def h_signatures(cfg, obst, batch, mode, prescaler=1.0):
+    """mode 2: HSignature -> [B, 2]; mode 3: HSignature3d -> [B, M]."""
+    c = cfg.to_c()
+    bs = batch.c_struct()
+    M = len(obst)
+    out = np.zeros((batch.count, 2 if mode == 2 else M))
+    for b in range(batch.count):
+        row = np.zeros(out.shape[1])
+        if mode == 2:
+            _check(lib().teb_oracle_h_signature_2d(C.byref(c), C.byref(obst.freeze()), C.byref(bs), b, C.c_double(prescaler), _P(row)),
+                   "h_signature_2d")
+        else:
+            _check(lib().teb_oracle_h_signature_3d(C.byref(c), C.byref(obst.freeze()), C.byref(bs), b, _P(row)), "h_signature_3d")
+        out[b] = row
+    return out
+
+
+def filter_equivalence_classes(mode, sig, threshold=0.1, best=-1, max_number_plans_in_current_class=1):
+    sig = np.ascontiguousarray(sig, np.float64)
+    B = sig.shape[0]
+    M = sig.shape[1]
+    keep = np.zeros(B, np.int32); valid = np.zeros(B, np.int32); reas = np.zeros(B, np.int32)
+    I = lambda a: _abi._ptr(a, C.c_int32)
+    _check(lib().teb_oracle_filter_equivalence_classes(int(mode), B, M, _P(sig), C.c_double(threshold), int(best),
+                                                       int(max_number_plans_in_current_class), I(keep), I(valid), I(reas)),
+           "filter_equivalence_classes")
+    return keep, valid, reas

@@ -211,3 +211,15 @@ def consumers(cfg, batch, b, look_ahead_poses=1, prevent_look_ahead_poses_near_g
                                _P(vs), int(batch.has_vel_goal[b]), _P(vg), int(look_ahead_poses), int(prevent_look_ahead_poses_near_goal),
                                _P(cmd), C.byref(ok), _P(prof), _P(traj)) == 0
     return dict(cmd=cmd, ok=bool(ok.value), profile=prof, trajectory=traj)
+
+
+def h_signatures(cfg, obst, batch, mode, prescaler=1.0, threshold=0.1):
+    """The reference's HSignature (mode 2) / HSignature3d (mode 3) on every band: dict(sig, equal [B,B], valid, reasonable)."""
+    c = cfg.to_c()
+    bs = batch.c_struct()
+    B, M = batch.count, len(obst)
+    sig = np.zeros((B, 2 if mode == 2 else M)); eq = np.zeros((B, B), np.int32); valid = np.zeros(B, np.int32); reas = np.zeros(B, np.int32)
+    I = lambda a: _abi._ptr(a, C.c_int32)
+    assert lib().ref_h_signatures(C.byref(c), C.byref(obst.freeze()), C.byref(bs), int(mode), C.c_double(prescaler), C.c_double(threshold),
+                                  _P(sig), I(eq), I(valid), I(reas)) == 0
+    return dict(sig=sig, equal=eq, valid=valid, reasonable=reas)

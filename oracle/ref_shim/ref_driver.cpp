@@ -335,4 +335,42 @@ int ref_consumers(const teb_amd_config_t* acfg, int n, const double* x, const do
   return 0;
 }
 
+// ---- row f3, arithmetic core: the reference's HSignature / HSignature3d (h_signature.h) on a batch of bands ---------------------
+// mode 2: HSignature (sig [B*2] = re, im); mode 3: HSignature3d (sig [B*M]). equal [B*B] = a.isEqual(b); valid, reasonable [B].
+int ref_h_signatures(const teb_amd_config_t* acfg, const teb_amd_obstacles_t* o, const teb_amd_teb_batch_t* bt, int mode, double prescaler,
+                     double threshold, double* sig, int32_t* equal, int32_t* valid, int32_t* reasonable) {
+  TebConfig cfg;
+  to_ref_config(*acfg, cfg);
+  cfg.hcp.h_signature_prescaler = prescaler;
+  cfg.hcp.h_signature_threshold = threshold;
+  ObstContainer obst;
+  to_ref_obstacles(o, obst);
+  const int B = bt->count, S = bt->stride, M = (int)obst.size();
+  auto fun = [](const VertexPose* pose) { return std::complex<long double>(pose->x(), pose->y()); };   // getCplxFromVertexPosePtr, homotopy_class_planner.h:72-75
+  std::vector<std::unique_ptr<TimedElasticBand>> bands;
+  std::vector<std::unique_ptr<EquivalenceClass>> cls;
+  for (int b = 0; b < B; ++b) {
+    bands.emplace_back(new TimedElasticBand());
+    const size_t so = (size_t)b * S;
+    band_in(*bands.back(), bt->n[b], bt->x + so, bt->y + so, bt->theta + so, bt->dt + so);
+    TimedElasticBand& teb = *bands.back();
+    if (mode == 2) {
+      HSignature* H = new HSignature(cfg);
+      H->calculateHSignature(teb.poses().begin(), teb.poses().end(), fun, &obst);
+      sig[2 * b] = (double)H->value().real(); sig[2 * b + 1] = (double)H->value().imag();
+      cls.emplace_back(H);
+    } else {
+      HSignature3d* H = new HSignature3d(cfg);
+      H->calculateHSignature(teb.poses().begin(), teb.poses().end(), fun, &obst, teb.timediffs().begin(), teb.timediffs().end());
+      for (int l = 0; l < M; ++l) sig[(size_t)b * M + l] = H->values()[l];
+      cls.emplace_back(H);
+    }
+    valid[b] = cls.back()->isValid();
+    reasonable[b] = cls.back()->isReasonable();
+  }
+  for (int a = 0; a < B; ++a)
+    for (int b = 0; b < B; ++b) equal[a * B + b] = cls[a]->isEqual(*cls[b]);
+  return 0;
+}
+
 }  // extern "C"

@@ -42,6 +42,12 @@ class Matrix {
   void fill(T v) { setConstant(v); }
   T squaredNorm() const { T s = T(0); for (int i = 0; i < R * C; ++i) s += d[i] * d[i]; return s; }
   T norm() const { return std::sqrt(squaredNorm()); }
+  // first n coefficients of a vector as an aliasing 2-vector (only head(2) of a 3-vector is used: h_signature.h:302)
+  Matrix<T, 2, 1>& head(int) { return *reinterpret_cast<Matrix<T, 2, 1>*>(d); }
+  Matrix cross(const Matrix& o) const {   // Eigen: (a1 b2 - a2 b1, a2 b0 - a0 b2, a0 b1 - a1 b0)
+    static_assert(R * C == 3, "cross of 3-vectors");
+    Matrix m; m.d[0] = d[1] * o.d[2] - d[2] * o.d[1]; m.d[1] = d[2] * o.d[0] - d[0] * o.d[2]; m.d[2] = d[0] * o.d[1] - d[1] * o.d[0]; return m;
+  }
   T dot(const Matrix& o) const { T s = T(0); for (int i = 0; i < R * C; ++i) s += d[i] * o.d[i]; return s; }
   Matrix normalized() const { T n = norm(); Matrix m(*this); if (n > T(0)) for (int i = 0; i < R * C; ++i) m.d[i] = d[i] / n; return m; }
   bool isApprox(const Matrix& o, T prec = T(1e-12)) const {   // Eigen: ||a-b||^2 <= prec^2 * min(||a||^2, ||b||^2)

@@ -74,6 +74,9 @@ class optional<const T&> {
   const T& operator*() const { return *p_; }
   const T* operator->() const { return p_; }
 };
+template <typename T> bool operator==(const optional<T>& o, none_t) { return !static_cast<bool>(o); }
+template <typename T> bool operator!=(const optional<T>& o, none_t) { return static_cast<bool>(o); }
+namespace math { template <typename T> inline int sign(const T& z) { return (z == 0) ? 0 : (z < 0 ? -1 : 1); } }
 }  // namespace boost
 
 namespace std_msgs {

@@ -29,6 +29,7 @@
 #include <array>
 #include <atomic>
 #include <cmath>
+#include <complex>
 #include <cstdio>
 #include <cstring>
 #include <limits>
@@ -45,6 +46,8 @@ inline V2 operator+(V2 a, V2 b) { return {a.x + b.x, a.y + b.y}; }
 inline V2 operator-(V2 a, V2 b) { return {a.x - b.x, a.y - b.y}; }
 inline V2 operator*(double s, V2 a) { return {s * a.x, s * a.y}; }
 inline double dot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
+// Eigen cross product: (a1 b2 - a2 b1, a2 b0 - a0 b2, a0 b1 - a1 b0)
+inline void cross3(const double* a, const double* b, double* o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; }
 inline double sqnorm(V2 a) { return a.x * a.x + a.y * a.y; }
 inline double norm(V2 a) { return std::sqrt(a.x * a.x + a.y * a.y); }
 
@@ -2119,6 +2122,192 @@ int teb_oracle_full_trajectory(const teb_amd_config_t* cfg, const teb_amd_teb_ba
     curr_time += t.dt[i];
   }
   put(n - 1, t.vg[0], t.vg[1], t.vg[2], curr_time);
+  return TEB_AMD_OK;
+}
+
+// ================================================================================================================
+// SURVEY section 8(f) row f3, arithmetic core: equivalence classes of candidate bands (h_signature.h).
+// ================================================================================================================
+namespace {
+
+typedef std::complex<long double> cplx;
+
+// HSignature::calculateHSignature, h_signature.h:96-188 (2-D complex-log signature; long double like the reference)
+cplx h_signature_2d(const Scene& s, const Teb& t, double prescaler) {
+  const int M = (int)s.obst.size();
+  if (M == 0) return cplx(0, 0);
+  int m = std::max(M - 1, 5);
+  int a = (int)std::ceil(double(m) / 2.0);
+  int b = m - a;
+  const int last = t.n() - 1;
+  cplx start((long double)t.x[0], (long double)t.y[0]);
+  cplx end((long double)t.x[last], (long double)t.y[last]);
+  cplx delta = end - start;
+  cplx normal(-delta.imag(), delta.real());
+  cplx map_bottom_left, map_top_right;
+  if (std::abs(delta) < 3.0) {
+    map_bottom_left = start + cplx(0, -3);
+    map_top_right = start + cplx(3, 3);
+  } else {
+    map_bottom_left = start - normal;
+    map_top_right = start + delta + normal;
+  }
+  cplx hsig = 0;
+  std::vector<double> imag_proposals(5);
+  for (int i = 0; i < last; ++i) {
+    cplx z1((long double)t.x[i], (long double)t.y[i]);
+    cplx z2((long double)t.x[i + 1], (long double)t.y[i + 1]);
+    for (int l = 0; l < M; ++l) {
+      cplx obst_l((long double)s.obst[l].c.x, (long double)s.obst[l].c.y);   // getCentroidCplx
+      cplx f0 = (long double)prescaler * (long double)a * (obst_l - map_bottom_left) * (long double)b * (obst_l - map_top_right);
+      cplx Al = f0;
+      for (int j = 0; j < M; ++j) {
+        if (j == l) continue;
+        cplx obst_j((long double)s.obst[j].c.x, (long double)s.obst[j].c.y);
+        cplx diff = obst_l - obst_j;
+        if (std::abs(diff) < 0.05) continue;
+        else Al /= diff;
+      }
+      double diff2 = std::abs(z2 - obst_l);
+      double diff1 = std::abs(z1 - obst_l);
+      if (diff2 == 0 || diff1 == 0) continue;
+      double log_real = std::log(diff2) - std::log(diff1);
+      double arg_diff = std::arg(z2 - obst_l) - std::arg(z1 - obst_l);
+      imag_proposals[0] = arg_diff;
+      imag_proposals[1] = arg_diff + 2 * M_PI;
+      imag_proposals[2] = arg_diff - 2 * M_PI;
+      imag_proposals[3] = arg_diff + 4 * M_PI;
+      imag_proposals[4] = arg_diff - 4 * M_PI;
+      double log_imag = *std::min_element(imag_proposals.begin(), imag_proposals.end(),
+                                          [](double x, double y) { return std::abs(x) < std::abs(y); });   // smaller_than_abs, misc.h
+      cplx log_value(log_real, log_imag);
+      hsig += Al * log_value;
+    }
+  }
+  return hsig;
+}
+
+// HSignature3d::calculateHSignature, h_signature.h:281-347 (x-y-t Biot-Savart signature, one value per obstacle)
+void h_signature_3d(const Scene& s, const Teb& t, std::vector<double>& out) {
+  const int M = (int)s.obst.size();
+  out.assign(M, 0.0);
+  const int last = t.n() - 1;
+  constexpr int num_int_steps_per_segment = 10;
+  for (int l = 0; l < M; ++l) {
+    double H = 0;
+    double transition_time = 0;
+    double next_transition_time = 0;
+    const double s1[3] = {s.obst[l].c.x, s.obst[l].c.y, 0};
+    double tt = 120;
+    const double s2[3] = {s.obst[l].c.x + tt * s.obst[l].vel.x, s.obst[l].c.y + tt * s.obst[l].vel.y, tt};   // predictCentroidConstantVelocity
+    const double ds[3] = {s2[0] - s1[0], s2[1] - s1[1], s2[2] - s1[2]};
+    const double ds_sq_norm = ((0.0 + ds[0] * ds[0]) + ds[1] * ds[1]) + ds[2] * ds[2];
+    for (int i = 0; i < last; ++i) {
+      cplx z1((long double)t.x[i], (long double)t.y[i]);
+      cplx z2((long double)t.x[i + 1], (long double)t.y[i + 1]);
+      transition_time = next_transition_time;
+      next_transition_time += t.dt[i];
+      double dir[3];
+      dir[0] = (double)(z2.real() - z1.real());
+      dir[1] = (double)(z2.imag() - z1.imag());
+      dir[2] = next_transition_time - transition_time;
+      if (std::sqrt(((0.0 + dir[0] * dir[0]) + dir[1] * dir[1]) + dir[2] * dir[2]) < 1e-15) continue;
+      double r[3] = {(double)z1.real(), (double)z1.imag(), transition_time};
+      const double sc = 1.0 / static_cast<double>(num_int_steps_per_segment);
+      const double dl[3] = {dir[0] * sc, dir[1] * sc, dir[2] * sc};
+      for (int k = 0; k < num_int_steps_per_segment; ++k) {
+        double p1[3], p2[3], c12[3], d[3], c2[3], c1[3], phi[3];
+        for (int q = 0; q < 3; ++q) { p1[q] = s1[q] - r[q]; p2[q] = s2[q] - r[q]; }
+        cross3(p1, p2, c12);
+        cross3(ds, c12, d);
+        for (int q = 0; q < 3; ++q) d[q] = d[q] / ds_sq_norm;
+        cross3(d, p2, c2);
+        cross3(d, p1, c1);
+        const double n2 = std::sqrt(((0.0 + p2[0] * p2[0]) + p2[1] * p2[1]) + p2[2] * p2[2]);
+        const double n1 = std::sqrt(((0.0 + p1[0] * p1[0]) + p1[1] * p1[1]) + p1[2] * p1[2]);
+        const double f = 1.0 / (((0.0 + d[0] * d[0]) + d[1] * d[1]) + d[2] * d[2]);
+        for (int q = 0; q < 3; ++q) phi[q] = (c2[q] / n2 - c1[q] / n1) * f;   // scalar * vector: coefficient * scalar in the shim / Eigen
+        H += ((0.0 + phi[0] * dl[0]) + phi[1] * dl[1]) + phi[2] * dl[2];
+        for (int q = 0; q < 3; ++q) r[q] += dl[q];
+      }
+    }
+    out[l] = H / (4.0 * M_PI);
+  }
+}
+
+}  // namespace
+
+int teb_oracle_h_signature_2d(const teb_amd_config_t* cfg, const teb_amd_obstacles_t* obst, const teb_amd_teb_batch_t* batch, int32_t b,
+                              double prescaler, double* re_im) {
+  Scene s;
+  int rc = load_scene(s, cfg, obst, 0, nullptr, nullptr);
+  if (rc) return rc;
+  Teb t;
+  teb_from_batch(batch, b, t);
+  cplx h = h_signature_2d(s, t, prescaler);
+  re_im[0] = (double)h.real(); re_im[1] = (double)h.imag();
+  return TEB_AMD_OK;
+}
+
+int teb_oracle_h_signature_3d(const teb_amd_config_t* cfg, const teb_amd_obstacles_t* obst, const teb_amd_teb_batch_t* batch, int32_t b,
+                              double* values) {
+  Scene s;
+  int rc = load_scene(s, cfg, obst, 0, nullptr, nullptr);
+  if (rc) return rc;
+  Teb t;
+  teb_from_batch(batch, b, t);
+  std::vector<double> v;
+  h_signature_3d(s, t, v);
+  std::copy(v.begin(), v.end(), values);
+  return TEB_AMD_OK;
+}
+
+// isValid / isReasonable / isEqual of both classes (h_signature.h:190-226, 349-409) and the "first come first serve" class list of
+// HomotopyClassPlanner::renewAndAnalyzeOldTebs / addEquivalenceClassIfNew (src/homotopy_class_planner.cpp:178-254).
+// sig: mode 2 -> [B*2] (re, im); mode 3 -> [B*M]. best = index of the last best TEB or -1. keep[b] = 1 iff the band survives.
+int teb_oracle_filter_equivalence_classes(int32_t mode, int32_t B, int32_t M, const double* sig, double threshold, int32_t best,
+                                          int32_t max_number_plans_in_current_class, int32_t* keep, int32_t* valid,
+                                          int32_t* reasonable) {
+  const int W = mode == 2 ? 2 : M;
+  auto is_valid = [&](int b) { for (int k = 0; k < W; ++k) if (!std::isfinite(sig[(size_t)b * W + k])) return false; return true; };
+  auto is_reasonable = [&](int b) { if (mode == 2) return true; for (int k = 0; k < W; ++k) if (sig[(size_t)b * W + k] > 1.0) return false; return true; };
+  auto sgn = [](double z) { return (z == 0) ? 0 : (z < 0 ? -1 : 1); };   // boost::math::sign
+  auto is_equal = [&](int a, int b) {   // a.isEqual(b)
+    const double* x = sig + (size_t)a * W; const double* y = sig + (size_t)b * W;
+    if (mode == 2) {
+      double diff_real = std::abs(y[0] - x[0]);
+      double diff_imag = std::abs(y[1] - x[1]);
+      return diff_real <= threshold && diff_imag <= threshold;
+    }
+    for (int i = 0; i < W; ++i) {
+      if (std::abs(y[i]) < threshold || std::abs(x[i]) < threshold) continue;
+      if (sgn(y[i]) != sgn(x[i])) return false;
+    }
+    return true;
+  };
+  std::vector<int> order(B);
+  for (int b = 0; b < B; ++b) order[b] = b;
+  const bool has_best = best >= 0 && best < B;
+  if (has_best) std::swap(order[0], order[best]);   // std::iter_swap(tebs_.begin(), it_best_teb)
+  std::vector<int> classes;   // equivalence_classes_ (band indices)
+  for (int b = 0; b < B; ++b) { keep[b] = 0; valid[b] = is_valid(b); reasonable[b] = is_reasonable(b); }
+  for (int k = 0; k < B; ++k) {
+    const int b = order[k];
+    bool add;
+    if (!valid[b]) add = false;
+    else {
+      bool has = false;
+      for (int c : classes) if (is_equal(b, c)) { has = true; break; }
+      add = true;
+      if (has) {
+        bool in_best = has_best && is_equal(order[0], b);                      // best_teb_eq_class_->isEqual(*eq_class)
+        int count = 0;
+        if (has_best) for (int c : classes) if (is_equal(order[0], c)) ++count;   // numTebsInBestTebClass
+        if (!in_best || count >= max_number_plans_in_current_class) add = false;
+      }
+    }
+    if (add) { classes.push_back(b); keep[b] = 1; }
+  }
   return TEB_AMD_OK;
 }
 

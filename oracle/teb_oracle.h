@@ -118,6 +118,19 @@ int teb_oracle_velocity_profile(const teb_amd_config_t* cfg, const teb_amd_teb_b
 /* getFullTrajectory (:1198-1247): out[n*7] = (x, y, theta, vx, vy, omega, time_from_start). */
 int teb_oracle_full_trajectory(const teb_amd_config_t* cfg, const teb_amd_teb_batch_t* batch, int32_t b, double* out);
 
+/* ---- row f3, arithmetic core: equivalence classes (h_signature.h) ---------------------------------------------------------- */
+/* HSignature::calculateHSignature, h_signature.h:96-188 -> re_im[2] (long double inside, like the reference) */
+int teb_oracle_h_signature_2d(const teb_amd_config_t* cfg, const teb_amd_obstacles_t* obst, const teb_amd_teb_batch_t* batch, int32_t b,
+                              double prescaler, double* re_im);
+/* HSignature3d::calculateHSignature, h_signature.h:281-347 -> values[M] */
+int teb_oracle_h_signature_3d(const teb_amd_config_t* cfg, const teb_amd_obstacles_t* obst, const teb_amd_teb_batch_t* batch, int32_t b,
+                              double* values);
+/* isValid / isReasonable / isEqual + the class list of renewAndAnalyzeOldTebs / addEquivalenceClassIfNew
+ * (src/homotopy_class_planner.cpp:178-254). mode 2: sig [B*2]; mode 3: sig [B*M]. */
+int teb_oracle_filter_equivalence_classes(int32_t mode, int32_t B, int32_t M, const double* sig, double threshold, int32_t best,
+                                          int32_t max_number_plans_in_current_class, int32_t* keep, int32_t* valid,
+                                          int32_t* reasonable);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,7 @@
 #include "../../include/teb_amd_debug.h"
 #include "teb_kernel.hpp"
 #include "teb_strip.hpp"
+#include "teb_hsig.hpp"
 
 using namespace tebamd;
 
@@ -157,6 +158,11 @@ struct teb_amd_handle {
   // strip producers / consumers (f1, f2)
   DevBuf<double> stage_x, stage_y, stage_yaw, out_cmd, out_prof, out_traj;
   bool consumers_valid = false;
+  // equivalence classes (f3)
+  DevBuf<double> hsig, hs_pre, hs_pim;
+  DevBuf<int> hs_pex;
+  std::vector<double> hsig_host;
+  int hsig_mode = 0, hsig_B = 0, hsig_M = 0;
   int consumers_la = 0, consumers_prevent = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
@@ -342,6 +348,7 @@ int teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_po
   A(h->sel_cost.alloc(1)); A(h->sel_idx.alloc(1)); A(h->err_flag.alloc(1));
   A(h->stage_x.alloc((size_t)max_poses + 2)); A(h->stage_y.alloc((size_t)max_poses + 2)); A(h->stage_yaw.alloc((size_t)max_poses + 2));
   A(h->out_cmd.alloc(4 * (size_t)max_tebs)); A(h->out_prof.alloc((size_t)max_tebs * (max_poses + 1) * 3)); A(h->out_traj.alloc(BS * 7));
+  A(h->hsig.alloc((size_t)max_tebs * (Mo > 2 ? Mo : 2))); A(h->hs_pre.alloc(Mo)); A(h->hs_pim.alloc(Mo)); A(h->hs_pex.alloc(Mo));
   if (ok && hipEventCreate(&h->ev0) != hipSuccess) ok = false;
   if (ok && hipEventCreate(&h->ev1) != hipSuccess) ok = false;
   for (int jm : {TEB_AMD_JACOBIAN_ANALYTIC, TEB_AMD_JACOBIAN_G2O_NUMERIC})
@@ -362,12 +369,12 @@ void teb_amd_destroy(teb_amd_handle_t* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   DevBuf<int>* ib[] = {&h->o_type, &h->o_dyn, &h->o_voff, &h->o_static, &h->o_dynidx, &h->n, &h->has_vs, &h->has_vg, &h->rotdir,
                        &h->via_en, &h->status, &h->iters, &h->trials, &h->assoc_cnt, &h->assoc, &h->assoc_ovf, &h->via_pose, &h->legacy_idx,
-                       &h->snap_n, &h->sel_idx, &h->err_flag};
+                       &h->snap_n, &h->sel_idx, &h->err_flag, &h->hs_pex};
   for (auto* q : ib) q->free();
   DevBuf<double>* db[] = {&h->o_ax, &h->o_ay, &h->o_bx, &h->o_by, &h->o_rad, &h->o_vx, &h->o_vy, &h->o_cx, &h->o_cy, &h->o_pvx,
                           &h->o_pvy, &h->viax, &h->viay, &h->x, &h->y, &h->th, &h->dt, &h->vs, &h->vg, &h->chi2, &h->cost,
                           &h->lambda, &h->Hbackup, &h->rs_scratch, &h->snap_x, &h->snap_y, &h->snap_th, &h->snap_dt, &h->dbg_H,
-                          &h->dbg_b, &h->dbg_chi2, &h->sel_cost, &h->stage_x, &h->stage_y, &h->stage_yaw, &h->out_cmd, &h->out_prof, &h->out_traj};
+                          &h->dbg_b, &h->dbg_chi2, &h->sel_cost, &h->stage_x, &h->stage_y, &h->stage_yaw, &h->out_cmd, &h->out_prof, &h->out_traj, &h->hsig, &h->hs_pre, &h->hs_pim};
   for (auto* q : db) q->free();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -799,6 +806,88 @@ int teb_amd_has_diverged(teb_amd_handle_t* h, int32_t b, int32_t* diverged) {
   HIPCHK(hipStreamSynchronize(h->stream));
   if (iters <= 0) return TEB_AMD_OK;                                      // no statistics yet, :1031-1033
   *diverged = chi2 > h->cfg.divergence_detection_max_chi_squared;
+  return TEB_AMD_OK;
+}
+
+// ---- f3 (arithmetic core): equivalence classes of the device-resident bands (kernels in teb_hsig.hpp) ----------------------------
+int teb_amd_compute_h_signatures(teb_amd_handle_t* h, double prescaler, double* values, int32_t* width) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (h->B <= 0) return fail(TEB_AMD_ERR_INVALID_ARG, "no TEBs on the device");
+  SceneDev sc = scene_of(h);
+  BatchDev bt = batch_of(h);
+  const int M = h->M, B = h->B;
+  const int mode = h->cfg.include_dynamic_obstacles ? 3 : 2;   // homotopy_class_planner.hpp:50
+  const int W = mode == 3 ? M : 2;
+  if (width) *width = W;
+  h->hsig_mode = mode; h->hsig_B = B; h->hsig_M = M;
+  h->hsig_host.assign((size_t)B * (W > 0 ? W : 1), 0.0);
+  if (mode == 3) {
+    if (M > 0) {
+      hipLaunchKernelGGL(hsig3d_kernel, dim3((M + kThreads - 1) / kThreads, B), dim3(kThreads), 3 * (size_t)h->stride * sizeof(double),
+                         h->stream, sc, bt, h->hsig.p);
+      HIPCHK(hipGetLastError());
+    }
+  } else {
+    if (M > 0) {
+      hipLaunchKernelGGL(hsig2d_prod_kernel, dim3((M + kThreads - 1) / kThreads), dim3(kThreads), 0, h->stream, sc, h->hs_pre.p,
+                         h->hs_pim.p, h->hs_pex.p);
+      HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(hsig2d_kernel, dim3(B), dim3(kThreads), 2 * (size_t)h->stride * sizeof(double), h->stream, sc, bt, prescaler,
+                       h->hs_pre.p, h->hs_pim.p, h->hs_pex.p, h->hsig.p);
+    HIPCHK(hipGetLastError());
+  }
+  if ((size_t)B * W > 0)
+    HIPCHK(hipMemcpyAsync(h->hsig_host.data(), h->hsig.p, (size_t)B * W * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (values && (size_t)B * W > 0) std::memcpy(values, h->hsig_host.data(), (size_t)B * W * sizeof(double));
+  return TEB_AMD_OK;
+}
+
+int teb_amd_filter_equivalence_classes(teb_amd_handle_t* h, double threshold, int32_t best, int32_t max_number_plans_in_current_class,
+                                       int32_t* keep, int32_t* valid, int32_t* reasonable) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (h->hsig_mode == 0 || h->hsig_B != h->B) return fail(TEB_AMD_ERR_INVALID_ARG, "call teb_amd_compute_h_signatures first");
+  const int B = h->hsig_B, mode = h->hsig_mode, W = mode == 3 ? h->hsig_M : 2;
+  const double* sig = h->hsig_host.data();
+  auto row = [&](int b) { return sig + (size_t)b * W; };
+  auto is_valid = [&](int b) { for (int k = 0; k < W; ++k) if (!std::isfinite(row(b)[k])) return false; return true; };
+  auto is_reasonable = [&](int b) { if (mode == 2) return true; for (int k = 0; k < W; ++k) if (row(b)[k] > 1.0) return false; return true; };
+  auto sign_of = [](double z) { return z == 0 ? 0 : (z < 0 ? -1 : 1); };
+  auto is_equal = [&](int a, int b) {   // cls[a]->isEqual(*cls[b])
+    const double* x = row(a); const double* y = row(b);
+    if (mode == 2) return std::fabs(y[0] - x[0]) <= threshold && std::fabs(y[1] - x[1]) <= threshold;   // h_signature.h:196-204
+    for (int i = 0; i < W; ++i) {                                                                          // h_signature.h:360-377
+      if (std::fabs(y[i]) < threshold || std::fabs(x[i]) < threshold) continue;   // far-away obstacle: ignored
+      if (sign_of(y[i]) != sign_of(x[i])) return false;
+    }
+    return true;
+  };
+  std::vector<int> order(B), vld(B), classes;
+  for (int b = 0; b < B; ++b) { order[b] = b; vld[b] = is_valid(b); }
+  const bool has_best = best >= 0 && best < B;
+  if (has_best) std::swap(order[0], order[best]);
+  std::vector<int> kp(B, 0);
+  for (int k = 0; k < B; ++k) {
+    const int b = order[k];
+    if (!vld[b]) continue;                                   // "Ignoring invalid H-signature"
+    bool has = false;
+    for (int c : classes) if (is_equal(b, c)) { has = true; break; }
+    if (has) {
+      const bool in_best = has_best && is_equal(order[0], b);
+      int count = 0;
+      if (has_best) for (int c : classes) if (is_equal(order[0], c)) ++count;
+      if (!in_best || count >= max_number_plans_in_current_class) continue;
+    }
+    classes.push_back(b); kp[b] = 1;
+  }
+  for (int b = 0; b < B; ++b) {
+    if (keep) keep[b] = kp[b];
+    if (valid) valid[b] = vld[b];
+    if (reasonable) reasonable[b] = is_reasonable(b);
+  }
   return TEB_AMD_OK;
 }
 

@@ -76,6 +76,8 @@ def lib():
         L.teb_amd_get_velocity_profile.argtypes = [vp, i32, _abi.p_f64, i32, _abi.p_i32]
         L.teb_amd_get_full_trajectory.argtypes = [vp, i32, _abi.p_f64, i32, _abi.p_i32]
         L.teb_amd_has_diverged.argtypes = [vp, i32, _abi.p_i32]
+        L.teb_amd_compute_h_signatures.argtypes = [vp, d, _abi.p_f64, _abi.p_i32]
+        L.teb_amd_filter_equivalence_classes.argtypes = [vp, d, i32, i32, _abi.p_i32, _abi.p_i32, _abi.p_i32]
         _LIB = L
     return _LIB
 
@@ -256,6 +258,24 @@ class TebBatchSolver:
         d = C.c_int32(0)
         _chk(lib().teb_amd_has_diverged(self._h, b, C.byref(d)), "teb_amd_has_diverged")
         return bool(d.value)
+
+    # -- equivalence classes of the resident bands (SURVEY 8f row f3, arithmetic core) ----------------------
+    def h_signatures(self, prescaler=1.0):
+        """[B, M] (HSignature3d, include_dynamic_obstacles) or [B, 2] (HSignature: re, im)."""
+        self._sync_count()
+        w = C.c_int32(0)
+        _chk(lib().teb_amd_compute_h_signatures(self._h, prescaler, None, C.byref(w)), "teb_amd_compute_h_signatures")
+        out = np.zeros((self.count, max(w.value, 1)))
+        _chk(lib().teb_amd_compute_h_signatures(self._h, prescaler, _abi._ptr(out, C.c_double), C.byref(w)),
+             "teb_amd_compute_h_signatures")
+        return out[:, :w.value]
+
+    def filter_equivalence_classes(self, threshold=0.1, best=-1, max_number_plans_in_current_class=1):
+        keep = np.zeros(self.count, np.int32); valid = np.zeros(self.count, np.int32); reas = np.zeros(self.count, np.int32)
+        I = lambda a: _abi._ptr(a, C.c_int32)
+        _chk(lib().teb_amd_filter_equivalence_classes(self._h, threshold, best, max_number_plans_in_current_class, I(keep), I(valid),
+                                                      I(reas)), "teb_amd_filter_equivalence_classes")
+        return keep, valid, reas
 
     # -- test hooks -----------------------------------------------------------------------------------
     def debug_linearize(self, b, n, weight_multiplier=1.0, assoc_cap=1 << 16):

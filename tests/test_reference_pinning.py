@@ -259,3 +259,29 @@ def test_f2_velocity_command_profile_and_trajectory_match_reference(oracle):
         t = ref["trajectory"][to:to + n]; to += n
         np.testing.assert_array_equal(r["trajectory"][:, [0, 1, 3, 4, 5, 6]], t[:, [0, 1, 3, 4, 5, 6]])
         np.testing.assert_allclose(r["trajectory"][:, 2], t[:, 2], rtol=0, atol=1e-15)   # yaw went through a quaternion in the reference
+
+
+# ---- SURVEY section 8(f) row f3, arithmetic core: H-signatures (h_signature.h) ------------------------------------------------------
+
+def _class_list(equal, valid):
+    """renewAndAnalyzeOldTebs without a best TEB, driven by the REFERENCE's isEqual / isValid results."""
+    cls, keep = [], np.zeros(len(valid), np.int32)
+    for b in range(len(valid)):
+        if valid[b] and not any(equal[b, c] for c in cls):
+            cls.append(b); keep[b] = 1
+    return keep
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+def test_f3_h_signatures_and_equivalence_match_reference(oracle, mode):
+    ref, src = _ref_results("f3_hsig_%dd" % mode)
+    classes_seen = 0
+    for cname, cfg, obst, batch in G.h_signature_cases():
+        sig = oracle.h_signatures(cfg, obst, batch, mode, 1.0)
+        np.testing.assert_array_equal(sig, ref[cname + "_sig"])          # long double (2-D) / double (3-D) like the reference: bit-equal
+        keep, valid, reas = oracle.filter_equivalence_classes(mode, sig, 0.1, -1, 1)
+        np.testing.assert_array_equal(valid, ref[cname + "_valid"])
+        np.testing.assert_array_equal(reas, ref[cname + "_reasonable"])
+        np.testing.assert_array_equal(keep, _class_list(ref[cname + "_equal"], ref[cname + "_valid"]))
+        classes_seen = max(classes_seen, int(keep.sum()))
+    assert classes_seen >= 3
