@@ -210,6 +210,22 @@ def main():
                 "sample": "%d of the %d C4 candidates, one optimizeTEB each (4x5), g2o-numeric Jacobians, "
                           "one std::thread per TEB capped at %d, best of 3 runs, %.1f s wall; the port is bit-identical to the "
                           "reference's src/optimal_planner.cpp on the pinned bands (tests/test_reference_pinning.py)" % (ks, B, cores, cpu_t)}
+            # the reference's OWN code on the same sample (oracle/_ref: src/optimal_planner.cpp + edge classes compiled in place; only
+            # the LM iteration / banded Cholesky inside is a stand-in for the absent libg2o). Same results bit for bit; slower than the
+            # port because of the g2o-style virtual edge interface. Reported beside the port, which stays the (faster) baseline value.
+            try:
+                from oracle import ref_py
+                if os.path.exists(ref_py.SO):
+                    rt = float("inf")
+                    for _rep in range(2):
+                        t1 = time.perf_counter()
+                        _, rok, _, rit = ref_py.optimize_batch(cfg_cpu, obst, via, cb, threads=cores)
+                        rt = min(rt, time.perf_counter() - t1)
+                    out["cpu_baseline"]["reference_code"] = {
+                        "value": float(rit.sum()) / rt, "unit": "TEB.LM-iterations/s", "cores": cores,
+                        "sample": "same %d candidates through oracle/_ref/libteb_ref.so, best of 2 runs, %.1f s wall" % (ks, rt)}
+            except Exception as e:   # the checker library is optional on the bench box
+                out["cpu_baseline"]["reference_code"] = {"error": str(e)[:200]}
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

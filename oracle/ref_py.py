@@ -223,3 +223,22 @@ def h_signatures(cfg, obst, batch, mode, prescaler=1.0, threshold=0.1):
     assert lib().ref_h_signatures(C.byref(c), C.byref(obst.freeze()), C.byref(bs), int(mode), C.c_double(prescaler), C.c_double(threshold),
                                   _P(sig), I(eq), I(valid), I(reas)) == 0
     return dict(sig=sig, equal=eq, valid=valid, reasonable=reas)
+
+
+def optimize_batch(cfg, obst, via, batch, inner=None, outer=None, compute_cost=True, threads=1):
+    """B x the reference's TebOptimalPlanner::optimizeTEB (thread per band, capped): (new_batch, ok [B], cost [B], lm_iterations [B])."""
+    c = cfg.to_c()
+    out = batch.copy()
+    bs = out.c_struct()
+    vx, vy = _via_xy(via)
+    inner = cfg.optim.no_inner_iterations if inner is None else inner
+    outer = cfg.optim.no_outer_iterations if outer is None else outer
+    B = batch.count
+    ok = np.zeros(B, np.int32); cost = np.zeros(B); it = np.zeros(B, np.int32)
+    I = lambda a: _abi._ptr(a, C.c_int32)
+    rc = lib().ref_optimize_batch(C.byref(c), C.byref(obst.freeze()), len(via), _P(vx), _P(vy), C.byref(bs), int(inner), int(outer),
+                                  int(compute_cost), C.c_double(cfg.hcp.selection_obst_cost_scale),
+                                  C.c_double(cfg.hcp.selection_viapoint_cost_scale), int(cfg.hcp.selection_alternative_time_cost),
+                                  int(threads), I(ok), _P(cost), I(it))
+    assert rc == 0, rc
+    return out, ok, cost, it

@@ -8,6 +8,9 @@
 // What is NOT (external, absent): libg2o, Eigen, ROS, Boost -> ./shim_*.h.
 #include "ref_common.h"
 
+#include <atomic>
+#include <thread>
+
 using namespace teb_local_planner;
 using namespace refshim;
 
@@ -371,6 +374,46 @@ int ref_h_signatures(const teb_amd_config_t* acfg, const teb_amd_obstacles_t* o,
   for (int a = 0; a < B; ++a)
     for (int b = 0; b < B; ++b) equal[a * B + b] = cls[a]->isEqual(*cls[b]);
   return 0;
+}
+
+// B x TebOptimalPlanner::optimizeTEB of the reference, one std::thread per band capped at `threads` - the reference's own
+// optimizeAllTEBs uses one boost::thread per candidate (src/homotopy_class_planner.cpp:476-483). Used as the CPU baseline of bench.py.
+int ref_optimize_batch(const teb_amd_config_t* acfg, const teb_amd_obstacles_t* o, int n_via, const double* via_x, const double* via_y,
+                       teb_amd_teb_batch_t* bt, int inner, int outer, int compute_cost, double osc, double vsc, int atc, int threads,
+                       int32_t* ok_out, double* cost_out, int32_t* lm_iterations) {
+  TebConfig cfg;
+  to_ref_config(*acfg, cfg);
+  ObstContainer obst;
+  to_ref_obstacles(o, obst);
+  ViaPointContainer via;
+  for (int i = 0; i < n_via; ++i) via.push_back(Eigen::Vector2d(via_x[i], via_y[i]));
+  const int B = bt->count, S = bt->stride;
+  { PlannerProbe warm(cfg, &obst, TebVisualizationPtr(), nullptr); }   // registerG2OTypes once, before the threads start
+  std::atomic<int> next(0);
+  std::atomic<int> err(0);
+  auto work = [&]() {
+    for (;;) {
+      const int b = next.fetch_add(1);
+      if (b >= B) break;
+      const size_t so = (size_t)b * S;
+      PlannerProbe pl(cfg, &obst, TebVisualizationPtr(), (!bt->via_points_enabled || bt->via_points_enabled[b]) ? &via : nullptr);
+      fill_planner(pl, bt->n[b], bt->x + so, bt->y + so, bt->theta + so, bt->dt + so, bt->has_vel_start ? bt->has_vel_start[b] : 1,
+                   bt->vel_start ? bt->vel_start + 3 * b : nullptr, bt->has_vel_goal ? bt->has_vel_goal[b] : 1,
+                   bt->vel_goal ? bt->vel_goal + 3 * b : nullptr, bt->prefer_rotdir ? bt->prefer_rotdir[b] : TEB_AMD_ROT_NONE);
+      g2o::SparseOptimizer::iterationCounter() = 0;
+      const bool ok = pl.optimizeTEB(inner, outer, compute_cost != 0, osc, vsc, atc != 0);
+      if (ok_out) ok_out[b] = ok;
+      if (cost_out) cost_out[b] = pl.getCurrentCost();
+      if (lm_iterations) lm_iterations[b] = (int32_t)g2o::SparseOptimizer::iterationCounter();
+      if (band_out(pl.teb(), bt->x + so, bt->y + so, bt->theta + so, bt->dt + so, bt->n + b, S)) err = 4;
+    }
+  };
+  std::vector<std::thread> pool;
+  const int T = std::max(1, std::min(threads, B));
+  for (int t = 1; t < T; ++t) pool.emplace_back(work);
+  work();
+  for (std::thread& t : pool) t.join();
+  return err.load();
 }
 
 }  // extern "C"

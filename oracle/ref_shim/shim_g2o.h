@@ -5,7 +5,7 @@
 //     / oplusImpl() code compiles unchanged;
 //   * the default numeric linearizeOplus (central differences, delta = 1e-9) of Base{Unary,Binary,Multi}Edge;
 //   * a SparseOptimizer that RECORDS the graph the reference's buildGraph() creates and runs a restatement of
-//     OptimizationAlgorithmLevenberg on it (dense normal equations + Cholesky) — SURVEY.md Appendix B.
+//     OptimizationAlgorithmLevenberg on it (banded normal equations + Cholesky) — SURVEY.md Appendix B.
 // The restated parts pin nothing by themselves; they let the reference's real graph construction, weights, edge
 // order, cost evaluation and outer loop (src/optimal_planner.cpp) run end-to-end for comparison with the oracle.
 #pragma once
@@ -291,11 +291,22 @@ class SparseOptimizer : public OptimizableGraph {
       v->_hessianIndex = off; off += v->dimension(); _index.push_back(v);
     }
     _N = off;
+    _KD = 0;   // half bandwidth of the normal matrix in this variable order
+    for (OptimizableGraph::Edge* e : _active) {
+      int lo = 1 << 30, hi = -1;
+      for (int i = 0; i < e->nVertices(); ++i) {
+        OptimizableGraph::Vertex* v = e->vertexAt(i);
+        if (v->fixed()) continue;
+        lo = std::min(lo, v->_hessianIndex); hi = std::max(hi, v->_hessianIndex + v->dimension() - 1);
+      }
+      if (hi >= 0) _KD = std::max(_KD, hi - lo);
+    }
     return true;
   }
   void computeActiveErrors() { for (OptimizableGraph::Edge* e : _active) e->computeError(); }
   double activeChi2() const { double c = 0; for (OptimizableGraph::Edge* e : _active) c += e->chi2(); return c; }
 
+  static long& iterationCounter() { static thread_local long c = 0; return c; }   // LM iterations run by this thread (bench accounting)
   int optimize(int iterations) {
     if (_index.empty()) return -1;
     _batch.clear();
@@ -307,6 +318,7 @@ class SparseOptimizer : public OptimizableGraph {
       if (_stats) { computeActiveErrors(); _batch[i].iteration = i; _batch[i].chi2 = activeChi2(); }
       ++cj;
     }
+    iterationCounter() += cj;
     return cj;
   }
 
@@ -316,7 +328,8 @@ class SparseOptimizer : public OptimizableGraph {
     computeActiveErrors();
     double currentChi = activeChi2();
     double tempChi = currentChi;
-    std::vector<double> H((size_t)N * N, 0.0), b(N, 0.0), x(N, 0.0);
+    const int W = _KD + 1;   // band storage: H(ia, ic) at [ia * W + (ia - ic)], ic <= ia (the zeros outside the band never enter the arithmetic)
+    std::vector<double> H((size_t)N * W, 0.0), b(N, 0.0), x(N, 0.0);
     for (OptimizableGraph::Edge* e : _active) {
       e->linearizeOplus();
       const int D = e->dimension();
@@ -336,7 +349,7 @@ class SparseOptimizer : public OptimizableGraph {
               if (ic > ia) continue;
               double h = 0;
               for (int k = 0; k < D; ++k) h += (e->jacAt(i, k, a) * e->infoAt(k, k)) * e->jacAt(j, k, c);
-              H[(size_t)ia * N + ic] += h;
+              H[(size_t)ia * W + (ia - ic)] += h;
             }
           }
         }
@@ -344,7 +357,7 @@ class SparseOptimizer : public OptimizableGraph {
     }
     if (iteration == 0) {
       double maxDiagonal = 0;
-      for (int k = 0; k < N; ++k) maxDiagonal = std::max(std::fabs(H[(size_t)k * N + k]), maxDiagonal);
+      for (int k = 0; k < N; ++k) maxDiagonal = std::max(std::fabs(H[(size_t)k * W]), maxDiagonal);
       _lambda = 1e-5 * maxDiagonal;
       _ni = 2;
     }
@@ -352,7 +365,7 @@ class SparseOptimizer : public OptimizableGraph {
     int qmax = 0;
     do {
       for (OptimizableGraph::Vertex* v : _index) v->push();
-      bool ok2 = cholSolve(H, b, x, N, _lambda);
+      bool ok2 = cholSolve(H, b, x, N, _KD, _lambda);
       if (!ok2) x = b;
       for (OptimizableGraph::Vertex* v : _index) v->oplus(&x[v->_hessianIndex]);
       computeActiveErrors();
@@ -382,19 +395,22 @@ class SparseOptimizer : public OptimizableGraph {
     if (qmax == 10 || rho == 0 || !std::isfinite(_lambda)) return false;
     return true;
   }
-  static bool cholSolve(const std::vector<double>& H, const std::vector<double>& b, std::vector<double>& x, int N, double lambda) {
-    std::vector<double> L((size_t)N * N, 0.0);
+  // (H + lambda I) x = b by banded Cholesky; fails iff a pivot is <= 0, the condition under which CSparse's cs_chol gives up
+  static bool cholSolve(const std::vector<double>& H, const std::vector<double>& b, std::vector<double>& x, int N, int KD, double lambda) {
+    const int W = KD + 1;
+    std::vector<double> L((size_t)N * W, 0.0);
     for (int j = 0; j < N; ++j) {
-      for (int c = 0; c <= j; ++c) {
-        double sum = H[(size_t)j * N + c];
+      const int c0 = std::max(0, j - KD);
+      for (int c = c0; c <= j; ++c) {
+        double sum = H[(size_t)j * W + (j - c)];
         if (c == j) sum += lambda;
-        for (int k = 0; k < c; ++k) sum -= L[(size_t)j * N + k] * L[(size_t)c * N + k];
-        if (c == j) { if (sum <= 0) return false; L[(size_t)j * N + j] = std::sqrt(sum); }
-        else L[(size_t)j * N + c] = sum / L[(size_t)c * N + c];
+        for (int k = std::max(c0, c - KD); k < c; ++k) sum -= L[(size_t)j * W + (j - k)] * L[(size_t)c * W + (c - k)];
+        if (c == j) { if (sum <= 0) return false; L[(size_t)j * W] = std::sqrt(sum); }
+        else L[(size_t)j * W + (j - c)] = sum / L[(size_t)c * W];
       }
     }
-    for (int i = 0; i < N; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= L[(size_t)i * N + k] * x[k]; x[i] = s / L[(size_t)i * N + i]; }
-    for (int i = N - 1; i >= 0; --i) { double s = x[i]; for (int k = i + 1; k < N; ++k) s -= L[(size_t)k * N + i] * x[k]; x[i] = s / L[(size_t)i * N + i]; }
+    for (int i = 0; i < N; ++i) { double s = b[i]; for (int k = std::max(0, i - KD); k < i; ++k) s -= L[(size_t)i * W + (i - k)] * x[k]; x[i] = s / L[(size_t)i * W]; }
+    for (int i = N - 1; i >= 0; --i) { double s = x[i]; for (int k = i + 1; k <= std::min(N - 1, i + KD); ++k) s -= L[(size_t)k * W + (k - i)] * x[k]; x[i] = s / L[(size_t)i * W]; }
     return true;
   }
 
@@ -405,7 +421,7 @@ class SparseOptimizer : public OptimizableGraph {
   std::vector<OptimizableGraph::Vertex*> _index;
   OptimizationAlgorithm* _algorithm = nullptr;
   long long _nextEdgeId = 0;
-  int _N = 0;
+  int _N = 0, _KD = 0;
   bool _stats = false;
   BatchStatisticsContainer _batch;
   double _lambda = 0, _ni = 2;
