@@ -199,16 +199,26 @@ def main():
             cfg_cpu = scenes.scene_c4(B=1, n=n)[0]
             cfg_cpu.trajectory.teb_autosize = False
             cfg_cpu.jacobian_mode = _abi.JACOBIAN_G2O_NUMERIC
-            cpu_t = float("inf")
-            for _rep in range(3):   # best of 3: 256 threads on a shared host are noisy
-                t1 = time.perf_counter()
-                _, cres = oracle_py.optimize_batch(cfg_cpu, obst, via, cb, threads=cores)
-                cpu_t = min(cpu_t, time.perf_counter() - t1)
+            # thread-per-TEB like the reference's optimizeAllTEBs; the thread count that gives the CPU its best rate is searched
+            # (a shared 256-thread host is not fastest with 256 busy threads) and reported as `cores`
+            try:
+                avail = len(os.sched_getaffinity(0))
+            except Exception:
+                avail = cores
+            cand = sorted({t for t in (avail, avail // 2, avail // 4, 64, 32, 16) if 1 <= t <= max(avail, 1)}, reverse=True)
+            cpu_t, cores = float("inf"), avail
+            for th in cand:
+                for _rep in range(2):
+                    t1 = time.perf_counter()
+                    _, cres = oracle_py.optimize_batch(cfg_cpu, obst, via, cb, threads=th)
+                    dtc = time.perf_counter() - t1
+                    if dtc < cpu_t:
+                        cpu_t, cores = dtc, th
             out["cpu_baseline"] = {
                 "value": float(cres.lm_iterations.sum()) / cpu_t, "unit": "TEB.LM-iterations/s", "cores": cores,
                 "kind": "port",
                 "sample": "%d of the %d C4 candidates, one optimizeTEB each (4x5), g2o-numeric Jacobians, "
-                          "one std::thread per TEB capped at %d, best of 3 runs, %.1f s wall; the port is bit-identical to the "
+                          "one std::thread per TEB capped at %d (best of the thread counts tried, 2 runs each), %.1f s wall; the port is bit-identical to the "
                           "reference's src/optimal_planner.cpp on the pinned bands (tests/test_reference_pinning.py)" % (ks, B, cores, cpu_t)}
             # the reference's OWN code on the same sample (oracle/_ref: src/optimal_planner.cpp + edge classes compiled in place; only
             # the LM iteration / banded Cholesky inside is a stand-in for the absent libg2o). Same results bit for bit; slower than the
