@@ -68,8 +68,6 @@ __device__ inline int init_tail(StripDev s, int n, double gx, double gy, double 
 __global__ void init_line_kernel(BatchDev bt, int b, double sx, double sy, double sth, double gx, double gy, double gth,
                                  double diststep, double max_vel_x, int min_samples, int guess_backwards, int* err) {
   StripDev s = strip_of(bt, b);
-  __shared__ int sh_n;
-  __shared__ double sh_ts;
   double timestep = 0.1;
   int n = 1;
   if (threadIdx.x == 0) { s.x[0] = sx; s.y[0] = sy; s.th[0] = sth; }
@@ -99,7 +97,6 @@ __global__ void init_line_kernel(BatchDev bt, int b, double sx, double sy, doubl
     const int r = init_tail<0>(s, n, gx, gy, gth, max_vel_x, 0.0, timestep, min_samples);
     if (r < 0) { *err = 1; *s.n = 0; } else *s.n = r;
   }
-  (void)sh_n; (void)sh_ts;
 }
 
 // initTrajectoryToGoal(plan, max_vel_x, max_vel_theta, estimate_orient, min_samples, guess_backwards_motion), :380-452.
