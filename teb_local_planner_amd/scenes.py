@@ -103,8 +103,8 @@ def scene_c3(B=64, n=150, M=200, seed=1003, stride=None):
     return _multi_band_scene(B, n, 15.0, M, 0, (-4.0, 4.0), seed, stride=stride)
 
 
-def scene_c4(B=256, n=200, M_static=450, M_dyn=50, seed=1004, stride=None):
-    cfg, obst, via, batch = _multi_band_scene(B, n, 20.0, M_static, M_dyn, (-5.0, 5.0), seed, stride=stride)
+def scene_c4(B=256, n=200, M_static=450, M_dyn=50, seed=1004, stride=None, length=20.0):
+    cfg, obst, via, batch = _multi_band_scene(B, n, length, M_static, M_dyn, (-5.0, 5.0), seed, stride=stride)
     cfg.obstacles.include_dynamic_obstacles = True
     return cfg, obst, via, batch
 

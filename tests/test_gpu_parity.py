@@ -444,3 +444,68 @@ def test_legacy_association_matches_oracle(oracle, kind, poses_affected):
     out, res, best = run_gpu(cfg, obst, via, batch)
     ref, rres = oracle.optimize_batch(cfg, obst, via, batch)
     assert_full_parity(out, res, ref, rres)
+
+
+# ---- edge cases: empty scene, minimal / ragged bands, maximum capacities, non-finite input ------------------------------------------
+def _straight_batch(cfg, ns, stride, rng):
+    batch = _abi.TebBatchHost(len(ns), stride)
+    for b, n in enumerate(ns):
+        px, py, th, dt = scenes.sine_band(n, 0.25 * n, rng.uniform(-0.3, 0.3), 1.0, cfg.robot.max_vel_x)
+        batch.set_teb(b, px, py, th, dt)
+    return batch
+
+
+def test_empty_scene_and_minimal_and_ragged_bands(oracle):
+    cfg, _, _, _ = scenes.scene_small_mixed(footprint="point")
+    rng = np.random.default_rng(4)
+    obst = _abi.ObstacleTable()                               # no obstacles, no via-points
+    batch = _straight_batch(cfg, [3, 4, 17, 120, 2], 320, rng)   # ragged: autoResize grows them to 8 ... 239 poses
+    out, res, best = run_gpu(cfg, obst, [], batch)
+    ref, rres = oracle.optimize_batch(cfg, obst, [], batch)
+    assert_full_parity(out, res, ref, rres)
+    assert (res.status == _abi.TEB_OK).all() and out.n[3] > 200
+    assert best[0] == oracle.select_best(cfg, rres.cost)[0]
+    # the same bands without resizing: the 3-pose band is optimised as it is (one free pose); the 2-pose band has no free vertex
+    # and fewer poses than min_samples, so optimizeGraph refuses it (src/optimal_planner.cpp:376-381)
+    cfg.trajectory.teb_autosize = False
+    out, res, _ = run_gpu(cfg, obst, [], batch)
+    ref, rres = oracle.optimize_batch(cfg, obst, [], batch)
+    np.testing.assert_array_equal(out.n, ref.n)
+    np.testing.assert_array_equal(res.status, rres.status)
+    assert out.n[0] == 3 and res.status[0] == _abi.TEB_OK and res.status[4] == _abi.TEB_FAILED
+    for b in range(4):
+        for u, v in zip(out.get_teb(b), ref.get_teb(b)):
+            assert np.abs(u - v).max() <= 1e-8
+    np.testing.assert_allclose(res.cost[:4], rres.cost[:4], rtol=1e-8)
+
+
+@pytest.mark.parametrize("n,solver", [(245, "cr"), (343, "band")])
+def test_maximum_pose_capacities(oracle, n, solver):
+    """S = 245 is the largest band the block-cyclic-reduction solver holds in LDS, S = 343 the largest for the banded solver."""
+    cfg, obst, via, _ = scenes.scene_small_mixed(footprint="point")
+    cfg.trajectory.teb_autosize = False
+    cfg.trajectory.max_samples = 500
+    rng = np.random.default_rng(n)
+    batch = _straight_batch(cfg, [n, n - 7], n, rng)
+    s = planner.make_solver(cfg, obst, via, batch)
+    lds, cap = s.capacity()
+    assert cap >= n
+    s.optimize(3, 2, True, cfg.hcp.selection_obst_cost_scale, cfg.hcp.selection_viapoint_cost_scale,
+               cfg.hcp.selection_alternative_time_cost)
+    res = s.results(); out = s.download(batch.copy()); s.close()
+    ref, rres = oracle.optimize_batch(cfg, obst, via, batch, inner=3, outer=2)
+    assert_full_parity(out, res, ref, rres, pos_tol=1e-7, rtol=1e-7)
+    with pytest.raises(planner.TebAmdError):                  # one more pose does not fit the LDS plan of the 343-pose handle
+        planner.TebBatchSolver(cfg, 1, 344, 4, 4, 1)
+
+
+def test_non_finite_input_is_reported_not_propagated(oracle):
+    cfg, obst, via, batch = scenes.scene_small_mixed(footprint="point")
+    bad = batch.copy()
+    bad.x[1, 5] = np.nan
+    out, res, best = run_gpu(cfg, obst, via, bad)
+    assert res.status[1] == _abi.TEB_NONFINITE
+    good, gres, _ = run_gpu(cfg, obst, via, batch)
+    for b in (0, 2):                                          # the other candidates are unaffected
+        assert res.status[b] == _abi.TEB_OK
+        np.testing.assert_array_equal(out.get_teb(b)[0], good.get_teb(b)[0])
