@@ -679,7 +679,7 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve(const LdsPlan plan, int n, double lam
 }
 
 // ---- TimedElasticBand::autoResize (src/timed_elastic_band.cpp:227-286) -------------------------------------
-// One sweep, executed by thread 0 as a streaming pass LDS strip -> global scratch (no O(n) inserts).
+// One sweep, executed by thread 0 as a streaming pass LDS strip -> LDS scratch (no O(n) inserts).
 // Reproduces the sequential i-- re-check semantics: `cur` is the interval under test, `stack` holds the
 // right halves produced by splits that still wait to be visited.
 __device__ inline void autoresize_sweep_thread0(const teb_amd_config_t& c, const Lds& l, int n_in, double* ox,
@@ -959,7 +959,6 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   int* via_pose = bt.via_pose + (size_t)b * bt.via_cap;
   t.assoc_cnt = assoc_cnt; t.assoc = assoc; t.via_pose = via_pose;
   double* Hbk = bt.Hbackup + (size_t)b * bt.hmat_stride;
-  double* rs = bt.rs_scratch + (size_t)b * (4 * (size_t)S + 256);
 
   int status = TEB_AMD_TEB_OK, iters = 0, trials = 0;
   double chi2_final = 0, lambda = 0, cost = __longlong_as_double(0x7ff8000000000000LL);
@@ -976,7 +975,8 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     if (c.teb_autosize && !args.debug_linearize) {
       int ovf = 0;
       PROF_START();
-      n = autoresize(c, l, n, rs, S, fast_mode, &ovf);
+      // sweep output + split stack (4 S + 256 doubles) live in the LDS region of the normal matrix, which is rebuilt afterwards
+      n = autoresize(c, l, n, SOLVER == SOLVER_CR ? l.Db : l.Hb, S, fast_mode, &ovf);
       PROF_END(0);
       if (ovf) { status = TEB_AMD_TEB_FAILED; if (tid == 0) bt.assoc_overflow[b] |= 2; break; }
     }

@@ -479,9 +479,10 @@ def test_empty_scene_and_minimal_and_ragged_bands(oracle):
     np.testing.assert_allclose(res.cost[:4], rres.cost[:4], rtol=1e-8)
 
 
-@pytest.mark.parametrize("n,solver", [(245, "cr"), (343, "band")])
+@pytest.mark.parametrize("n,solver", [(238, "cr"), (343, "band")])
 def test_maximum_pose_capacities(oracle, n, solver):
-    """S = 245 is the largest band the block-cyclic-reduction solver holds in LDS, S = 343 the largest for the banded solver."""
+    """S = 238 is the largest band the block-cyclic-reduction solver holds in LDS (without the obstacle cache), S = 343 the largest for
+    the banded solver."""
     cfg, obst, via, _ = scenes.scene_small_mixed(footprint="point")
     cfg.trajectory.teb_autosize = False
     cfg.trajectory.max_samples = 500
