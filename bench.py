@@ -58,8 +58,10 @@ def main():
 
     B, n = args.tebs, args.poses
     # every rank owns its own candidates (different seed -> different bands), the scene is replicated
-    cfg, obst, via, batch = scenes.scene_c4(B=B, n=n, seed=1004 + 7919 * rank)
-    cfg.trajectory.teb_autosize = False
+    # TebConfig defaults throughout (teb_autosize on: the bands are resized on the device every outer iteration and end with
+    # 190 .. 290 poses); capacity 288 poses per band = band-form normal matrix in LDS + the 500-obstacle LDS cache
+    STRIDE = max(288, n)
+    cfg, obst, via, batch = scenes.scene_c4(B=B, n=n, seed=1004 + 7919 * rank, stride=STRIDE)
     inner, outer = cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations
     hp = planner.HomotopyClassPlanner(cfg, obst, via, batch, device=local_rank)
     s = hp.solver
@@ -88,6 +90,8 @@ def main():
     elapsed = time.perf_counter() - t0
     res = s.results()
     units_step = int(res.lm_iterations.sum())
+    n_after = s.pose_counts()
+    tebs_ok = int((res.status == 0).sum())
     tt = torch.tensor([elapsed, float(units_step)], dtype=torch.float64, device="cuda")
     if distributed:
         tmax = tt.clone()
@@ -104,9 +108,11 @@ def main():
         kms = float(np.mean(kernel_ms))
         M = len(obst)
         # association list size for the algorithmic-byte model: measured on TEB 0 of this rank
+        s.restore()                                   # association list size of the initial band of TEB 0
         dbg = s.debug_linearize(0, n, 1.0)
         e_assoc = len(dbg["assoc_pose"])
-        abu = alg_bytes_per_unit(n, M, e_assoc, inner)
+        n_eff = float(n_after.mean())                 # pose count the iterations of this step actually worked on
+        abu = alg_bytes_per_unit(n_eff, M, e_assoc, inner)
         alg_bytes_launch = abu * units_step
         achieved = alg_bytes_launch / (kms * 1e-3) / 1e9
         # HBM-side traffic per launch from the committed rocprofv3 PMC passes of THIS command (FETCH_SIZE / WRITE_SIZE in
@@ -135,10 +141,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed_max / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C4: %d candidate TEBs/GPU x %d poses, %d point obstacles (%d dynamic), "
-                                   "diff-drive, point footprint, teb_autosize off, 4 outer x 5 inner" %
-                                   (B, n, M, int(np.sum(obst.dynamic))),
-                       "tebs_per_gpu": B, "poses": n, "obstacles": M, "units_per_step_per_gpu": units_step,
+            "config": {"workload": "C4: %d candidate TEBs/GPU x %d poses at the start (teb_autosize on, the reference default: "
+                                   "%d..%d poses, mean %.0f, after the step), %d point obstacles (%d dynamic), diff-drive, point "
+                                   "footprint, TebConfig defaults, 4 outer x 5 inner" %
+                                   (B, n, int(n_after.min()), int(n_after.max()), n_eff, M, int(np.sum(obst.dynamic))),
+                       "tebs_per_gpu": B, "poses": n, "poses_after": [int(n_after.min()), int(n_after.max())],
+                       "pose_capacity": STRIDE, "tebs_ok": tebs_ok, "obstacles": M, "units_per_step_per_gpu": units_step,
                        "lm_trials_per_step_per_gpu": int(res.lm_trials.sum())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_unit": "bytes/launch",
@@ -152,7 +160,7 @@ def main():
         #      association, cost -> select -> download (single TEB, config C2, and the C4 batch)
         lat = {}
         for name, (c2, o2, v2, b2) in ((("c2_single_teb", scenes.scene_c2(stride=208)),
-                                        ("c4_batch", scenes.scene_c4(B=B, n=n, stride=max(n, 208)))) if args.latency_reps > 0 else ()):
+                                        ("c4_batch", scenes.scene_c4(B=B, n=n, stride=STRIDE))) if args.latency_reps > 0 else ()):
             s2 = planner.make_solver(c2, o2, v2, b2)
             ts = []
             for _ in range(args.latency_reps):
@@ -186,9 +194,8 @@ def main():
             lat[name + "_device_resident_p50_ms"] = 1e3 * float(np.median(ts))
             s2.close()
         out["plan_latency"] = lat
-        # ---- BASELINE configs[2] with teb_autosize ON (the reference default): 64 candidates x 150 poses, 200 obstacles; the bands
-        #      are resized on the device every outer iteration (K1) and end with different pose counts. Not the headline workload
-        #      (C4 keeps n = 200 by switching autoResize off, see config.workload) - reported so that the cost of K1 is visible.
+        # ---- secondary numbers: C4 with autoResize switched off (every band keeps exactly 200 poses, block-form normal matrix in
+        #      LDS - the fastest configuration of the kernel) and BASELINE configs[2] (64 x 150 poses, 200 obstacles, defaults)
         if args.latency_reps > 0:
             c3, o3, v3, b3 = scenes.scene_c3(stride=208)
             s3 = planner.make_solver(c3, o3, v3, b3)
@@ -205,7 +212,27 @@ def main():
                 ms3.append(s3.last_kernel_ms())
             n3 = s3.pose_counts()
             u3 = int(r3.lm_iterations.sum())
-            out["secondary"] = {"c3_autosize_on": {
+            c4f, o4f, v4f, b4f = scenes.scene_c4(B=B, n=n, stride=max(n, 208))
+            c4f.trajectory.teb_autosize = False
+            s4 = planner.make_solver(c4f, o4f, v4f, b4f)
+            s4.snapshot()
+            ms4, t4 = [], []
+            for _ in range(max(3, args.latency_reps // 2)):
+                s4.restore()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                s4.optimize(inner, outer, True, c4f.hcp.selection_obst_cost_scale, c4f.hcp.selection_viapoint_cost_scale,
+                            c4f.hcp.selection_alternative_time_cost)
+                r4 = s4.results()
+                t4.append(time.perf_counter() - t1)
+                ms4.append(s4.last_kernel_ms())
+            u4 = int(r4.lm_iterations.sum())
+            s4.close()
+            out["secondary"] = {"c4_fixed_200_poses": {
+                "workload": "C4 with teb_autosize off: every band keeps exactly %d poses; normal matrix as 8x8 blocks in LDS" % n,
+                "kernel_ms": float(np.median(ms4)), "ms_per_step": 1e3 * float(np.median(t4)), "units_per_step": u4,
+                "value": u4 / float(np.median(t4)), "unit": "TEB.LM-iterations/s", "tebs_ok": int((r4.status == 0).sum())},
+                                "c3_autosize_on": {
                 "workload": "C3: 64 candidate TEBs x 150 poses, 200 point obstacles, teb_autosize on, 4 outer x 5 inner",
                 "kernel_ms": float(np.median(ms3)), "ms_per_step": 1e3 * float(np.median(t3)), "units_per_step": u3,
                 "value": u3 / float(np.median(t3)), "unit": "TEB.LM-iterations/s",
@@ -217,12 +244,11 @@ def main():
             oracle_py.build()
             cores = os.cpu_count() or 1
             ks = min(args.cpu_sample, B)
-            cb = _abi.TebBatchHost(ks, batch.stride)
+            cb = _abi.TebBatchHost(ks, max(batch.stride, 320))
             for b in range(ks):
                 cb.set_teb(b, *batch.get_teb(b))
             cb.has_vel_goal[:] = batch.has_vel_goal[:ks]
             cfg_cpu = scenes.scene_c4(B=1, n=n)[0]
-            cfg_cpu.trajectory.teb_autosize = False
             cfg_cpu.jacobian_mode = _abi.JACOBIAN_G2O_NUMERIC
             # thread-per-TEB like the reference's optimizeAllTEBs; the thread count that gives the CPU its best rate is searched
             # (a shared 256-thread host is not fastest with 256 busy threads) and reported as `cores`
@@ -242,7 +268,7 @@ def main():
             out["cpu_baseline"] = {
                 "value": float(cres.lm_iterations.sum()) / cpu_t, "unit": "TEB.LM-iterations/s", "cores": cores,
                 "kind": "port",
-                "sample": "%d of the %d C4 candidates, one optimizeTEB each (4x5), g2o-numeric Jacobians, "
+                "sample": "%d of the %d C4 candidates, one optimizeTEB each (4x5, teb_autosize on), g2o-numeric Jacobians, "
                           "one std::thread per TEB capped at %d (best of the thread counts tried, 2 runs each), %.1f s wall; the port is bit-identical to the "
                           "reference's src/optimal_planner.cpp on the pinned bands (tests/test_reference_pinning.py)" % (ks, B, cores, cpu_t)}
             # the reference's OWN code on the same sample (oracle/_ref: src/optimal_planner.cpp + edge classes compiled in place; only

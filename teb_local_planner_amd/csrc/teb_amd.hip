@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -139,6 +140,7 @@ struct teb_amd_handle {
   size_t lds_bytes = 0;
   int solver = 0;
   size_t hmat_stride = 0;
+  int band_ldlt = 0;   // SOLVER_BAND: 1 = sequential banded LDL^T (TEB_AMD_BAND_SOLVE=ldlt), 0 = cyclic reduction on HBM blocks
   size_t lds_limit = 0;
   LdsPlan plan;
   int fast_points = 0;
@@ -148,7 +150,7 @@ struct teb_amd_handle {
   DevBuf<double> o_ax, o_ay, o_bx, o_by, o_rad, o_vx, o_vy, o_cx, o_cy, o_pvx, o_pvy, viax, viay;
   // batch
   DevBuf<int> n, has_vs, has_vg, rotdir, via_en, status, iters, trials, assoc_cnt, assoc, assoc_ovf, via_pose, legacy_idx;
-  DevBuf<double> x, y, th, dt, vs, vg, chi2, cost, lambda, Hbackup, rs_scratch;
+  DevBuf<double> x, y, th, dt, vs, vg, chi2, cost, lambda, Hbackup;
   // snapshot
   DevBuf<int> snap_n;
   DevBuf<double> snap_x, snap_y, snap_th, snap_dt;
@@ -200,7 +202,7 @@ BatchDev batch_of(teb_amd_handle* h) {
   b.assoc_cnt = h->assoc_cnt.p; b.assoc = h->assoc.p; b.assoc_cap = h->max_obst > 0 ? h->max_obst : 1;
   b.assoc_overflow = h->assoc_ovf.p; b.legacy_idx = h->legacy_idx.p;
   b.via_pose = h->via_pose.p; b.via_cap = h->max_via > 0 ? h->max_via : 1;
-  b.Hbackup = h->Hbackup.p; b.hmat_stride = h->hmat_stride; b.rs_scratch = h->rs_scratch.p;
+  b.Hbackup = h->Hbackup.p; b.hmat_stride = h->hmat_stride;
   return b;
 }
 
@@ -297,12 +299,21 @@ int teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_po
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(TEB_AMD_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
   HIPCHK(hipSetDevice(device));
-  // block cyclic reduction when its block storage fits the LDS, else the sequential band solver
+  // Normal matrix as 8x8 blocks in LDS (SOLVER_CR: cyclic reduction in place, fastest) when that fits TOGETHER with the LDS cache
+  // of a full obstacle table of max_obstacles point-like entries; otherwise as a band in LDS (SOLVER_BAND: 44 instead of 70
+  // doubles per pose) with the cyclic reduction on HBM-resident blocks - ~15 % slower per step, but it keeps the obstacle cache
+  // and holds bands up to 343 poses.
   int solver = SOLVER_CR;
-  if (const char* env = getenv("TEB_AMD_SOLVER")) solver = (std::strcmp(env, "band") == 0) ? SOLVER_BAND : SOLVER_CR;
   // the kernel also owns a little static LDS (__syncthreads_or scratch): keep 1 KiB of head-room
   const size_t lds_limit = (size_t)prop.sharedMemPerBlock - 1024;
   if (lds_bytes_for(max_poses, SOLVER_CR) > lds_limit) solver = SOLVER_BAND;
+  else if ((size_t)make_lds_plan(max_poses, SOLVER_CR, max_obstacles > 0 ? max_obstacles : 0).total_bytes > lds_limit &&
+           (size_t)make_lds_plan(max_poses, SOLVER_BAND, max_obstacles > 0 ? max_obstacles : 0).total_bytes <= lds_limit)
+    solver = SOLVER_BAND;
+  if (const char* env = getenv("TEB_AMD_SOLVER")) {
+    if (std::strcmp(env, "band") == 0) solver = SOLVER_BAND;
+    else if (lds_bytes_for(max_poses, SOLVER_CR) <= lds_limit) solver = SOLVER_CR;
+  }
   const size_t lds = lds_bytes_for(max_poses, solver);
   if (max_poses > kThreads * kMaxPoseIter || lds > lds_limit) {
     char buf[256];
@@ -322,7 +333,11 @@ int teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_po
   h->solver = solver;
   h->lds_limit = lds_limit;
   h->plan = make_lds_plan(max_poses, solver, 0);
-  h->hmat_stride = hmat_doubles(max_poses, solver);
+  // per-band HBM buffer: the copy of H for rejected trials (SOLVER_CR, banded LDL^T) or the blocks the cyclic reduction of a
+  // SOLVER_BAND handle works on (D, L, f: nb * (2 * kBlk + 8) doubles)
+  h->hmat_stride = std::max(hmat_doubles(max_poses, solver), (size_t)nb_for(max_poses) * (2 * kBlk + 8));
+  h->band_ldlt = 0;
+  if (const char* env = getenv("TEB_AMD_BAND_SOLVE")) h->band_ldlt = std::strcmp(env, "ldlt") == 0;
   if (stream) { h->stream = reinterpret_cast<hipStream_t>(stream); h->own_stream = false; }
   else {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(TEB_AMD_ERR_HIP, "hipStreamCreate failed"); }
@@ -344,7 +359,7 @@ int teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_po
   A(h->x.alloc(BS)); A(h->y.alloc(BS)); A(h->th.alloc(BS)); A(h->dt.alloc(BS));
   A(h->vs.alloc(3 * (size_t)max_tebs)); A(h->vg.alloc(3 * (size_t)max_tebs));
   A(h->chi2.alloc(max_tebs)); A(h->cost.alloc(max_tebs)); A(h->lambda.alloc(max_tebs));
-  A(h->Hbackup.alloc((size_t)max_tebs * h->hmat_stride)); A(h->rs_scratch.alloc((size_t)max_tebs * (4 * (size_t)max_poses + 256)));
+  A(h->Hbackup.alloc((size_t)max_tebs * h->hmat_stride));
   A(h->snap_n.alloc(max_tebs)); A(h->snap_x.alloc(BS)); A(h->snap_y.alloc(BS)); A(h->snap_th.alloc(BS)); A(h->snap_dt.alloc(BS));
   A(h->dbg_H.alloc((size_t)4 * max_poses * kBand)); A(h->dbg_b.alloc((size_t)4 * max_poses)); A(h->dbg_chi2.alloc(4));
   A(h->sel_cost.alloc(1)); A(h->sel_idx.alloc(1)); A(h->err_flag.alloc(1));
@@ -375,7 +390,7 @@ void teb_amd_destroy(teb_amd_handle_t* h) {
   for (auto* q : ib) q->free();
   DevBuf<double>* db[] = {&h->o_ax, &h->o_ay, &h->o_bx, &h->o_by, &h->o_rad, &h->o_vx, &h->o_vy, &h->o_cx, &h->o_cy, &h->o_pvx,
                           &h->o_pvy, &h->viax, &h->viay, &h->x, &h->y, &h->th, &h->dt, &h->vs, &h->vg, &h->chi2, &h->cost,
-                          &h->lambda, &h->Hbackup, &h->rs_scratch, &h->snap_x, &h->snap_y, &h->snap_th, &h->snap_dt, &h->dbg_H,
+                          &h->lambda, &h->Hbackup, &h->snap_x, &h->snap_y, &h->snap_th, &h->snap_dt, &h->dbg_H,
                           &h->dbg_b, &h->dbg_chi2, &h->sel_cost, &h->stage_x, &h->stage_y, &h->stage_yaw, &h->out_cmd, &h->out_prof, &h->out_traj, &h->hsig, &h->hs_pre, &h->hs_pim};
   for (auto* q : db) q->free();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -541,7 +556,7 @@ int teb_amd_optimize_batch(teb_amd_handle_t* h, int32_t inner, int32_t outer, in
   if (inner < 0 || outer < 0) return fail(TEB_AMD_ERR_INVALID_ARG, "negative iteration count");
   OptArgs a;
   std::memset(&a, 0, sizeof a);
-  a.inner = inner; a.outer = outer; a.compute_cost = compute_cost;
+  a.inner = inner; a.outer = outer; a.compute_cost = compute_cost; a.band_ldlt = h->band_ldlt;
   a.obst_scale = obst_cost_scale; a.via_scale = viapoint_cost_scale; a.alt_time = alternative_time_cost;
 #ifdef TEB_PROFILE
   a.dbg_H = h->dbg_H.p;
@@ -945,7 +960,6 @@ int teb_amd_capacity(teb_amd_handle_t* h, int32_t* lds_bytes, int32_t* max_poses
     int S = kThreads * kMaxPoseIter;
     while (S > 2 && lds_bytes_for(S, SOLVER_BAND) > h->lds_limit) --S;
     *max_poses_supported = S;
-    (void)0;
   }
   return TEB_AMD_OK;
 }
@@ -959,7 +973,7 @@ int teb_amd_debug_linearize(teb_amd_handle_t* h, int32_t b, double weight_multip
   // run the kernel in debug mode on TEB b only: temporarily view the batch as starting at b
   OptArgs a;
   std::memset(&a, 0, sizeof a);
-  a.inner = 1; a.outer = 1; a.debug_linearize = 1; a.debug_weight_multiplier = weight_multiplier;
+  a.inner = 1; a.outer = 1; a.debug_linearize = 1; a.debug_weight_multiplier = weight_multiplier; a.band_ldlt = h->band_ldlt;
   a.dbg_H = h->dbg_H.p; a.dbg_b = h->dbg_b.p; a.dbg_chi2 = h->dbg_chi2.p;
   SceneDev sc = scene_of(h);
   BatchDev bt = batch_of(h);
@@ -969,7 +983,7 @@ int teb_amd_debug_linearize(teb_amd_handle_t* h, int32_t b, double weight_multip
   bt.has_vs += b; bt.vs += 3 * b; bt.has_vg += b; bt.vg += 3 * b; bt.rotdir += b; bt.via_en += b;
   bt.status += b; bt.iters += b; bt.trials += b; bt.chi2 += b; bt.cost += b; bt.lambda += b;
   bt.assoc_cnt += so; bt.assoc += (size_t)b * bt.assoc_cap * h->stride; bt.assoc_overflow += b;
-  bt.via_pose += (size_t)b * bt.via_cap; bt.Hbackup += (size_t)b * h->hmat_stride; bt.rs_scratch += (size_t)b * (4 * (size_t)h->stride + 256);
+  bt.via_pose += (size_t)b * bt.via_cap; bt.Hbackup += (size_t)b * h->hmat_stride;
   // results of TEB b must not be clobbered by the debug run: save and restore them
   int sv_i[3]; double sv_d[3];
   HIPCHK(hipMemcpy(&sv_i[0], h->status.p + b, sizeof(int), hipMemcpyDeviceToHost));

@@ -82,13 +82,13 @@ struct BatchDev {
   int via_cap;
   double* Hbackup;  // [B][hmat_stride]
   size_t hmat_stride;
-  double* rs_scratch;  // [B][4][stride] autoResize output buffers
 };
 
 struct OptArgs {
   int inner, outer, compute_cost;
   double obst_scale, via_scale;
   int alt_time;
+  int band_ldlt;         // SOLVER_BAND only: 1 = sequential banded LDL^T in LDS (v1), 0 = cyclic reduction on HBM-resident blocks
   int debug_linearize;   // test hook: stop after the first linearisation and dump H, b, chi2 categories
   double debug_weight_multiplier;
   double* dbg_H;         // [4*stride*kBand] of TEB 0

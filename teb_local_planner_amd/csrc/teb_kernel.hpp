@@ -536,19 +536,46 @@ __device__ long long g_cr_prof[8];
 #else
 #define TEB_SOLVE_LINKAGE __noinline__
 #endif
-__device__ TEB_SOLVE_LINKAGE void cr_solve(const LdsPlan plan, int n, double lambda) {
+// GLOBAL == false: the blocks are the LDS-resident normal matrix (SOLVER_CR), which the solve destroys.
+// GLOBAL == true : the normal matrix stays in LDS in band form (SOLVER_BAND, bands too long for the block layout); its 8x8
+//                  blocks (+ lambda) are expanded into a per-band HBM buffer (L2-resident: ~70 doubles per pose) and the same
+//                  reduction runs there - log2(n/2) levels of round trips to L2 instead of 4n sequential pivots, and no
+//                  backup / restore of H since the band is never touched.
+template <bool GLOBAL>
+__device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, int n, double lambda, double* gbuf) {
   TEB_SOLVER_FMA
   extern __shared__ __attribute__((aligned(16))) double lds_base[];
   CRP_DECL
   const Lds l = carve(lds_base, plan);
   const int tid = threadIdx.x;
   const int Nt = 4 * n, Nb = (Nt + 7) >> 3;
-  double* __restrict__ D = l.Db;
-  double* __restrict__ L = l.Lb;
-  double* __restrict__ f = l.fb;
-  for (int q = tid; q < Nb * 8; q += kThreads) {
-    f[q] = (q < Nt) ? l.bv[q] : 0.0;
-    D[(q >> 3) * kBlk + (q & 7) * 9] += lambda;
+  double* __restrict__ D = GLOBAL ? gbuf : l.Db;
+  double* __restrict__ L = GLOBAL ? gbuf + (size_t)Nb * kBlk : l.Lb;
+  double* __restrict__ f = GLOBAL ? gbuf + (size_t)2 * Nb * kBlk : l.fb;
+  if (GLOBAL) {
+    const double* Hb = l.Hb;
+    for (int q = tid; q < Nb * 128; q += kThreads) {
+      const int j = q >> 7, w = q & 127, a = (w & 63) >> 3, bcol = w & 7;
+      const int r = 8 * j + a;
+      double v = 0;
+      if (w < 64) {            // D_j[a][bcol]
+        const int cc = 8 * j + bcol;
+        if (r < Nt && cc < Nt) v = (cc <= r) ? Hb[r * kBand + (r - cc)] : Hb[cc * kBand + (cc - r)];
+        else if (r == cc) v = 1.0;
+        if (r == cc) v += lambda;
+        D[j * kBlk + a * 8 + bcol] = v;
+      } else {                 // L_j[a][bcol] = H[8j+a][8(j-1)+bcol]
+        const int d = 8 + a - bcol;
+        if (j >= 1 && r < Nt && d < kBand) v = Hb[r * kBand + d];
+        L[j * kBlk + a * 8 + bcol] = v;
+      }
+    }
+    for (int q = tid; q < Nb * 8; q += kThreads) f[q] = (q < Nt) ? l.bv[q] : 0.0;
+  } else {
+    for (int q = tid; q < Nb * 8; q += kThreads) {
+      f[q] = (q < Nt) ? l.bv[q] : 0.0;
+      D[(q >> 3) * kBlk + (q & 7) * 9] += lambda;
+    }
   }
   if (tid == 0) l.ired[0] = 1;
   __syncthreads();
@@ -1070,7 +1097,9 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       }
       PROF_START();
       const int hsz = (SOLVER == SOLVER_BAND) ? Nt * kBand : ((Nt + 7) >> 3) * 2 * kBlk;
-      for (int q = tid; q < hsz; q += kThreads) Hbk[q] = *hmat_ptr<SOLVER>(l, q, Nt);   // saved for rejected trials
+      const bool keep_copy = !(SOLVER == SOLVER_BAND && !args.band_ldlt);   // the HBM-block reduction never touches the band
+      if (keep_copy)
+        for (int q = tid; q < hsz; q += kThreads) Hbk[q] = *hmat_ptr<SOLVER>(l, q, Nt);   // saved for rejected trials
       PROF_END(3);
       double rho = 0;
       int qmax = 0;
@@ -1078,13 +1107,17 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
         // --- damped solve
         PROF_START();
         if (SOLVER == SOLVER_BAND) {
-          if (tid < 64) {
-            bool ok = banded_ldlt_solve_wave0(l, Nt, lambda);
-            if (tid == 0) l.ired[0] = ok ? 1 : 0;
+          if (args.band_ldlt) {
+            if (tid < 64) {
+              bool ok = banded_ldlt_solve_wave0(l, Nt, lambda);
+              if (tid == 0) l.ired[0] = ok ? 1 : 0;
+            }
+            __syncthreads();
+          } else {
+            cr_solve_t<true>(plan, n, lambda, Hbk);
           }
-          __syncthreads();
         } else {
-          cr_solve(plan, n, lambda);
+          cr_solve_t<false>(plan, n, lambda, nullptr);
         }
         PROF_END(4);
         PROF_START();
@@ -1141,7 +1174,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
             if (i < n) { l.sx[i] = bx_[kk]; l.sy[i] = by_[kk]; l.sth[i] = bth_[kk]; l.sdt[i] = bdt_[kk]; }
           }
           if (!isfinite(lambda)) { ++qmax; __syncthreads(); break; }
-          if (rho < 0 && qmax + 1 < 10)   // another trial follows: bring back the un-factored H
+          if (keep_copy && rho < 0 && qmax + 1 < 10)   // another trial follows: bring back the un-factored H
             for (int q = tid; q < hsz; q += kThreads) *hmat_ptr<SOLVER>(l, q, Nt) = Hbk[q];
         }
         __syncthreads();

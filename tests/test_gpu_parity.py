@@ -300,11 +300,15 @@ def test_reference_style_planner_objects(oracle):
     assert p.optimizeTEB(5, 4) is False
 
 
-@pytest.mark.parametrize("solver", ["band", "cr"])
+@pytest.mark.parametrize("solver", ["cr", "band", "band_ldlt"])
 def test_both_damped_solvers_match_the_oracle(oracle, solver, monkeypatch):
-    """K6 v1 (sequential banded LDL^T) and K6 v2 (block cyclic reduction) solve the same damped system:
-    identical accept/reject decisions, trajectories within 1e-8. Even and odd pose counts (block padding)."""
-    monkeypatch.setenv("TEB_AMD_SOLVER", solver)
+    """The three damped solves - block cyclic reduction on the LDS-resident blocks ("cr"), the same reduction on HBM-resident
+    blocks expanded from the LDS band (what long bands use: "band"), and the sequential banded LDL^T ("band_ldlt", kept as a
+    cross-check) - solve the same system: identical accept / reject decisions, trajectories within 1e-8. Even and odd pose
+    counts (block padding)."""
+    monkeypatch.setenv("TEB_AMD_SOLVER", "band" if solver.startswith("band") else "cr")
+    if solver == "band_ldlt":
+        monkeypatch.setenv("TEB_AMD_BAND_SOLVE", "ldlt")
     for n0 in (24, 25):
         cfg, obst, via, batch = scenes.scene_small_mixed(footprint="polygon", n=n0)
         for autosize in (True, False):

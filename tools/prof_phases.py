@@ -24,6 +24,8 @@ names = ["autoresize", "assoc+via+tdyn", "linearize", "H backup", "solve", "upda
 for which in sys.argv[1:] or ["c4", "c2", "c5"]:
     if which == "c4":
         cfg, obst, via, batch = scenes.scene_c4(); cfg.trajectory.teb_autosize = False
+    elif which == "c4on":
+        cfg, obst, via, batch = scenes.scene_c4(stride=288)
     elif which == "c3":
         cfg, obst, via, batch = scenes.scene_c3(stride=208)
     elif which == "c2":
