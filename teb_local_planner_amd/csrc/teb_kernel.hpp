@@ -709,7 +709,7 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, int n, double l
 // One sweep, executed by thread 0 as a streaming pass LDS strip -> LDS scratch (no O(n) inserts).
 // Reproduces the sequential i-- re-check semantics: `cur` is the interval under test, `stack` holds the
 // right halves produced by splits that still wait to be visited.
-__device__ inline void autoresize_sweep_thread0(const teb_amd_config_t& c, const Lds& l, int n_in, double* ox,
+__device__ __noinline__ void autoresize_sweep_thread0(const teb_amd_config_t& c, const Lds& l, int n_in, double* ox,
                                                 double* oy, double* oth, double* odt, double* stk, int stride,
                                                 int* n_out, int* modified_out, int* overflow) {
   const double dt_ref = c.dt_ref, hyst = c.dt_hysteresis;
@@ -721,6 +721,12 @@ __device__ inline void autoresize_sweep_thread0(const teb_amd_config_t& c, const
   bool modified = false;
   double cx = l.sx[0], cy = l.sy[0], cth = l.sth[0], cdt = l.sdt[0];
   const double gx = l.sx[n_in - 1], gy = l.sy[n_in - 1], gth = l.sth[n_in - 1];
+  // cos / sin of the input poses come from the per-pose cache (refreshed by the caller); poses created by a split compute theirs
+  // only if they are split again. ci < 0: the current pose is such a new pose.
+  int ci = 0;
+  // the next unread input interval is kept in registers one step ahead, so that its LDS latency overlaps the rule evaluation
+  double px = 0, py = 0, pth = 0, pdt = 0;
+  if (j < Tin) { px = l.sx[j]; py = l.sy[j]; pth = l.sth[j]; pdt = l.sdt[j]; }
   bool alive = Tin >= 1;
   while (alive) {
     const bool has_next = (sp > 0) || (j < Tin);
@@ -728,12 +734,15 @@ __device__ inline void autoresize_sweep_thread0(const teb_amd_config_t& c, const
       if (cdt > 2 * dt_ref) {
         double newtime = 0.5 * cdt;
         double ex, ey, eth;   // Pose(i+1)
-        if (sp > 0) { ex = stk[4 * (sp - 1)]; ey = stk[4 * (sp - 1) + 1]; eth = stk[4 * (sp - 1) + 2]; }
-        else if (j < Tin) { ex = l.sx[j]; ey = l.sy[j]; eth = l.sth[j]; }
-        else { ex = gx; ey = gy; eth = gth; }
+        int ei;               // its input index, or -1 for a pose created in this sweep
+        if (sp > 0) { ex = stk[4 * (sp - 1)]; ey = stk[4 * (sp - 1) + 1]; eth = stk[4 * (sp - 1) + 2]; ei = -1; }
+        else if (j < Tin) { ex = px; ey = py; eth = pth; ei = j; }
+        else { ex = gx; ey = gy; eth = gth; ei = n_in - 1; }
         if (sp >= 64) { *overflow = 1; break; }
         // PoseSE2::average (pose_se2.h:266-269) with g2o::average_angle
-        double sxn = cos(cth) + cos(eth), syn = sin(cth) + sin(eth);
+        const double cc = ci >= 0 ? l.cs[ci] : cos(cth), cs_ = ci >= 0 ? l.sn[ci] : sin(cth);
+        const double ec = ei >= 0 ? l.cs[ei] : cos(eth), es = ei >= 0 ? l.sn[ei] : sin(eth);
+        double sxn = cc + ec, syn = cs_ + es;
         stk[4 * sp] = (cx + ex) / 2; stk[4 * sp + 1] = (cy + ey) / 2;
         stk[4 * sp + 2] = (sxn == 0 && syn == 0) ? 0.0 : atan2(syn, sxn);
         stk[4 * sp + 3] = newtime;
@@ -745,7 +754,7 @@ __device__ inline void autoresize_sweep_thread0(const teb_amd_config_t& c, const
       } else {
         if (has_next) {
           if (sp > 0) stk[4 * (sp - 1) + 3] += cdt - dt_ref;
-          else l.sdt[j] += cdt - dt_ref;
+          else pdt += cdt - dt_ref;
         }
         cdt = dt_ref;
       }
@@ -753,7 +762,10 @@ __device__ inline void autoresize_sweep_thread0(const teb_amd_config_t& c, const
       if (has_next) {
         // TimeDiff(i+1) += TimeDiff(i); deleteTimeDiff(i); deletePose(i+1); i--
         if (sp > 0) { cdt = stk[4 * (sp - 1) + 3] + cdt; --sp; }
-        else { cdt = l.sdt[j] + cdt; ++j; }
+        else {
+          cdt = pdt + cdt; ++j;
+          if (j < Tin) { px = l.sx[j]; py = l.sy[j]; pth = l.sth[j]; pdt = l.sdt[j]; }
+        }
         --T;
         modified = true;
         continue;
@@ -770,8 +782,11 @@ __device__ inline void autoresize_sweep_thread0(const teb_amd_config_t& c, const
     if (k >= stride - 1) { *overflow = 1; break; }
     ox[k] = cx; oy[k] = cy; oth[k] = cth; odt[k] = cdt;
     ++k;
-    if (sp > 0) { --sp; cx = stk[4 * sp]; cy = stk[4 * sp + 1]; cth = stk[4 * sp + 2]; cdt = stk[4 * sp + 3]; }
-    else if (j < Tin) { cx = l.sx[j]; cy = l.sy[j]; cth = l.sth[j]; cdt = l.sdt[j]; ++j; }
+    if (sp > 0) { --sp; cx = stk[4 * sp]; cy = stk[4 * sp + 1]; cth = stk[4 * sp + 2]; cdt = stk[4 * sp + 3]; ci = -1; }
+    else if (j < Tin) {
+      cx = px; cy = py; cth = pth; cdt = pdt; ci = j; ++j;
+      if (j < Tin) { px = l.sx[j]; py = l.sy[j]; pth = l.sth[j]; pdt = l.sdt[j]; }
+    }
     else alive = false;
   }
   ox[k] = gx; oy[k] = gy; oth[k] = gth;
@@ -794,9 +809,17 @@ __device__ inline int autoresize(const teb_amd_config_t& c, const Lds& l, int n,
     }
     trig = __syncthreads_or(trig);
     if (!trig) break;
+    refresh_trig(l, n);   // cos / sin of the poses as they are now (the cache may date from a rejected LM trial)
+    __syncthreads();
     if (tid == 0) {
       int n_out = n, mod = 0, ovf = 0;
+#ifdef TEB_PROFILE
+      const long long sw_t0 = clock64();
+#endif
       autoresize_sweep_thread0(c, l, n, ox, oy, oth, odt, stk, stride, &n_out, &mod, &ovf);
+#ifdef TEB_PROFILE
+      l.ired[12] += (int)(clock64() - sw_t0); l.ired[13] += 1;
+#endif
       l.ired[8] = n_out; l.ired[9] = mod; l.ired[10] = ovf;
       __threadfence_block();
     }
@@ -994,6 +1017,9 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   const bool fast_mode = !c.include_dynamic_obstacles;
   bool done = false;
   PROF_DECL
+#ifdef TEB_PROFILE
+  if (threadIdx.x == 0) { l.ired[12] = 0; l.ired[13] = 0; }
+#endif
 
   if (!c.optimization_activate) { status = TEB_AMD_TEB_FAILED; done = true; }
 
@@ -1220,7 +1246,10 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   }
   nonfinite = __syncthreads_or(nonfinite);
 #ifdef TEB_PROFILE
-  if (tid == 0 && b == 0 && args.dbg_H) for (int q = 0; q < 8; ++q) args.dbg_H[q] = (double)prof_acc[q];
+  if (tid == 0 && b == 0 && args.dbg_H) {
+    prof_acc[7] = (long long)l.ired[12] + 1000000000LL * l.ired[13];   // autoResize: cycles inside the sequential sweeps + 1e9 * #sweeps
+    for (int q = 0; q < 8; ++q) args.dbg_H[q] = (double)prof_acc[q];
+  }
 #endif
   if (tid == 0) {
     if (nonfinite) status = TEB_AMD_TEB_NONFINITE;

@@ -41,8 +41,10 @@ for which in sys.argv[1:] or ["c4", "c2", "c5"]:
     rc = Lb.teb_amd_debug_profile(s._h, _abi._ptr(cyc, C.c_double))
     ms = s.last_kernel_ms()
     print("== %s kernel %.3f ms, TEB0: iters %d trials %d" % (which, ms, res.lm_iterations[0], res.lm_trials[0]))
-    tot = cyc.sum()
+    tot = cyc[:7].sum()
     for k, nm in enumerate(names):
         print("   %-18s %12.0f cycles  %5.1f %%   (%.1f us @100MHz-clock64?)" % (nm, cyc[k], 100 * cyc[k] / tot, cyc[k] / 100.0))
+    print("   autoResize detail: %d sequential sweeps, %.0f cycles inside them" % (int(cyc[7] // 1e9), cyc[7] % 1e9))
+    tot = cyc[:7].sum()
     print("   total cycles %.0f -> implied counter rate %.1f MHz" % (tot, tot / (ms * 1e3)))
     s.close()
