@@ -48,7 +48,12 @@ class TebConfig:
         self.robot_model = RobotFootprintModel.point()
         self.trajectory = SimpleNamespace(
             teb_autosize=True, dt_ref=0.3, dt_hysteresis=0.1, min_samples=3, max_samples=500,
-            exact_arc_length=False, via_points_ordered=False)
+            exact_arc_length=False, via_points_ordered=False,
+            # warm start / read-out parameters of plan() and getVelocityCommand() (teb_config.h:259-273); they are arguments of the
+            # C-ABI entry points, not fields of teb_amd_config_t
+            global_plan_overwrite_orientation=True, allow_init_with_backwards_motion=False, force_reinit_new_goal_dist=1.0,
+            force_reinit_new_goal_angular=0.5 * 3.141592653589793, control_look_ahead_poses=1,
+            prevent_look_ahead_poses_near_goal=0)
         self.robot = SimpleNamespace(
             max_vel_x=0.4, max_vel_x_backwards=0.2, max_vel_y=0.0, max_vel_trans=0.0, max_vel_theta=0.3,
             acc_lim_x=0.5, acc_lim_y=0.5, acc_lim_theta=0.5, min_turning_radius=0.0)

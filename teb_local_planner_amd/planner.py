@@ -385,6 +385,87 @@ class TebOptimalPlanner:
         return True
 
 
+    # ---- plan(): warm start on the device-resident band, then optimizeTEB (src/optimal_planner.cpp:247-320) -------------------
+    def _ensure_solver(self):
+        if self._solver is None:
+            self._solver = TebBatchSolver(self.cfg_, 1, self.max_poses, max(len(self.obstacles_), 1),
+                                          max(len(self.obstacles_.vert_x), 1), max(len(self.via_points_), 1), device=self.device)
+            self._resident = False
+        return self._solver
+
+    def clearPlanner(self):
+        """clearPlanner(): the next plan() initialises a new band (optimal_planner.h:315-320)."""
+        self.teb_.n[0] = 0
+        self._resident = False
+        self.optimized_ = False
+
+    def _tick(self, init, start, goal, start_vel, free_goal_vel):
+        import math
+        s = self._ensure_solver()
+        t = self.cfg_.trajectory
+        n = int(self.teb_.n[0])
+        warm = False
+        if getattr(self, "_resident", False) and n > 0:
+            gx, gy, gth = self.teb_.x[0, n - 1], self.teb_.y[0, n - 1], self.teb_.theta[0, n - 1]
+            d = math.hypot(goal[0] - gx, goal[1] - gy)
+            a = abs((goal[2] - gth + math.pi) % (2 * math.pi) - math.pi)      # fabs(g2o::normalize_theta(...))
+            warm = d < t.force_reinit_new_goal_dist and a < t.force_reinit_new_goal_angular
+        if warm:
+            s.update_and_prune(start, goal, t.min_samples)                          # updateAndPruneTEB on the device
+        else:
+            init(s)                                                                 # initTrajectoryToGoal on the device
+        self._resident = True
+        if start_vel is not None:
+            self.setVelocityStart(*start_vel)
+        self.teb_.has_vel_goal[0] = 0 if free_goal_vel else 1                       # setVelocityGoalFree() / vel_goal_.first = true
+        s.set_velocity_start(self.teb_.vel_start[0], bool(self.teb_.has_vel_start[0]))
+        s.set_velocity_goal(self.teb_.vel_goal[0], bool(self.teb_.has_vel_goal[0]))
+        s.set_config(self.cfg_)
+        s.set_obstacles(self.obstacles_)
+        s.set_via_points(self.via_points_)
+        o = self.cfg_.optim
+        if not o.optimization_activate:
+            return False
+        self.optimized_ = False
+        s.optimize(o.no_inner_iterations, o.no_outer_iterations)
+        res = s.results()
+        s.download(self.teb_)               # host copy for teb() / the next warm-start test; the band itself stays on the device
+        self.last_results = res
+        self.optimized_ = res.status[0] == _abi.TEB_OK
+        return bool(self.optimized_)
+
+    def plan(self, start, goal, start_vel=None, free_goal_vel=False):
+        """plan(const PoseSE2& start, const PoseSE2& goal, start_vel, free_goal_vel), src/optimal_planner.cpp:292-320.
+        start / goal = (x, y, theta), start_vel = (vx, vy, omega) or None."""
+        t, r = self.cfg_.trajectory, self.cfg_.robot
+        return self._tick(lambda s: s.init_trajectory_line(0, start, goal, 0, r.max_vel_x, t.min_samples,
+                                                           t.allow_init_with_backwards_motion), start, goal, start_vel, free_goal_vel)
+
+    def planFromPath(self, plan_x, plan_y, plan_yaw, start_vel=None, free_goal_vel=False):
+        """plan(const std::vector<geometry_msgs::PoseStamped>& initial_plan, ...), src/optimal_planner.cpp:247-283."""
+        t, r = self.cfg_.trajectory, self.cfg_.robot
+        start = (plan_x[0], plan_y[0], plan_yaw[0]); goal = (plan_x[-1], plan_y[-1], plan_yaw[-1])
+        return self._tick(lambda s: s.init_trajectory_plan(0, plan_x, plan_y, plan_yaw, r.max_vel_x, r.max_vel_theta,
+                                                           t.global_plan_overwrite_orientation, t.min_samples,
+                                                           t.allow_init_with_backwards_motion), start, goal, start_vel, free_goal_vel)
+
+    # ---- consumers (src/optimal_planner.cpp:1023-1247) on the device-resident band ---------------------------------------------
+    def getVelocityCommand(self, look_ahead_poses=None):
+        t = self.cfg_.trajectory
+        ok, v = self._ensure_solver().velocity_command(0, t.control_look_ahead_poses if look_ahead_poses is None else look_ahead_poses,
+                                                       t.prevent_look_ahead_poses_near_goal)
+        return ok, float(v[0]), float(v[1]), float(v[2])
+
+    def getVelocityProfile(self):
+        return self._ensure_solver().velocity_profile(0)
+
+    def getFullTrajectory(self):
+        return self._ensure_solver().full_trajectory(0)
+
+    def hasDiverged(self):
+        return self._ensure_solver().has_diverged(0)
+
+
 class HomotopyClassPlanner:
     """Batch view: owns B candidates resident on one GPU (reference homotopy_class_planner.h)."""
 

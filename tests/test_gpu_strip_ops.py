@@ -196,3 +196,41 @@ def test_has_diverged_follows_last_chi2():
     s.set_config(cfg)
     assert not s.has_diverged(0)
     s.close()
+
+
+def test_planner_mirror_plan_ticks_like_the_reference_plan(oracle):
+    """TebOptimalPlanner.plan() of the host mirror (warm start on the device, optimise, velocity command) against the same sequence
+    of reference steps on the CPU oracle: first tick initTrajectoryToGoal, later ticks updateAndPruneTEB, goal jump -> re-init."""
+    cfg, obst, via, _ = scenes.scene_small_mixed(footprint="circular")
+    p = planner.TebOptimalPlanner(cfg, obst, via, max_poses=200)
+    t, r, o = cfg.trajectory, cfg.robot, cfg.optim
+    start, goal, vel = [0.0, 0.0, 0.0], [6.0, 0.2, 0.0], (0.0, 0.0, 0.0)
+    host = None
+    for tick, new_goal in enumerate(([6.0, 0.2, 0.0], [6.0, 0.2, 0.0], [6.1, 0.25, 0.05], [2.0, 3.0, 1.0])):
+        goal = new_goal
+        assert p.plan(start, goal, vel)
+        # the oracle does what plan() does in the reference
+        reinit = host is None
+        if host is not None:
+            gx, gy, gth = host.x[0, host.n[0] - 1], host.y[0, host.n[0] - 1], host.theta[0, host.n[0] - 1]
+            d = np.hypot(goal[0] - gx, goal[1] - gy); a = abs((goal[2] - gth + np.pi) % (2 * np.pi) - np.pi)
+            reinit = not (d < t.force_reinit_new_goal_dist and a < t.force_reinit_new_goal_angular)
+        if reinit:
+            band = oracle.init_trajectory_line(start, goal, 0, r.max_vel_x, t.min_samples, t.allow_init_with_backwards_motion)
+        else:
+            band = oracle.update_and_prune(*host.get_teb(0), start, goal, t.min_samples)
+        host = _abi.TebBatchHost(1, 200)
+        host.set_teb(0, *band)
+        host.vel_start[0] = vel
+        host, res = oracle.optimize_batch(cfg, obst, via, host, compute_cost=False)
+        got, want = p.teb().get_teb(0), host.get_teb(0)
+        assert len(got[0]) == len(want[0]), (tick, len(got[0]), len(want[0]))
+        for u, v in zip(got, want):
+            assert np.abs(u - v).max() <= 1e-6, (tick, np.abs(u - v).max())
+        ok, vx, vy, om = p.getVelocityCommand()
+        wc = oracle.consumers(cfg, host, 0, t.control_look_ahead_poses, t.prevent_look_ahead_poses_near_goal)
+        assert ok == wc["ok"] and np.abs(np.array([vx, vy, om]) - wc["cmd"]).max() <= 1e-6
+        assert np.abs(p.getFullTrajectory() - wc["trajectory"]).max() <= 1e-6 and not p.hasDiverged()
+        start = [float(want[0][1]), float(want[1][1]), float(want[2][1])]      # the robot advanced to the second pose
+        vel = tuple(wc["cmd"])
+    assert tick == 3
