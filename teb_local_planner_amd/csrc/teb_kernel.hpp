@@ -709,28 +709,34 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, int n, double l
 // One sweep, executed by thread 0 as a streaming pass LDS strip -> LDS scratch (no O(n) inserts).
 // Reproduces the sequential i-- re-check semantics: `cur` is the interval under test, `stack` holds the
 // right halves produced by splits that still wait to be visited.
-__device__ __noinline__ void autoresize_sweep_thread0(const teb_amd_config_t& c, const Lds& l, int n_in, double* ox,
-                                                double* oy, double* oth, double* odt, double* stk, int stride,
-                                                int* n_out, int* modified_out, int* overflow) {
-  const double dt_ref = c.dt_ref, hyst = c.dt_hysteresis;
+__device__ __noinline__ void autoresize_sweep_thread0(double dt_ref, double hyst, int max_samples, int min_samples, int off_state,
+                                                        int off_scratch, int n_in, int stride, int* n_out, int* modified_out,
+                                                        int* overflow) {
+  // all operands are addressed from the dynamic LDS base inside this function, so that the sequential loop is compiled to
+  // ds_read / ds_write (generic pointers handed in from the caller would make every access a flat_load / flat_store)
+  extern __shared__ __attribute__((aligned(16))) double lds_base[];
+  const double* in_x = lds_base + off_state; const double* in_y = in_x + stride; const double* in_th = in_y + stride;
+  const double* in_dt = in_th + stride; const double* in_cs = in_dt + 2 * stride; const double* in_sn = in_cs + stride;   // Lds: sx sy sth sdt tdyn cs sn
+  double* ox = lds_base + off_scratch; double* oy = ox + stride; double* oth = oy + stride; double* odt = oth + stride;
+  double* stk = odt + stride;
   const int Tin = n_in - 1;
   int T = Tin;           // sizeTimeDiffs()
   int j = 1;             // next unread input interval
   int sp = 0;            // stack size (entries: x, y, th, dt)
   int k = 0;             // emitted intervals
   bool modified = false;
-  double cx = l.sx[0], cy = l.sy[0], cth = l.sth[0], cdt = l.sdt[0];
-  const double gx = l.sx[n_in - 1], gy = l.sy[n_in - 1], gth = l.sth[n_in - 1];
+  double cx = in_x[0], cy = in_y[0], cth = in_th[0], cdt = in_dt[0];
+  const double gx = in_x[n_in - 1], gy = in_y[n_in - 1], gth = in_th[n_in - 1];
   // cos / sin of the input poses come from the per-pose cache (refreshed by the caller); poses created by a split compute theirs
   // only if they are split again. ci < 0: the current pose is such a new pose.
   int ci = 0;
   // the next unread input interval is kept in registers one step ahead, so that its LDS latency overlaps the rule evaluation
   double px = 0, py = 0, pth = 0, pdt = 0;
-  if (j < Tin) { px = l.sx[j]; py = l.sy[j]; pth = l.sth[j]; pdt = l.sdt[j]; }
+  if (j < Tin) { px = in_x[j]; py = in_y[j]; pth = in_th[j]; pdt = in_dt[j]; }
   bool alive = Tin >= 1;
   while (alive) {
     const bool has_next = (sp > 0) || (j < Tin);
-    if (cdt > dt_ref + hyst && T < c.max_samples) {
+    if (cdt > dt_ref + hyst && T < max_samples) {
       if (cdt > 2 * dt_ref) {
         double newtime = 0.5 * cdt;
         double ex, ey, eth;   // Pose(i+1)
@@ -740,8 +746,8 @@ __device__ __noinline__ void autoresize_sweep_thread0(const teb_amd_config_t& c,
         else { ex = gx; ey = gy; eth = gth; ei = n_in - 1; }
         if (sp >= 64) { *overflow = 1; break; }
         // PoseSE2::average (pose_se2.h:266-269) with g2o::average_angle
-        const double cc = ci >= 0 ? l.cs[ci] : cos(cth), cs_ = ci >= 0 ? l.sn[ci] : sin(cth);
-        const double ec = ei >= 0 ? l.cs[ei] : cos(eth), es = ei >= 0 ? l.sn[ei] : sin(eth);
+        const double cc = ci >= 0 ? in_cs[ci] : cos(cth), cs_ = ci >= 0 ? in_sn[ci] : sin(cth);
+        const double ec = ei >= 0 ? in_cs[ei] : cos(eth), es = ei >= 0 ? in_sn[ei] : sin(eth);
         double sxn = cc + ec, syn = cs_ + es;
         stk[4 * sp] = (cx + ex) / 2; stk[4 * sp + 1] = (cy + ey) / 2;
         stk[4 * sp + 2] = (sxn == 0 && syn == 0) ? 0.0 : atan2(syn, sxn);
@@ -758,13 +764,13 @@ __device__ __noinline__ void autoresize_sweep_thread0(const teb_amd_config_t& c,
         }
         cdt = dt_ref;
       }
-    } else if (cdt < dt_ref - hyst && T > c.min_samples) {
+    } else if (cdt < dt_ref - hyst && T > min_samples) {
       if (has_next) {
         // TimeDiff(i+1) += TimeDiff(i); deleteTimeDiff(i); deletePose(i+1); i--
         if (sp > 0) { cdt = stk[4 * (sp - 1) + 3] + cdt; --sp; }
         else {
           cdt = pdt + cdt; ++j;
-          if (j < Tin) { px = l.sx[j]; py = l.sy[j]; pth = l.sth[j]; pdt = l.sdt[j]; }
+          if (j < Tin) { px = in_x[j]; py = in_y[j]; pth = in_th[j]; pdt = in_dt[j]; }
         }
         --T;
         modified = true;
@@ -785,7 +791,7 @@ __device__ __noinline__ void autoresize_sweep_thread0(const teb_amd_config_t& c,
     if (sp > 0) { --sp; cx = stk[4 * sp]; cy = stk[4 * sp + 1]; cth = stk[4 * sp + 2]; cdt = stk[4 * sp + 3]; ci = -1; }
     else if (j < Tin) {
       cx = px; cy = py; cth = pth; cdt = pdt; ci = j; ++j;
-      if (j < Tin) { px = l.sx[j]; py = l.sy[j]; pth = l.sth[j]; pdt = l.sdt[j]; }
+      if (j < Tin) { px = in_x[j]; py = in_y[j]; pth = in_th[j]; pdt = in_dt[j]; }
     }
     else alive = false;
   }
@@ -794,11 +800,11 @@ __device__ __noinline__ void autoresize_sweep_thread0(const teb_amd_config_t& c,
   *modified_out = modified ? 1 : 0;
 }
 
-__device__ inline int autoresize(const teb_amd_config_t& c, const Lds& l, int n, double* scratch, int stride,
+__device__ inline int autoresize(const teb_amd_config_t& c, const Lds& l, int n, int off_state, int off_scratch, int stride,
                                  bool fast_mode, int* overflow_flag) {
+  extern __shared__ __attribute__((aligned(16))) double lds_base[];
   const int tid = threadIdx.x;
-  double* ox = scratch; double* oy = ox + stride; double* oth = oy + stride; double* odt = oth + stride;
-  double* stk = odt + stride;
+  double* ox = lds_base + off_scratch; double* oy = ox + stride; double* oth = oy + stride; double* odt = oth + stride;
   for (int rep = 0; rep < 100; ++rep) {
     // parallel pre-check: a sweep is a no-op iff no interval satisfies either trigger condition
     const int T = n - 1;
@@ -816,7 +822,8 @@ __device__ inline int autoresize(const teb_amd_config_t& c, const Lds& l, int n,
 #ifdef TEB_PROFILE
       const long long sw_t0 = clock64();
 #endif
-      autoresize_sweep_thread0(c, l, n, ox, oy, oth, odt, stk, stride, &n_out, &mod, &ovf);
+      autoresize_sweep_thread0(c.dt_ref, c.dt_hysteresis, c.max_samples, c.min_samples, off_state, off_scratch, n, stride, &n_out,
+                               &mod, &ovf);
 #ifdef TEB_PROFILE
       l.ired[12] += (int)(clock64() - sw_t0); l.ired[13] += 1;
 #endif
@@ -1029,7 +1036,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       int ovf = 0;
       PROF_START();
       // sweep output + split stack (4 S + 256 doubles) live in the LDS region of the normal matrix, which is rebuilt afterwards
-      n = autoresize(c, l, n, SOLVER == SOLVER_CR ? l.Db : l.Hb, S, fast_mode, &ovf);
+      n = autoresize(c, l, n, plan.off_state, plan.off_H, S, fast_mode, &ovf);
       PROF_END(0);
       if (ovf) { status = TEB_AMD_TEB_FAILED; if (tid == 0) bt.assoc_overflow[b] |= 2; break; }
     }
