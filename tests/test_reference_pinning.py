@@ -285,3 +285,23 @@ def test_f3_h_signatures_and_equivalence_match_reference(oracle, mode):
         np.testing.assert_array_equal(keep, _class_list(ref[cname + "_equal"], ref[cname + "_valid"]))
         classes_seen = max(classes_seen, int(keep.sum()))
     assert classes_seen >= 3
+
+
+# ---- randomised pin: every option toggled at random, whole optimizeTEB, oracle vs the reference's src/optimal_planner.cpp ----------
+@pytest.mark.parametrize("seed", range(40))
+def test_randomized_optimizeTEB_is_bit_equal_to_reference_code(oracle, seed):
+    r = _ref()
+    if r is None:
+        pytest.skip("libteb_ref.so not available")
+    sys.path.insert(0, HERE)
+    from random_cases import random_case
+    cfg, obst, via, batch = random_case(seed)
+    cfg.jacobian_mode = _abi.JACOBIAN_G2O_NUMERIC
+    nb, res = oracle.optimize_batch(cfg, obst, via, batch, compute_cost=True)
+    for b in range(batch.count):
+        ref = r.optimize_teb(cfg, obst, via, batch, b)
+        x, y, th, dt = nb.get_teb(b)
+        assert len(x) == len(ref["x"]) and ref["success"] == (res.status[b] == _abi.TEB_OK), (seed, b)
+        np.testing.assert_array_equal(x, ref["x"]); np.testing.assert_array_equal(y, ref["y"])
+        np.testing.assert_array_equal(th, ref["theta"]); np.testing.assert_array_equal(dt, ref["dt"])
+        assert res.cost[b] == ref["cost"], (seed, b, res.cost[b], ref["cost"])
