@@ -11,6 +11,11 @@ using namespace teb_local_planner;
 using namespace refshim;
 
 namespace {
+void band_in_common(TimedElasticBand& teb, int n, const double* x, const double* y, const double* th, const double* dt) {
+  teb.addPose(x[0], y[0], th[0], true);
+  for (int i = 1; i < n; ++i) teb.addPoseAndTimeDiff(x[i], y[i], th[i], dt[i - 1]);
+  teb.setPoseVertexFixed(n - 1, true);
+}
 void read_band(const TimedElasticBand& teb, int S, double* x, double* y, double* th, double* dt, int32_t* n) {
   const int k = teb.sizePoses();
   *n = k;
@@ -129,6 +134,84 @@ int backend_check_run(const teb_amd_config_t* acfg, const teb_amd_obstacles_t* o
     if (tebs[b]->teb().sizePoses() > S) return 4;
     const size_t so = (size_t)b * S;
     read_band(tebs[b]->teb(), S, amd_x + so, amd_y + so, amd_th + so, amd_dt + so, amd_n + b);
+  }
+  return 0;
+}
+
+// The rows either side of the path through the backend, against the reference's own member functions on the same objects:
+//   updateAllTEBs  vs TimedElasticBand::updateAndPruneTEB                    -> prune_* arrays (band after pruning, both sides)
+//   renewAndAnalyzeOldTebs vs HSignature3d / HSignature + isEqual / isValid  -> sig_*, keep_*
+//   getVelocityCommand (device band) vs TebOptimalPlanner::getVelocityCommand on the written-back band -> cmd_*
+// Sequence: updateAllTEBs(start, goal, start_vel) -> optimizeAllTEBs -> renewAndAnalyzeOldTebs(best = -1) -> getVelocityCommand.
+int backend_check_rows(const teb_amd_config_t* acfg, const teb_amd_obstacles_t* o, const teb_amd_teb_batch_t* bt, const double* start,
+                       const double* goal, const double* start_vel, int inner, int outer, int look_ahead,
+                       double* prune_ref /*[B*S*4]*/, double* prune_amd, int32_t* prune_n_ref, int32_t* prune_n_amd,
+                       double* sig_ref /*[B*W]*/, double* sig_amd, int32_t* keep_ref, int32_t* keep_amd, int32_t* width,
+                       double* cmd_ref /*[B*4]*/, double* cmd_amd) {
+  TebConfig cfg;
+  to_ref_config(*acfg, cfg);
+  ObstContainer obst;
+  to_ref_obstacles(o, obst);
+  const int B = bt->count, S = bt->stride, M = (int)obst.size();
+  setAmdJacobianMode(TEB_AMD_JACOBIAN_ANALYTIC);
+  PoseSE2 ps(start[0], start[1], start[2]), pg(goal[0], goal[1], goal[2]);
+  geometry_msgs::Twist sv; sv.linear.x = start_vel[0]; sv.linear.y = start_vel[1]; sv.angular.z = start_vel[2];
+  std::vector<std::unique_ptr<TebOptimalPlannerAmd>> own;
+  std::vector<TebOptimalPlannerAmd*> tebs;
+  for (int b = 0; b < B; ++b) {
+    own.emplace_back(new TebOptimalPlannerAmd(cfg, &obst, TebVisualizationPtr(), nullptr));
+    const size_t so = (size_t)b * S;
+    const double zero3[3] = {0, 0, 0};
+    fill_planner(*own.back(), bt->n[b], bt->x + so, bt->y + so, bt->theta + so, bt->dt + so, 1, zero3, 1, zero3, TEB_AMD_ROT_NONE);
+    tebs.push_back(own.back().get());
+    // reference side of the pruning: the same band, the reference's own updateAndPruneTEB
+    TimedElasticBand rt;
+    band_in_common(rt, bt->n[b], bt->x + so, bt->y + so, bt->theta + so, bt->dt + so);
+    rt.updateAndPruneTEB(boost::optional<const PoseSE2&>(ps), boost::optional<const PoseSE2&>(pg), cfg.trajectory.min_samples);
+    read_band(rt, S, prune_ref + 4 * so, prune_ref + 4 * so + S, prune_ref + 4 * so + 2 * S, prune_ref + 4 * so + 3 * S, prune_n_ref + b);
+  }
+  TebAmdBatch batch(cfg, B, S, M > 0 ? M : 1, o->vert_offset ? std::max(1, (int)o->vert_offset[o->count]) : 1, 1);
+  if (!batch.updateAllTEBs(tebs, &ps, &pg, &sv)) return 3;
+  for (int b = 0; b < B; ++b) {
+    const size_t so = (size_t)b * S;
+    read_band(tebs[b]->teb(), S, prune_amd + 4 * so, prune_amd + 4 * so + S, prune_amd + 4 * so + 2 * S, prune_amd + 4 * so + 3 * S, prune_n_amd + b);
+  }
+  batch.optimizeAllTEBs(tebs, inner, outer, true, cfg.hcp.selection_obst_cost_scale, cfg.hcp.selection_viapoint_cost_scale,
+                        cfg.hcp.selection_alternative_time_cost);
+  if (!batch.lastError().empty()) return 3;
+  // equivalence classes: backend (device) vs the reference's classes on the planners' bands (which now hold the optimised bands)
+  std::vector<bool> keep;
+  std::vector<double> values;
+  int W = 0;
+  if (!batch.renewAndAnalyzeOldTebs(cfg, -1, keep, &values, &W)) return 3;
+  *width = W;
+  auto fun = [](const VertexPose* pose) { return std::complex<long double>(pose->x(), pose->y()); };
+  std::vector<std::unique_ptr<EquivalenceClass>> cls;
+  std::vector<int> classes;
+  for (int b = 0; b < B; ++b) {
+    TimedElasticBand& teb = tebs[b]->teb();
+    if (cfg.obstacles.include_dynamic_obstacles) {
+      HSignature3d* H = new HSignature3d(cfg);
+      H->calculateHSignature(teb.poses().begin(), teb.poses().end(), fun, &obst, teb.timediffs().begin(), teb.timediffs().end());
+      for (int l = 0; l < M; ++l) sig_ref[(size_t)b * W + l] = H->values()[l];
+      cls.emplace_back(H);
+    } else {
+      HSignature* H = new HSignature(cfg);
+      H->calculateHSignature(teb.poses().begin(), teb.poses().end(), fun, &obst);
+      sig_ref[2 * b] = (double)H->value().real(); sig_ref[2 * b + 1] = (double)H->value().imag();
+      cls.emplace_back(H);
+    }
+    for (int l = 0; l < W; ++l) sig_amd[(size_t)b * W + l] = values[(size_t)b * W + l];
+    bool is_new = cls.back()->isValid();
+    for (int cidx : classes) if (is_new && cls.back()->isEqual(*cls[cidx])) is_new = false;   // hasEquivalenceClass
+    if (is_new) classes.push_back(b);
+    keep_ref[b] = is_new; keep_amd[b] = keep[b];
+    // velocity command: device-resident band vs the reference's getVelocityCommand on the planner object
+    double vx, vy, om;
+    const bool okr = tebs[b]->TebOptimalPlanner::getVelocityCommand(vx, vy, om, look_ahead);
+    cmd_ref[4 * b] = vx; cmd_ref[4 * b + 1] = vy; cmd_ref[4 * b + 2] = om; cmd_ref[4 * b + 3] = okr;
+    const bool oka = batch.getVelocityCommand(cfg, b, vx, vy, om, look_ahead);
+    cmd_amd[4 * b] = vx; cmd_amd[4 * b + 1] = vy; cmd_amd[4 * b + 2] = om; cmd_amd[4 * b + 3] = oka;
   }
   return 0;
 }

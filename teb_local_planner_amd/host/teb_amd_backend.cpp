@@ -300,6 +300,101 @@ int TebAmdBatch::optimizeAllTEBs(const std::vector<TebOptimalPlannerAmd*>& tebs,
   return ok;
 }
 
+bool TebAmdBatch::uploadBands(const std::vector<TebOptimalPlannerAmd*>& tebs)
+{
+  const int B = (int)tebs.size(), S = max_poses_;
+  if (!h_ || B == 0 || B > max_tebs_) return false;
+  std::vector<int32_t> n(B), hvs(B), hvg(B), rot(B), via(B);
+  std::vector<double> x((size_t)B * S, 0.0), y((size_t)B * S, 0.0), th((size_t)B * S, 0.0), dt((size_t)B * S, 0.0), vs(3 * (size_t)B), vg(3 * (size_t)B);
+  for (int b = 0; b < B; ++b)
+  {
+    TebOptimalPlannerAmd& p = *tebs[b];
+    const TimedElasticBand& t = p.teb_;
+    if (t.sizePoses() > S) return check(TEB_AMD_ERR_CAPACITY, "uploadBands (band longer than max_poses)");
+    n[b] = t.sizePoses();
+    for (int i = 0; i < t.sizePoses(); ++i) { x[(size_t)b * S + i] = t.Pose(i).x(); y[(size_t)b * S + i] = t.Pose(i).y(); th[(size_t)b * S + i] = t.Pose(i).theta(); }
+    for (int i = 0; i < t.sizeTimeDiffs(); ++i) dt[(size_t)b * S + i] = t.TimeDiff(i);
+    hvs[b] = p.vel_start_.first; hvg[b] = p.vel_goal_.first;
+    vs[3 * b] = p.vel_start_.second.linear.x; vs[3 * b + 1] = p.vel_start_.second.linear.y; vs[3 * b + 2] = p.vel_start_.second.angular.z;
+    vg[3 * b] = p.vel_goal_.second.linear.x;  vg[3 * b + 1] = p.vel_goal_.second.linear.y;  vg[3 * b + 2] = p.vel_goal_.second.angular.z;
+    rot[b] = p.prefer_rotdir_ == RotType::left ? TEB_AMD_ROT_LEFT : (p.prefer_rotdir_ == RotType::right ? TEB_AMD_ROT_RIGHT : TEB_AMD_ROT_NONE);
+    via[b] = p.via_points_ != NULL;
+  }
+  teb_amd_teb_batch_t batch;
+  std::memset(&batch, 0, sizeof(batch));
+  batch.count = B; batch.stride = S; batch.n = n.data(); batch.x = x.data(); batch.y = y.data(); batch.theta = th.data(); batch.dt = dt.data();
+  batch.has_vel_start = hvs.data(); batch.vel_start = vs.data(); batch.has_vel_goal = hvg.data(); batch.vel_goal = vg.data();
+  batch.prefer_rotdir = rot.data(); batch.via_points_enabled = via.data();
+  return check(teb_amd_upload_tebs(h_, &batch), "teb_amd_upload_tebs");
+}
+
+bool TebAmdBatch::downloadBands(const std::vector<TebOptimalPlannerAmd*>& tebs)
+{
+  const int B = (int)tebs.size(), S = max_poses_;
+  std::vector<int32_t> n(B);
+  std::vector<double> x((size_t)B * S), y((size_t)B * S), th((size_t)B * S), dt((size_t)B * S);
+  teb_amd_teb_batch_t batch;
+  std::memset(&batch, 0, sizeof(batch));
+  batch.count = B; batch.stride = S; batch.n = n.data(); batch.x = x.data(); batch.y = y.data(); batch.theta = th.data(); batch.dt = dt.data();
+  if (!check(teb_amd_download_tebs(h_, &batch), "teb_amd_download_tebs")) return false;
+  for (int b = 0; b < B; ++b)
+  {
+    TimedElasticBand& t = tebs[b]->teb_;
+    const size_t o = (size_t)b * S;
+    t.clearTimedElasticBand();
+    t.addPose(x[o], y[o], th[o], true);
+    for (int i = 1; i < n[b]; ++i) t.addPoseAndTimeDiff(x[o + i], y[o + i], th[o + i], dt[o + i - 1]);
+    t.setPoseVertexFixed(n[b] - 1, true);
+  }
+  return true;
+}
+
+bool TebAmdBatch::updateAllTEBs(const std::vector<TebOptimalPlannerAmd*>& tebs, const PoseSE2* start, const PoseSE2* goal,
+                                const geometry_msgs::Twist* start_velocity)
+{
+  if (tebs.empty() || !uploadBands(tebs)) return false;
+  double s[3], g[3];
+  if (start) { s[0] = start->x(); s[1] = start->y(); s[2] = start->theta(); }
+  if (goal) { g[0] = goal->x(); g[1] = goal->y(); g[2] = goal->theta(); }
+  if (!check(teb_amd_update_and_prune(h_, -1, start ? s : NULL, goal ? g : NULL, tebs.front()->cfg_->trajectory.min_samples),
+             "teb_amd_update_and_prune")) return false;
+  if (start_velocity)
+  {
+    const double v[3] = { start_velocity->linear.x, start_velocity->linear.y, start_velocity->angular.z };
+    if (!check(teb_amd_set_velocity_start(h_, -1, 1, v), "teb_amd_set_velocity_start")) return false;
+    for (TebOptimalPlannerAmd* p : tebs) p->setVelocityStart(*start_velocity);
+  }
+  return downloadBands(tebs);
+}
+
+bool TebAmdBatch::renewAndAnalyzeOldTebs(const TebConfig& cfg, int best_index, std::vector<bool>& keep, std::vector<double>* values, int* width)
+{
+  int32_t w = 0, count = 0;
+  if (!check(teb_amd_get_pose_counts(h_, NULL, &count), "teb_amd_get_pose_counts") || count <= 0) return false;
+  if (!check(teb_amd_compute_h_signatures(h_, cfg.hcp.h_signature_prescaler, NULL, &w), "teb_amd_compute_h_signatures")) return false;
+  if (values)
+  {
+    values->assign((size_t)count * (w > 0 ? w : 1), 0.0);
+    if (!check(teb_amd_compute_h_signatures(h_, cfg.hcp.h_signature_prescaler, values->data(), &w), "teb_amd_compute_h_signatures")) return false;
+  }
+  if (width) *width = w;
+  std::vector<int32_t> k(count), valid(count), reasonable(count);
+  if (!check(teb_amd_filter_equivalence_classes(h_, cfg.hcp.h_signature_threshold, best_index, cfg.hcp.max_number_plans_in_current_class,
+                                                k.data(), valid.data(), reasonable.data()), "teb_amd_filter_equivalence_classes")) return false;
+  keep.assign(count, false);
+  for (int b = 0; b < count; ++b) keep[b] = k[b] != 0;
+  return true;
+}
+
+bool TebAmdBatch::getVelocityCommand(const TebConfig& cfg, int index, double& vx, double& vy, double& omega, int look_ahead_poses)
+{
+  int32_t ok = 0;
+  vx = vy = omega = 0;
+  if (!check(teb_amd_get_velocity_command(h_, index, look_ahead_poses, cfg.trajectory.prevent_look_ahead_poses_near_goal, &vx, &vy, &omega, &ok),
+             "teb_amd_get_velocity_command")) return false;
+  return ok != 0;
+}
+
 int TebAmdBatch::selectBestTeb(int last_best, int initial_plan, double* best_cost)
 {
   int32_t best = -1;

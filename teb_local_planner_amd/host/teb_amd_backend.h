@@ -98,11 +98,32 @@ public:
   int selectBestTeb(int last_best, int initial_plan, double* best_cost = NULL);
 
   int maxPoses() const { return max_poses_; }
+  /**
+   * HomotopyClassPlanner::updateAllTEBs (src/homotopy_class_planner.cpp:539-562): TimedElasticBand::updateAndPruneTEB(start, goal,
+   * cfg.trajectory.min_samples) on every candidate - one launch on the device - and setVelocityStart(*start_velocity).
+   * NULL = boost::none / no new start velocity. The pruned bands are written back into the planner objects.
+   */
+  bool updateAllTEBs(const std::vector<TebOptimalPlannerAmd*>& tebs, const PoseSE2* start, const PoseSE2* goal,
+                     const geometry_msgs::Twist* start_velocity);
+
+  /**
+   * The equivalence classes of renewAndAnalyzeOldTebs (src/homotopy_class_planner.cpp:214-254) for the candidates of the last
+   * optimizeAllTEBs / updateAllTEBs call: HSignature3d or HSignature of every band in one launch (values(): [B * width]), then the
+   * first-come-first-served class list with the last best candidate first. keep[b] == false -> the reference erases candidate b.
+   */
+  bool renewAndAnalyzeOldTebs(const TebConfig& cfg, int best_index, std::vector<bool>& keep, std::vector<double>* values = NULL,
+                              int* width = NULL);
+
+  //! TebOptimalPlanner::getVelocityCommand (src/optimal_planner.cpp:1135-1168) of candidate `index`, from the device-resident band.
+  bool getVelocityCommand(const TebConfig& cfg, int index, double& vx, double& vy, double& omega, int look_ahead_poses);
+
   const std::string& lastError() const { return error_; }
   float lastKernelMs() const;
 
 private:
   bool check(int rc, const char* what);
+  bool uploadBands(const std::vector<TebOptimalPlannerAmd*>& tebs);
+  bool downloadBands(const std::vector<TebOptimalPlannerAmd*>& tebs);
   teb_amd_handle_t* h_ = NULL;
   int max_tebs_, max_poses_;
   std::string error_;

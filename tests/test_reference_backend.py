@@ -141,3 +141,44 @@ def test_selection_hysteresis_through_backend():
     cfg.hcp.selection_cost_hysteresis = float(0.5 * costs[order[0]] / costs[runner_up])   # makes the runner-up win when it was last best
     out2 = run(cfg, obst, via, batch, _abi.JACOBIAN_ANALYTIC, mode=0, run_reference=False, last_best=runner_up)
     assert out2["best"] == runner_up
+
+
+# ---- rows either side of the path through the C++ backend, against the reference's own member functions --------------------------
+@pytest.mark.parametrize("dynamic", [True, False])
+def test_backend_rows_f1_f2_f3_on_reference_objects(dynamic):
+    """TebAmdBatch::updateAllTEBs / renewAndAnalyzeOldTebs / getVelocityCommand against TimedElasticBand::updateAndPruneTEB,
+    HSignature3d / HSignature (+ isEqual / isValid) and TebOptimalPlanner::getVelocityCommand of the reference, same objects."""
+    L = _lib()
+    cname, cfg, obst, batch = RG.h_signature_cases()[2]
+    cfg.obstacles.include_dynamic_obstacles = dynamic
+    c = cfg.to_c()
+    B, S, M = batch.count, batch.stride, len(obst)
+    W = M if dynamic else 2
+    x0, y0, th0, _ = batch.get_teb(0)
+    start = _abi.f64([x0[2] + 0.01, y0[2] - 0.01, th0[2]]); goal = _abi.f64([x0[-1], y0[-1], th0[-1]]); sv = _abi.f64([0.1, 0.0, 0.02])
+    P = lambda a: _abi._ptr(a, C.c_double)
+    I = lambda a: _abi._ptr(a, C.c_int32)
+    pr = np.zeros((B, 4, S)); pa = np.zeros((B, 4, S)); nr = np.zeros(B, np.int32); na = np.zeros(B, np.int32)
+    sr = np.zeros((B, W)); sa = np.zeros((B, W)); kr = np.zeros(B, np.int32); ka = np.zeros(B, np.int32); w = C.c_int32(0)
+    cr = np.zeros((B, 4)); ca = np.zeros((B, 4))
+    bs = batch.c_struct()
+    rc = L.backend_check_rows(C.byref(c), C.byref(obst.freeze()), C.byref(bs), P(start), P(goal), P(sv), 5, 4, 1,
+                              P(pr), P(pa), I(nr), I(na), P(sr), P(sa), I(kr), I(ka), C.byref(w), P(cr), P(ca))
+    assert rc == 0, rc
+    assert w.value == W
+    # f1: pruning is IEEE-exact on both sides
+    np.testing.assert_array_equal(nr, na)
+    assert (nr < batch.n).any()
+    for b in range(B):
+        n = int(nr[b])
+        np.testing.assert_array_equal(pa[b, :3, :n], pr[b, :3, :n]); np.testing.assert_array_equal(pa[b, 3, :n - 1], pr[b, 3, :n - 1])
+    # f3: signatures of the optimised bands (the reference evaluates them on the bands the backend wrote back)
+    if dynamic:
+        assert np.abs(sa - sr).max() <= 4 * np.finfo(float).eps * max(1.0, np.abs(sr).max())
+    else:
+        assert np.abs(sa - sr).max() <= 1e-10 * max(np.abs(sr).max(), 1e-300)
+    np.testing.assert_array_equal(ka, kr)
+    assert ka[0] == 1
+    # f2: velocity command from the device-resident band == the reference's on the written-back band
+    np.testing.assert_array_equal(ca[:, 3], cr[:, 3])
+    assert np.abs(ca[:, :3] - cr[:, :3]).max() <= 1e-12
