@@ -1,0 +1,1 @@
+#include "../../../shim_boost_graph.h"

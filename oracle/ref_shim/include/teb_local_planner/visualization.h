@@ -14,6 +14,9 @@ class TebVisualization {
                                   const std_msgs::ColorRGBA& = std_msgs::ColorRGBA()) {}
   void publishInfeasibleRobotPose(const PoseSE2&, const BaseRobotFootprintModel&, const std::vector<geometry_msgs::Point>& = {}) {}
   void publishFeedbackMessage(const TebOptimalPlanner&, const ObstContainer&) {}
+  template <class TebContainer> void publishFeedbackMessage(const TebContainer&, unsigned int, const ObstContainer&) {}
+  template <class Graph> void publishGraph(const Graph&, const std::string& = "Graph") {}
+  template <class TebContainer> void publishTebContainer(const TebContainer&, const std::string& = "TebContainer") {}
 };
 typedef boost::shared_ptr<TebVisualization> TebVisualizationPtr;
 typedef boost::shared_ptr<const TebVisualization> TebVisualizationConstPtr;

@@ -50,6 +50,7 @@ class Matrix {
   }
   T dot(const Matrix& o) const { T s = T(0); for (int i = 0; i < R * C; ++i) s += d[i] * o.d[i]; return s; }
   Matrix normalized() const { T n = norm(); Matrix m(*this); if (n > T(0)) for (int i = 0; i < R * C; ++i) m.d[i] = d[i] / n; return m; }
+  void normalize() { T n = norm(); if (n > T(0)) for (int i = 0; i < R * C; ++i) d[i] = d[i] / n; }
   bool isApprox(const Matrix& o, T prec = T(1e-12)) const {   // Eigen: ||a-b||^2 <= prec^2 * min(||a||^2, ||b||^2)
     Matrix df = *this - o;
     T m = squaredNorm() < o.squaredNorm() ? squaredNorm() : o.squaredNorm();
@@ -111,5 +112,8 @@ class Rotation2Dd {
   Vector2d operator*(const Vector2d& v) const { return Vector2d(std::cos(a_) * v.x() - std::sin(a_) * v.y(), std::sin(a_) * v.x() + std::cos(a_) * v.y()); }
   Matrix2d toRotationMatrix() const { Matrix2d m; m(0, 0) = std::cos(a_); m(0, 1) = -std::sin(a_); m(1, 0) = std::sin(a_); m(1, 1) = std::cos(a_); return m; }
 };
+
+template <typename T> class Rotation2D;
+template <> class Rotation2D<double> : public Rotation2Dd { public: explicit Rotation2D(double a) : Rotation2Dd(a) {} };
 
 }  // namespace Eigen

@@ -1,6 +1,7 @@
 // shim_ros.h — stand-ins for the ROS / Boost / message types that appear in the signatures of the reference headers on
 // the optimiser path. TEST INFRASTRUCTURE (oracle/_ref build only). No behaviour of the path lives in these types.
 #pragma once
+#include <cfloat>
 #include <algorithm>
 #include <array>
 #include <cassert>
@@ -30,8 +31,9 @@
 
 namespace ros {
 class NodeHandle {};
-struct Time { double t = 0; static Time now() { return Time(); } double toSec() const { return t; } };
 struct Duration { double d = 0; explicit Duration(double x = 0) : d(x) {} double toSec() const { return d; } Duration& fromSec(double x) { d = x; return *this; } };
+struct Time { double t = 0; static Time now() { return Time(); } double toSec() const { return t; } Duration operator-(const Time& o) const { return Duration(t - o.t); } };
+inline bool ok() { return true; }
 }  // namespace ros
 
 namespace boost {

@@ -17,7 +17,11 @@
 
 namespace tebamd {
 
-constexpr int kThreads = 256;       // 4 wave64 per workgroup, one workgroup per candidate TEB
+#ifndef TEB_AMD_THREADS
+#define TEB_AMD_THREADS 256
+#endif
+constexpr int kThreads = TEB_AMD_THREADS;   // 4 wave64 per workgroup, one workgroup per candidate TEB
+constexpr int kWaves = kThreads / 64;
 constexpr int kBand = 11;           // diagonal + scalar half-bandwidth 10
 constexpr int kMaxPoseIter = 2;     // poses handled per thread: n <= kThreads * kMaxPoseIter
 

@@ -79,7 +79,7 @@ __device__ __forceinline__ Lds carve(double* base, const LdsPlan& p) {
   return l;
 }
 
-// ---- deterministic block reductions (fixed tree: lanes via shuffles, then the 4 waves in order) ---------
+// ---- deterministic block reductions (fixed tree: lanes via shuffles, then the waves in order) ---------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -91,11 +91,16 @@ __device__ __forceinline__ void block_sum(double* v, double* red) {
 #pragma unroll
   for (int q = 0; q < K; ++q) {
     double s = wave_sum(v[q]);
-    if (lane == 0) red[q * 4 + wv] = s;
+    if (lane == 0) red[q * kWaves + wv] = s;
   }
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < K; ++q) v[q] = ((red[q * 4 + 0] + red[q * 4 + 1]) + red[q * 4 + 2]) + red[q * 4 + 3];
+  for (int q = 0; q < K; ++q) {
+    double a = red[q * kWaves];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) a += red[q * kWaves + w];
+    v[q] = a;
+  }
   __syncthreads();
 }
 __device__ __forceinline__ double block_max(double v, double* red) {
@@ -104,7 +109,9 @@ __device__ __forceinline__ double block_max(double v, double* red) {
   for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
   if (lane == 0) red[wv] = v;
   __syncthreads();
-  double r = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  double r = red[0];
+#pragma unroll
+  for (int w = 1; w < kWaves; ++w) r = fmax(r, red[w]);
   __syncthreads();
   return r;
 }
@@ -122,7 +129,7 @@ __device__ __forceinline__ int block_argmin(double v, int idx, double* red, int*
   double bv = red[0];
   int bi = ired[0];
 #pragma unroll
-  for (int q = 1; q < 4; ++q)
+  for (int q = 1; q < kWaves; ++q)
     if (red[q] < bv || (red[q] == bv && ired[q] < bi)) { bv = red[q]; bi = ired[q]; }
   __syncthreads();
   return bi;
@@ -528,6 +535,138 @@ __device__ long long g_cr_prof[8];
 #define CRP_DECL
 #define CRP(k)
 #endif
+// ---- pieces of the block cyclic reduction, usable on blocks in either memory (used by the HBM variant, which runs the finer
+//      levels on HBM-resident blocks and the coarser ones on a compact copy in LDS). Same arithmetic as cr_solve_t<false>.
+// rows live at D + i * kBlk, L + i * kBlk (coupling of row i with the previous surviving row), f + i * 8; levels s_lo, 2 s_lo, .. < s_hi
+__device__ __forceinline__ bool cr_forward(double* __restrict__ D, double* __restrict__ L, double* __restrict__ f, int Nb, int s_lo,
+                                           int s_hi) {
+  TEB_SOLVER_FMA
+  const int tid = threadIdx.x;
+  const int grp = tid >> 3, c = tid & 7;
+  bool ok = true;
+  for (int s = s_lo; s < s_hi; s <<= 1) {
+    const int E = (Nb - 1 - s) / (2 * s) + 1;
+    for (int e0 = 0; e0 < E; e0 += kThreads / 8) {
+      const int e = e0 + grp;
+      const bool act = e < E;
+      const int i = s * (2 * e + 1);
+      const bool hasU = act && (i + s < Nb);
+      double wL[8], wU[8], wf[8], o1[8], o2[8], o3[8];
+      double s1 = 0, s2 = 0;
+      if (act) {
+        const double* Di = D + i * kBlk;
+        const double* Li = L + i * kBlk;
+        const double* Lp = L + (i + s) * kBlk;   // U_i^T, valid iff hasU
+        Ldl8 F;
+        F.load(Di);
+        ok = F.factor() && ok;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          wL[k] = Li[k * 8 + c];
+          wU[k] = hasU ? Lp[c * 8 + k] : 0.0;
+          wf[k] = f[i * 8 + k];
+        }
+        F.solve3(wL, wU, wf);
+#pragma unroll
+        for (int aa = 0; aa < 8; ++aa) { o1[aa] = 0; o2[aa] = 0; o3[aa] = 0; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+          for (int aa = 0; aa < 8; ++aa) o1[aa] += Li[k * 8 + aa] * wL[k];
+          s1 += Li[k * 8 + c] * wf[k];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (hasU) {
+#pragma unroll
+          for (int aa = 0; aa < 8; ++aa) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const double lp = Lp[aa * 8 + k];
+              o2[aa] -= lp * wL[k];
+              o3[aa] += lp * wU[k];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) s2 += Lp[c * 8 + k] * wf[k];
+        }
+      }
+      __syncthreads();   // every read of this round is done
+      if (act) {
+        double* Dm = D + (i - s) * kBlk;
+        double* Di = D + i * kBlk;
+        double* Li = L + i * kBlk;
+#pragma unroll
+        for (int aa = 0; aa < 8; ++aa) Dm[aa * 8 + c] -= o1[aa];
+        if (hasU) {
+          double* Lp = L + (i + s) * kBlk;
+#pragma unroll
+          for (int aa = 0; aa < 8; ++aa) Lp[aa * 8 + c] = o2[aa];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { Di[k * 8 + c] = wL[k]; Li[k * 8 + c] = wU[k]; }
+        f[(i - s) * 8 + c] -= s1;
+        f[i * 8 + c] = wf[c];
+      }
+      __syncthreads();
+      if (hasU) {
+        double* Dp = D + (i + s) * kBlk;
+#pragma unroll
+        for (int aa = 0; aa < 8; ++aa) Dp[aa * 8 + c] -= o3[aa];
+        f[(i + s) * 8 + c] -= s2;
+      }
+      __syncthreads();
+    }
+  }
+  return ok;
+}
+// x_0 = D_0^{-1} f_0 of the last surviving row
+__device__ __forceinline__ bool cr_top(const double* __restrict__ D, double* __restrict__ f) {
+  TEB_SOLVER_FMA
+  bool ok = true;
+  const int tid = threadIdx.x;
+  if (tid < 8) {
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = f[k];
+    Ldl8 F;
+    F.load(D);
+    ok = F.factor();
+    F.solve(v);
+    double mine = v[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) mine = (tid == k) ? v[k] : mine;
+    f[tid] = mine;
+  }
+  return ok;
+}
+// back substitution for the levels s_from, s_from / 2, .., s_to
+__device__ __forceinline__ void cr_backward(const double* __restrict__ D, const double* __restrict__ L, double* __restrict__ f, int Nb,
+                                            int s_from, int s_to) {
+  TEB_SOLVER_FMA
+  const int tid = threadIdx.x;
+  for (int s = s_from; s >= s_to; s >>= 1) {
+    const int E = (Nb - 1 - s) / (2 * s) + 1;
+    for (int u = tid; u < E * 8; u += kThreads) {
+      const int e = u >> 3, r = u & 7;
+      const int i = s * (2 * e + 1);
+      double acc = f[i * 8 + r], acc2 = 0;
+      const double* WL = D + i * kBlk + r * 8;
+      const double* xm = f + (i - s) * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc -= WL[k] * xm[k];
+      if (i + s < Nb) {
+        const double* WU = L + i * kBlk + r * 8;
+        const double* xp = f + (i + s) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc2 -= WU[k] * xp[k];
+      }
+      f[i * 8 + r] = acc + acc2;
+    }
+    __syncthreads();
+  }
+}
+
 // Out of line by default: measured on MI355X (C4 step, 3 runs each) 4.72 ms vs 4.82 ms inlined. The price of the call is the
 // callee-saved VGPR block it spills and reloads (~1.9 GB of scratch traffic per launch, absorbed by L2 / MALL and off the critical
 // path); -DTEB_AMD_INLINE_SOLVE builds the inlined variant (HBM traffic 3.5 -> 1.6 GB per launch, 2 % slower).
@@ -542,7 +681,7 @@ __device__ long long g_cr_prof[8];
 //                  reduction runs there - log2(n/2) levels of round trips to L2 instead of 4n sequential pivots, and no
 //                  backup / restore of H since the band is never touched.
 template <bool GLOBAL>
-__device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, int n, double lambda, double* gbuf) {
+__device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, const SceneDev& sc, int n, double lambda, double* gbuf) {
   TEB_SOLVER_FMA
   extern __shared__ __attribute__((aligned(16))) double lds_base[];
   CRP_DECL
@@ -580,6 +719,63 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, int n, double l
   if (tid == 0) l.ired[0] = 1;
   __syncthreads();
   CRP(0);
+  if constexpr (GLOBAL) {
+    // Finer levels on the HBM blocks; as soon as the surviving rows (every s0-th) fit the LDS region of the obstacle cache - which
+    // nobody reads during the solve - they are copied there and the remaining levels, the top solve and their back substitution
+    // run in LDS; the cache is reloaded from the (L2-resident) obstacle table afterwards. The compact system is an exact
+    // re-indexing (row j' = j / s0, stride s' = s / s0), so the arithmetic is that of the all-HBM reduction.
+    const int lds_doubles = 5 * plan.ob_cap;
+    int s0 = 1;
+    while (s0 < Nb && 2 * ((Nb + s0 - 1) / s0) * kBlk > lds_doubles) s0 <<= 1;
+    const bool use_lds = lds_doubles > 0 && s0 < Nb && 8 * ((Nb + s0 - 1) / s0) <= 4 * plan.S + 8;
+    if (!use_lds) s0 = Nb;   // everything on the HBM blocks
+    bool ok = cr_forward(D, L, f, Nb, 1, s0 < Nb ? s0 : Nb);
+    CRP(1);
+    if (use_lds) {
+      const int Nc = (Nb + s0 - 1) / s0;
+      double* Dc = lds_base + plan.off_ob;
+      double* Lc = Dc + Nc * kBlk;
+      double* fc = lds_base + plan.off_dx;
+      for (int q = tid; q < Nc * 64; q += kThreads) {
+        const int j = q >> 6, w = q & 63;
+        Dc[j * kBlk + w] = D[(size_t)j * s0 * kBlk + w];
+        Lc[j * kBlk + w] = L[(size_t)j * s0 * kBlk + w];
+      }
+      for (int q = tid; q < Nc * 8; q += kThreads) fc[q] = f[(size_t)(q >> 3) * s0 * 8 + (q & 7)];
+      __syncthreads();
+      CRP(2);
+      ok = cr_forward(Dc, Lc, fc, Nc, 1, Nc) && ok;
+      ok = cr_top(Dc, fc) && ok;
+      __syncthreads();
+      int stop = 1;
+      while (stop * 2 < Nc) stop *= 2;
+      if (Nc > 1) cr_backward(Dc, Lc, fc, Nc, stop, 1);
+      for (int q = tid; q < Nc * 8; q += kThreads) f[(size_t)(q >> 3) * s0 * 8 + (q & 7)] = fc[q];
+      __syncthreads();
+      CRP(3);
+      if (s0 > 1) cr_backward(D, L, f, Nb, s0 >> 1, 1);
+      // the obstacle cache comes back (same staging as at kernel start)
+      const int tot = sc.n_static + sc.n_dyn;
+      for (int k = tid; k < tot; k += kThreads) {
+        const int oi = (k < sc.n_static) ? sc.static_idx[k] : sc.dyn_idx[k - sc.n_static];
+        l.obx[k] = sc.ax[oi]; l.oby[k] = sc.ay[oi]; l.obvx[k] = sc.vx[oi]; l.obvy[k] = sc.vy[oi];
+        l.obr[k] = (sc.type[oi] == TEB_AMD_OBST_CIRCULAR) ? sc.rad[oi] : 0.0;
+      }
+    } else {
+      ok = cr_top(D, f) && ok;
+      __syncthreads();
+      int stop = 1;
+      while (stop * 2 < Nb) stop *= 2;
+      if (Nb > 1) cr_backward(D, L, f, Nb, stop, 1);
+    }
+    if (!ok) l.ired[0] = 0;   // some lane met a pivot <= 0 (every lane of its 8-lane group did)
+    __syncthreads();
+    CRP(4);
+    for (int q = tid; q < Nt; q += kThreads) l.dxv[q] = f[q];
+    __syncthreads();
+    CRP(5);
+    return;
+  }
   // 8 lanes per elimination: lane c owns column c of L_i, of U_i and (redundantly) f_i; 32 eliminations per round
   const int grp = tid >> 3, c = tid & 7;
   bool ok = true;
@@ -1147,10 +1343,10 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
             }
             __syncthreads();
           } else {
-            cr_solve_t<true>(plan, n, lambda, Hbk);
+            cr_solve_t<true>(plan, sc, n, lambda, Hbk);
           }
         } else {
-          cr_solve_t<false>(plan, n, lambda, nullptr);
+          cr_solve_t<false>(plan, sc, n, lambda, nullptr);
         }
         PROF_END(4);
         PROF_START();
