@@ -268,6 +268,56 @@ int  teb_amd_select_best(teb_amd_handle_t* h, int32_t last_best, int32_t initial
                          int32_t* best, double* best_cost);
 
 /* -- zero-copy access for callers that already live on the GPU (benchmarks, torch interop) ---------- */
+/*
+ * f3 (candidate generation) — HomotopyClassPlanner::exploreEquivalenceClassesAndInitTebs after renewAndAnalyzeOldTebs
+ * (src/homotopy_class_planner.cpp:318-340): GraphSearchInterface::createGraph (lrKeyPointGraph src/graph_search.cpp:95-223 when
+ * simple_exploration, else ProbRoadmapGraph :227-340), the depth-first path enumeration (:45-91) and, for every start-goal path in
+ * the reference's order, addAndInitNewTeb (homotopy_class_planner.hpp:66-93): band from the path (timed_elastic_band.hpp:46-183),
+ * its equivalence class, addEquivalenceClassIfNew (src/homotopy_class_planner.cpp:189-212).
+ */
+typedef struct teb_amd_hcp_params {
+  int32_t simple_exploration;                 /* hcp.simple_exploration: 1 = lrKeyPointGraph, 0 = ProbRoadmapGraph          */
+  int32_t roadmap_graph_no_samples;           /* hcp.roadmap_graph_no_samples                                               */
+  double  roadmap_graph_area_width;           /* hcp.roadmap_graph_area_width                                               */
+  double  roadmap_graph_area_length_scale;    /* hcp.roadmap_graph_area_length_scale                                        */
+  double  obstacle_heading_threshold;         /* hcp.obstacle_heading_threshold                                             */
+  double  xy_goal_tolerance;                  /* goal_tolerance.xy_goal_tolerance                                           */
+  int32_t max_number_classes;                 /* hcp.max_number_classes                                                     */
+  int32_t max_number_plans_in_current_class;  /* hcp.max_number_plans_in_current_class                                      */
+  double  h_signature_prescaler;              /* hcp.h_signature_prescaler                                                  */
+  double  h_signature_threshold;              /* hcp.h_signature_threshold                                                  */
+  int32_t allow_init_with_backwards_motion;   /* trajectory.allow_init_with_backwards_motion                                */
+  int32_t reserved;
+} teb_amd_hcp_params_t;
+void teb_amd_hcp_params_default(teb_amd_hcp_params_t* p);   /* the defaults of teb_config.h:330-360 */
+/*
+ * The bands of the batch are the planner's tebs_ after renewAndAnalyzeOldTebs (teb_amd_compute_h_signatures,
+ * teb_amd_filter_equivalence_classes, teb_amd_compact_bands; an empty batch is a planner without trajectories), best = index of
+ * the last best band (its class may hold up to max_number_plans_in_current_class bands) or -1. New candidates are appended to the
+ * batch while it holds fewer than max_number_classes (and than max_tebs) bands; *n_total = batch size afterwards.
+ * start_vel = (linear.x, linear.y, angular.z) for setVelocityStart on the new bands or NULL; free_goal_vel = setVelocityGoalFree().
+ * The collision tests of all vertex pairs against all obstacles, the band initialisation and the H-signatures of a chunk of
+ * candidate paths run on the device; the depth-first enumeration (pointer chasing over the adjacency lists) runs on the host and
+ * feeds the device in chunks of paths, which are accepted in the reference's order.
+ * unit_samples: ProbRoadmapGraph only - [2*roadmap_graph_no_samples] uniform numbers in [0,1) replacing the planner's generator,
+ * in draw order: per sample first the one scaled to the area width, then the one scaled to the area length (the order GCC gives
+ * Eigen::Vector2d(distribution_x(g), distribution_y(g)), src/graph_search.cpp:274); NULL = the handle's own generator, the
+ * default-seeded mt19937 + boost::random::uniform_real_distribution stream of the reference's member generator.
+ * *n_vertices / *n_paths (may be NULL): graph size and number of start-goal paths examined. max_paths > 0 bounds the enumeration
+ * (the reference has no bound: without new classes it enumerates every simple path); TEB_AMD_OK is returned either way.
+ */
+int  teb_amd_explore_candidates(teb_amd_handle_t* h, const teb_amd_hcp_params_t* p, const double* start, const double* goal,
+                                double dist_to_obst, const double* start_vel, int32_t free_goal_vel, int32_t best,
+                                const double* unit_samples, int64_t max_paths, int32_t* n_total, int32_t* n_vertices, int32_t* n_paths);
+/* the graph of the last teb_amd_explore_candidates call: vertices (x, y) [n_vertices], adjacency bytes [n_vertices^2] (row = from) */
+int  teb_amd_get_exploration_graph(teb_amd_handle_t* h, double* vx, double* vy, unsigned char* adjacency, int32_t capacity_vertices,
+                                   int32_t* n_vertices);
+/*
+ * Compaction of the batch after teb_amd_filter_equivalence_classes: the bands with keep[b] != 0 move to the front, in the order of
+ * renewAndAnalyzeOldTebs (the last best band, best >= 0, swapped with the first one, src/homotopy_class_planner.cpp:220-224); the
+ * batch shrinks to them. *n_kept = batch size afterwards, *new_best = position of the best band afterwards (0) or -1.
+ */
+int  teb_amd_compact_bands(teb_amd_handle_t* h, const int32_t* keep, int32_t best, int32_t* n_kept, int32_t* new_best);
 /* Device pointers (hipDeviceptr as void*) of the resident SoA strips: x, y, theta, dt, each
  * [max_tebs*max_poses] doubles, and n [max_tebs] int32. Valid until destroy.                          */
 int  teb_amd_device_state(teb_amd_handle_t* h, void** x, void** y, void** theta, void** dt, void** n,

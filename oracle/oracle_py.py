@@ -274,3 +274,32 @@ def filter_equivalence_classes(mode, sig, threshold=0.1, best=-1, max_number_pla
                                                        int(max_number_plans_in_current_class), I(keep), I(valid), I(reas)),
            "filter_equivalence_classes")
     return keep, valid, reas
+
+
+# ---- row f3 (candidate generation): createGraph + DepthFirst + addAndInitNewTeb --------------------------------------------------
+def explore_candidates(cfg, obst, batch, n_tebs, best, start, goal, dist_to_obst=None, unit_samples=None, skip_draws=0,
+                       vcap=4096, acap=1 << 20, max_paths=0):
+    """Bands 0..n_tebs-1 of `batch` are tebs_ after renewAndAnalyzeOldTebs; returns dict(batch (copy, candidates appended), n_total,
+    vertices [nv, 2], adjacency (list of lists, insertion order), n_paths)."""
+    c = cfg.to_c()
+    p = cfg.hcp_params()
+    out = batch.copy()
+    bs = out.c_struct()
+    dist_to_obst = cfg.obstacles.min_obstacle_dist if dist_to_obst is None else dist_to_obst
+    st = np.ascontiguousarray(start, np.float64); gl = np.ascontiguousarray(goal, np.float64)
+    us = None if unit_samples is None else np.ascontiguousarray(unit_samples, np.float64).ravel()
+    vx = np.zeros(vcap); vy = np.zeros(vcap); off = np.zeros(vcap + 1, np.int32); adj = np.zeros(acap, np.int32)
+    nt = C.c_int32(0); nv = C.c_int32(0); npth = C.c_int32(0)
+    I = lambda a: _abi._ptr(a, C.c_int32)
+    f = lib().teb_oracle_explore_candidates
+    f.restype = C.c_int
+    f.argtypes = [C.POINTER(_abi.Config), C.POINTER(_abi.HcpParams), C.POINTER(_abi.Obstacles), C.POINTER(_abi.TebBatch), C.c_int32,
+                  C.c_int32, _abi.p_f64, _abi.p_f64, C.c_double, _abi.p_f64, C.c_int64, C.c_int64, _abi.p_i32, C.c_int32, _abi.p_f64, _abi.p_f64,
+                  _abi.p_i32, C.c_int32, _abi.p_i32, _abi.p_i32, _abi.p_i32]
+    _check(f(C.byref(c), C.byref(p), C.byref(obst.freeze()), C.byref(bs), int(n_tebs), int(best), _P(st), _P(gl),
+             float(dist_to_obst), _abi._ptr(us, C.c_double), int(skip_draws), int(max_paths), C.byref(nt), vcap, _P(vx), _P(vy), C.byref(nv), acap,
+             I(off), I(adj), C.byref(npth)), "explore_candidates")
+    N = nv.value
+    assert N <= vcap and off[N] <= acap
+    return dict(batch=out, n_total=nt.value, vertices=np.stack([vx[:N], vy[:N]], 1),
+                adjacency=[adj[off[v]:off[v + 1]].tolist() for v in range(N)], n_paths=npth.value)

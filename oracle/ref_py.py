@@ -242,3 +242,37 @@ def optimize_batch(cfg, obst, via, batch, inner=None, outer=None, compute_cost=T
                                   int(threads), I(ok), _P(cost), I(it))
     assert rc == 0, rc
     return out, ok, cost, it
+
+
+def explore_candidates(cfg, obst, batch, best, start, goal, dist_to_obst=None, start_vel=None, free_goal_vel=False, skip_draws=0,
+                       slots=None, vcap=4096, acap=1 << 20):
+    """The reference's HomotopyClassPlanner::exploreEquivalenceClassesAndInitTebs (renewAndAnalyzeOldTebs without detour deletion,
+    then createGraph / DepthFirst / addAndInitNewTeb) with tebs_ = the bands of `batch` (may be None) and best_teb_ = band `best`.
+    dict(batch, n_total, vertices, adjacency, has_vel_start, vel_start, has_vel_goal)."""
+    from teb_local_planner_amd import _abi as A
+    c = cfg.to_c()
+    p = cfg.hcp_params()
+    stride = batch.stride if batch is not None else 2048
+    slots = slots or max(cfg.hcp.max_number_classes + (batch.count if batch is not None else 0), 1)
+    out = A.TebBatchHost(slots, stride)
+    obs = out.c_struct()
+    dist_to_obst = cfg.obstacles.min_obstacle_dist if dist_to_obst is None else dist_to_obst
+    st = np.ascontiguousarray(start, np.float64); gl = np.ascontiguousarray(goal, np.float64)
+    sv = None if start_vel is None else np.ascontiguousarray(start_vel, np.float64)
+    vx = np.zeros(vcap); vy = np.zeros(vcap); off = np.zeros(vcap + 1, np.int32); adj = np.zeros(acap, np.int32)
+    nt = C.c_int32(0); nv = C.c_int32(0)
+    hvs = np.zeros(slots, np.int32); vs = np.zeros((slots, 3)); hvg = np.zeros(slots, np.int32)
+    I = lambda a: _abi._ptr(a, C.c_int32)
+    f = lib().ref_explore_candidates
+    f.restype = C.c_int
+    f.argtypes = [C.POINTER(A.Config), C.POINTER(A.HcpParams), C.POINTER(A.Obstacles), C.POINTER(A.TebBatch), C.c_int, A.p_f64, A.p_f64,
+                  C.c_double, A.p_f64, C.c_int, C.c_long, C.POINTER(A.TebBatch), A.p_i32, A.p_i32, A.p_f64, A.p_i32, C.c_int, A.p_f64,
+                  A.p_f64, A.p_i32, C.c_int, A.p_i32, A.p_i32]
+    ins = batch.c_struct() if batch is not None else None
+    rc = f(C.byref(c), C.byref(p), C.byref(obst.freeze()), C.byref(ins) if ins is not None else None, int(best), _P(st), _P(gl),
+           float(dist_to_obst), _abi._ptr(sv, C.c_double), int(bool(free_goal_vel)), int(skip_draws), C.byref(obs), C.byref(nt), I(hvs),
+           _P(vs), I(hvg), vcap, _P(vx), _P(vy), C.byref(nv), acap, I(off), I(adj))
+    assert rc == 0, rc
+    N = nv.value
+    return dict(batch=out, n_total=nt.value, vertices=np.stack([vx[:N], vy[:N]], 1),
+                adjacency=[adj[off[v]:off[v + 1]].tolist() for v in range(N)], has_vel_start=hvs, vel_start=vs, has_vel_goal=hvg)

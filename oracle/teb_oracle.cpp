@@ -25,6 +25,7 @@
  */
 #include "teb_oracle.h"
 
+#include <cfloat>
 #include <algorithm>
 #include <array>
 #include <atomic>
@@ -2309,6 +2310,307 @@ int teb_oracle_filter_equivalence_classes(int32_t mode, int32_t B, int32_t M, co
     if (add) { classes.push_back(b); keep[b] = 1; }
   }
   return TEB_AMD_OK;
+}
+
+// ---- row f3, candidate generation: graph_search.cpp + addAndInitNewTeb --------------------------------------------------------
+namespace {
+
+// Obstacle::checkLineIntersection per class (obstacles.h:339-354, 483-498, 647-650, 794-797; src/obstacles.cpp:178-191)
+bool segments_intersect(V2 l1s, V2 l1e, V2 l2s, V2 l2e) {   // check_line_segments_intersection_2d, distance_calculations.h:97-127
+  V2 line1 = l1e - l1s;
+  V2 line2 = l2e - l2s;
+  double denom = line1.x * line2.y - line2.x * line1.y;
+  if (denom == 0) return false;
+  bool denomPositive = denom > 0;
+  V2 aux = l1s - l2s;
+  double s_numer = line1.x * aux.y - line1.y * aux.x;
+  if ((s_numer < 0) == denomPositive) return false;
+  double t_numer = line2.x * aux.y - line2.y * aux.x;
+  if ((t_numer < 0) == denomPositive) return false;
+  if (((s_numer > denom) == denomPositive) || ((t_numer > denom) == denomPositive)) return false;
+  return true;
+}
+bool check_line_intersection(const Obst& o, V2 ls, V2 le, double min_dist) {
+  switch (o.type) {
+    case TEB_AMD_OBST_POINT:
+    case TEB_AMD_OBST_CIRCULAR: {
+      V2 a = le - ls;
+      V2 b = o.a - ls;
+      double t = dot(a, b) / dot(a, a);
+      if (t < 0) t = 0; else if (t > 1) t = 1;
+      V2 nearest = ls + t * a;   // line_start + a*t
+      double d = norm(nearest - o.a);
+      if (o.type == TEB_AMD_OBST_CIRCULAR) d = d - o.r;
+      return d < min_dist;
+    }
+    case TEB_AMD_OBST_LINE:
+    case TEB_AMD_OBST_PILL:
+      return segments_intersect(ls, le, o.a, o.b);
+    default: {
+      const int nv = (int)o.verts.size();
+      for (int i = 0; i < nv - 1; ++i)
+        if (segments_intersect(ls, le, o.verts[i], o.verts[i + 1])) return true;
+      if (nv == 2) return false;
+      return segments_intersect(ls, le, o.verts[nv - 1], o.verts[0]);
+    }
+  }
+}
+
+V2 normalized_in_place(V2 v) {   // Eigen normalize(): v /= sqrt(squaredNorm) when squaredNorm > 0
+  double z = v.x * v.x + v.y * v.y;
+  if (z > 0) { double n = std::sqrt(z); v.x = v.x / n; v.y = v.y / n; }
+  return v;
+}
+
+struct HcGraph {
+  std::vector<V2> pos;
+  std::vector<std::vector<int>> adj;   // out-edges in insertion order
+  int add_vertex(V2 p) { pos.push_back(p); adj.emplace_back(); return (int)pos.size() - 1; }
+};
+
+struct ClassSig { std::vector<double> v; };
+
+struct Explorer {
+  const Scene* s;
+  const teb_amd_hcp_params_t* p;
+  int mode, W;
+  std::vector<Teb> tebs;
+  std::vector<ClassSig> classes;     // equivalence_classes_ (one per teb, same order)
+  bool has_best = false;
+  ClassSig best_class;
+  int cap = 0;                       // slots available (the reference has no such bound; max_number_classes <= cap is required)
+  int n_paths = 0;
+  int64_t max_paths = 0;             // > 0: stop after this many start-goal paths (guard of the tests; the reference has none)
+
+  ClassSig signature(const Teb& t) const {
+    ClassSig c;
+    if (mode == 2) { cplx h = h_signature_2d(*s, t, p->h_signature_prescaler); c.v = {(double)h.real(), (double)h.imag()}; }
+    else h_signature_3d(*s, t, c.v);
+    return c;
+  }
+  bool is_valid(const ClassSig& c) const { for (double z : c.v) if (!std::isfinite(z)) return false; return true; }
+  bool is_equal(const ClassSig& a, const ClassSig& b) const {   // a.isEqual(b)
+    const double thr = p->h_signature_threshold;
+    if (mode == 2) return std::abs(b.v[0] - a.v[0]) <= thr && std::abs(b.v[1] - a.v[1]) <= thr;
+    auto sgn = [](double z) { return (z == 0) ? 0 : (z < 0 ? -1 : 1); };
+    for (size_t i = 0; i < a.v.size(); ++i) {
+      if (std::abs(b.v[i]) < thr || std::abs(a.v[i]) < thr) continue;
+      if (sgn(b.v[i]) != sgn(a.v[i])) return false;
+    }
+    return true;
+  }
+  // addEquivalenceClassIfNew, src/homotopy_class_planner.cpp:189-212
+  bool add_class_if_new(const ClassSig& c) {
+    if (!is_valid(c)) return false;
+    bool has = false;
+    for (const ClassSig& e : classes) if (is_equal(c, e)) { has = true; break; }
+    if (has) {
+      bool in_best = has_best && is_equal(best_class, c);
+      int count = 0;
+      if (has_best) for (const ClassSig& e : classes) if (is_equal(best_class, e)) ++count;
+      if (!in_best || count >= p->max_number_plans_in_current_class) return false;
+    }
+    classes.push_back(c);
+    return true;
+  }
+  // addAndInitNewTeb(path_start, path_end, fun_position, start_orientation, goal_orientation, ...), homotopy_class_planner.hpp:66-93
+  void add_and_init_path(const HcGraph& g, const std::vector<int>& path, double start_orientation, double goal_orientation) {
+    ++n_paths;
+    std::vector<double> px, py;
+    for (int v : path) { px.push_back(g.pos[v].x); py.push_back(g.pos[v].y); }
+    Teb t;
+    const teb_amd_config_t& c = s->cfg;
+    init_trajectory_path(t, (int)path.size(), px.data(), py.data(), c.max_vel_x, c.max_vel_theta, true, c.acc_lim_x, true, start_orientation,
+                         true, goal_orientation, c.min_samples, p->allow_init_with_backwards_motion != 0);
+    ClassSig H = signature(t);
+    if (add_class_if_new(H)) tebs.push_back(t);
+  }
+  // addAndInitNewTeb(start, goal, ...), src/homotopy_class_planner.cpp:358-384
+  void add_and_init_line(const double* start, const double* goal) {
+    if ((int)tebs.size() >= p->max_number_classes) return;
+    Teb t;
+    const teb_amd_config_t& c = s->cfg;
+    init_trajectory_line(t, start, goal, 0, c.max_vel_x, c.min_samples, p->allow_init_with_backwards_motion != 0);
+    ClassSig H = signature(t);
+    if (add_class_if_new(H)) tebs.push_back(t);
+  }
+  // GraphSearchInterface::DepthFirst, src/graph_search.cpp:45-91
+  void depth_first(const HcGraph& g, std::vector<int>& visited, int goal, double start_orientation, double goal_orientation) {
+    if ((int)tebs.size() >= p->max_number_classes || (int)tebs.size() >= cap) return;
+    if (max_paths > 0 && n_paths >= max_paths) return;
+    const int back = visited.back();
+    for (int v : g.adj[back]) {
+      if (std::find(visited.begin(), visited.end(), v) != visited.end()) continue;
+      if (v == goal) {
+        visited.push_back(v);
+        add_and_init_path(g, visited, start_orientation, goal_orientation);
+        visited.pop_back();
+        break;
+      }
+    }
+    for (int v : g.adj[back]) {
+      if (std::find(visited.begin(), visited.end(), v) != visited.end() || v == goal) continue;
+      visited.push_back(v);
+      depth_first(g, visited, goal, start_orientation, goal_orientation);
+      visited.pop_back();
+    }
+  }
+};
+
+// boost::random::uniform_real_distribution<double>(a, b) on mt19937 (one 32-bit draw per value), boost/random/uniform_real_distribution.hpp
+struct Mt19937 {   // the 32-bit Mersenne twister (Matsumoto & Nishimura 1998), default seed 5489 as boost::random::mt19937()
+  uint32_t mt[624]; int idx = 624;
+  explicit Mt19937(uint32_t seed = 5489u) { mt[0] = seed; for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i; }
+  uint32_t next() {
+    if (idx >= 624) {
+      for (int i = 0; i < 624; ++i) {
+        uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+        mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      idx = 0;
+    }
+    uint32_t y = mt[idx++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+  }
+};
+
+}  // namespace
+
+// createGraph + DepthFirst + addAndInitNewTeb on bands 0..n_tebs-1 (= tebs_ after renewAndAnalyzeOldTebs). batch->count = slots.
+// unit_samples [2*no_samples] (u in [0,1): value = u * (b - a) + a) or NULL = boost mt19937 default stream after skip_draws draws.
+int teb_oracle_explore_candidates(const teb_amd_config_t* cfg, const teb_amd_hcp_params_t* p, const teb_amd_obstacles_t* obst,
+                                  teb_amd_teb_batch_t* batch, int32_t n_tebs, int32_t best, const double* start, const double* goal,
+                                  double dist_to_obst, const double* unit_samples, int64_t skip_draws, int64_t max_paths, int32_t* n_total,
+                                  int32_t vcap, double* vx, double* vy, int32_t* nv, int32_t acap, int32_t* adj_off, int32_t* adj,
+                                  int32_t* n_paths) {
+  Scene s;
+  int rc = load_scene(s, cfg, obst, 0, nullptr, nullptr);
+  if (rc) return rc;
+  Explorer ex;
+  ex.s = &s; ex.p = p; ex.mode = cfg->include_dynamic_obstacles ? 3 : 2; ex.W = ex.mode == 2 ? 2 : (int)s.obst.size();
+  ex.cap = batch->count;
+  ex.max_paths = max_paths;
+  for (int b = 0; b < n_tebs; ++b) {
+    Teb t;
+    teb_from_batch(batch, b, t);
+    ex.classes.push_back(ex.signature(t));
+    ex.tebs.push_back(t);
+  }
+  if (best >= 0 && best < n_tebs) { ex.has_best = true; ex.best_class = ex.classes[best]; }
+  HcGraph g;
+  const double thr = p->obstacle_heading_threshold;
+  const V2 sp{start[0], start[1]}, gp{goal[0], goal[1]};
+  auto finish = [&]() {
+    *n_total = (int)ex.tebs.size();
+    for (int b = n_tebs; b < (int)ex.tebs.size(); ++b) { int r = teb_to_batch(ex.tebs[b], batch, b); if (r) return r; }
+    for (int b = (int)ex.tebs.size(); b < batch->count; ++b) batch->n[b] = 0;
+    const int N = (int)g.pos.size();
+    if (nv) *nv = N;
+    if (n_paths) *n_paths = ex.n_paths;
+    int e = 0;
+    for (int v = 0; v < N && v < vcap; ++v) {
+      vx[v] = g.pos[v].x; vy[v] = g.pos[v].y; adj_off[v] = e;
+      for (int w : g.adj[v]) { if (e < acap) adj[e] = w; ++e; }
+    }
+    if (N <= vcap && adj_off) adj_off[N] = e;
+    return (int)TEB_AMD_OK;
+  };
+  if ((int)ex.tebs.size() >= p->max_number_classes) return finish();   // src/graph_search.cpp:99-100, 231-232
+  V2 diff = gp - sp;
+  const double start_goal_dist = norm(diff);
+  if (start_goal_dist < p->xy_goal_tolerance) {                          // :104-113, :237-246
+    if (ex.tebs.empty()) ex.add_and_init_line(start, goal);
+    return finish();
+  }
+  int start_vtx, goal_vtx;
+  if (p->simple_exploration) {                                           // lrKeyPointGraph::createGraph, :95-223
+    V2 normal{-diff.y, diff.x};
+    normal = normalized_in_place(normal);
+    normal = dist_to_obst * normal;
+    start_vtx = g.add_vertex(sp);
+    diff = normalized_in_place(diff);
+    int near_u = -1, near_v = -1;
+    double min_dist = DBL_MAX;
+    for (const Obst& o : s.obst) {
+      V2 start2obst = o.c - sp;
+      double dist = norm(start2obst);
+      if (dot(start2obst, diff) / dist < 0.1) continue;
+      int u = g.add_vertex(o.c + normal);
+      int v = g.add_vertex(o.c - normal);
+      if (thr && dist < min_dist) { min_dist = dist; near_u = u; near_v = v; }
+    }
+    goal_vtx = g.add_vertex(gp);
+    const int N = (int)g.pos.size();
+    for (int i = 0; i < N - 1; ++i)
+      for (int j = 0; j < N; ++j) {
+        if (i == j) continue;
+        V2 distij = normalized_in_place(g.pos[j] - g.pos[i]);
+        if (dot(distij, diff) <= thr) continue;
+        if (thr && i == start_vtx && min_dist != DBL_MAX) {
+          if (j == near_u || j == near_v) {
+            V2 keypoint_dist = normalized_in_place(g.pos[j] - sp);
+            V2 start_orient_vec{std::cos(start[2]), std::sin(start[2])};
+            if (dot(start_orient_vec, keypoint_dist) <= thr) continue;
+          }
+        }
+        bool collision = false;
+        for (const Obst& o : s.obst)
+          if (check_line_intersection(o, g.pos[i], g.pos[j], 0.5 * dist_to_obst)) { collision = true; break; }
+        if (collision) continue;
+        g.adj[i].push_back(j);
+      }
+  } else {                                                               // ProbRoadmapGraph::createGraph, :227-340
+    V2 normal = normalized_in_place(V2{-diff.y, diff.x});
+    const double area_width = p->roadmap_graph_area_width;
+    const double bx = start_goal_dist * p->roadmap_graph_area_length_scale;   // distribution_x(0, bx), distribution_y(0, area_width)
+    const double phi = std::atan2(diff.y, diff.x);
+    V2 area_origin;
+    if (p->roadmap_graph_area_length_scale != 1.0) {
+      V2 dn = normalized_in_place(diff);   // diff.normalized(): same quotients
+      area_origin = (sp + (0.5 * (1.0 - p->roadmap_graph_area_length_scale) * start_goal_dist) * dn) - (0.5 * area_width) * normal;
+    } else {
+      area_origin = sp - (0.5 * area_width) * normal;
+    }
+    start_vtx = g.add_vertex(sp);
+    diff = normalized_in_place(diff);
+    Mt19937 eng;
+    for (int64_t k = 0; k < skip_draws; ++k) eng.next();
+    int drawn = 0;
+    auto draw = [&](double a, double b) {
+      if (unit_samples) { double u = unit_samples[drawn++]; return u * (b - a) + a; }
+      for (;;) {
+        double numerator = (double)eng.next();
+        double divisor = 4294967295.0 + 1;
+        double result = numerator / divisor * (b - a) + a;
+        if (result < b) return result;
+      }
+    };
+    for (int i = 0; i < p->roadmap_graph_no_samples; ++i) {
+      // Eigen::Vector2d(distribution_x(rnd), distribution_y(rnd)), :274: the order of the two draws is unspecified in C++; GCC
+      // (the compiler of every ROS distribution the reference targets) evaluates the arguments right to left: y is drawn first
+      double uy = draw(0, area_width);
+      double ux = draw(0, bx);
+      V2 rot{std::cos(phi) * ux - std::sin(phi) * uy, std::sin(phi) * ux + std::cos(phi) * uy};
+      g.add_vertex(area_origin + rot);
+    }
+    goal_vtx = g.add_vertex(gp);
+    const int N = (int)g.pos.size();
+    for (int i = 0; i < N - 1; ++i)
+      for (int j = 0; j < N; ++j) {
+        if (i == j) continue;
+        V2 distij = normalized_in_place(g.pos[j] - g.pos[i]);
+        if (dot(distij, diff) <= thr) continue;
+        bool collision = false;
+        for (const Obst& o : s.obst)
+          if (check_line_intersection(o, g.pos[i], g.pos[j], dist_to_obst)) { collision = true; break; }
+        if (collision) continue;
+        g.adj[i].push_back(j);
+      }
+  }
+  std::vector<int> visited{start_vtx};
+  ex.depth_first(g, visited, goal_vtx, start[2], goal[2]);
+  return finish();
 }
 
 int teb_oracle_linearize(const teb_amd_config_t* cfg, const teb_amd_obstacles_t* obst, int32_t n_via,

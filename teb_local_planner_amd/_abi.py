@@ -78,6 +78,15 @@ class TebBatch(C.Structure):
     ]
 
 
+class HcpParams(C.Structure):
+    _fields_ = [
+        ("simple_exploration", c_i32), ("roadmap_graph_no_samples", c_i32), ("roadmap_graph_area_width", c_f64),
+        ("roadmap_graph_area_length_scale", c_f64), ("obstacle_heading_threshold", c_f64), ("xy_goal_tolerance", c_f64),
+        ("max_number_classes", c_i32), ("max_number_plans_in_current_class", c_i32), ("h_signature_prescaler", c_f64),
+        ("h_signature_threshold", c_f64), ("allow_init_with_backwards_motion", c_i32), ("reserved", c_i32),
+    ]
+
+
 class Results(C.Structure):
     _fields_ = [
         ("status", p_i32), ("lm_iterations", p_i32), ("lm_trials", p_i32), ("chi2", p_f64),

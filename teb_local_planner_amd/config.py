@@ -76,11 +76,28 @@ class TebConfig:
             enable_multithreading=True, max_number_classes=5, selection_cost_hysteresis=1.0,
             selection_prefer_initial_plan=0.95, selection_obst_cost_scale=100.0,
             selection_viapoint_cost_scale=1.0, selection_alternative_time_cost=False,
-            viapoints_all_candidates=True)
+            viapoints_all_candidates=True,
+            # candidate generation (teb_config.h:352-367; max_number_plans_in_current_class has no constructor default in the
+            # reference, its dynamic-reconfigure default is 1): fields of teb_amd_hcp_params_t
+            simple_exploration=False, max_number_plans_in_current_class=1, obstacle_heading_threshold=0.45,
+            roadmap_graph_no_samples=15, roadmap_graph_area_width=6.0, roadmap_graph_area_length_scale=1.0,
+            h_signature_prescaler=1.0, h_signature_threshold=0.1)
+        self.goal_tolerance = SimpleNamespace(xy_goal_tolerance=0.2, yaw_goal_tolerance=0.2)
         self.recovery = SimpleNamespace(divergence_detection_enable=False,
                                         divergence_detection_max_chi_squared=10.0)
         # extension (not in the reference): Jacobian mode of the GPU path / oracle
         self.jacobian_mode = _abi.JACOBIAN_ANALYTIC
+
+    def hcp_params(self):
+        """teb_amd_hcp_params_t of this configuration (candidate generation, include/teb_amd.h)."""
+        p = _abi.HcpParams()
+        for k, _ in _abi.HcpParams._fields_:
+            if hasattr(self.hcp, k):
+                v = getattr(self.hcp, k)
+                setattr(p, k, int(v) if isinstance(v, bool) else v)
+        p.xy_goal_tolerance = self.goal_tolerance.xy_goal_tolerance
+        p.allow_init_with_backwards_motion = int(self.trajectory.allow_init_with_backwards_motion)
+        return p
 
     def to_c(self):
         c = _abi.Config()

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <random>
 #include <vector>
 
 #include "../../include/teb_amd.h"
@@ -16,6 +17,7 @@
 #include "teb_kernel.hpp"
 #include "teb_strip.hpp"
 #include "teb_hsig.hpp"
+#include "teb_graph.hpp"
 
 using namespace tebamd;
 
@@ -169,6 +171,15 @@ struct teb_amd_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   std::vector<int> host_type;
+  // candidate generation (f3): host copy of the obstacle centroids, graph + candidate scratch strips, boost-compatible generator
+  std::vector<double> host_cx, host_cy;
+  DevBuf<double> g_vx, g_vy, cand_x, cand_y, cand_th, cand_dt, cand_sig, cand_px, cand_py, tmp_x, tmp_y, tmp_th, tmp_dt, tmp_vs, tmp_vg,
+      tmp_chi2, tmp_cost, tmp_lambda;
+  DevBuf<int> cand_n, cand_off, cand_map, tmp_n, tmp_i;
+  DevBuf<unsigned char> g_adj;
+  size_t g_cap = 0;
+  bool cand_ready = false, tmp_ready = false;
+  std::mt19937 rnd_generator;   // ProbRoadmapGraph::rnd_generator_ (graph_search.h:211): default-seeded 32-bit Mersenne twister
 };
 
 namespace {
@@ -393,6 +404,12 @@ void teb_amd_destroy(teb_amd_handle_t* h) {
                           &h->lambda, &h->Hbackup, &h->snap_x, &h->snap_y, &h->snap_th, &h->snap_dt, &h->dbg_H,
                           &h->dbg_b, &h->dbg_chi2, &h->sel_cost, &h->stage_x, &h->stage_y, &h->stage_yaw, &h->out_cmd, &h->out_prof, &h->out_traj, &h->hsig, &h->hs_pre, &h->hs_pim};
   for (auto* q : db) q->free();
+  DevBuf<double>* gb[] = {&h->g_vx, &h->g_vy, &h->cand_x, &h->cand_y, &h->cand_th, &h->cand_dt, &h->cand_sig, &h->cand_px, &h->cand_py,
+                          &h->tmp_x, &h->tmp_y, &h->tmp_th, &h->tmp_dt, &h->tmp_vs, &h->tmp_vg, &h->tmp_chi2, &h->tmp_cost, &h->tmp_lambda};
+  for (auto* q : gb) q->free();
+  DevBuf<int>* gi[] = {&h->cand_n, &h->cand_off, &h->cand_map, &h->tmp_n, &h->tmp_i};
+  for (auto* q : gi) q->free();
+  h->g_adj.free();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -458,6 +475,7 @@ int teb_amd_set_obstacles(teb_amd_handle_t* h, const teb_amd_obstacles_t* o) {
   HIPCHK(hipStreamSynchronize(h->stream));   // host vectors go out of scope
   h->M = M; h->n_static = (int)st.size(); h->n_dyn = (int)dy.size();
   h->host_type = type;
+  h->host_cx = cx; h->host_cy = cy;
   h->host_static = st;
   // point-like fast path: all obstacles Point/Circular, footprint Point/Circular, and the cache fits the LDS
   bool pointlike = (h->cfg.footprint_type == TEB_AMD_FOOTPRINT_POINT || h->cfg.footprint_type == TEB_AMD_FOOTPRINT_CIRCULAR);
@@ -826,6 +844,32 @@ int teb_amd_has_diverged(teb_amd_handle_t* h, int32_t b, int32_t* diverged) {
   return TEB_AMD_OK;
 }
 
+namespace {
+// H-signatures of the B bands of bt (the batch or the candidate scratch strips) into out [B * W], W = M (3-D) or 2 (2-D)
+int launch_hsig(teb_amd_handle* h, const BatchDev& bt, int B, double prescaler, double* out) {
+  SceneDev sc = scene_of(h);
+  const int M = h->M;
+  if (B <= 0) return TEB_AMD_OK;
+  if (h->cfg.include_dynamic_obstacles) {
+    if (M > 0) {
+      hipLaunchKernelGGL(hsig3d_kernel, dim3((M + kThreads - 1) / kThreads, B), dim3(kThreads), 3 * (size_t)h->stride * sizeof(double),
+                         h->stream, sc, bt, out);
+      HIPCHK(hipGetLastError());
+    }
+  } else {
+    if (M > 0) {
+      hipLaunchKernelGGL(hsig2d_prod_kernel, dim3((M + kThreads - 1) / kThreads), dim3(kThreads), 0, h->stream, sc, h->hs_pre.p,
+                         h->hs_pim.p, h->hs_pex.p);
+      HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(hsig2d_kernel, dim3(B), dim3(kThreads), 2 * (size_t)h->stride * sizeof(double), h->stream, sc, bt, prescaler,
+                       h->hs_pre.p, h->hs_pim.p, h->hs_pex.p, out);
+    HIPCHK(hipGetLastError());
+  }
+  return TEB_AMD_OK;
+}
+}  // namespace
+
 // ---- f3 (arithmetic core): equivalence classes of the device-resident bands (kernels in teb_hsig.hpp) ----------------------------
 int teb_amd_compute_h_signatures(teb_amd_handle_t* h, double prescaler, double* values, int32_t* width) {
   int rc = check_handle(h);
@@ -839,22 +883,7 @@ int teb_amd_compute_h_signatures(teb_amd_handle_t* h, double prescaler, double* 
   if (width) *width = W;
   h->hsig_mode = mode; h->hsig_B = B; h->hsig_M = M;
   h->hsig_host.assign((size_t)B * (W > 0 ? W : 1), 0.0);
-  if (mode == 3) {
-    if (M > 0) {
-      hipLaunchKernelGGL(hsig3d_kernel, dim3((M + kThreads - 1) / kThreads, B), dim3(kThreads), 3 * (size_t)h->stride * sizeof(double),
-                         h->stream, sc, bt, h->hsig.p);
-      HIPCHK(hipGetLastError());
-    }
-  } else {
-    if (M > 0) {
-      hipLaunchKernelGGL(hsig2d_prod_kernel, dim3((M + kThreads - 1) / kThreads), dim3(kThreads), 0, h->stream, sc, h->hs_pre.p,
-                         h->hs_pim.p, h->hs_pex.p);
-      HIPCHK(hipGetLastError());
-    }
-    hipLaunchKernelGGL(hsig2d_kernel, dim3(B), dim3(kThreads), 2 * (size_t)h->stride * sizeof(double), h->stream, sc, bt, prescaler,
-                       h->hs_pre.p, h->hs_pim.p, h->hs_pex.p, h->hsig.p);
-    HIPCHK(hipGetLastError());
-  }
+  if ((rc = launch_hsig(h, bt, B, prescaler, h->hsig.p))) return rc;
   if ((size_t)B * W > 0)
     HIPCHK(hipMemcpyAsync(h->hsig_host.data(), h->hsig.p, (size_t)B * W * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -905,6 +934,353 @@ int teb_amd_filter_equivalence_classes(teb_amd_handle_t* h, double threshold, in
     if (valid) valid[b] = vld[b];
     if (reasonable) reasonable[b] = is_reasonable(b);
   }
+  return TEB_AMD_OK;
+}
+
+// ---- f3 (candidate generation): createGraph + DepthFirst + addAndInitNewTeb (kernels in teb_graph.hpp) ---------------------------
+void teb_amd_hcp_params_default(teb_amd_hcp_params_t* p) {   // teb_config.h:352-367, :260, :293
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  p->simple_exploration = 0; p->roadmap_graph_no_samples = 15; p->roadmap_graph_area_width = 6; p->roadmap_graph_area_length_scale = 1.0;
+  p->obstacle_heading_threshold = 0.45; p->xy_goal_tolerance = 0.2; p->max_number_classes = 5;
+  p->max_number_plans_in_current_class = 1;   // no constructor default in the reference; 1 is its dynamic-reconfigure default
+  p->h_signature_prescaler = 1; p->h_signature_threshold = 0.1; p->allow_init_with_backwards_motion = 0;
+}
+
+namespace {
+constexpr int kCandChunk = 64;   // candidate paths initialised and classified per device round trip
+
+int ensure_candidate_buffers(teb_amd_handle* h) {
+  if (h->cand_ready) return TEB_AMD_OK;
+  const size_t KS = (size_t)kCandChunk * h->stride, W = (size_t)(h->max_obst > 2 ? h->max_obst : 2);
+  bool ok = true;
+  auto A = [&](hipError_t e) { if (e != hipSuccess) ok = false; };
+  A(h->cand_x.alloc(KS)); A(h->cand_y.alloc(KS)); A(h->cand_th.alloc(KS)); A(h->cand_dt.alloc(KS)); A(h->cand_n.alloc(kCandChunk));
+  A(h->cand_sig.alloc(kCandChunk * W)); A(h->cand_px.alloc((size_t)kCandChunk * (h->stride + 1)));
+  A(h->cand_py.alloc((size_t)kCandChunk * (h->stride + 1))); A(h->cand_off.alloc(kCandChunk + 1)); A(h->cand_map.alloc(h->max_tebs));
+  if (!ok) return fail(TEB_AMD_ERR_HIP, "candidate scratch allocation failed");
+  h->cand_ready = true;
+  return TEB_AMD_OK;
+}
+
+BatchDev candidates_of(teb_amd_handle* h) {   // the scratch strips seen as a batch of kCandChunk bands
+  BatchDev c = batch_of(h);
+  c.B = kCandChunk;
+  c.n = h->cand_n.p; c.x = h->cand_x.p; c.y = h->cand_y.p; c.th = h->cand_th.p; c.dt = h->cand_dt.p;
+  return c;
+}
+
+// isValid / isEqual of HSignature and HSignature3d (h_signature.h:190-226, 349-409) on rows of W doubles
+struct ClassTable {
+  int mode = 2, W = 2, max_in_best = 1;
+  double thr = 0.1;
+  std::vector<std::vector<double>> classes;   // equivalence_classes_
+  bool has_best = false;
+  std::vector<double> best;                   // best_teb_eq_class_
+  static int sign_of(double z) { return z == 0 ? 0 : (z < 0 ? -1 : 1); }
+  bool valid(const double* v) const { for (int k = 0; k < W; ++k) if (!std::isfinite(v[k])) return false; return true; }
+  bool equal(const double* a, const double* b) const {   // a.isEqual(b)
+    if (mode == 2) return std::fabs(b[0] - a[0]) <= thr && std::fabs(b[1] - a[1]) <= thr;
+    for (int i = 0; i < W; ++i) {
+      if (std::fabs(b[i]) < thr || std::fabs(a[i]) < thr) continue;
+      if (sign_of(b[i]) != sign_of(a[i])) return false;
+    }
+    return true;
+  }
+  bool add_if_new(const double* v) {   // addEquivalenceClassIfNew, src/homotopy_class_planner.cpp:189-212
+    if (!valid(v)) return false;
+    bool has = false;
+    for (const auto& c : classes) if (equal(v, c.data())) { has = true; break; }
+    if (has) {
+      const bool in_best = has_best && equal(best.data(), v);
+      int count = 0;
+      if (has_best) for (const auto& c : classes) if (equal(best.data(), c.data())) ++count;
+      if (!in_best || count >= max_in_best) return false;
+    }
+    classes.emplace_back(v, v + W);
+    return true;
+  }
+};
+
+// GraphSearchInterface::DepthFirst (src/graph_search.cpp:45-91) as a resumable generator of start-goal paths in the reference's order
+struct PathEnumerator {
+  const std::vector<std::vector<int>>* adj;
+  int goal;
+  struct Frame { int v; int phase; size_t k; };
+  std::vector<Frame> stack;
+  std::vector<int> visited;
+  std::vector<char> on_path;
+  PathEnumerator(const std::vector<std::vector<int>>& a, int start, int goal_) : adj(&a), goal(goal_), on_path(a.size(), 0) {
+    stack.push_back({start, 0, 0}); visited.push_back(start); on_path[start] = 1;
+  }
+  bool next(std::vector<int>& path) {
+    while (!stack.empty()) {
+      Frame& f = stack.back();
+      const std::vector<int>& out = (*adj)[f.v];
+      if (f.phase == 0) {       // first loop: the goal, if adjacent, closes one path
+        f.phase = 1; f.k = 0;
+        if (std::find(out.begin(), out.end(), goal) != out.end()) { path = visited; path.push_back(goal); return true; }
+      }
+      bool descended = false;
+      while (f.k < out.size()) {   // second loop: recursion into every adjacent vertex not yet on the path
+        const int w = out[f.k++];
+        if (on_path[w] || w == goal) continue;
+        visited.push_back(w); on_path[w] = 1;
+        stack.push_back({w, 0, 0});
+        descended = true;
+        break;
+      }
+      if (descended) continue;
+      on_path[f.v] = 0; visited.pop_back(); stack.pop_back();
+    }
+    return false;
+  }
+};
+}  // namespace
+
+int teb_amd_explore_candidates(teb_amd_handle_t* h, const teb_amd_hcp_params_t* p, const double* start, const double* goal,
+                               double dist_to_obst, const double* start_vel, int32_t free_goal_vel, int32_t best,
+                               const double* unit_samples, int64_t max_paths, int32_t* n_total, int32_t* n_vertices, int32_t* n_paths) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!p || !start || !goal) return fail(TEB_AMD_ERR_INVALID_ARG, "null argument");
+  if ((rc = ensure_candidate_buffers(h))) return rc;
+  const teb_amd_config_t& c = h->cfg;
+  const int M = h->M;
+  const int mode = c.include_dynamic_obstacles ? 3 : 2, W = mode == 3 ? M : 2;
+  const int slots = std::min<int>(p->max_number_classes, h->max_tebs);
+  h->g_cap = 0;
+  if (n_vertices) *n_vertices = 0;
+  if (n_paths) *n_paths = 0;
+  if (n_total) *n_total = h->B;
+  // equivalence_classes_ of the existing bands
+  ClassTable ct;
+  ct.mode = mode; ct.W = W; ct.thr = p->h_signature_threshold; ct.max_in_best = p->max_number_plans_in_current_class;
+  if (h->B > 0) {
+    if ((rc = teb_amd_compute_h_signatures(h, p->h_signature_prescaler, nullptr, nullptr))) return rc;
+    for (int b = 0; b < h->B; ++b) ct.classes.emplace_back(h->hsig_host.data() + (size_t)b * W, h->hsig_host.data() + (size_t)(b + 1) * W);
+    if (best >= 0 && best < h->B) { ct.has_best = true; ct.best = ct.classes[best]; }
+  }
+  h->hsig_mode = 0;   // the batch is about to change: signatures have to be recomputed before the next filter call
+  if (h->B >= slots) return TEB_AMD_OK;                                     // src/graph_search.cpp:99-100, 231-232
+  const double one3[3] = {0, 0, 0};
+  auto accept = [&](int cand_index) -> int {   // tebs_.push_back(candidate): scratch band -> next slot of the batch
+    const int slot = h->B;
+    int r = extend_batch(h, slot);              // default attributes of a new TebOptimalPlanner (fixed zero start / goal velocity)
+    if (r) return r;
+    HIPCHK(hipMemcpyAsync(h->cand_map.p, &cand_index, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(move_bands_kernel, dim3(1), dim3(kThreads), 0, h->stream, candidates_of(h), batch_of(h), h->cand_map.p, slot, 0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));   // cand_index lives on this stack frame
+    if (start_vel && (r = set_velocity(h, h->has_vs, h->vs, slot, 1, start_vel))) return r;
+    if (free_goal_vel && (r = set_velocity(h, h->has_vg, h->vg, slot, 0, nullptr))) return r;
+    (void)one3;
+    return TEB_AMD_OK;
+  };
+  std::vector<double> sig((size_t)kCandChunk * (W > 0 ? W : 1));
+  auto classify = [&](int count) -> int {      // signatures of scratch bands 0..count-1 -> sig
+    int r = launch_hsig(h, candidates_of(h), count, p->h_signature_prescaler, h->cand_sig.p);
+    if (r) return r;
+    if ((size_t)count * W > 0) HIPCHK(hipMemcpyAsync(sig.data(), h->cand_sig.p, (size_t)count * W * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    int err = 0;
+    HIPCHK(hipMemcpyAsync(&err, h->err_flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (err) return fail(TEB_AMD_ERR_CAPACITY, "candidate band needs more poses than max_poses");
+    return TEB_AMD_OK;
+  };
+  const double sx = start[0], sy = start[1], gx = goal[0], gy = goal[1];
+  double dfx = gx - sx, dfy = gy - sy;
+  const double start_goal_dist = std::sqrt(dfx * dfx + dfy * dfy);
+  h->consumers_valid = false;
+  if (start_goal_dist < p->xy_goal_tolerance) {                             // :104-113, :237-246
+    if (h->B == 0) {                                                        // addAndInitNewTeb(start, goal, ...), hcp.cpp:358-384
+      HIPCHK(hipMemsetAsync(h->err_flag.p, 0, sizeof(int), h->stream));
+      hipLaunchKernelGGL(init_line_kernel, dim3(1), dim3(kThreads), 0, h->stream, candidates_of(h), 0, start[0], start[1], start[2],
+                         goal[0], goal[1], goal[2], 0.0, c.max_vel_x, c.min_samples, p->allow_init_with_backwards_motion, h->err_flag.p);
+      HIPCHK(hipGetLastError());
+      if ((rc = classify(1))) return rc;
+      if (ct.add_if_new(sig.data()) && (rc = accept(0))) return rc;
+    }
+    if (n_total) *n_total = h->B;
+    return TEB_AMD_OK;
+  }
+  // ---- vertices (host: O(M) on the centroids kept from teb_amd_set_obstacles) ------------------------------------------------------
+  auto normalize = [](double& x, double& y) { const double z = x * x + y * y; if (z > 0) { const double n = std::sqrt(z); x = x / n; y = y / n; } };
+  std::vector<double> vx{sx}, vy{sy};
+  GraphArgs ga;
+  ga.keypoint = p->simple_exploration ? 1 : 0; ga.near_u = ga.near_v = -1; ga.thr = p->obstacle_heading_threshold;
+  ga.sox = std::cos(start[2]); ga.soy = std::sin(start[2]);
+  if (p->simple_exploration) {                                              // lrKeyPointGraph::createGraph, :115-153
+    double nx = -dfy, ny = dfx;
+    normalize(nx, ny);
+    nx = nx * dist_to_obst; ny = ny * dist_to_obst;
+    normalize(dfx, dfy);
+    double min_dist = std::numeric_limits<double>::max();
+    for (int o = 0; o < M; ++o) {
+      const double ox = h->host_cx[o] - sx, oy = h->host_cy[o] - sy;
+      const double dist = std::sqrt(ox * ox + oy * oy);
+      if ((ox * dfx + oy * dfy) / dist < 0.1) continue;                     // obstacle not in front of the start
+      vx.push_back(h->host_cx[o] + nx); vy.push_back(h->host_cy[o] + ny);
+      vx.push_back(h->host_cx[o] - nx); vy.push_back(h->host_cy[o] - ny);
+      if (p->obstacle_heading_threshold && dist < min_dist) { min_dist = dist; ga.near_u = (int)vx.size() - 2; ga.near_v = (int)vx.size() - 1; }
+    }
+    ga.min_dist = 0.5 * dist_to_obst;
+  } else {                                                                  // ProbRoadmapGraph::createGraph, :247-290
+    double nx = -dfy, ny = dfx;
+    normalize(nx, ny);
+    const double area_width = p->roadmap_graph_area_width;
+    const double len = start_goal_dist * p->roadmap_graph_area_length_scale;
+    const double phi = std::atan2(dfy, dfx);
+    double ox, oy;
+    if (p->roadmap_graph_area_length_scale != 1.0) {
+      double ux = dfx, uy = dfy;
+      normalize(ux, uy);
+      const double f = 0.5 * (1.0 - p->roadmap_graph_area_length_scale) * start_goal_dist, w2 = 0.5 * area_width;
+      ox = (sx + f * ux) - w2 * nx; oy = (sy + f * uy) - w2 * ny;
+    } else {
+      const double w2 = 0.5 * area_width;
+      ox = sx - w2 * nx; oy = sy - w2 * ny;
+    }
+    normalize(dfx, dfy);
+    int drawn = 0;
+    auto draw = [&](double a, double b) {    // boost::random::uniform_real_distribution<double>(a, b) on the 32-bit engine
+      if (unit_samples) return unit_samples[drawn++] * (b - a) + a;
+      for (;;) {
+        const double numerator = (double)(h->rnd_generator() - std::mt19937::min());
+        const double divisor = (double)(std::mt19937::max() - std::mt19937::min()) + 1;
+        const double result = numerator / divisor * (b - a) + a;
+        if (result < b) return result;
+      }
+    };
+    const double cphi = std::cos(phi), sphi = std::sin(phi);
+    for (int i = 0; i < p->roadmap_graph_no_samples; ++i) {
+      const double uy = draw(0, area_width);   // GCC evaluates Eigen::Vector2d(distribution_x(g), distribution_y(g)) right to left
+      const double ux = draw(0, len);
+      vx.push_back(ox + (cphi * ux - sphi * uy)); vy.push_back(oy + (sphi * ux + cphi * uy));
+    }
+    ga.min_dist = dist_to_obst;
+  }
+  vx.push_back(gx); vy.push_back(gy);
+  const int N = (int)vx.size();
+  if (n_vertices) *n_vertices = N;
+  if (N - 1 > h->stride) return fail(TEB_AMD_ERR_CAPACITY, "graph has more vertices than a band has poses (max_poses)");
+  // ---- edges (device) -------------------------------------------------------------------------------------------------------------
+  if (h->g_vx.n < (size_t)N) { h->g_vx.free(); h->g_vy.free(); HIPCHK(h->g_vx.alloc(N)); HIPCHK(h->g_vy.alloc(N)); }
+  if (h->g_adj.n < (size_t)N * N) { h->g_adj.free(); HIPCHK(h->g_adj.alloc((size_t)N * N)); }
+  HIPCHK(hipMemcpyAsync(h->g_vx.p, vx.data(), N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->g_vy.p, vy.data(), N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  ga.N = N; ga.gx = h->g_vx.p; ga.gy = h->g_vy.p; ga.dnx = dfx; ga.dny = dfy; ga.adj = h->g_adj.p;
+  const long long pairs = (long long)N * N;
+  hipLaunchKernelGGL(graph_edges_kernel, dim3((unsigned)((pairs + kThreads - 1) / kThreads)), dim3(kThreads), 0, h->stream, scene_of(h), ga);
+  HIPCHK(hipGetLastError());
+  std::vector<unsigned char> adjm((size_t)pairs);
+  HIPCHK(hipMemcpyAsync(adjm.data(), h->g_adj.p, (size_t)pairs, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->g_cap = N;
+  std::vector<std::vector<int>> adj(N);
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) if (adjm[(size_t)i * N + j]) adj[i].push_back(j);   // add_edge order of the double loop
+  // ---- paths in depth-first order, a chunk at a time: init + signature on the device, first come first served on the host ----------
+  PathEnumerator en(adj, 0, N - 1);
+  std::vector<int> path, off;
+  std::vector<double> px, py;
+  int64_t examined = 0;
+  bool more = true;
+  while (more && h->B < slots) {
+    off.assign(1, 0); px.clear(); py.clear();
+    int count = 0;
+    while (count < kCandChunk && (max_paths <= 0 || examined + count < max_paths)) {
+      if (!en.next(path)) { more = false; break; }
+      for (int v : path) { px.push_back(vx[v]); py.push_back(vy[v]); }
+      off.push_back((int)px.size());
+      ++count;
+    }
+    if (count == kCandChunk && max_paths > 0 && examined + count >= max_paths) more = false;
+    if (count == 0) break;
+    HIPCHK(hipMemcpyAsync(h->cand_off.p, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->cand_px.p, px.data(), px.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->cand_py.p, py.data(), py.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->err_flag.p, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(init_path_batch_kernel, dim3(count), dim3(kThreads), 0, h->stream, candidates_of(h), h->cand_off.p, h->cand_px.p,
+                       h->cand_py.p, c.max_vel_x, c.acc_lim_x, start[2], goal[2], c.min_samples, p->allow_init_with_backwards_motion,
+                       h->err_flag.p);
+    HIPCHK(hipGetLastError());
+    if ((rc = classify(count))) return rc;
+    for (int k = 0; k < count && h->B < slots; ++k) {
+      ++examined;
+      if (ct.add_if_new(sig.data() + (size_t)k * W) && (rc = accept(k))) return rc;
+    }
+  }
+  if (n_paths) *n_paths = (int32_t)std::min<int64_t>(examined, std::numeric_limits<int32_t>::max());
+  if (n_total) *n_total = h->B;
+  return TEB_AMD_OK;
+}
+
+int teb_amd_get_exploration_graph(teb_amd_handle_t* h, double* vx, double* vy, unsigned char* adjacency, int32_t capacity_vertices,
+                                  int32_t* n_vertices) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  const int N = (int)h->g_cap;
+  if (n_vertices) *n_vertices = N;
+  if (N == 0 || (!vx && !vy && !adjacency)) return TEB_AMD_OK;
+  if (capacity_vertices < N) return fail(TEB_AMD_ERR_CAPACITY, "graph has more vertices than capacity_vertices");
+  if (vx) HIPCHK(hipMemcpyAsync(vx, h->g_vx.p, N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (vy) HIPCHK(hipMemcpyAsync(vy, h->g_vy.p, N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (adjacency) HIPCHK(hipMemcpyAsync(adjacency, h->g_adj.p, (size_t)N * N, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return TEB_AMD_OK;
+}
+
+int teb_amd_compact_bands(teb_amd_handle_t* h, const int32_t* keep, int32_t best, int32_t* n_kept, int32_t* new_best) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!keep) return fail(TEB_AMD_ERR_INVALID_ARG, "null keep");
+  const int B = h->B;
+  if (new_best) *new_best = -1;
+  if (n_kept) *n_kept = 0;
+  if (B <= 0) return TEB_AMD_OK;
+  if (!h->tmp_ready) {
+    const size_t BS = (size_t)h->max_tebs * h->stride;
+    bool ok = true;
+    auto A = [&](hipError_t e) { if (e != hipSuccess) ok = false; };
+    A(h->tmp_x.alloc(BS)); A(h->tmp_y.alloc(BS)); A(h->tmp_th.alloc(BS)); A(h->tmp_dt.alloc(BS)); A(h->tmp_n.alloc(h->max_tebs));
+    A(h->tmp_vs.alloc(3 * (size_t)h->max_tebs)); A(h->tmp_vg.alloc(3 * (size_t)h->max_tebs)); A(h->tmp_i.alloc(7 * (size_t)h->max_tebs));
+    A(h->tmp_chi2.alloc(h->max_tebs)); A(h->tmp_cost.alloc(h->max_tebs)); A(h->tmp_lambda.alloc(h->max_tebs));
+    if (!h->cand_ready && ensure_candidate_buffers(h) != TEB_AMD_OK) ok = false;
+    if (!ok) return fail(TEB_AMD_ERR_HIP, "compaction scratch allocation failed");
+    h->tmp_ready = true;
+  }
+  std::vector<int> order(B), map;
+  for (int b = 0; b < B; ++b) order[b] = b;
+  const bool has_best = best >= 0 && best < B;
+  if (has_best) std::swap(order[0], order[best]);   // std::iter_swap(tebs_.begin(), it_best_teb)
+  for (int k = 0; k < B; ++k) if (keep[order[k]]) map.push_back(order[k]);
+  const int K = (int)map.size();
+  if (has_best && keep[best] && new_best) *new_best = 0;
+  if (n_kept) *n_kept = K;
+  bool identity = true;
+  for (int k = 0; k < K; ++k) if (map[k] != k) identity = false;
+  if (!identity && K > 0) {
+    BatchDev src = batch_of(h), tmp = src;
+    tmp.n = h->tmp_n.p; tmp.x = h->tmp_x.p; tmp.y = h->tmp_y.p; tmp.th = h->tmp_th.p; tmp.dt = h->tmp_dt.p;
+    tmp.has_vs = h->tmp_i.p; tmp.has_vg = h->tmp_i.p + h->max_tebs; tmp.rotdir = h->tmp_i.p + 2 * (size_t)h->max_tebs;
+    tmp.via_en = h->tmp_i.p + 3 * (size_t)h->max_tebs; tmp.status = h->tmp_i.p + 4 * (size_t)h->max_tebs;
+    tmp.iters = h->tmp_i.p + 5 * (size_t)h->max_tebs; tmp.trials = h->tmp_i.p + 6 * (size_t)h->max_tebs;
+    tmp.vs = h->tmp_vs.p; tmp.vg = h->tmp_vg.p; tmp.chi2 = h->tmp_chi2.p; tmp.cost = h->tmp_cost.p; tmp.lambda = h->tmp_lambda.p;
+    std::vector<int> ident(K);
+    for (int k = 0; k < K; ++k) ident[k] = k;
+    HIPCHK(hipMemcpyAsync(h->cand_map.p, map.data(), K * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(move_bands_kernel, dim3(K), dim3(kThreads), 0, h->stream, src, tmp, h->cand_map.p, 0, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpyAsync(h->cand_map.p, ident.data(), K * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(move_bands_kernel, dim3(K), dim3(kThreads), 0, h->stream, tmp, src, h->cand_map.p, 0, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  h->B = K;
+  h->consumers_valid = false;
+  h->hsig_mode = 0;
   return TEB_AMD_OK;
 }
 

@@ -131,51 +131,6 @@ __global__ void init_plan_kernel(BatchDev bt, int b, int np, const double* px, c
   }
 }
 
-// template initTrajectoryToGoal(path_start, path_end, fun_position, ...), timed_elastic_band.hpp:46-183. One workgroup.
-__global__ void init_path_kernel(BatchDev bt, int b, int np, const double* px, const double* py, double max_vel_x,
-                                 int has_max_acc_x, double max_acc_x, int has_start_orient, double start_orientation,
-                                 int has_goal_orient, double goal_orientation, int min_samples, int guess_backwards, int* err) {
-  StripDev s = strip_of(bt, b);
-  const double sx = px[0], sy = py[0], gx = px[np - 1], gy = py[np - 1];
-  bool backwards = false;
-  double start_orient;
-  if (has_start_orient) {
-    start_orient = start_orientation;
-    if (guess_backwards && ((gx - sx) * cos(start_orient) + (gy - sy) * sin(start_orient)) < 0) backwards = true;
-  } else start_orient = atan2(gy - sy, gx - sx);
-  const double goal_orient = has_goal_orient ? goal_orientation : start_orient;
-  const int n = np >= 2 ? np - 1 : 1;
-  if (n > s.cap) { if (threadIdx.x == 0) { *err = 1; *s.n = 0; } return; }
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    if (i == 0) { s.x[0] = sx; s.y[0] = sy; s.th[0] = start_orient; continue; }
-    const double dlx = px[i] - px[i - 1], dly = py[i] - py[i - 1];   // curr_point - Pose(idx).position(): the previous path point
-    const double diff_norm = nrm2(dlx, dly);
-    const double timestep_vel = diff_norm / max_vel_x;
-    double timestep;
-    if (has_max_acc_x) {
-      const double timestep_acc = sqrt(2 * diff_norm / max_acc_x);
-      timestep = (timestep_vel < timestep_acc) ? timestep_acc : timestep_vel;
-    } else timestep = timestep_vel;
-    if (timestep <= 0) timestep = 0.2;
-    double yaw = atan2(dly, dlx);
-    if (backwards) yaw = normalize_theta(yaw + M_PI);
-    s.x[i] = px[i]; s.y[i] = py[i]; s.th[i] = yaw; s.dt[i - 1] = timestep;
-  }
-  __threadfence_block();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const double diff_norm = nrm2(gx - s.x[n - 1], gy - s.y[n - 1]);
-    const double timestep_vel = diff_norm / max_vel_x;
-    double timestep;
-    if (has_max_acc_x) {
-      const double timestep_acc = sqrt(2 * diff_norm / max_acc_x);
-      timestep = (timestep_vel < timestep_acc) ? timestep_acc : timestep_vel;
-    } else timestep = timestep_vel;
-    const int r = init_tail<2>(s, n, gx, gy, goal_orient, max_vel_x, 0.0, timestep, min_samples);
-    if (r < 0) { *err = 1; *s.n = 0; } else *s.n = r;
-  }
-}
-
 // updateAndPruneTEB, :555-597. One workgroup per band (blockIdx.x + b0). Dynamic LDS: 4 * stride doubles.
 __global__ void prune_kernel(BatchDev bt, int b0, int has_start, double sx, double sy, double sth, int has_goal, double gx,
                              double gy, double gth, int min_samples) {

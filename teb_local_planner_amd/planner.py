@@ -78,6 +78,12 @@ def lib():
         L.teb_amd_has_diverged.argtypes = [vp, i32, _abi.p_i32]
         L.teb_amd_compute_h_signatures.argtypes = [vp, d, _abi.p_f64, _abi.p_i32]
         L.teb_amd_filter_equivalence_classes.argtypes = [vp, d, i32, i32, _abi.p_i32, _abi.p_i32, _abi.p_i32]
+        L.teb_amd_explore_candidates.argtypes = [vp, C.POINTER(_abi.HcpParams), _abi.p_f64, _abi.p_f64, d, _abi.p_f64, i32, i32,
+                                                 _abi.p_f64, C.c_int64, _abi.p_i32, _abi.p_i32, _abi.p_i32]
+        L.teb_amd_get_exploration_graph.argtypes = [vp, _abi.p_f64, _abi.p_f64, C.POINTER(C.c_ubyte), i32, _abi.p_i32]
+        L.teb_amd_compact_bands.argtypes = [vp, _abi.p_i32, i32, _abi.p_i32, _abi.p_i32]
+        L.teb_amd_hcp_params_default.argtypes = [C.POINTER(_abi.HcpParams)]
+        L.teb_amd_hcp_params_default.restype = None
         _LIB = L
     return _LIB
 
@@ -276,6 +282,44 @@ class TebBatchSolver:
         _chk(lib().teb_amd_filter_equivalence_classes(self._h, threshold, best, max_number_plans_in_current_class, I(keep), I(valid),
                                                       I(reas)), "teb_amd_filter_equivalence_classes")
         return keep, valid, reas
+
+    # -- candidate generation: createGraph + DepthFirst + addAndInitNewTeb -----------------
+    def compact_bands(self, keep, best=-1):
+        """Keeps the bands with keep[b] != 0, last best band first (renewAndAnalyzeOldTebs): (n_kept, new_best)."""
+        keep = _abi.i32(keep)
+        nk = C.c_int32(0); nb = C.c_int32(-1)
+        _chk(lib().teb_amd_compact_bands(self._h, _abi._ptr(keep, C.c_int32), int(best), C.byref(nk), C.byref(nb)),
+             "teb_amd_compact_bands")
+        self.count = nk.value
+        return nk.value, nb.value
+
+    def explore_candidates(self, start, goal, dist_to_obst=None, start_vel=None, free_goal_vel=False, best=-1, unit_samples=None,
+                           max_paths=0, params=None):
+        """exploreEquivalenceClassesAndInitTebs after renewAndAnalyzeOldTebs on the resident batch: dict(n_total, n_vertices, n_paths)."""
+        p = params if params is not None else self.cfg.hcp_params()
+        st = _abi.f64(start); gl = _abi.f64(goal)
+        sv = None if start_vel is None else _abi.f64(start_vel)
+        us = None if unit_samples is None else _abi.f64(np.asarray(unit_samples).ravel())
+        dist_to_obst = self.cfg.obstacles.min_obstacle_dist if dist_to_obst is None else dist_to_obst
+        nt = C.c_int32(0); nv = C.c_int32(0); npth = C.c_int32(0)
+        _chk(lib().teb_amd_explore_candidates(self._h, C.byref(p), _abi._ptr(st, C.c_double), _abi._ptr(gl, C.c_double),
+                                              float(dist_to_obst), _abi._ptr(sv, C.c_double), int(bool(free_goal_vel)), int(best),
+                                              _abi._ptr(us, C.c_double), int(max_paths), C.byref(nt), C.byref(nv), C.byref(npth)),
+             "teb_amd_explore_candidates")
+        self.count = nt.value
+        return dict(n_total=nt.value, n_vertices=nv.value, n_paths=npth.value)
+
+    def exploration_graph(self):
+        """(vertices [N, 2], adjacency [N, N] uint8) of the last explore_candidates call."""
+        nv = C.c_int32(0)
+        _chk(lib().teb_amd_get_exploration_graph(self._h, None, None, None, 0, C.byref(nv)), "teb_amd_get_exploration_graph")
+        N = nv.value
+        vx = np.zeros(max(N, 1)); vy = np.zeros(max(N, 1)); adj = np.zeros((max(N, 1), max(N, 1)), np.uint8)
+        if N:
+            _chk(lib().teb_amd_get_exploration_graph(self._h, _abi._ptr(vx, C.c_double), _abi._ptr(vy, C.c_double),
+                                                     adj.ctypes.data_as(C.POINTER(C.c_ubyte)), N, C.byref(nv)),
+                 "teb_amd_get_exploration_graph")
+        return np.stack([vx[:N], vy[:N]], 1), adj[:N, :N]
 
     # -- test hooks -----------------------------------------------------------------------------------
     def debug_linearize(self, b, n, weight_multiplier=1.0, assoc_cap=1 << 16):

@@ -1,0 +1,178 @@
+"""SURVEY section 8(f) row f3, candidate generation: HomotopyClassPlanner::exploreEquivalenceClassesAndInitTebs through the C-ABI
+(teb_amd_compute_h_signatures / teb_amd_filter_equivalence_classes / teb_amd_compact_bands / teb_amd_explore_candidates; kernels in
+teb_graph.hpp) against the CPU oracle - which is bit-equal to the reference's own graph_search.cpp + homotopy_class_planner.hpp on
+these cases (tests/test_reference_pinning.py) - and against the committed vectors of the reference code.
+
+What is compared, and how tightly:
+  * graph vertices: the same IEEE expressions evaluated on the host side of the library: <= 1e-12;
+  * graph edges (N^2 * M collision tests on the device, no transcendental function): identical;
+  * number of bands and every band: the device evaluates atan2 / sqrt where the reference does: <= 1e-12 absolute;
+  * the order in which classes are discovered (= band order): identical."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, HERE)
+import make_ref_golden as RG  # noqa: E402
+from test_reference_pinning import renew_on_host  # noqa: E402
+
+from teb_local_planner_amd import planner, _abi, scenes  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def _make(case, max_tebs=16, stride=256):
+    cfg, obst, batch = case["cfg"], case["obst"], case["batch"]
+    s = planner.TebBatchSolver(cfg, max_tebs, stride, max(len(obst), 1), max(len(obst.vert_x), 1), 1)
+    s.set_obstacles(obst)
+    s.set_via_points([])
+    if batch is not None:
+        s.upload(batch)
+    return s
+
+
+def _renew_on_device(s, case):
+    """renewAndAnalyzeOldTebs with the C-ABI pieces; returns the new index of the best band."""
+    cfg = case["cfg"]
+    if case["batch"] is None:
+        return -1
+    s.h_signatures(cfg.hcp.h_signature_prescaler)
+    keep, _, _ = s.filter_equivalence_classes(cfg.hcp.h_signature_threshold, case["best"], cfg.hcp.max_number_plans_in_current_class)
+    _, best = s.compact_bands(keep, case["best"])
+    return best
+
+
+def _explore(s, case, best):
+    return s.explore_candidates(case["start"], case["goal"], dist_to_obst=case.get("dist_to_obst"), start_vel=case.get("start_vel"),
+                                free_goal_vel=case.get("free_goal_vel", False), best=best)
+
+
+def _bands(s, stride=256):
+    b = _abi.TebBatchHost(max(s.count, 1), stride)
+    if s.count:
+        s.download(b)
+    return [b.get_teb(k) for k in range(s.count)]
+
+
+@pytest.mark.parametrize("name", sorted(RG.explore_cases()))
+def test_explore_candidates_matches_oracle_and_reference_vectors(oracle, name):
+    case = RG.explore_cases()[name]
+    g = np.load(os.path.join(HERE, "golden", "ref_f3_explore.npz"))
+    ref = {k[len(name) + 2:]: g[k] for k in g.files if k.startswith(name + "__")}
+    s = _make(case)
+    best = _renew_on_device(s, case)
+    if case.get("skip_draws"):   # "second call": the handle's generator has produced the samples of an earlier graph already
+        p = case["cfg"].hcp_params()
+        assert case["skip_draws"] == 2 * p.roadmap_graph_no_samples
+        _explore(s, case, best)
+        s.compact_bands(np.zeros(s.count, np.int32))
+        assert s.count == 0
+    r = _explore(s, case, best)
+    b, n_tebs, obest = renew_on_host(oracle, case)
+    assert obest == best
+    o = oracle.explore_candidates(case["cfg"], case["obst"], b, n_tebs, obest, case["start"], case["goal"],
+                                  skip_draws=case.get("skip_draws", 0), dist_to_obst=case.get("dist_to_obst"))
+    assert r["n_total"] == o["n_total"] == int(ref["n_total"]) == s.count
+    assert r["n_vertices"] == len(o["vertices"])
+    if r["n_total"] > n_tebs or name == "max_two_classes":
+        assert r["n_paths"] <= o["n_paths"] or o["n_paths"] == 0   # the device may stop inside a chunk exactly where the oracle stops
+    V, A = s.exploration_graph()
+    if len(o["vertices"]):
+        assert np.abs(V - o["vertices"]).max() <= TOL
+        assert np.abs(V - ref["vertices"]).max() <= TOL
+        np.testing.assert_array_equal(A, ref["adjacency"])
+    got = _bands(s)
+    for k in range(r["n_total"]):
+        want = o["batch"].get_teb(k)
+        for u, v, w in zip(got[k], want, RG.unpack(ref, k)):
+            assert len(u) == len(v) == len(w)
+            assert np.abs(u - v).max(initial=0) <= TOL and np.abs(u - w).max(initial=0) <= TOL
+    s.close()
+
+
+def test_new_bands_carry_start_velocity_and_free_goal_flags(oracle):
+    """setVelocityStart / setVelocityGoalFree of addAndInitNewTeb, observed through the optimiser: the new bands optimise like oracle
+    bands with the same flags, and differently from bands with the default (fixed, zero) velocities."""
+    case = RG.explore_cases()["backwards_start_velocity_free_goal"]
+    cfg = case["cfg"]
+    s = _make(case)
+    r = _explore(s, case, -1)
+    n = r["n_total"]
+    assert n >= 2
+    host = _abi.TebBatchHost(n, 256)
+    s.download(host)
+    host.vel_start[:] = case["start_vel"]; host.has_vel_goal[:] = 0
+    s.optimize(cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations)
+    s.synchronize()
+    got = _abi.TebBatchHost(n, 256)
+    s.download(got)
+    want, _ = oracle.optimize_batch(cfg, case["obst"], [], host)
+    plain = host.copy(); plain.vel_start[:] = 0; plain.has_vel_goal[:] = 1
+    other, _ = oracle.optimize_batch(cfg, case["obst"], [], plain)
+    for k in range(n):
+        assert got.n[k] == want.n[k]
+        m = int(got.n[k])
+        d_same = max(np.abs(got.x[k, :m] - want.x[k, :m]).max(), np.abs(got.dt[k, :m - 1] - want.dt[k, :m - 1]).max())
+        assert d_same <= 1e-6, (k, d_same)
+        if other.n[k] == want.n[k]:
+            assert np.abs(other.dt[k, :m - 1] - want.dt[k, :m - 1]).max() > 100 * max(d_same, 1e-9)
+    s.close()
+
+
+def test_compact_bands_moves_attributes_and_keeps_reference_order(oracle):
+    cfg, obst, via, batch = scenes.scene_small_mixed(B=6, n=24, seed=3, with_via=False)
+    batch.vel_start[:] = np.arange(18).reshape(6, 3) * 0.01
+    s = planner.make_solver(cfg, obst, [], batch, max_tebs=8)
+    keep = np.array([1, 0, 1, 1, 0, 1], np.int32)
+    nk, nb = s.compact_bands(keep, best=3)
+    assert (nk, nb) == (4, 0) and s.count == 4
+    order = [3, 2, 0, 5]          # iter_swap(first, best) then erase: [3, 1, 2, 0, 4, 5] minus the dropped ones
+    got = _bands(s, batch.stride)
+    for k, b in enumerate(order):
+        for u, v in zip(got[k], batch.get_teb(b)):
+            np.testing.assert_array_equal(u, v)
+    # attributes travel with the band: optimise and compare with the oracle on the reordered host batch
+    host = _abi.TebBatchHost(4, batch.stride)
+    for k, b in enumerate(order):
+        host.set_teb(k, *batch.get_teb(b)); host.vel_start[k] = batch.vel_start[b]
+    s.optimize(cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations)
+    s.synchronize()
+    dev = _abi.TebBatchHost(4, batch.stride)
+    s.download(dev)
+    want, _ = oracle.optimize_batch(cfg, obst, [], host)
+    for k in range(4):
+        m = int(want.n[k])
+        assert dev.n[k] == m and np.abs(dev.x[k, :m] - want.x[k, :m]).max() <= 1e-6
+    nk, nb = s.compact_bands(np.array([0, 1, 0, 0], np.int32), best=0)
+    assert (nk, nb) == (1, -1)
+    s.close()
+
+
+def test_large_keypoint_graph_all_pairs_on_the_device(oracle):
+    """160 point obstacles -> up to 322 vertices (a band holds one pose per path vertex: max_poses bounds the graph), 10^5 ordered pairs
+    x 160 obstacles on the device; adjacency identical to the oracle's."""
+    rng = np.random.default_rng(12)
+    cfg = RG.explore_cases()["keypoint_points_2d"]["cfg"]
+    cfg.hcp.max_number_classes = 3
+    ob = _abi.ObstacleTable()
+    for _ in range(160):
+        ob.add_point(rng.uniform(0.5, 19.5), rng.uniform(-4, 4))
+    case = dict(cfg=cfg, obst=ob, batch=None, best=-1, start=[0, 0, 0], goal=[20, 0, 0])
+    s = _make(case, max_tebs=4, stride=336)
+    r = s.explore_candidates(case["start"], case["goal"], max_paths=256)
+    b = _abi.TebBatchHost(4, 336)
+    o = oracle.explore_candidates(cfg, ob, b, 0, -1, case["start"], case["goal"], vcap=1024, max_paths=256)
+    V, A = s.exploration_graph()
+    assert r["n_vertices"] == len(o["vertices"]) == len(V) > 250
+    assert np.abs(V - o["vertices"]).max() <= TOL
+    want = np.zeros_like(A)
+    for i, row in enumerate(o["adjacency"]):
+        want[i, row] = 1
+    np.testing.assert_array_equal(A, want)
+    assert A.sum() > 100
+    s.close()

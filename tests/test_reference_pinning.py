@@ -287,6 +287,67 @@ def test_f3_h_signatures_and_equivalence_match_reference(oracle, mode):
     assert classes_seen >= 3
 
 
+# ---- SURVEY section 8(f) row f3, candidate generation: graph_search.cpp + addAndInitNewTeb -----------------------------------------
+
+def renew_on_host(oracle, case, slots=None):
+    """renewAndAnalyzeOldTebs on the existing bands with the oracle's signature / filter functions: (batch with `slots` slots holding the
+    kept bands in the reference's order, n_tebs, best)."""
+    cfg, obst, batch, best = case["cfg"], case["obst"], case["batch"], case["best"]
+    slots = slots or cfg.hcp.max_number_classes + (batch.count if batch is not None else 0)
+    stride = batch.stride if batch is not None else 256
+    out = _abi.TebBatchHost(slots, stride)
+    if batch is None:
+        return out, 0, -1
+    mode = 3 if cfg.obstacles.include_dynamic_obstacles else 2
+    sig = oracle.h_signatures(cfg, obst, batch, mode, cfg.hcp.h_signature_prescaler)
+    keep, _, _ = oracle.filter_equivalence_classes(mode, sig, cfg.hcp.h_signature_threshold, best, cfg.hcp.max_number_plans_in_current_class)
+    order = list(range(batch.count))
+    if best >= 0:
+        order[0], order[best] = order[best], order[0]
+    kept = [b for b in order if keep[b]]
+    for k, b in enumerate(kept):
+        out.set_teb(k, *batch.get_teb(b))
+    return out, len(kept), (0 if best >= 0 and keep[best] else -1)
+
+
+@pytest.mark.parametrize("name", sorted(G.explore_cases()))
+def test_f3_candidate_generation_matches_reference_graph_search(oracle, name):
+    """createGraph (both graph types), DepthFirst and addAndInitNewTeb: vertices, edges and every resulting band bit-equal to the
+    reference's own src/graph_search.cpp / homotopy_class_planner.hpp run on the same inputs."""
+    case = G.explore_cases()[name]
+    r = _ref()
+    ref = G.explore_reference(r, case) if r is not None else None
+    if ref is None:
+        g = np.load(os.path.join(HERE, "golden", "ref_f3_explore.npz"))
+        ref = {k[len(name) + 2:]: g[k] for k in g.files if k.startswith(name + "__")}
+    b, n_tebs, best = renew_on_host(oracle, case)
+    o = oracle.explore_candidates(case["cfg"], case["obst"], b, n_tebs, best, case["start"], case["goal"], skip_draws=case.get("skip_draws", 0),
+                                  dist_to_obst=case.get("dist_to_obst"))
+    assert o["n_total"] == int(ref["n_total"])
+    np.testing.assert_array_equal(o["vertices"], ref["vertices"])
+    N = len(o["vertices"])
+    adj = np.zeros((N, N), np.uint8)
+    for i, row in enumerate(o["adjacency"]):
+        adj[i, row] = 1
+    np.testing.assert_array_equal(adj, ref["adjacency"])
+    for k in range(o["n_total"]):
+        for a, e in zip(o["batch"].get_teb(k), G.unpack(ref, k)):
+            np.testing.assert_array_equal(a, e)
+
+
+def test_f3_candidate_cases_cover_both_graphs_and_find_several_classes(oracle):
+    seen = {}
+    for name, case in G.explore_cases().items():
+        b, n_tebs, best = renew_on_host(oracle, case)
+        o = oracle.explore_candidates(case["cfg"], case["obst"], b, n_tebs, best, case["start"], case["goal"], skip_draws=case.get("skip_draws", 0),
+                                  dist_to_obst=case.get("dist_to_obst"))
+        seen[name] = (n_tebs, o["n_total"], o["n_paths"])
+    assert seen["keypoint_12_obstacles"][1] >= 5 and seen["roadmap_points_3d"][1] >= 3
+    assert seen["goal_reached_line_init"] == (0, 1, 0) and seen["already_full"][1] == seen["already_full"][0] == 2
+    assert seen["roadmap_existing_tebs_best"][0] == 4          # 5 bands in 3 classes, 2 allowed in the best band's class
+    assert seen["max_two_classes"][1] == 2
+
+
 # ---- randomised pin: every option toggled at random, whole optimizeTEB, oracle vs the reference's src/optimal_planner.cpp ----------
 @pytest.mark.parametrize("seed", range(40))
 def test_randomized_optimizeTEB_is_bit_equal_to_reference_code(oracle, seed):
