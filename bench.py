@@ -193,6 +193,40 @@ def main():
                 ts.append(time.perf_counter() - t1)
             lat[name + "_device_resident_p50_ms"] = 1e3 * float(np.median(ts))
             s2.close()
+        if args.latency_reps > 0:
+            # whole HomotopyClassPlanner::plan() tick on device-resident bands: updateAllTEBs, H-signatures +
+            # class filter + detour deletion + compaction, roadmap graph (15 samples) with all-pairs collision tests, depth-first
+            # candidate paths -> band init + signatures, optimizeAllTEBs (4x5, autosize), selectBestTeb, velocity command
+            hc = scenes.scene_c4(B=1, n=n)[0]
+            hc.hcp.max_number_classes = 5
+            rng = np.random.default_rng(3)
+            hob = _abi.ObstacleTable()
+            for _ in range(30):
+                hob.add_point(rng.uniform(1.5, 14.5), rng.uniform(-3.0, 3.0))
+            ticks = max(8, args.latency_reps)
+            starts = [[0.05 * k, 0.0, 0.0] for k in range(ticks)]
+            goals = [[16.0, 0.0, 0.0]] * ticks
+            hp = planner.HomotopyClassPlanner(hc, hob, [], None, max_tebs=8, max_poses=256)
+            ts, nb = [], []
+            for k in range(ticks):
+                t1 = time.perf_counter()
+                hp.plan(starts[k], goals[k], [0.3, 0.0, 0.0])
+                hp.getVelocityCommand()
+                ts.append(time.perf_counter() - t1)
+                nb.append(hp.solver.count)
+            hp.solver.close()
+            lat["hcp_plan_tick_p50_ms"] = 1e3 * float(np.median(ts[1:]))
+            lat["hcp_plan_tick"] = {"workload": "HomotopyClassPlanner::plan() ticks on one planner: 16 m straight task, 30 point obstacles, "
+                                                "roadmap graph (15 samples), max_number_classes 5, 4x5 iterations, teb_autosize on",
+                                    "ticks": ticks, "first_tick_ms": 1e3 * ts[0], "bands_per_tick": [int(min(nb)), int(max(nb))]}
+            try:
+                from oracle import ref_py
+                if os.path.exists(ref_py.SO):
+                    t1 = time.perf_counter()
+                    ref_py.hcp_plan_ticks(hc, hob, starts, goals, [[0.3, 0.0, 0.0]] * ticks)
+                    lat["hcp_plan_tick"]["reference_code_cpu_ms_per_tick"] = 1e3 * (time.perf_counter() - t1) / ticks
+            except Exception as e:
+                lat["hcp_plan_tick"]["reference_code_cpu_ms_per_tick"] = str(e)[:120]
         out["plan_latency"] = lat
         # ---- secondary numbers: C4 with autoResize switched off (every band keeps exactly 200 poses, block-form normal matrix in
         #      LDS - the fastest configuration of the kernel) and BASELINE configs[2] (64 x 150 poses, 200 obstacles, defaults)

@@ -287,7 +287,10 @@ typedef struct teb_amd_hcp_params {
   double  h_signature_prescaler;              /* hcp.h_signature_prescaler                                                  */
   double  h_signature_threshold;              /* hcp.h_signature_threshold                                                  */
   int32_t allow_init_with_backwards_motion;   /* trajectory.allow_init_with_backwards_motion                                */
-  int32_t reserved;
+  int32_t delete_detours_backwards;           /* hcp.delete_detours_backwards                                               */
+  double  detours_orientation_tolerance;      /* hcp.detours_orientation_tolerance                                          */
+  double  length_start_orientation_vector;    /* hcp.length_start_orientation_vector                                        */
+  double  max_ratio_detours_duration_best_duration; /* hcp.max_ratio_detours_duration_best_duration                        */
 } teb_amd_hcp_params_t;
 void teb_amd_hcp_params_default(teb_amd_hcp_params_t* p);   /* the defaults of teb_config.h:330-360 */
 /*
@@ -318,6 +321,21 @@ int  teb_amd_get_exploration_graph(teb_amd_handle_t* h, double* vx, double* vy, 
  * batch shrinks to them. *n_kept = batch size afterwards, *new_best = position of the best band afterwards (0) or -1.
  */
 int  teb_amd_compact_bands(teb_amd_handle_t* h, const int32_t* keep, int32_t best, int32_t* n_kept, int32_t* new_best);
+/*
+ * HomotopyClassPlanner::deletePlansDetouringBackwards (src/homotopy_class_planner.cpp:766-838), the second half of
+ * renewAndAnalyzeOldTebs when hcp.delete_detours_backwards: keep [B] in/out - bands with keep[b] = 0 (erased by
+ * teb_amd_filter_equivalence_classes) are not looked at; a remaining band other than the last best one (best) is dropped when it
+ * has fewer than 2 poses, no pose further than length_start_orientation_vector from its start, a start direction more than
+ * detours_orientation_tolerance away from the best band's, was not optimised by the last teb_amd_optimize_batch call
+ * (TebOptimalPlanner::isOptimized), or lasts more than max_ratio_detours_duration_best_duration times the best band's duration.
+ * Start directions and durations of all bands are computed in one launch. Call before teb_amd_compact_bands.
+ */
+int  teb_amd_filter_detours(teb_amd_handle_t* h, const teb_amd_hcp_params_t* p, int32_t best, int32_t* keep);
+/* TebOptimalPlanner::optimized_ (optimal_planner.h:386, 691) of the resident bands: set by teb_amd_optimize_batch exactly as
+ * optimizeTEB sets it (src/optimal_planner.cpp:189, 220), cleared by teb_amd_upload_tebs and for new bands; flags [B] overrides it
+ * for bands whose history lives on the host (get: flags receives the current values). */
+int  teb_amd_set_optimized_flags(teb_amd_handle_t* h, const int32_t* flags);
+int  teb_amd_get_optimized_flags(teb_amd_handle_t* h, int32_t* flags);
 /* Device pointers (hipDeviceptr as void*) of the resident SoA strips: x, y, theta, dt, each
  * [max_tebs*max_poses] doubles, and n [max_tebs] int32. Valid until destroy.                          */
 int  teb_amd_device_state(teb_amd_handle_t* h, void** x, void** y, void** theta, void** dt, void** n,

@@ -264,21 +264,24 @@ def h_signatures(cfg, obst, batch, mode, prescaler=1.0):
     return out
 
 
-def filter_equivalence_classes(mode, sig, threshold=0.1, best=-1, max_number_plans_in_current_class=1):
+def filter_equivalence_classes(mode, sig, threshold=0.1, best=-1, max_number_plans_in_current_class=1, stale_best_sig=None):
     sig = np.ascontiguousarray(sig, np.float64)
     B = sig.shape[0]
     M = sig.shape[1]
     keep = np.zeros(B, np.int32); valid = np.zeros(B, np.int32); reas = np.zeros(B, np.int32)
     I = lambda a: _abi._ptr(a, C.c_int32)
-    _check(lib().teb_oracle_filter_equivalence_classes(int(mode), B, M, _P(sig), C.c_double(threshold), int(best),
-                                                       int(max_number_plans_in_current_class), I(keep), I(valid), I(reas)),
-           "filter_equivalence_classes")
+    f = lib().teb_oracle_filter_equivalence_classes_stale
+    f.restype = C.c_int
+    f.argtypes = [C.c_int32, C.c_int32, C.c_int32, _abi.p_f64, C.c_double, C.c_int32, C.c_int32, _abi.p_f64, _abi.p_i32, _abi.p_i32, _abi.p_i32]
+    st = None if stale_best_sig is None else np.ascontiguousarray(stale_best_sig, np.float64)
+    _check(f(int(mode), B, M, _P(sig), C.c_double(threshold), int(best), int(max_number_plans_in_current_class),
+             _abi._ptr(st, C.c_double), I(keep), I(valid), I(reas)), "filter_equivalence_classes")
     return keep, valid, reas
 
 
 # ---- row f3 (candidate generation): createGraph + DepthFirst + addAndInitNewTeb --------------------------------------------------
 def explore_candidates(cfg, obst, batch, n_tebs, best, start, goal, dist_to_obst=None, unit_samples=None, skip_draws=0,
-                       vcap=4096, acap=1 << 20, max_paths=0):
+                       vcap=4096, acap=1 << 20, max_paths=0, stale_best_sig=None):
     """Bands 0..n_tebs-1 of `batch` are tebs_ after renewAndAnalyzeOldTebs; returns dict(batch (copy, candidates appended), n_total,
     vertices [nv, 2], adjacency (list of lists, insertion order), n_paths)."""
     c = cfg.to_c()
@@ -294,12 +297,26 @@ def explore_candidates(cfg, obst, batch, n_tebs, best, start, goal, dist_to_obst
     f = lib().teb_oracle_explore_candidates
     f.restype = C.c_int
     f.argtypes = [C.POINTER(_abi.Config), C.POINTER(_abi.HcpParams), C.POINTER(_abi.Obstacles), C.POINTER(_abi.TebBatch), C.c_int32,
-                  C.c_int32, _abi.p_f64, _abi.p_f64, C.c_double, _abi.p_f64, C.c_int64, C.c_int64, _abi.p_i32, C.c_int32, _abi.p_f64, _abi.p_f64,
+                  C.c_int32, _abi.p_f64, _abi.p_f64, C.c_double, _abi.p_f64, C.c_int64, C.c_int64, _abi.p_f64, _abi.p_i32, C.c_int32, _abi.p_f64, _abi.p_f64,
                   _abi.p_i32, C.c_int32, _abi.p_i32, _abi.p_i32, _abi.p_i32]
     _check(f(C.byref(c), C.byref(p), C.byref(obst.freeze()), C.byref(bs), int(n_tebs), int(best), _P(st), _P(gl),
-             float(dist_to_obst), _abi._ptr(us, C.c_double), int(skip_draws), int(max_paths), C.byref(nt), vcap, _P(vx), _P(vy), C.byref(nv), acap,
+             float(dist_to_obst), _abi._ptr(us, C.c_double), int(skip_draws), int(max_paths),
+             _abi._ptr(None if stale_best_sig is None else np.ascontiguousarray(stale_best_sig, np.float64), C.c_double), C.byref(nt), vcap, _P(vx), _P(vy), C.byref(nv), acap,
              I(off), I(adj), C.byref(npth)), "explore_candidates")
     N = nv.value
     assert N <= vcap and off[N] <= acap
     return dict(batch=out, n_total=nt.value, vertices=np.stack([vx[:N], vy[:N]], 1),
                 adjacency=[adj[off[v]:off[v + 1]].tolist() for v in range(N)], n_paths=npth.value)
+
+
+def filter_detours(cfg, batch, keep, best, optimized):
+    """deletePlansDetouringBackwards on the bands with keep != 0: returns the new keep array."""
+    p = cfg.hcp_params()
+    bs = batch.c_struct()
+    keep = np.ascontiguousarray(keep, np.int32).copy()
+    opt = np.ascontiguousarray(optimized, np.int32)
+    f = lib().teb_oracle_filter_detours
+    f.restype = C.c_int
+    f.argtypes = [C.POINTER(_abi.TebBatch), C.POINTER(_abi.HcpParams), C.c_int32, _abi.p_i32, _abi.p_i32]
+    _check(f(C.byref(bs), C.byref(p), int(best), _abi._ptr(opt, C.c_int32), _abi._ptr(keep, C.c_int32)), "filter_detours")
+    return keep

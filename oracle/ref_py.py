@@ -245,7 +245,7 @@ def optimize_batch(cfg, obst, via, batch, inner=None, outer=None, compute_cost=T
 
 
 def explore_candidates(cfg, obst, batch, best, start, goal, dist_to_obst=None, start_vel=None, free_goal_vel=False, skip_draws=0,
-                       slots=None, vcap=4096, acap=1 << 20):
+                       slots=None, vcap=4096, acap=1 << 20, optimized=None, stale_band=None):
     """The reference's HomotopyClassPlanner::exploreEquivalenceClassesAndInitTebs (renewAndAnalyzeOldTebs without detour deletion,
     then createGraph / DepthFirst / addAndInitNewTeb) with tebs_ = the bands of `batch` (may be None) and best_teb_ = band `best`.
     dict(batch, n_total, vertices, adjacency, has_vel_start, vel_start, has_vel_goal)."""
@@ -266,13 +266,44 @@ def explore_candidates(cfg, obst, batch, best, start, goal, dist_to_obst=None, s
     f = lib().ref_explore_candidates
     f.restype = C.c_int
     f.argtypes = [C.POINTER(A.Config), C.POINTER(A.HcpParams), C.POINTER(A.Obstacles), C.POINTER(A.TebBatch), C.c_int, A.p_f64, A.p_f64,
-                  C.c_double, A.p_f64, C.c_int, C.c_long, C.POINTER(A.TebBatch), A.p_i32, A.p_i32, A.p_f64, A.p_i32, C.c_int, A.p_f64,
+                  C.c_double, A.p_f64, C.c_int, C.c_long, A.p_i32, C.c_int, A.p_f64, A.p_f64, A.p_f64, A.p_f64, C.POINTER(A.TebBatch), A.p_i32, A.p_i32,
+                  A.p_f64, A.p_i32, C.c_int, A.p_f64,
                   A.p_f64, A.p_i32, C.c_int, A.p_i32, A.p_i32]
     ins = batch.c_struct() if batch is not None else None
+    sb = [np.ascontiguousarray(a, np.float64) for a in stale_band] if stale_band is not None else [np.zeros(0)] * 4
+    sb[3] = np.append(sb[3], 0.0)
     rc = f(C.byref(c), C.byref(p), C.byref(obst.freeze()), C.byref(ins) if ins is not None else None, int(best), _P(st), _P(gl),
-           float(dist_to_obst), _abi._ptr(sv, C.c_double), int(bool(free_goal_vel)), int(skip_draws), C.byref(obs), C.byref(nt), I(hvs),
+           float(dist_to_obst), _abi._ptr(sv, C.c_double), int(bool(free_goal_vel)), int(skip_draws),
+           _abi._ptr(None if optimized is None else np.ascontiguousarray(optimized, np.int32), C.c_int32), len(sb[0]), _P(sb[0]), _P(sb[1]),
+           _P(sb[2]), _P(sb[3]), C.byref(obs), C.byref(nt), I(hvs),
            _P(vs), I(hvg), vcap, _P(vx), _P(vy), C.byref(nv), acap, I(off), I(adj))
     assert rc == 0, rc
     N = nv.value
     return dict(batch=out, n_total=nt.value, vertices=np.stack([vx[:N], vy[:N]], 1),
                 adjacency=[adj[off[v]:off[v + 1]].tolist() for v in range(N)], has_vel_start=hvs, vel_start=vs, has_vel_goal=hvg)
+
+
+def hcp_plan_ticks(cfg, obst, starts, goals, start_vels=None, free_goal_vel=False, slots=8, stride=512):
+    """n_ticks x the reference's HomotopyClassPlanner::plan() on one planner object: list of dict(bands, best, costs) per tick."""
+    from teb_local_planner_amd import _abi as A
+    c = cfg.to_c()
+    p = cfg.hcp_params()
+    st = np.ascontiguousarray(starts, np.float64).reshape(-1, 3); gl = np.ascontiguousarray(goals, np.float64).reshape(-1, 3)
+    T = len(st)
+    sv = None if start_vels is None else np.ascontiguousarray(start_vels, np.float64).reshape(T, 3)
+    out = A.TebBatchHost(T * slots, stride)
+    obs = out.c_struct()
+    counts = np.zeros(T, np.int32); best = np.zeros(T, np.int32); costs = np.zeros(T * slots)
+    f = lib().ref_hcp_plan_ticks
+    f.restype = C.c_int
+    f.argtypes = [C.POINTER(A.Config), C.POINTER(A.HcpParams), C.POINTER(A.Obstacles), C.c_int, A.p_f64, A.p_f64, A.p_f64, C.c_int, C.c_int,
+                  C.POINTER(A.TebBatch), A.p_i32, A.p_i32, A.p_f64]
+    rc = f(C.byref(c), C.byref(p), C.byref(obst.freeze()), T, _P(st), _P(gl), _abi._ptr(sv, C.c_double), int(bool(free_goal_vel)), slots,
+           C.byref(obs), _abi._ptr(counts, C.c_int32), _abi._ptr(best, C.c_int32), _P(costs))
+    assert rc == 0, rc
+    res = []
+    for t in range(T):
+        assert counts[t] <= slots
+        res.append(dict(bands=[out.get_teb(t * slots + k) for k in range(counts[t])], best=int(best[t]),
+                        costs=costs[t * slots:t * slots + counts[t]].copy()))
+    return res

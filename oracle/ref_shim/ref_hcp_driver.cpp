@@ -28,12 +28,14 @@ extern "C" {
 void band_in(TimedElasticBand& teb, int n, const double* x, const double* y, const double* th, const double* dt);
 int band_out(const TimedElasticBand& teb, double* x, double* y, double* th, double* dt, int32_t* n, int cap);
 
-// in: bands 0..in->count-1 = tebs_ (before renewAndAnalyzeOldTebs), best = index of best_teb_ or -1.
+// in: bands 0..in->count-1 = tebs_ (before renewAndAnalyzeOldTebs), best = index of best_teb_ or -1, optimized [count] = optimized_
+// of every band (NULL = all true). stale_*: a band whose class is installed as best_teb_eq_class_ while best_teb_ is not in tebs_.
 // out: bands (capacity out->count slots of out->stride), *n_out = tebs_.size() afterwards; graph: vertices vx, vy [vcap], *nv,
 // adjacency in insertion order as CSR (adj_off [nv+1], adj [acap]). skip_draws: engine draws discarded first (PRM only).
 int ref_explore_candidates(const teb_amd_config_t* acfg, const teb_amd_hcp_params_t* p, const teb_amd_obstacles_t* o,
                            const teb_amd_teb_batch_t* in, int best, const double* start, const double* goal, double dist_to_obst,
-                           const double* start_vel, int free_goal_vel, long skip_draws, teb_amd_teb_batch_t* out, int32_t* n_out,
+                           const double* start_vel, int free_goal_vel, long skip_draws, const int32_t* optimized, int stale_n,
+                           const double* stale_x, const double* stale_y, const double* stale_th, const double* stale_dt, teb_amd_teb_batch_t* out, int32_t* n_out,
                            int32_t* has_vs_out, double* vs_out, int32_t* has_vg_out, int vcap, double* vx, double* vy, int32_t* nv,
                            int acap, int32_t* adj_off, int32_t* adj) {
   TebConfig cfg;
@@ -49,7 +51,10 @@ int ref_explore_candidates(const teb_amd_config_t* acfg, const teb_amd_hcp_param
   cfg.hcp.h_signature_prescaler = p->h_signature_prescaler;
   cfg.hcp.h_signature_threshold = p->h_signature_threshold;
   cfg.trajectory.allow_init_with_backwards_motion = p->allow_init_with_backwards_motion;
-  cfg.hcp.delete_detours_backwards = false;       // deletePlansDetouringBackwards is not part of this row
+  cfg.hcp.delete_detours_backwards = p->delete_detours_backwards;
+  cfg.hcp.detours_orientation_tolerance = p->detours_orientation_tolerance;
+  cfg.hcp.length_start_orientation_vector = p->length_start_orientation_vector;
+  cfg.hcp.max_ratio_detours_duration_best_duration = p->max_ratio_detours_duration_best_duration;
   cfg.hcp.selection_dropping_probability = 0.0;   // randomlyDropTebs off (it draws from std::random_device)
   cfg.hcp.enable_multithreading = false;
   ObstContainer obst;
@@ -60,9 +65,16 @@ int ref_explore_candidates(const teb_amd_config_t* acfg, const teb_amd_hcp_param
     TebOptimalPlannerPtr t(new TebOptimalPlanner(cfg, &obst));
     const size_t so = (size_t)b * in->stride;
     band_in(t->teb(), in->n[b], in->x + so, in->y + so, in->theta + so, in->dt + so);
+    t->optimized_ = optimized ? optimized[b] != 0 : true;
     hcp.tebs_.push_back(t);
   }
   if (in && best >= 0 && best < in->count) hcp.best_teb_ = hcp.tebs_[best];
+  TimedElasticBand stale;   // a band that was the best one in an earlier tick and is gone: only its class (best_teb_eq_class_) is left
+  if (stale_n > 0) {
+    band_in(stale, stale_n, stale_x, stale_y, stale_th, stale_dt);
+    hcp.best_teb_eq_class_ = hcp.calculateEquivalenceClass(stale.poses().begin(), stale.poses().end(), getCplxFromVertexPosePtr, &obst,
+                                                           stale.timediffs().begin(), stale.timediffs().end());
+  }
   if (skip_draws > 0) {
     ProbRoadmapGraph* g = dynamic_cast<ProbRoadmapGraph*>(hcp.graph_search_.get());
     if (g) g->rnd_generator_.discard(skip_draws);
@@ -91,5 +103,54 @@ int ref_explore_candidates(const teb_amd_config_t* acfg, const teb_amd_hcp_param
   }
   if (N <= vcap) adj_off[N] = e;
   return (N > vcap || e > acap || nt > out->count) ? 1 : 0;
+}
+
+// n_ticks x HomotopyClassPlanner::plan(start_k, goal_k, start_vel_k, free_goal_vel) of the reference on ONE planner object
+// (src/homotopy_class_planner.cpp:107-125): updateAllTEBs, exploreEquivalenceClassesAndInitTebs, optimizeAllTEBs (the reference's
+// optimizeTEB through the recording g2o stand-in), selectBestTeb. starts / goals [n_ticks*3], start_vels [n_ticks*3] or NULL.
+// out: slots bands per tick (band k of tick t at out slot t*slots+k), counts [n_ticks], best [n_ticks], costs [n_ticks*slots].
+int ref_hcp_plan_ticks(const teb_amd_config_t* acfg, const teb_amd_hcp_params_t* p, const teb_amd_obstacles_t* o, int n_ticks,
+                       const double* starts, const double* goals, const double* start_vels, int free_goal_vel, int slots,
+                       teb_amd_teb_batch_t* out, int32_t* counts, int32_t* best, double* costs) {
+  TebConfig cfg;
+  to_ref_config(*acfg, cfg);
+  cfg.hcp.simple_exploration = p->simple_exploration;
+  cfg.hcp.roadmap_graph_no_samples = p->roadmap_graph_no_samples;
+  cfg.hcp.roadmap_graph_area_width = p->roadmap_graph_area_width;
+  cfg.hcp.roadmap_graph_area_length_scale = p->roadmap_graph_area_length_scale;
+  cfg.hcp.obstacle_heading_threshold = p->obstacle_heading_threshold;
+  cfg.goal_tolerance.xy_goal_tolerance = p->xy_goal_tolerance;
+  cfg.hcp.max_number_classes = p->max_number_classes;
+  cfg.hcp.max_number_plans_in_current_class = p->max_number_plans_in_current_class;
+  cfg.hcp.h_signature_prescaler = p->h_signature_prescaler;
+  cfg.hcp.h_signature_threshold = p->h_signature_threshold;
+  cfg.trajectory.allow_init_with_backwards_motion = p->allow_init_with_backwards_motion;
+  cfg.hcp.delete_detours_backwards = p->delete_detours_backwards;
+  cfg.hcp.detours_orientation_tolerance = p->detours_orientation_tolerance;
+  cfg.hcp.length_start_orientation_vector = p->length_start_orientation_vector;
+  cfg.hcp.max_ratio_detours_duration_best_duration = p->max_ratio_detours_duration_best_duration;
+  cfg.hcp.selection_dropping_probability = 0.0;
+  cfg.hcp.switching_blocking_period = 0.0;
+  cfg.hcp.enable_multithreading = false;
+  cfg.hcp.viapoints_all_candidates = true;
+  ObstContainer obst;
+  to_ref_obstacles(o, obst);
+  HomotopyClassPlanner hcp;
+  hcp.initialize(cfg, &obst, TebVisualizationPtr(), NULL);
+  for (int t = 0; t < n_ticks; ++t) {
+    PoseSE2 s(starts[3 * t], starts[3 * t + 1], starts[3 * t + 2]), g(goals[3 * t], goals[3 * t + 1], goals[3 * t + 2]);
+    geometry_msgs::Twist tw;
+    if (start_vels) { tw.linear.x = start_vels[3 * t]; tw.linear.y = start_vels[3 * t + 1]; tw.angular.z = start_vels[3 * t + 2]; }
+    hcp.plan(s, g, start_vels ? &tw : NULL, free_goal_vel != 0);
+    const int nt = (int)hcp.tebs_.size();
+    counts[t] = nt;
+    best[t] = hcp.bestTebIdx();
+    for (int b = 0; b < nt && b < slots; ++b) {
+      const size_t slot = (size_t)t * slots + b, so = slot * out->stride;
+      band_out(hcp.tebs_[b]->teb(), out->x + so, out->y + so, out->theta + so, out->dt + so, &out->n[slot], out->stride);
+      costs[slot] = hcp.tebs_[b]->getCurrentCost();
+    }
+  }
+  return 0;
 }
 }

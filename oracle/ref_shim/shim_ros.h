@@ -32,7 +32,8 @@
 namespace ros {
 class NodeHandle {};
 struct Duration { double d = 0; explicit Duration(double x = 0) : d(x) {} double toSec() const { return d; } Duration& fromSec(double x) { d = x; return *this; } };
-struct Time { double t = 0; static Time now() { return Time(); } double toSec() const { return t; } Duration operator-(const Time& o) const { return Duration(t - o.t); } };
+struct Time { double t = 0; static Time now() { static double clock = 0; Time r; r.t = (clock += 1.0); return r; }   // a clock that advances: 1 s per call
+  double toSec() const { return t; } Duration operator-(const Time& o) const { return Duration(t - o.t); } };
 inline bool ok() { return true; }
 }  // namespace ros
 

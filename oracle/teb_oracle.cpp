@@ -2266,13 +2266,36 @@ int teb_oracle_h_signature_3d(const teb_amd_config_t* cfg, const teb_amd_obstacl
 // isValid / isReasonable / isEqual of both classes (h_signature.h:190-226, 349-409) and the "first come first serve" class list of
 // HomotopyClassPlanner::renewAndAnalyzeOldTebs / addEquivalenceClassIfNew (src/homotopy_class_planner.cpp:178-254).
 // sig: mode 2 -> [B*2] (re, im); mode 3 -> [B*M]. best = index of the last best TEB or -1. keep[b] = 1 iff the band survives.
+int teb_oracle_filter_equivalence_classes_stale(int32_t mode, int32_t B, int32_t M, const double* sig, double threshold, int32_t best,
+                                                int32_t max_number_plans_in_current_class, const double* stale_best_sig, int32_t* keep,
+                                                int32_t* valid, int32_t* reasonable);
 int teb_oracle_filter_equivalence_classes(int32_t mode, int32_t B, int32_t M, const double* sig, double threshold, int32_t best,
                                           int32_t max_number_plans_in_current_class, int32_t* keep, int32_t* valid,
                                           int32_t* reasonable) {
+  return teb_oracle_filter_equivalence_classes_stale(mode, B, M, sig, threshold, best, max_number_plans_in_current_class, nullptr, keep,
+                                                     valid, reasonable);
+}
+// stale_best_sig: best_teb_eq_class_ left over from an earlier call (the member outlives the band it was computed from and is only
+// replaced when a best band exists, src/homotopy_class_planner.cpp:220-228); NULL = none. Used when best < 0.
+int teb_oracle_filter_equivalence_classes_stale(int32_t mode, int32_t B, int32_t M, const double* sig, double threshold, int32_t best,
+                                                int32_t max_number_plans_in_current_class, const double* stale_best_sig, int32_t* keep,
+                                                int32_t* valid, int32_t* reasonable) {
   const int W = mode == 2 ? 2 : M;
   auto is_valid = [&](int b) { for (int k = 0; k < W; ++k) if (!std::isfinite(sig[(size_t)b * W + k])) return false; return true; };
   auto is_reasonable = [&](int b) { if (mode == 2) return true; for (int k = 0; k < W; ++k) if (sig[(size_t)b * W + k] > 1.0) return false; return true; };
   auto sgn = [](double z) { return (z == 0) ? 0 : (z < 0 ? -1 : 1); };   // boost::math::sign
+  auto rows_equal = [&](const double* x, const double* y) {   // x.isEqual(y)
+    if (mode == 2) {
+      double diff_real = std::abs(y[0] - x[0]);
+      double diff_imag = std::abs(y[1] - x[1]);
+      return diff_real <= threshold && diff_imag <= threshold;
+    }
+    for (int i = 0; i < W; ++i) {
+      if (std::abs(y[i]) < threshold || std::abs(x[i]) < threshold) continue;
+      if (sgn(y[i]) != sgn(x[i])) return false;
+    }
+    return true;
+  };
   auto is_equal = [&](int a, int b) {   // a.isEqual(b)
     const double* x = sig + (size_t)a * W; const double* y = sig + (size_t)b * W;
     if (mode == 2) {
@@ -2301,9 +2324,10 @@ int teb_oracle_filter_equivalence_classes(int32_t mode, int32_t B, int32_t M, co
       for (int c : classes) if (is_equal(b, c)) { has = true; break; }
       add = true;
       if (has) {
-        bool in_best = has_best && is_equal(order[0], b);                      // best_teb_eq_class_->isEqual(*eq_class)
+        const double* best_sig = has_best ? sig + (size_t)order[0] * W : stale_best_sig;   // best_teb_eq_class_
+        bool in_best = best_sig && rows_equal(best_sig, sig + (size_t)b * W);             // best_teb_eq_class_->isEqual(*eq_class)
         int count = 0;
-        if (has_best) for (int c : classes) if (is_equal(order[0], c)) ++count;   // numTebsInBestTebClass
+        if (best_sig) for (int c : classes) if (rows_equal(best_sig, sig + (size_t)c * W)) ++count;   // numTebsInBestTebClass
         if (!in_best || count >= max_number_plans_in_current_class) add = false;
       }
     }
@@ -2481,9 +2505,9 @@ struct Mt19937 {   // the 32-bit Mersenne twister (Matsumoto & Nishimura 1998), 
 // unit_samples [2*no_samples] (u in [0,1): value = u * (b - a) + a) or NULL = boost mt19937 default stream after skip_draws draws.
 int teb_oracle_explore_candidates(const teb_amd_config_t* cfg, const teb_amd_hcp_params_t* p, const teb_amd_obstacles_t* obst,
                                   teb_amd_teb_batch_t* batch, int32_t n_tebs, int32_t best, const double* start, const double* goal,
-                                  double dist_to_obst, const double* unit_samples, int64_t skip_draws, int64_t max_paths, int32_t* n_total,
-                                  int32_t vcap, double* vx, double* vy, int32_t* nv, int32_t acap, int32_t* adj_off, int32_t* adj,
-                                  int32_t* n_paths) {
+                                  double dist_to_obst, const double* unit_samples, int64_t skip_draws, int64_t max_paths,
+                                  const double* stale_best_sig, int32_t* n_total, int32_t vcap, double* vx, double* vy, int32_t* nv,
+                                  int32_t acap, int32_t* adj_off, int32_t* adj, int32_t* n_paths) {
   Scene s;
   int rc = load_scene(s, cfg, obst, 0, nullptr, nullptr);
   if (rc) return rc;
@@ -2498,6 +2522,7 @@ int teb_oracle_explore_candidates(const teb_amd_config_t* cfg, const teb_amd_hcp
     ex.tebs.push_back(t);
   }
   if (best >= 0 && best < n_tebs) { ex.has_best = true; ex.best_class = ex.classes[best]; }
+  else if (stale_best_sig) { ex.has_best = true; ex.best_class.v.assign(stale_best_sig, stale_best_sig + ex.W); }   // stale best_teb_eq_class_
   HcGraph g;
   const double thr = p->obstacle_heading_threshold;
   const V2 sp{start[0], start[1]}, gp{goal[0], goal[1]};
@@ -2611,6 +2636,48 @@ int teb_oracle_explore_candidates(const teb_amd_config_t* cfg, const teb_amd_hcp
   std::vector<int> visited{start_vtx};
   ex.depth_first(g, visited, goal_vtx, start[2], goal[2]);
   return finish();
+}
+
+// HomotopyClassPlanner::deletePlansDetouringBackwards + computeStartOrientation (src/homotopy_class_planner.cpp:766-838) on the bands
+// with keep[b] != 0 (keep in/out); optimized [B] = TebOptimalPlanner::isOptimized() of every band.
+int teb_oracle_filter_detours(const teb_amd_teb_batch_t* batch, const teb_amd_hcp_params_t* p, int32_t best, const int32_t* optimized,
+                              int32_t* keep) {
+  const int B = batch->count;
+  int kept = 0;
+  for (int b = 0; b < B; ++b) kept += keep[b] != 0;
+  if (kept < 2 || best < 0 || best >= B || !keep[best] || batch->n[best] < 2) return TEB_AMD_OK;
+  auto start_orientation = [&](int b, double& orientation) {
+    Teb t;
+    teb_from_batch(batch, b, t);
+    bool second_pose_found = false;
+    V2 start_vector{0, 0};
+    for (int i = 0; i < t.n(); ++i) {
+      start_vector = V2{t.x[0], t.y[0]} - V2{t.x[i], t.y[i]};
+      if (norm(start_vector) > p->length_start_orientation_vector) { second_pose_found = true; break; }
+    }
+    if (!second_pose_found) return false;
+    orientation = std::atan2(start_vector.y, start_vector.x);
+    return true;
+  };
+  auto sum_dt = [&](int b) {   // getSumOfAllTimeDiffs, src/timed_elastic_band.cpp:227-236
+    double time = 0;
+    const size_t o = (size_t)b * batch->stride;
+    for (int i = 0; i < batch->n[b] - 1; ++i) time += batch->dt[o + i];
+    return time;
+  };
+  double current_movement_orientation;
+  const double best_plan_duration = std::max(sum_dt(best), 1.0);
+  if (!start_orientation(best, current_movement_orientation)) return TEB_AMD_OK;
+  for (int b = 0; b < B; ++b) {
+    if (!keep[b] || b == best) continue;
+    if (batch->n[b] < 2) { keep[b] = 0; continue; }
+    double plan_orientation;
+    if (!start_orientation(b, plan_orientation)) { keep[b] = 0; continue; }
+    if (std::fabs(normalize_theta(plan_orientation - current_movement_orientation)) > p->detours_orientation_tolerance) { keep[b] = 0; continue; }
+    if (!optimized[b]) { keep[b] = 0; continue; }
+    if (sum_dt(b) / best_plan_duration > p->max_ratio_detours_duration_best_duration) { keep[b] = 0; continue; }
+  }
+  return TEB_AMD_OK;
 }
 
 int teb_oracle_linearize(const teb_amd_config_t* cfg, const teb_amd_obstacles_t* obst, int32_t n_via,

@@ -131,15 +131,22 @@ int teb_oracle_filter_equivalence_classes(int32_t mode, int32_t B, int32_t M, co
                                           int32_t max_number_plans_in_current_class, int32_t* keep, int32_t* valid,
                                           int32_t* reasonable);
 
+/* as teb_oracle_filter_equivalence_classes, with best_teb_eq_class_ left over from an earlier tick (used when best < 0; NULL = none) */
+int teb_oracle_filter_equivalence_classes_stale(int32_t mode, int32_t B, int32_t M, const double* sig, double threshold, int32_t best,
+                                                int32_t max_number_plans_in_current_class, const double* stale_best_sig, int32_t* keep,
+                                                int32_t* valid, int32_t* reasonable);
+/* deletePlansDetouringBackwards (src/homotopy_class_planner.cpp:766-838): keep [B] in/out, optimized [B] = isOptimized() per band */
+int teb_oracle_filter_detours(const teb_amd_teb_batch_t* batch, const teb_amd_hcp_params_t* p, int32_t best, const int32_t* optimized,
+                              int32_t* keep);
 /* ---- row f3, candidate generation: GraphSearchInterface::createGraph (src/graph_search.cpp:95-340), DepthFirst (:45-91),
  * addAndInitNewTeb (homotopy_class_planner.hpp:66-93) on bands 0..n_tebs-1 (= tebs_ after renewAndAnalyzeOldTebs); batch->count = slots.
  * max_paths > 0 bounds the number of start-goal paths examined (test guard; the reference has no bound).
  * Graph out: vertices vx, vy [vcap], adjacency in insertion order as CSR (adj_off [nv+1], adj [acap]). */
 int teb_oracle_explore_candidates(const teb_amd_config_t* cfg, const teb_amd_hcp_params_t* p, const teb_amd_obstacles_t* obst,
                                   teb_amd_teb_batch_t* batch, int32_t n_tebs, int32_t best, const double* start, const double* goal,
-                                  double dist_to_obst, const double* unit_samples, int64_t skip_draws, int64_t max_paths, int32_t* n_total,
-                                  int32_t vcap, double* vx, double* vy, int32_t* nv, int32_t acap, int32_t* adj_off, int32_t* adj,
-                                  int32_t* n_paths);
+                                  double dist_to_obst, const double* unit_samples, int64_t skip_draws, int64_t max_paths,
+                                  const double* stale_best_sig, int32_t* n_total, int32_t vcap, double* vx, double* vy, int32_t* nv,
+                                  int32_t acap, int32_t* adj_off, int32_t* adj, int32_t* n_paths);
 
 #ifdef __cplusplus
 }

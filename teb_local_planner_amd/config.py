@@ -81,7 +81,9 @@ class TebConfig:
             # reference, its dynamic-reconfigure default is 1): fields of teb_amd_hcp_params_t
             simple_exploration=False, max_number_plans_in_current_class=1, obstacle_heading_threshold=0.45,
             roadmap_graph_no_samples=15, roadmap_graph_area_width=6.0, roadmap_graph_area_length_scale=1.0,
-            h_signature_prescaler=1.0, h_signature_threshold=0.1)
+            h_signature_prescaler=1.0, h_signature_threshold=0.1, delete_detours_backwards=True,
+            detours_orientation_tolerance=0.5 * 3.141592653589793, length_start_orientation_vector=0.4,
+            max_ratio_detours_duration_best_duration=3.0, selection_dropping_probability=0.0, switching_blocking_period=0.0)
         self.goal_tolerance = SimpleNamespace(xy_goal_tolerance=0.2, yaw_goal_tolerance=0.2)
         self.recovery = SimpleNamespace(divergence_detection_enable=False,
                                         divergence_detection_max_chi_squared=10.0)

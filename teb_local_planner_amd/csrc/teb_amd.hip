@@ -151,7 +151,7 @@ struct teb_amd_handle {
   DevBuf<int> o_type, o_dyn, o_voff, o_static, o_dynidx;
   DevBuf<double> o_ax, o_ay, o_bx, o_by, o_rad, o_vx, o_vy, o_cx, o_cy, o_pvx, o_pvy, viax, viay;
   // batch
-  DevBuf<int> n, has_vs, has_vg, rotdir, via_en, status, iters, trials, assoc_cnt, assoc, assoc_ovf, via_pose, legacy_idx;
+  DevBuf<int> n, has_vs, has_vg, rotdir, via_en, status, optimized, iters, trials, assoc_cnt, assoc, assoc_ovf, via_pose, legacy_idx;
   DevBuf<double> x, y, th, dt, vs, vg, chi2, cost, lambda, Hbackup;
   // snapshot
   DevBuf<int> snap_n;
@@ -179,6 +179,8 @@ struct teb_amd_handle {
   DevBuf<unsigned char> g_adj;
   size_t g_cap = 0;
   bool cand_ready = false, tmp_ready = false;
+  std::vector<double> best_class;   // best_teb_eq_class_ (homotopy_class_planner.h): signature of the last best band; survives the band
+  int best_class_mode = 0;          // 0 = none yet, 2 / 3 = HSignature / HSignature3d
   std::mt19937 rnd_generator;   // ProbRoadmapGraph::rnd_generator_ (graph_search.h:211): default-seeded 32-bit Mersenne twister
 };
 
@@ -208,7 +210,7 @@ BatchDev batch_of(teb_amd_handle* h) {
   b.n = h->n.p; b.x = h->x.p; b.y = h->y.p; b.th = h->th.p; b.dt = h->dt.p;
   b.has_vs = h->has_vs.p; b.vs = h->vs.p; b.has_vg = h->has_vg.p; b.vg = h->vg.p;
   b.rotdir = h->rotdir.p; b.via_en = h->via_en.p;
-  b.status = h->status.p; b.iters = h->iters.p; b.trials = h->trials.p;
+  b.status = h->status.p; b.optimized = h->optimized.p; b.iters = h->iters.p; b.trials = h->trials.p;
   b.chi2 = h->chi2.p; b.cost = h->cost.p; b.lambda = h->lambda.p;
   b.assoc_cnt = h->assoc_cnt.p; b.assoc = h->assoc.p; b.assoc_cap = h->max_obst > 0 ? h->max_obst : 1;
   b.assoc_overflow = h->assoc_ovf.p; b.legacy_idx = h->legacy_idx.p;
@@ -364,7 +366,7 @@ int teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_po
   A(h->o_pvx.alloc(max_obstacle_vertices)); A(h->o_pvy.alloc(max_obstacle_vertices));
   A(h->viax.alloc(max_via_points)); A(h->viay.alloc(max_via_points));
   A(h->n.alloc(max_tebs)); A(h->has_vs.alloc(max_tebs)); A(h->has_vg.alloc(max_tebs)); A(h->rotdir.alloc(max_tebs));
-  A(h->via_en.alloc(max_tebs)); A(h->status.alloc(max_tebs)); A(h->iters.alloc(max_tebs)); A(h->trials.alloc(max_tebs));
+  A(h->via_en.alloc(max_tebs)); A(h->status.alloc(max_tebs)); A(h->optimized.alloc(max_tebs)); A(h->iters.alloc(max_tebs)); A(h->trials.alloc(max_tebs));
   A(h->assoc_cnt.alloc(BS)); A(h->assoc.alloc(BS * Mo)); A(h->assoc_ovf.alloc(max_tebs)); A(h->legacy_idx.alloc((size_t)max_tebs * Mo));
   A(h->via_pose.alloc((size_t)max_tebs * (max_via_points > 0 ? max_via_points : 1)));
   A(h->x.alloc(BS)); A(h->y.alloc(BS)); A(h->th.alloc(BS)); A(h->dt.alloc(BS));
@@ -386,6 +388,7 @@ int teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_po
   if (ok && hipMemset(h->chi2.p, 0, sizeof(double) * max_tebs) != hipSuccess) ok = false;
   if (ok && hipMemset(h->iters.p, 0, sizeof(int) * max_tebs) != hipSuccess) ok = false;   // hasDiverged: "no statistics yet"
   if (ok && hipMemset(h->status.p, 0, sizeof(int) * max_tebs) != hipSuccess) ok = false;
+  if (ok && hipMemset(h->optimized.p, 0, sizeof(int) * max_tebs) != hipSuccess) ok = false;
   if (!ok) { teb_amd_destroy(h); return fail(TEB_AMD_ERR_HIP, "device allocation / kernel attribute setup failed"); }
   *out = h;
   return TEB_AMD_OK;
@@ -396,7 +399,7 @@ void teb_amd_destroy(teb_amd_handle_t* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   DevBuf<int>* ib[] = {&h->o_type, &h->o_dyn, &h->o_voff, &h->o_static, &h->o_dynidx, &h->n, &h->has_vs, &h->has_vg, &h->rotdir,
-                       &h->via_en, &h->status, &h->iters, &h->trials, &h->assoc_cnt, &h->assoc, &h->assoc_ovf, &h->via_pose, &h->legacy_idx,
+                       &h->via_en, &h->status, &h->optimized, &h->iters, &h->trials, &h->assoc_cnt, &h->assoc, &h->assoc_ovf, &h->via_pose, &h->legacy_idx,
                        &h->snap_n, &h->sel_idx, &h->err_flag, &h->hs_pex};
   for (auto* q : ib) q->free();
   DevBuf<double>* db[] = {&h->o_ax, &h->o_ay, &h->o_bx, &h->o_by, &h->o_rad, &h->o_vx, &h->o_vy, &h->o_cx, &h->o_cy, &h->o_pvx,
@@ -540,6 +543,7 @@ int teb_amd_upload_tebs(teb_amd_handle_t* h, const teb_amd_teb_batch_t* bt) {
   HIPCHK(hipMemcpyAsync(h->via_en.p, ve.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->vs.p, vs.data(), 3 * (size_t)B * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->vg.p, vg.data(), 3 * (size_t)B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemsetAsync(h->optimized.p, 0, B * sizeof(int), h->stream));   // bands from the host: optimized_ unknown -> false
   HIPCHK(hipStreamSynchronize(h->stream));
   h->B = B;
   h->consumers_valid = false;
@@ -636,6 +640,7 @@ int extend_batch(teb_amd_handle* h, int b) {
     HIPCHK(hipMemcpyAsync(h->has_vg.p + k, &one, sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->rotdir.p + k, &none, sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->via_en.p + k, &one, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->optimized.p + k, 0, sizeof(int), h->stream));   // a new TebOptimalPlanner: optimized_(false)
     HIPCHK(hipMemcpyAsync(h->vs.p + 3 * k, z3, sizeof(z3), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->vg.p + 3 * k, z3, sizeof(z3), hipMemcpyHostToDevice, h->stream));
     if (k < b) {   // a skipped slot becomes the trivial two-pose band at the origin so that the batch stays well-formed
@@ -914,7 +919,21 @@ int teb_amd_filter_equivalence_classes(teb_amd_handle_t* h, double threshold, in
   std::vector<int> order(B), vld(B), classes;
   for (int b = 0; b < B; ++b) { order[b] = b; vld[b] = is_valid(b); }
   const bool has_best = best >= 0 && best < B;
-  if (has_best) std::swap(order[0], order[best]);
+  if (has_best) {   // best_teb_eq_class_ = calculateEquivalenceClass(best_teb_), src/homotopy_class_planner.cpp:224-227
+    std::swap(order[0], order[best]);
+    h->best_class.assign(row(best), row(best) + W); h->best_class_mode = mode;
+  }
+  // isInBestTebClass / numTebsInBestTebClass use best_teb_eq_class_, which outlives the band it was computed from (:385-410)
+  const bool have_best_class = h->best_class_mode == mode && (int)h->best_class.size() == W;
+  auto equal_to_best = [&](int b) {   // best_teb_eq_class_->isEqual(*cls[b])
+    const double* x = h->best_class.data(); const double* y = row(b);
+    if (mode == 2) return std::fabs(y[0] - x[0]) <= threshold && std::fabs(y[1] - x[1]) <= threshold;
+    for (int i = 0; i < W; ++i) {
+      if (std::fabs(y[i]) < threshold || std::fabs(x[i]) < threshold) continue;
+      if (sign_of(y[i]) != sign_of(x[i])) return false;
+    }
+    return true;
+  };
   std::vector<int> kp(B, 0);
   for (int k = 0; k < B; ++k) {
     const int b = order[k];
@@ -922,9 +941,9 @@ int teb_amd_filter_equivalence_classes(teb_amd_handle_t* h, double threshold, in
     bool has = false;
     for (int c : classes) if (is_equal(b, c)) { has = true; break; }
     if (has) {
-      const bool in_best = has_best && is_equal(order[0], b);
+      const bool in_best = have_best_class && equal_to_best(b);
       int count = 0;
-      if (has_best) for (int c : classes) if (is_equal(order[0], c)) ++count;
+      if (have_best_class) for (int c : classes) if (equal_to_best(c)) ++count;
       if (!in_best || count >= max_number_plans_in_current_class) continue;
     }
     classes.push_back(b); kp[b] = 1;
@@ -945,6 +964,8 @@ void teb_amd_hcp_params_default(teb_amd_hcp_params_t* p) {   // teb_config.h:352
   p->obstacle_heading_threshold = 0.45; p->xy_goal_tolerance = 0.2; p->max_number_classes = 5;
   p->max_number_plans_in_current_class = 1;   // no constructor default in the reference; 1 is its dynamic-reconfigure default
   p->h_signature_prescaler = 1; p->h_signature_threshold = 0.1; p->allow_init_with_backwards_motion = 0;
+  p->delete_detours_backwards = 1; p->detours_orientation_tolerance = M_PI / 2.0; p->length_start_orientation_vector = 0.4;   // :374-377
+  p->max_ratio_detours_duration_best_duration = 3.0;
 }
 
 namespace {
@@ -956,7 +977,8 @@ int ensure_candidate_buffers(teb_amd_handle* h) {
   bool ok = true;
   auto A = [&](hipError_t e) { if (e != hipSuccess) ok = false; };
   A(h->cand_x.alloc(KS)); A(h->cand_y.alloc(KS)); A(h->cand_th.alloc(KS)); A(h->cand_dt.alloc(KS)); A(h->cand_n.alloc(kCandChunk));
-  A(h->cand_sig.alloc(kCandChunk * W)); A(h->cand_px.alloc((size_t)kCandChunk * (h->stride + 1)));
+  A(h->cand_sig.alloc(std::max<size_t>(kCandChunk * W, 4 * (size_t)h->max_tebs)));   // signatures of a chunk / detour statistics of the batch
+  A(h->cand_px.alloc((size_t)kCandChunk * (h->stride + 1)));
   A(h->cand_py.alloc((size_t)kCandChunk * (h->stride + 1))); A(h->cand_off.alloc(kCandChunk + 1)); A(h->cand_map.alloc(h->max_tebs));
   if (!ok) return fail(TEB_AMD_ERR_HIP, "candidate scratch allocation failed");
   h->cand_ready = true;
@@ -1059,8 +1081,9 @@ int teb_amd_explore_candidates(teb_amd_handle_t* h, const teb_amd_hcp_params_t* 
   if (h->B > 0) {
     if ((rc = teb_amd_compute_h_signatures(h, p->h_signature_prescaler, nullptr, nullptr))) return rc;
     for (int b = 0; b < h->B; ++b) ct.classes.emplace_back(h->hsig_host.data() + (size_t)b * W, h->hsig_host.data() + (size_t)(b + 1) * W);
-    if (best >= 0 && best < h->B) { ct.has_best = true; ct.best = ct.classes[best]; }
+    if (best >= 0 && best < h->B) { h->best_class = ct.classes[best]; h->best_class_mode = mode; }
   }
+  if (h->best_class_mode == mode && (int)h->best_class.size() == W) { ct.has_best = true; ct.best = h->best_class; }   // best_teb_eq_class_
   h->hsig_mode = 0;   // the batch is about to change: signatures have to be recomputed before the next filter call
   if (h->B >= slots) return TEB_AMD_OK;                                     // src/graph_search.cpp:99-100, 231-232
   const double one3[3] = {0, 0, 0};
@@ -1244,7 +1267,7 @@ int teb_amd_compact_bands(teb_amd_handle_t* h, const int32_t* keep, int32_t best
     bool ok = true;
     auto A = [&](hipError_t e) { if (e != hipSuccess) ok = false; };
     A(h->tmp_x.alloc(BS)); A(h->tmp_y.alloc(BS)); A(h->tmp_th.alloc(BS)); A(h->tmp_dt.alloc(BS)); A(h->tmp_n.alloc(h->max_tebs));
-    A(h->tmp_vs.alloc(3 * (size_t)h->max_tebs)); A(h->tmp_vg.alloc(3 * (size_t)h->max_tebs)); A(h->tmp_i.alloc(7 * (size_t)h->max_tebs));
+    A(h->tmp_vs.alloc(3 * (size_t)h->max_tebs)); A(h->tmp_vg.alloc(3 * (size_t)h->max_tebs)); A(h->tmp_i.alloc(8 * (size_t)h->max_tebs));
     A(h->tmp_chi2.alloc(h->max_tebs)); A(h->tmp_cost.alloc(h->max_tebs)); A(h->tmp_lambda.alloc(h->max_tebs));
     if (!h->cand_ready && ensure_candidate_buffers(h) != TEB_AMD_OK) ok = false;
     if (!ok) return fail(TEB_AMD_ERR_HIP, "compaction scratch allocation failed");
@@ -1266,6 +1289,7 @@ int teb_amd_compact_bands(teb_amd_handle_t* h, const int32_t* keep, int32_t best
     tmp.has_vs = h->tmp_i.p; tmp.has_vg = h->tmp_i.p + h->max_tebs; tmp.rotdir = h->tmp_i.p + 2 * (size_t)h->max_tebs;
     tmp.via_en = h->tmp_i.p + 3 * (size_t)h->max_tebs; tmp.status = h->tmp_i.p + 4 * (size_t)h->max_tebs;
     tmp.iters = h->tmp_i.p + 5 * (size_t)h->max_tebs; tmp.trials = h->tmp_i.p + 6 * (size_t)h->max_tebs;
+    tmp.optimized = h->tmp_i.p + 7 * (size_t)h->max_tebs;
     tmp.vs = h->tmp_vs.p; tmp.vg = h->tmp_vg.p; tmp.chi2 = h->tmp_chi2.p; tmp.cost = h->tmp_cost.p; tmp.lambda = h->tmp_lambda.p;
     std::vector<int> ident(K);
     for (int k = 0; k < K; ++k) ident[k] = k;
@@ -1281,6 +1305,70 @@ int teb_amd_compact_bands(teb_amd_handle_t* h, const int32_t* keep, int32_t best
   h->B = K;
   h->consumers_valid = false;
   h->hsig_mode = 0;
+  return TEB_AMD_OK;
+}
+
+int teb_amd_filter_detours(teb_amd_handle_t* h, const teb_amd_hcp_params_t* p, int32_t best, int32_t* keep) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!p || !keep) return fail(TEB_AMD_ERR_INVALID_ARG, "null argument");
+  const int B = h->B;
+  if (B <= 0) return TEB_AMD_OK;
+  int kept = 0;
+  for (int b = 0; b < B; ++b) kept += keep[b] != 0;
+  if (kept < 2 || best < 0 || best >= B || !keep[best]) return TEB_AMD_OK;   // "a moving direction wasn't chosen yet", :769-773
+  if ((rc = ensure_candidate_buffers(h))) return rc;
+  hipLaunchKernelGGL(detour_stats_kernel, dim3(B), dim3(kThreads), 0, h->stream, batch_of(h), p->length_start_orientation_vector, h->cand_sig.p);
+  HIPCHK(hipGetLastError());
+  std::vector<double> st((size_t)4 * B);
+  std::vector<int> opt(B);
+  HIPCHK(hipMemcpyAsync(st.data(), h->cand_sig.p, st.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(opt.data(), h->optimized.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  auto found = [&](int b) { return st[4 * b] != 0; };
+  auto orient = [&](int b) { return st[4 * b + 1]; };
+  auto duration = [&](int b) { return st[4 * b + 2]; };
+  auto poses = [&](int b) { return (int)st[4 * b + 3]; };
+  if (poses(best) < 2) return TEB_AMD_OK;
+  const double best_plan_duration = std::max(duration(best), 1.0);
+  if (!found(best)) return TEB_AMD_OK;   // the plan is shorter than len_orientation_vector
+  auto normalize_theta = [](double theta) {   // g2o::normalize_theta (misc.h)
+    if (theta >= -M_PI && theta < M_PI) return theta;
+    const double multiplier = std::floor(theta / (2 * M_PI));
+    theta = theta - multiplier * 2 * M_PI;
+    if (theta >= M_PI) theta -= 2 * M_PI;
+    if (theta < -M_PI) theta += 2 * M_PI;
+    return theta;
+  };
+  for (int b = 0; b < B; ++b) {
+    if (!keep[b] || b == best) continue;
+    if (poses(b) < 2 || !found(b)) { keep[b] = 0; continue; }
+    if (std::fabs(normalize_theta(orient(b) - orient(best))) > p->detours_orientation_tolerance) { keep[b] = 0; continue; }
+    if (!opt[b]) { keep[b] = 0; continue; }
+    if (duration(b) / best_plan_duration > p->max_ratio_detours_duration_best_duration) { keep[b] = 0; continue; }
+  }
+  return TEB_AMD_OK;
+}
+
+int teb_amd_set_optimized_flags(teb_amd_handle_t* h, const int32_t* flags) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!flags) return fail(TEB_AMD_ERR_INVALID_ARG, "null flags");
+  if (h->B <= 0) return TEB_AMD_OK;
+  std::vector<int> f(h->B);
+  for (int b = 0; b < h->B; ++b) f[b] = flags[b] != 0;
+  HIPCHK(hipMemcpyAsync(h->optimized.p, f.data(), h->B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return TEB_AMD_OK;
+}
+
+int teb_amd_get_optimized_flags(teb_amd_handle_t* h, int32_t* flags) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!flags) return fail(TEB_AMD_ERR_INVALID_ARG, "null flags");
+  if (h->B <= 0) return TEB_AMD_OK;
+  HIPCHK(hipMemcpyAsync(flags, h->optimized.p, h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
   return TEB_AMD_OK;
 }
 

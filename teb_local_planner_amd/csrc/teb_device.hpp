@@ -71,6 +71,7 @@ struct BatchDev {
   const int* via_en;
   // results
   int* status;
+  int* optimized;   // TebOptimalPlanner::optimized_ (optimal_planner.h:691): an outer iteration of the last optimizeTEB call completed
   int* iters;
   int* trials;
   double* chi2;

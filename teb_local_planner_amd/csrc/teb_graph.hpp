@@ -165,9 +165,35 @@ __global__ void move_bands_kernel(BatchDev src, BatchDev dst, const int* map, in
       const_cast<int*>(dst.has_vs)[d] = src.has_vs[s]; const_cast<int*>(dst.has_vg)[d] = src.has_vg[s];
       const_cast<int*>(dst.rotdir)[d] = src.rotdir[s]; const_cast<int*>(dst.via_en)[d] = src.via_en[s];
       for (int k = 0; k < 3; ++k) { const_cast<double*>(dst.vs)[3 * d + k] = src.vs[3 * s + k]; const_cast<double*>(dst.vg)[3 * d + k] = src.vg[3 * s + k]; }
-      dst.status[d] = src.status[s]; dst.iters[d] = src.iters[s]; dst.trials[d] = src.trials[s];
+      dst.status[d] = src.status[s]; dst.iters[d] = src.iters[s]; dst.trials[d] = src.trials[s]; dst.optimized[d] = src.optimized[s];
       dst.chi2[d] = src.chi2[s]; dst.cost[d] = src.cost[s]; dst.lambda[d] = src.lambda[s];
     }
+  }
+}
+
+// per band: computeStartOrientation (src/homotopy_class_planner.cpp:819-838) and getSumOfAllTimeDiffs, the inputs of
+// deletePlansDetouringBackwards (:766-817). out [B * 4] = found (0/1), orientation, sum of time differences, number of poses
+__global__ void __launch_bounds__(kThreads) detour_stats_kernel(BatchDev bt, double len_orientation_vector, double* out) {
+  __shared__ int first;
+  const int b = blockIdx.x;
+  const int n = bt.n[b];
+  const size_t so = (size_t)b * bt.stride;
+  if (threadIdx.x == 0) first = n;
+  __syncthreads();
+  if (n > 0) {
+    const double x0 = bt.x[so], y0 = bt.y[so];
+    int mine = n;
+    for (int i = threadIdx.x; i < n; i += kThreads)
+      if (nrm2(x0 - bt.x[so + i], y0 - bt.y[so + i]) > len_orientation_vector) { mine = i; break; }   // ascending i per lane
+    if (mine < n) atomicMin(&first, mine);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int f = first;
+    double orient = 0, sum = 0;
+    if (f < n) orient = atan2(bt.y[so] - bt.y[so + f], bt.x[so] - bt.x[so + f]);
+    for (int i = 0; i < n - 1; ++i) sum += bt.dt[so + i];   // the reference's running sum, in order
+    out[4 * b] = f < n ? 1.0 : 0.0; out[4 * b + 1] = orient; out[4 * b + 2] = sum; out[4 * b + 3] = (double)n;
   }
 }
 

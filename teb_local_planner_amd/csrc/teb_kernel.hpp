@@ -1214,6 +1214,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   double* Hbk = bt.Hbackup + (size_t)b * bt.hmat_stride;
 
   int status = TEB_AMD_TEB_OK, iters = 0, trials = 0;
+  int optimized = c.optimization_activate ? 0 : bt.optimized[b];   // optimized_ = false (src/optimal_planner.cpp:189), after the early return
   double chi2_final = 0, lambda = 0, cost = __longlong_as_double(0x7ff8000000000000LL);
   double last_cats[4] = {0, 0, 0, 0};
   double weight_multiplier = args.debug_linearize ? args.debug_weight_multiplier : 1.0;
@@ -1436,6 +1437,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       cst += last_cats[CAT_OTHER];
       cost = cst;
     }
+    optimized = 1;   // :220 (set before computeCurrentCost there; nothing in between reads it)
     weight_multiplier *= c.weight_adapt_factor;
   }
 
@@ -1457,7 +1459,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   if (tid == 0) {
     if (nonfinite) status = TEB_AMD_TEB_NONFINITE;
     bt.n[b] = n;
-    bt.status[b] = status; bt.iters[b] = iters; bt.trials[b] = trials;
+    bt.status[b] = status; bt.iters[b] = iters; bt.trials[b] = trials; bt.optimized[b] = optimized;
     bt.chi2[b] = chi2_final; bt.cost[b] = cost; bt.lambda[b] = lambda;
   }
 }

@@ -386,6 +386,104 @@ bool TebAmdBatch::renewAndAnalyzeOldTebs(const TebConfig& cfg, int best_index, s
   return true;
 }
 
+void toAmdHcpParams(const TebConfig& cfg, teb_amd_hcp_params_t& p)
+{
+  teb_amd_hcp_params_default(&p);
+  p.simple_exploration = cfg.hcp.simple_exploration;
+  p.roadmap_graph_no_samples = cfg.hcp.roadmap_graph_no_samples;
+  p.roadmap_graph_area_width = cfg.hcp.roadmap_graph_area_width;
+  p.roadmap_graph_area_length_scale = cfg.hcp.roadmap_graph_area_length_scale;
+  p.obstacle_heading_threshold = cfg.hcp.obstacle_heading_threshold;
+  p.xy_goal_tolerance = cfg.goal_tolerance.xy_goal_tolerance;
+  p.max_number_classes = cfg.hcp.max_number_classes;
+  p.max_number_plans_in_current_class = cfg.hcp.max_number_plans_in_current_class;
+  p.h_signature_prescaler = cfg.hcp.h_signature_prescaler;
+  p.h_signature_threshold = cfg.hcp.h_signature_threshold;
+  p.allow_init_with_backwards_motion = cfg.trajectory.allow_init_with_backwards_motion;
+  p.delete_detours_backwards = cfg.hcp.delete_detours_backwards;
+  p.detours_orientation_tolerance = cfg.hcp.detours_orientation_tolerance;
+  p.length_start_orientation_vector = cfg.hcp.length_start_orientation_vector;
+  p.max_ratio_detours_duration_best_duration = cfg.hcp.max_ratio_detours_duration_best_duration;
+}
+
+bool TebAmdBatch::exploreEquivalenceClassesAndInitTebs(const TebConfig& cfg, ObstContainer* obstacles, const ViaPointContainer* via_points,
+                                                       std::vector<TebOptimalPlannerAmdPtr>& tebs, int& best_index, const PoseSE2& start,
+                                                       const PoseSE2& goal, double dist_to_obst, const geometry_msgs::Twist* start_vel,
+                                                       bool free_goal_vel)
+{
+  if (!h_) return false;
+  teb_amd_hcp_params_t hp;
+  toAmdHcpParams(cfg, hp);
+  // scene
+  teb_amd_config_t a;
+  toAmdConfig(cfg, a);
+  AmdObstacleTable table;
+  table.assign(obstacles);
+  teb_amd_obstacles_t ov = table.view();
+  int rc = teb_amd_set_config(h_, &a);
+  if (rc != TEB_AMD_OK && rc != TEB_AMD_ERR_INVALID_ARG) return check(rc, "teb_amd_set_config");
+  if (!check(teb_amd_set_obstacles(h_, &ov), "teb_amd_set_obstacles")) return false;
+  // ---- renewAndAnalyzeOldTebs on the existing candidates
+  int32_t n_kept = 0, new_best = -1;
+  if (!tebs.empty())
+  {
+    std::vector<TebOptimalPlannerAmd*> raw;
+    std::vector<int32_t> optimized;
+    for (const TebOptimalPlannerAmdPtr& t : tebs) { raw.push_back(t.get()); optimized.push_back(t->isOptimized()); }
+    if (!uploadBands(raw)) return false;
+    if (!check(teb_amd_set_optimized_flags(h_, optimized.data()), "teb_amd_set_optimized_flags")) return false;
+    int32_t w = 0;
+    if (!check(teb_amd_compute_h_signatures(h_, hp.h_signature_prescaler, NULL, &w), "teb_amd_compute_h_signatures")) return false;
+    std::vector<int32_t> keep(tebs.size());
+    if (!check(teb_amd_filter_equivalence_classes(h_, hp.h_signature_threshold, best_index, hp.max_number_plans_in_current_class, keep.data(),
+                                                  NULL, NULL), "teb_amd_filter_equivalence_classes")) return false;
+    if (hp.delete_detours_backwards && !check(teb_amd_filter_detours(h_, &hp, best_index, keep.data()), "teb_amd_filter_detours")) return false;
+    if (!check(teb_amd_compact_bands(h_, keep.data(), best_index, &n_kept, &new_best), "teb_amd_compact_bands")) return false;
+    std::vector<int> order(tebs.size());
+    for (size_t b = 0; b < tebs.size(); ++b) order[b] = (int)b;
+    if (best_index >= 0 && best_index < (int)tebs.size()) std::swap(order[0], order[best_index]);
+    std::vector<TebOptimalPlannerAmdPtr> kept;
+    for (int b : order) if (keep[b]) kept.push_back(tebs[b]);
+    tebs.swap(kept);
+  }
+  best_index = new_best;
+  // ---- createGraph + DepthFirst + addAndInitNewTeb
+  const double s[3] = { start.x(), start.y(), start.theta() }, g[3] = { goal.x(), goal.y(), goal.theta() };
+  double sv[3] = { 0, 0, 0 };
+  if (start_vel) { sv[0] = start_vel->linear.x; sv[1] = start_vel->linear.y; sv[2] = start_vel->angular.z; }
+  int32_t n_total = 0;
+  if (!check(teb_amd_explore_candidates(h_, &hp, s, g, dist_to_obst, start_vel ? sv : NULL, free_goal_vel ? 1 : 0, best_index, NULL, 0,
+                                        &n_total, NULL, NULL), "teb_amd_explore_candidates")) return false;
+  const size_t old = tebs.size();
+  for (int b = (int)old; b < n_total; ++b)
+  {
+    TebOptimalPlannerAmdPtr c(new TebOptimalPlannerAmd(cfg, obstacles, TebVisualizationPtr(), via_points));
+    if (start_vel) c->setVelocityStart(*start_vel);
+    if (free_goal_vel) c->setVelocityGoalFree();
+    tebs.push_back(c);
+  }
+  if (n_total > (int)old)   // bands of the new candidates (the old ones are unchanged)
+  {
+    const int B = n_total, S = max_poses_;
+    std::vector<int32_t> n(B);
+    std::vector<double> x((size_t)B * S), y((size_t)B * S), th((size_t)B * S), dt((size_t)B * S);
+    teb_amd_teb_batch_t batch;
+    std::memset(&batch, 0, sizeof(batch));
+    batch.count = B; batch.stride = S; batch.n = n.data(); batch.x = x.data(); batch.y = y.data(); batch.theta = th.data(); batch.dt = dt.data();
+    if (!check(teb_amd_download_tebs(h_, &batch), "teb_amd_download_tebs")) return false;
+    for (int b = (int)old; b < B; ++b)
+    {
+      TimedElasticBand& t = tebs[b]->teb_;
+      const size_t o = (size_t)b * S;
+      t.clearTimedElasticBand();
+      t.addPose(x[o], y[o], th[o], true);
+      for (int i = 1; i < n[b]; ++i) t.addPoseAndTimeDiff(x[o + i], y[o + i], th[o + i], dt[o + i - 1]);
+      t.setPoseVertexFixed(n[b] - 1, true);
+    }
+  }
+  return true;
+}
+
 bool TebAmdBatch::getVelocityCommand(const TebConfig& cfg, int index, double& vx, double& vy, double& omega, int look_ahead_poses)
 {
   int32_t ok = 0;

@@ -42,6 +42,9 @@ void setAmdJacobianMode(int mode);
 
 class TebAmdBatch;
 
+//! teb_amd_hcp_params_t of a TebConfig (hcp.*, goal_tolerance.xy_goal_tolerance, trajectory.allow_init_with_backwards_motion)
+void toAmdHcpParams(const TebConfig& cfg, teb_amd_hcp_params_t& p);
+
 /**
  * TebOptimalPlanner whose optimizeTEB() is executed by libteb_amd.so. Everything else (plan(), velocity extraction,
  * feasibility check, visualisation) is inherited unchanged; the g2o optimizer_ member is simply never used.
@@ -113,6 +116,19 @@ public:
    */
   bool renewAndAnalyzeOldTebs(const TebConfig& cfg, int best_index, std::vector<bool>& keep, std::vector<double>* values = NULL,
                               int* width = NULL);
+
+  /**
+   * Replaces the body of HomotopyClassPlanner::exploreEquivalenceClassesAndInitTebs (src/homotopy_class_planner.cpp:318-340; not the
+   * initial-plan branch :326-335 nor randomlyDropTebs): renewAndAnalyzeOldTebs incl. deletePlansDetouringBackwards on the
+   * candidates in `tebs` (erased ones leave the vector; the last best candidate, best_index, moves to the front), then
+   * createGraph / DepthFirst / addAndInitNewTeb on the device; every new band arrives as a new TebOptimalPlannerAmd appended to
+   * `tebs` (constructed like the reference's candidates: same cfg, obstacles, via-points; setVelocityStart / setVelocityGoalFree
+   * applied). best_index is updated (0 or -1). Returns false on a library error (lastError()).
+   */
+  bool exploreEquivalenceClassesAndInitTebs(const TebConfig& cfg, ObstContainer* obstacles, const ViaPointContainer* via_points,
+                                            std::vector<TebOptimalPlannerAmdPtr>& tebs, int& best_index, const PoseSE2& start,
+                                            const PoseSE2& goal, double dist_to_obst, const geometry_msgs::Twist* start_vel,
+                                            bool free_goal_vel);
 
   //! TebOptimalPlanner::getVelocityCommand (src/optimal_planner.cpp:1135-1168) of candidate `index`, from the device-resident band.
   bool getVelocityCommand(const TebConfig& cfg, int index, double& vx, double& vy, double& omega, int look_ahead_poses);

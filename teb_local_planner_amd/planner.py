@@ -82,6 +82,9 @@ def lib():
                                                  _abi.p_f64, C.c_int64, _abi.p_i32, _abi.p_i32, _abi.p_i32]
         L.teb_amd_get_exploration_graph.argtypes = [vp, _abi.p_f64, _abi.p_f64, C.POINTER(C.c_ubyte), i32, _abi.p_i32]
         L.teb_amd_compact_bands.argtypes = [vp, _abi.p_i32, i32, _abi.p_i32, _abi.p_i32]
+        L.teb_amd_filter_detours.argtypes = [vp, C.POINTER(_abi.HcpParams), i32, _abi.p_i32]
+        L.teb_amd_set_optimized_flags.argtypes = [vp, _abi.p_i32]
+        L.teb_amd_get_optimized_flags.argtypes = [vp, _abi.p_i32]
         L.teb_amd_hcp_params_default.argtypes = [C.POINTER(_abi.HcpParams)]
         L.teb_amd_hcp_params_default.restype = None
         _LIB = L
@@ -284,6 +287,23 @@ class TebBatchSolver:
         return keep, valid, reas
 
     # -- candidate generation: createGraph + DepthFirst + addAndInitNewTeb -----------------
+    def set_optimized_flags(self, flags):
+        f = _abi.i32(flags)
+        _chk(lib().teb_amd_set_optimized_flags(self._h, _abi._ptr(f, C.c_int32)), "teb_amd_set_optimized_flags")
+
+    def optimized_flags(self):
+        self._sync_count()
+        f = np.zeros(max(self.count, 1), np.int32)
+        _chk(lib().teb_amd_get_optimized_flags(self._h, _abi._ptr(f, C.c_int32)), "teb_amd_get_optimized_flags")
+        return f[:self.count]
+
+    def filter_detours(self, keep, best, params=None):
+        """deletePlansDetouringBackwards on the bands with keep != 0: returns the new keep array."""
+        p = params if params is not None else self.cfg.hcp_params()
+        keep = _abi.i32(keep).copy()
+        _chk(lib().teb_amd_filter_detours(self._h, C.byref(p), int(best), _abi._ptr(keep, C.c_int32)), "teb_amd_filter_detours")
+        return keep
+
     def compact_bands(self, keep, best=-1):
         """Keeps the bands with keep[b] != 0, last best band first (renewAndAnalyzeOldTebs): (n_kept, new_best)."""
         keep = _abi.i32(keep)
@@ -511,15 +531,89 @@ class TebOptimalPlanner:
 
 
 class HomotopyClassPlanner:
-    """Batch view: owns B candidates resident on one GPU (reference homotopy_class_planner.h)."""
+    """Batch view: owns the candidates resident on one GPU (reference homotopy_class_planner.h). Either constructed around a host
+    batch (optimizeAllTEBs / selectBestTeb on given bands) or empty (batch=None): plan() then runs the reference's whole tick on the
+    device-resident bands - updateAllTEBs, exploreEquivalenceClassesAndInitTebs, optimizeAllTEBs, selectBestTeb
+    (src/homotopy_class_planner.cpp:107-125). Not mirrored: the initial-plan candidate (initial_plan_, :326-335), randomlyDropTebs
+    (off by default) and switching_blocking_period (0 by default)."""
 
-    def __init__(self, cfg, obstacles, via_points, batch, device=0, stream=None):
+    def __init__(self, cfg, obstacles, via_points, batch=None, device=0, stream=None, max_tebs=None, max_poses=None):
         self.cfg_ = cfg
         self.tebs_ = batch
-        self.solver = make_solver(cfg, obstacles, via_points, batch, device=device, stream=stream)
+        self.obstacles_ = obstacles
+        self.via_points_ = list(via_points or [])
+        if batch is not None:
+            self.solver = make_solver(cfg, obstacles, via_points, batch, device=device, stream=stream, max_tebs=max_tebs,
+                                      max_poses=max_poses)
+        else:
+            self.solver = TebBatchSolver(cfg, max_tebs or max(cfg.hcp.max_number_classes, 1), max_poses or 256, max(len(obstacles), 1),
+                                         max(len(obstacles.vert_x), 1), max(len(self.via_points_), 1), device=device, stream=stream)
+            self.solver.set_obstacles(obstacles)
+            self.solver.set_via_points(self.via_points_)
         self.best_teb_ = -1
         self.initial_plan_teb_ = -1
         self.last_results = None
+        self.last_exploration = None
+        self._goal = None
+
+    # ---- src/homotopy_class_planner.cpp:539-562 ---------------------------------------------------------------------------------
+    def updateAllTEBs(self, start, goal, start_velocity=None):
+        import math
+        s, t = self.solver, self.cfg_.trajectory
+        if s.count > 0 and self._goal is not None:
+            d = math.hypot(goal[0] - self._goal[0], goal[1] - self._goal[1])
+            a = abs((goal[2] - self._goal[2] + math.pi) % (2 * math.pi) - math.pi)
+            if d >= t.force_reinit_new_goal_dist or a >= t.force_reinit_new_goal_angular:
+                s.compact_bands(np.zeros(s.count, np.int32))      # tebs_.clear(); equivalence_classes_.clear()
+                self.best_teb_ = -1
+        if s.count > 0:
+            s.update_and_prune(start, goal, t.min_samples)        # every band, one launch
+            if start_velocity is not None:
+                s.set_velocity_start(start_velocity, True)
+        self._goal = tuple(goal)
+
+    # ---- :318-340 (renewAndAnalyzeOldTebs :214-254, deletePlansDetouringBackwards :766-817, createGraph) -------------------------
+    def exploreEquivalenceClassesAndInitTebs(self, start, goal, dist_to_obst, start_vel=None, free_goal_vel=False):
+        s, h = self.solver, self.cfg_.hcp
+        if s.count > 0:
+            s.h_signatures(h.h_signature_prescaler)
+            keep, _, _ = s.filter_equivalence_classes(h.h_signature_threshold, self.best_teb_, h.max_number_plans_in_current_class)
+            if h.delete_detours_backwards:
+                keep = s.filter_detours(keep, self.best_teb_)
+            _, self.best_teb_ = s.compact_bands(keep, self.best_teb_)
+        self.last_exploration = s.explore_candidates(start, goal, dist_to_obst, start_vel, free_goal_vel, self.best_teb_)
+        return self.last_exploration["n_total"]
+
+    def plan(self, start, goal, start_vel=None, free_goal_vel=False):
+        """plan(const PoseSE2& start, const PoseSE2& goal, const geometry_msgs::Twist* start_vel, bool free_goal_vel), :107-125."""
+        o = self.cfg_.optim
+        self.solver.set_config(self.cfg_)
+        self.updateAllTEBs(start, goal, start_vel)
+        self.exploreEquivalenceClassesAndInitTebs(start, goal, self.cfg_.obstacles.min_obstacle_dist, start_vel, free_goal_vel)
+        if self.solver.count == 0:
+            self.best_teb_ = -1
+            return True
+        self.optimizeAllTEBs(o.no_inner_iterations, o.no_outer_iterations)
+        self.selectBestTeb()
+        return True
+
+    def getVelocityCommand(self, look_ahead_poses=None):
+        """(ok, vx, vy, omega) of the best band (:127-139)."""
+        if self.best_teb_ < 0:
+            return False, 0.0, 0.0, 0.0
+        t = self.cfg_.trajectory
+        ok, v = self.solver.velocity_command(self.best_teb_, t.control_look_ahead_poses if look_ahead_poses is None else look_ahead_poses,
+                                             t.prevent_look_ahead_poses_near_goal)
+        return ok, float(v[0]), float(v[1]), float(v[2])
+
+    def bands(self, stride=None):
+        """Host copy of the resident bands: list of (x, y, theta, dt)."""
+        s = self.solver
+        if s.count == 0:
+            return []
+        b = _abi.TebBatchHost(s.count, stride or s.max_poses)
+        s.download(b)
+        return [b.get_teb(k) for k in range(s.count)]
 
     def optimizeAllTEBs(self, iter_innerloop, iter_outerloop):
         h = self.cfg_.hcp

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
 sys.path.insert(0, HERE)
 import make_ref_golden as RG  # noqa: E402
-from test_reference_pinning import renew_on_host  # noqa: E402
+from test_reference_pinning import renew_on_host, stale_signature  # noqa: E402
 
 from teb_local_planner_amd import planner, _abi, scenes  # noqa: E402
 
@@ -33,6 +33,10 @@ def _make(case, max_tebs=16, stride=256):
     s.set_via_points([])
     if batch is not None:
         s.upload(batch)
+        opt = case.get("optimized")
+        if opt is None:
+            opt = [1] * batch.count
+        s.set_optimized_flags(opt)     # TebOptimalPlanner::optimized_ of bands that came from the host
     return s
 
 
@@ -43,6 +47,8 @@ def _renew_on_device(s, case):
         return -1
     s.h_signatures(cfg.hcp.h_signature_prescaler)
     keep, _, _ = s.filter_equivalence_classes(cfg.hcp.h_signature_threshold, case["best"], cfg.hcp.max_number_plans_in_current_class)
+    if cfg.hcp.delete_detours_backwards:
+        keep = s.filter_detours(keep, case["best"])
     _, best = s.compact_bands(keep, case["best"])
     return best
 
@@ -65,6 +71,14 @@ def test_explore_candidates_matches_oracle_and_reference_vectors(oracle, name):
     g = np.load(os.path.join(HERE, "golden", "ref_f3_explore.npz"))
     ref = {k[len(name) + 2:]: g[k] for k in g.files if k.startswith(name + "__")}
     s = _make(case)
+    if case.get("stale_band") is not None:   # a best band of an earlier tick that is gone (goal jump): its class stays in the handle
+        host = _abi.TebBatchHost(1, 256)
+        host.set_teb(0, *case["stale_band"])
+        s.upload(host)
+        s.h_signatures(case["cfg"].hcp.h_signature_prescaler)
+        s.filter_equivalence_classes(case["cfg"].hcp.h_signature_threshold, 0, case["cfg"].hcp.max_number_plans_in_current_class)
+        s.compact_bands(np.zeros(1, np.int32))          # tebs_.clear()
+        assert s.count == 0
     best = _renew_on_device(s, case)
     if case.get("skip_draws"):   # "second call": the handle's generator has produced the samples of an earlier graph already
         p = case["cfg"].hcp_params()
@@ -76,7 +90,8 @@ def test_explore_candidates_matches_oracle_and_reference_vectors(oracle, name):
     b, n_tebs, obest = renew_on_host(oracle, case)
     assert obest == best
     o = oracle.explore_candidates(case["cfg"], case["obst"], b, n_tebs, obest, case["start"], case["goal"],
-                                  skip_draws=case.get("skip_draws", 0), dist_to_obst=case.get("dist_to_obst"))
+                                  skip_draws=case.get("skip_draws", 0), dist_to_obst=case.get("dist_to_obst"),
+                                  stale_best_sig=stale_signature(oracle, case))
     assert r["n_total"] == o["n_total"] == int(ref["n_total"]) == s.count
     assert r["n_vertices"] == len(o["vertices"])
     if r["n_total"] > n_tebs or name == "max_two_classes":
@@ -176,3 +191,58 @@ def test_large_keypoint_graph_all_pairs_on_the_device(oracle):
     np.testing.assert_array_equal(A, want)
     assert A.sum() > 100
     s.close()
+
+
+def test_optimized_flag_follows_optimizeTEB(oracle):
+    """optimized_ = false at the start of optimizeTEB, true after the first completed outer iteration (src/optimal_planner.cpp:189, 220);
+    uploads and new candidates start with false; optimization_activate = false leaves it untouched."""
+    cfg, obst, via, batch = scenes.scene_small_mixed(B=3, n=24, seed=3, with_via=False)
+    cfg.trajectory.teb_autosize = False
+    batch.n[2] = 2                                   # fewer poses than min_samples: optimizeGraph fails in the first outer iteration
+    s = planner.make_solver(cfg, obst, [], batch, max_tebs=6)
+    np.testing.assert_array_equal(s.optimized_flags(), [0, 0, 0])
+    s.optimize(cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations); s.synchronize()
+    np.testing.assert_array_equal(s.optimized_flags(), [1, 1, 0])
+    np.testing.assert_array_equal(s.results().status, [_abi.TEB_OK, _abi.TEB_OK, _abi.TEB_FAILED])
+    cfg.optim.optimization_activate = False
+    s.set_config(cfg)
+    s.optimize(cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations); s.synchronize()
+    np.testing.assert_array_equal(s.optimized_flags(), [1, 1, 0])      # early return before optimized_ = false
+    cfg.optim.optimization_activate = True
+    s.set_config(cfg)
+    s.close()
+    case = RG.explore_cases()["roadmap_points_3d"]
+    s = _make(case)
+    r = _explore(s, case, -1)
+    assert r["n_total"] >= 3 and not s.optimized_flags().any()      # new TebOptimalPlanner: optimized_(false)
+    s.optimize(2, 2); s.synchronize()
+    assert s.optimized_flags().all()
+    s.close()
+
+
+@pytest.mark.parametrize("name", sorted(RG.hcp_tick_cases()))
+def test_whole_plan_ticks_match_the_reference_planner(name):
+    """HomotopyClassPlanner::plan() tick after tick on device-resident bands (updateAllTEBs, renewAndAnalyzeOldTebs with detour
+    deletion, graph exploration, optimizeAllTEBs, selectBestTeb) against the vectors of the reference's own HomotopyClassPlanner run
+    on the same inputs (oracle/ref_shim/ref_hcp_driver.cpp: reference classes, g2o's LM restated). Same number and order of bands,
+    same best band in every tick; states within 2e-5 (the optimiser parity of tests/test_gpu_parity.py carried over four ticks),
+    costs within 1e-6 relative."""
+    case = RG.hcp_tick_cases()[name]
+    g = np.load(os.path.join(HERE, "golden", "ref_f3_hcp_ticks.npz"))
+    hcp = planner.HomotopyClassPlanner(case["cfg"], case["obst"], [], None, max_tebs=8, max_poses=256)
+    for t, (st, gl) in enumerate(zip(case["starts"], case["goals"])):
+        sv = None if case["start_vels"] is None else case["start_vels"][t]
+        assert hcp.plan(st, gl, sv)
+        pre = "%s__%d__" % (name, t)
+        ref = {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)}
+        bands = hcp.bands()
+        assert len(bands) == len(ref["n"]) and hcp.best_teb_ == int(ref["best"]), (t, len(bands), hcp.best_teb_)
+        cost = np.array(hcp.results().cost[:len(bands)])
+        assert np.abs(cost - ref["costs"]).max() <= 1e-6 * np.abs(ref["costs"]).max()
+        for k, band in enumerate(bands):
+            want = RG.unpack(ref, k)
+            assert len(band[0]) == len(want[0]), (t, k)
+            assert max(np.abs(a - b).max() for a, b in zip(band, want)) <= 2e-5, (t, k)
+        ok, vx, vy, om = hcp.getVelocityCommand()
+        assert ok and np.isfinite([vx, vy, om]).all()
+    hcp.solver.close()

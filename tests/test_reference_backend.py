@@ -182,3 +182,45 @@ def test_backend_rows_f1_f2_f3_on_reference_objects(dynamic):
     # f2: velocity command from the device-resident band == the reference's on the written-back band
     np.testing.assert_array_equal(ca[:, 3], cr[:, 3])
     assert np.abs(ca[:, :3] - cr[:, :3]).max() <= 1e-12
+
+
+# ---- candidate generation through the binding: TebAmdBatch::exploreEquivalenceClassesAndInitTebs vs the reference's own method ----------
+@pytest.mark.parametrize("name", ["roadmap_existing_tebs_best", "detours_existing_tebs", "keypoint_mixed_3d", "keypoint_points_2d",
+                                  "backwards_start_velocity_free_goal", "goal_reached_line_init", "already_full"])
+def test_binding_explores_like_the_reference_planner(name):
+    """Same TebConfig / ObstContainer / TimedElasticBand objects -> (1) HomotopyClassPlanner::exploreEquivalenceClassesAndInitTebs of the
+    reference (CPU), (2) the binding (device). Same candidates in the same order; bands <= 1e-12 (no optimisation involved)."""
+    case = RG.explore_cases()[name]
+    if case.get("skip_draws"):
+        pytest.skip("needs a planner whose generator has been used before")
+    L = _lib()
+    cfg, obst, batch = case["cfg"], case["obst"], case["batch"]
+    c = cfg.to_c(); p = cfg.hcp_params()
+    slots, S = 12, 256
+    ref = _abi.TebBatchHost(slots, S); amd = _abi.TebBatchHost(slots, S)
+    rs, as_ = ref.c_struct(), amd.c_struct()
+    P = lambda a: _abi._ptr(a, C.c_double)
+    I = lambda a: _abi._ptr(a, C.c_int32)
+    st = _abi.f64(case["start"]); gl = _abi.f64(case["goal"])
+    sv = None if case.get("start_vel") is None else _abi.f64(case["start_vel"])
+    opt = None if case.get("optimized") is None else _abi.i32(case["optimized"])
+    nr = C.c_int32(0); na = C.c_int32(0); ab = C.c_int32(-2)
+    flags = np.zeros(2 * slots, np.int32)
+    ins = batch.c_struct() if batch is not None else None
+    L.backend_check_explore.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    vp = lambda x: C.cast(x, C.c_void_p) if x is not None else None
+    rc = L.backend_check_explore(vp(C.pointer(c)), vp(C.pointer(p)), vp(C.pointer(obst.freeze())), vp(C.pointer(ins)) if ins is not None else None,
+                                 int(case["best"]), vp(I(opt)) if opt is not None else None, vp(P(st)), vp(P(gl)),
+                                 float(case.get("dist_to_obst") or cfg.obstacles.min_obstacle_dist), vp(P(sv)) if sv is not None else None,
+                                 int(bool(case.get("free_goal_vel", False))), vp(C.pointer(rs)), vp(C.pointer(nr)), vp(C.pointer(as_)),
+                                 vp(C.pointer(na)), vp(C.pointer(ab)), vp(I(flags)))
+    assert rc == 0, rc
+    assert nr.value == na.value, (nr.value, na.value)
+    for k in range(nr.value):
+        for a, b in zip(ref.get_teb(k), amd.get_teb(k)):
+            assert len(a) == len(b) and np.abs(a - b).max(initial=0) <= 1e-12, (name, k)
+    n_old = 0 if batch is None else batch.count
+    if case.get("free_goal_vel") and na.value:
+        assert not flags[1:2 * na.value:2].any()      # setVelocityGoalFree() on every new candidate
+    assert ab.value in (-1, 0)

@@ -301,6 +301,9 @@ def renew_on_host(oracle, case, slots=None):
     mode = 3 if cfg.obstacles.include_dynamic_obstacles else 2
     sig = oracle.h_signatures(cfg, obst, batch, mode, cfg.hcp.h_signature_prescaler)
     keep, _, _ = oracle.filter_equivalence_classes(mode, sig, cfg.hcp.h_signature_threshold, best, cfg.hcp.max_number_plans_in_current_class)
+    if cfg.hcp.delete_detours_backwards:
+        opt = case.get("optimized") or [1] * batch.count
+        keep = oracle.filter_detours(cfg, batch, keep, best, opt)
     order = list(range(batch.count))
     if best >= 0:
         order[0], order[best] = order[best], order[0]
@@ -308,6 +311,16 @@ def renew_on_host(oracle, case, slots=None):
     for k, b in enumerate(kept):
         out.set_teb(k, *batch.get_teb(b))
     return out, len(kept), (0 if best >= 0 and keep[best] else -1)
+
+
+def stale_signature(oracle, case):
+    """Signature of case["stale_band"] (the class of a best band that no longer exists), or None."""
+    if case.get("stale_band") is None:
+        return None
+    cfg = case["cfg"]
+    b = _abi.TebBatchHost(1, 256)
+    b.set_teb(0, *case["stale_band"])
+    return oracle.h_signatures(cfg, case["obst"], b, 3 if cfg.obstacles.include_dynamic_obstacles else 2, cfg.hcp.h_signature_prescaler)[0]
 
 
 @pytest.mark.parametrize("name", sorted(G.explore_cases()))
@@ -322,7 +335,7 @@ def test_f3_candidate_generation_matches_reference_graph_search(oracle, name):
         ref = {k[len(name) + 2:]: g[k] for k in g.files if k.startswith(name + "__")}
     b, n_tebs, best = renew_on_host(oracle, case)
     o = oracle.explore_candidates(case["cfg"], case["obst"], b, n_tebs, best, case["start"], case["goal"], skip_draws=case.get("skip_draws", 0),
-                                  dist_to_obst=case.get("dist_to_obst"))
+                                  dist_to_obst=case.get("dist_to_obst"), stale_best_sig=stale_signature(oracle, case))
     assert o["n_total"] == int(ref["n_total"])
     np.testing.assert_array_equal(o["vertices"], ref["vertices"])
     N = len(o["vertices"])
@@ -346,6 +359,20 @@ def test_f3_candidate_cases_cover_both_graphs_and_find_several_classes(oracle):
     assert seen["goal_reached_line_init"] == (0, 1, 0) and seen["already_full"][1] == seen["already_full"][0] == 2
     assert seen["roadmap_existing_tebs_best"][0] == 4          # 5 bands in 3 classes, 2 allowed in the best band's class
     assert seen["max_two_classes"][1] == 2
+    assert seen["stale_best_class_2d"][1] == 3 and seen["stale_best_class_3d"][1] == 3     # without the left-over class: 3 classes ...
+    for name in ("stale_best_class_2d", "stale_best_class_3d"):                            # ... with it: two more plans in that class
+        case = G.explore_cases()[name]
+        b, n_tebs, best = renew_on_host(oracle, case)
+        o = oracle.explore_candidates(case["cfg"], case["obst"], b, n_tebs, best, case["start"], case["goal"],
+                                      stale_best_sig=stale_signature(oracle, case))
+        assert o["n_total"] == 5
+    # deletePlansDetouringBackwards: the backwards start (1), the 5x longer plan (2) and the not-optimised plan (3) go, each by its own rule
+    case = G.explore_cases()["detours_existing_tebs"]
+    ones = np.ones(6, np.int32)
+    np.testing.assert_array_equal(oracle.filter_detours(case["cfg"], case["batch"], ones, 0, case["optimized"]), [1, 0, 0, 0, 1, 1])
+    np.testing.assert_array_equal(oracle.filter_detours(case["cfg"], case["batch"], ones, 0, [1] * 6), [1, 0, 0, 1, 1, 1])
+    np.testing.assert_array_equal(oracle.filter_detours(case["cfg"], case["batch"], ones, -1, [1] * 6), ones)          # no best band yet
+    np.testing.assert_array_equal(oracle.filter_detours(G.explore_cases()["detours_best_too_short"]["cfg"], case["batch"], ones, 0, [1] * 6), ones)
 
 
 # ---- randomised pin: every option toggled at random, whole optimizeTEB, oracle vs the reference's src/optimal_planner.cpp ----------
