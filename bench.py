@@ -199,10 +199,10 @@ def main():
             # candidate paths -> band init + signatures, optimizeAllTEBs (4x5, autosize), selectBestTeb, velocity command
             hc = scenes.scene_c4(B=1, n=n)[0]
             hc.hcp.max_number_classes = 5
-            rng = np.random.default_rng(3)
+            rng = np.random.default_rng(5)
             hob = _abi.ObstacleTable()
-            for _ in range(30):
-                hob.add_point(rng.uniform(1.5, 14.5), rng.uniform(-3.0, 3.0))
+            for _ in range(12):
+                hob.add_point(rng.uniform(1.5, 14.5), rng.uniform(-2.5, 2.5))
             ticks = max(8, args.latency_reps)
             starts = [[0.05 * k, 0.0, 0.0] for k in range(ticks)]
             goals = [[16.0, 0.0, 0.0]] * ticks
@@ -216,7 +216,7 @@ def main():
                 nb.append(hp.solver.count)
             hp.solver.close()
             lat["hcp_plan_tick_p50_ms"] = 1e3 * float(np.median(ts[1:]))
-            lat["hcp_plan_tick"] = {"workload": "HomotopyClassPlanner::plan() ticks on one planner: 16 m straight task, 30 point obstacles, "
+            lat["hcp_plan_tick"] = {"workload": "HomotopyClassPlanner::plan() ticks on one planner: 16 m straight task, 12 point obstacles, "
                                                 "roadmap graph (15 samples), max_number_classes 5, 4x5 iterations, teb_autosize on",
                                     "ticks": ticks, "first_tick_ms": 1e3 * ts[0], "bands_per_tick": [int(min(nb)), int(max(nb))]}
             try:
@@ -224,7 +224,7 @@ def main():
                 if os.path.exists(ref_py.SO):
                     t1 = time.perf_counter()
                     ref_py.hcp_plan_ticks(hc, hob, starts, goals, [[0.3, 0.0, 0.0]] * ticks)
-                    lat["hcp_plan_tick"]["reference_code_cpu_ms_per_tick"] = 1e3 * (time.perf_counter() - t1) / ticks
+                    lat["hcp_plan_tick"]["reference_code_cpu_ms_per_tick"] = 1e3 * (time.perf_counter() - t1) / ticks   # oracle/_ref, one thread
             except Exception as e:
                 lat["hcp_plan_tick"]["reference_code_cpu_ms_per_tick"] = str(e)[:120]
         out["plan_latency"] = lat

@@ -857,8 +857,15 @@ int launch_hsig(teb_amd_handle* h, const BatchDev& bt, int B, double prescaler, 
   if (B <= 0) return TEB_AMD_OK;
   if (h->cfg.include_dynamic_obstacles) {
     if (M > 0) {
-      hipLaunchKernelGGL(hsig3d_kernel, dim3((M + kThreads - 1) / kThreads, B), dim3(kThreads), 3 * (size_t)h->stride * sizeof(double),
-                         h->stream, sc, bt, out);
+      // one lane per (band, obstacle) when that fills the chip; otherwise lanes over (obstacle, segment): same bits, lower latency
+      const char* force = std::getenv("TEB_AMD_HSIG3D");   // "wide" / "small": pin one of the two kernels (tests, tools/hsig_bench.py)
+      const bool wide = force ? std::strcmp(force, "wide") == 0 : (long long)B * M >= 32768;
+      if (wide)
+        hipLaunchKernelGGL(hsig3d_kernel, dim3((M + kThreads - 1) / kThreads, B), dim3(kThreads), 3 * (size_t)h->stride * sizeof(double),
+                           h->stream, sc, bt, out);
+      else
+        hipLaunchKernelGGL(hsig3d_small_kernel, dim3((M + kHsTile - 1) / kHsTile, B), dim3(kThreads), 3 * (size_t)h->stride * sizeof(double),
+                           h->stream, sc, bt, out);
       HIPCHK(hipGetLastError());
     }
   } else {

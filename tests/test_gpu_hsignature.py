@@ -91,3 +91,20 @@ def test_h_signature_2d_large_obstacle_count_stays_in_range(oracle):
     assert np.isfinite(sig).all()
     assert np.abs(sig - want).max() <= 1e-10 * max(np.abs(want).max(), 1e-300) + 1e-300
     s.close()
+
+
+def test_3d_signature_kernels_return_identical_bits(oracle):
+    """hsig3d_kernel (one lane per band x obstacle) and hsig3d_small_kernel (lanes over obstacle x segment, sequential sum by one lane
+    per obstacle) perform the same operations in the same order: identical results, on every case incl. ragged band lengths."""
+    try:
+        for cname, cfg, obst, batch in RG.h_signature_cases():
+            s = _solver(cfg, obst, batch, 3)
+            os.environ["TEB_AMD_HSIG3D"] = "wide"
+            a = s.h_signatures(1.0).copy()
+            os.environ["TEB_AMD_HSIG3D"] = "small"
+            b = s.h_signatures(1.0).copy()
+            np.testing.assert_array_equal(a, b)
+            assert np.isfinite(a).all() and np.abs(a).max() > 0
+            s.close()
+    finally:
+        os.environ.pop("TEB_AMD_HSIG3D", None)
