@@ -140,7 +140,7 @@ struct teb_amd_handle {
   int max_tebs = 0, stride = 0, max_obst = 0, max_verts = 0, max_via = 0;
   int B = 0, M = 0, nvia = 0, n_static = 0, n_dyn = 0;
   size_t lds_bytes = 0;
-  int solver = 0;
+  int solver = 0, solver_created = 0;   // solver_created: the choice of teb_amd_create; teb_amd_set_obstacles may move a band to HBM
   size_t hmat_stride = 0;
   int band_ldlt = 0;   // SOLVER_BAND: 1 = sequential banded LDL^T (TEB_AMD_BAND_SOLVE=ldlt), 0 = cyclic reduction on HBM blocks
   size_t lds_limit = 0;
@@ -152,7 +152,8 @@ struct teb_amd_handle {
   DevBuf<double> o_ax, o_ay, o_bx, o_by, o_rad, o_vx, o_vy, o_cx, o_cy, o_pvx, o_pvy, viax, viay;
   // batch
   DevBuf<int> n, has_vs, has_vg, rotdir, via_en, status, optimized, iters, trials, assoc_cnt, assoc, assoc_ovf, via_pose, legacy_idx;
-  DevBuf<double> x, y, th, dt, vs, vg, chi2, cost, lambda, Hbackup;
+  DevBuf<double> x, y, th, dt, vs, vg, chi2, cost, lambda, Hbackup, Hband;
+  size_t hband_stride = 0;
   // snapshot
   DevBuf<int> snap_n;
   DevBuf<double> snap_x, snap_y, snap_th, snap_dt;
@@ -167,6 +168,7 @@ struct teb_amd_handle {
   DevBuf<int> hs_pex;
   std::vector<double> hsig_host;
   int hsig_mode = 0, hsig_B = 0, hsig_M = 0;
+  double hsig_prescaler = 0;
   int consumers_la = 0, consumers_prevent = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
@@ -237,10 +239,12 @@ opt_kernel_t opt_kernel(int solver, int jmode) {
 #ifndef TEB_AMD_ANALYTIC_ONLY   // tools/ builds (-DTEB_AMD_ANALYTIC_ONLY) skip the numeric instantiations: 35 s instead of 3 min
   if (jmode == TEB_AMD_JACOBIAN_G2O_NUMERIC)
     return solver == SOLVER_CR ? teb_optimize_kernel<SOLVER_CR, TEB_AMD_JACOBIAN_G2O_NUMERIC>
-                               : teb_optimize_kernel<SOLVER_BAND, TEB_AMD_JACOBIAN_G2O_NUMERIC>;
+           : solver == SOLVER_BAND ? teb_optimize_kernel<SOLVER_BAND, TEB_AMD_JACOBIAN_G2O_NUMERIC>
+                                   : teb_optimize_kernel<SOLVER_BANDG, TEB_AMD_JACOBIAN_G2O_NUMERIC>;
 #endif
   return solver == SOLVER_CR ? teb_optimize_kernel<SOLVER_CR, TEB_AMD_JACOBIAN_ANALYTIC>
-                             : teb_optimize_kernel<SOLVER_BAND, TEB_AMD_JACOBIAN_ANALYTIC>;
+         : solver == SOLVER_BAND ? teb_optimize_kernel<SOLVER_BAND, TEB_AMD_JACOBIAN_ANALYTIC>
+                                 : teb_optimize_kernel<SOLVER_BANDG, TEB_AMD_JACOBIAN_ANALYTIC>;
 }
 void launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const BatchDev& bt, const OptArgs& a) {
   hipLaunchKernelGGL(opt_kernel(h->solver, h->cfg.jacobian_mode), dim3(grid), dim3(kThreads), h->plan.total_bytes, h->stream,
@@ -255,6 +259,7 @@ int launch(teb_amd_handle* h, const OptArgs& args) {
   HIPCHK(hipEventRecord(h->ev0, h->stream));
   launch_opt(h, h->B, sc, bt, args);
   h->consumers_valid = false;
+  h->hsig_mode = 0;   // the bands change: signatures of an earlier teb_amd_compute_h_signatures call are stale
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   h->timed = true;
@@ -325,8 +330,12 @@ int teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_po
     solver = SOLVER_BAND;
   if (const char* env = getenv("TEB_AMD_SOLVER")) {
     if (std::strcmp(env, "band") == 0) solver = SOLVER_BAND;
+    else if (std::strcmp(env, "bandg") == 0) solver = SOLVER_BANDG;
     else if (lds_bytes_for(max_poses, SOLVER_CR) <= lds_limit) solver = SOLVER_CR;
   }
+  // bands too long for the LDS band (> 343 poses; the reference's max_samples default is 500): the band form of the normal matrix
+  // moves to HBM (SOLVER_BANDG: 44 doubles per pose, L2-resident), everything else stays as it is
+  if (solver == SOLVER_BAND && lds_bytes_for(max_poses, SOLVER_BAND) > lds_limit) solver = SOLVER_BANDG;
   const size_t lds = lds_bytes_for(max_poses, solver);
   if (max_poses > kThreads * kMaxPoseIter || lds > lds_limit) {
     char buf[256];
@@ -343,7 +352,7 @@ int teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_po
   h->max_tebs = max_tebs; h->stride = max_poses; h->max_obst = max_obstacles; h->max_verts = max_obstacle_vertices;
   h->max_via = max_via_points;
   h->lds_bytes = lds;
-  h->solver = solver;
+  h->solver = solver; h->solver_created = solver;
   h->lds_limit = lds_limit;
   h->plan = make_lds_plan(max_poses, solver, 0);
   // per-band HBM buffer: the copy of H for rejected trials (SOLVER_CR, banded LDL^T) or the blocks the cyclic reduction of a
@@ -351,6 +360,7 @@ int teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_po
   h->hmat_stride = std::max(hmat_doubles(max_poses, solver), (size_t)nb_for(max_poses) * (2 * kBlk + 8));
   h->band_ldlt = 0;
   if (const char* env = getenv("TEB_AMD_BAND_SOLVE")) h->band_ldlt = std::strcmp(env, "ldlt") == 0;
+  if (solver == SOLVER_BANDG) h->band_ldlt = 0;   // the sequential LDL^T works in place on an LDS band only
   if (stream) { h->stream = reinterpret_cast<hipStream_t>(stream); h->own_stream = false; }
   else {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(TEB_AMD_ERR_HIP, "hipStreamCreate failed"); }
@@ -373,6 +383,8 @@ int teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_po
   A(h->vs.alloc(3 * (size_t)max_tebs)); A(h->vg.alloc(3 * (size_t)max_tebs));
   A(h->chi2.alloc(max_tebs)); A(h->cost.alloc(max_tebs)); A(h->lambda.alloc(max_tebs));
   A(h->Hbackup.alloc((size_t)max_tebs * h->hmat_stride));
+  h->hband_stride = solver == SOLVER_BANDG ? (size_t)4 * max_poses * kBand : 0;
+  A(h->Hband.alloc((size_t)max_tebs * h->hband_stride));
   A(h->snap_n.alloc(max_tebs)); A(h->snap_x.alloc(BS)); A(h->snap_y.alloc(BS)); A(h->snap_th.alloc(BS)); A(h->snap_dt.alloc(BS));
   A(h->dbg_H.alloc((size_t)4 * max_poses * kBand)); A(h->dbg_b.alloc((size_t)4 * max_poses)); A(h->dbg_chi2.alloc(4));
   A(h->sel_cost.alloc(1)); A(h->sel_idx.alloc(1)); A(h->err_flag.alloc(1));
@@ -404,7 +416,7 @@ void teb_amd_destroy(teb_amd_handle_t* h) {
   for (auto* q : ib) q->free();
   DevBuf<double>* db[] = {&h->o_ax, &h->o_ay, &h->o_bx, &h->o_by, &h->o_rad, &h->o_vx, &h->o_vy, &h->o_cx, &h->o_cy, &h->o_pvx,
                           &h->o_pvy, &h->viax, &h->viay, &h->x, &h->y, &h->th, &h->dt, &h->vs, &h->vg, &h->chi2, &h->cost,
-                          &h->lambda, &h->Hbackup, &h->snap_x, &h->snap_y, &h->snap_th, &h->snap_dt, &h->dbg_H,
+                          &h->lambda, &h->Hbackup, &h->Hband, &h->snap_x, &h->snap_y, &h->snap_th, &h->snap_dt, &h->dbg_H,
                           &h->dbg_b, &h->dbg_chi2, &h->sel_cost, &h->stage_x, &h->stage_y, &h->stage_yaw, &h->out_cmd, &h->out_prof, &h->out_traj, &h->hsig, &h->hs_pre, &h->hs_pim};
   for (auto* q : db) q->free();
   DevBuf<double>* gb[] = {&h->g_vx, &h->g_vy, &h->cand_x, &h->cand_y, &h->cand_th, &h->cand_dt, &h->cand_sig, &h->cand_px, &h->cand_py,
@@ -479,11 +491,25 @@ int teb_amd_set_obstacles(teb_amd_handle_t* h, const teb_amd_obstacles_t* o) {
   h->M = M; h->n_static = (int)st.size(); h->n_dyn = (int)dy.size();
   h->host_type = type;
   h->host_cx = cx; h->host_cy = cy;
+  h->hsig_mode = 0;   // signatures depend on the obstacle table
   h->host_static = st;
   // point-like fast path: all obstacles Point/Circular, footprint Point/Circular, and the cache fits the LDS
   bool pointlike = (h->cfg.footprint_type == TEB_AMD_FOOTPRINT_POINT || h->cfg.footprint_type == TEB_AMD_FOOTPRINT_CIRCULAR);
   for (int i = 0; i < M && pointlike; ++i) pointlike = (type[i] == TEB_AMD_OBST_POINT || type[i] == TEB_AMD_OBST_CIRCULAR);
   if (getenv("TEB_AMD_NO_FAST_POINTS")) pointlike = false;
+  // a point-like scene whose obstacle cache does not fit beside the LDS band: the band moves to HBM and the cache stays (measured,
+  // 64 bands x 343 poses x 500 obstacles: 9.0 instead of 11.8 ms per step)
+  h->solver = h->solver_created;
+  if (pointlike && M > 0 && h->solver == SOLVER_BAND && !getenv("TEB_AMD_SOLVER") &&
+      (size_t)make_lds_plan(h->stride, SOLVER_BAND, M).total_bytes > h->lds_limit &&
+      (size_t)make_lds_plan(h->stride, SOLVER_BANDG, M).total_bytes <= h->lds_limit) {
+    if (h->hband_stride == 0) {
+      h->hband_stride = (size_t)4 * h->stride * kBand;
+      h->Hband.free();
+      HIPCHK(h->Hband.alloc((size_t)h->max_tebs * h->hband_stride));
+    }
+    h->solver = SOLVER_BANDG;
+  }
   LdsPlan with_cache = make_lds_plan(h->stride, h->solver, M);
   if (pointlike && M > 0 && (size_t)with_cache.total_bytes <= h->lds_limit) { h->fast_points = 1; h->plan = with_cache; }
   else { h->fast_points = 0; h->plan = make_lds_plan(h->stride, h->solver, 0); }
@@ -547,6 +573,7 @@ int teb_amd_upload_tebs(teb_amd_handle_t* h, const teb_amd_teb_batch_t* bt) {
   HIPCHK(hipStreamSynchronize(h->stream));
   h->B = B;
   h->consumers_valid = false;
+  h->hsig_mode = 0;   // the bands change: signatures of an earlier teb_amd_compute_h_signatures call are stale
   return TEB_AMD_OK;
 }
 
@@ -578,7 +605,7 @@ int teb_amd_optimize_batch(teb_amd_handle_t* h, int32_t inner, int32_t outer, in
   if (inner < 0 || outer < 0) return fail(TEB_AMD_ERR_INVALID_ARG, "negative iteration count");
   OptArgs a;
   std::memset(&a, 0, sizeof a);
-  a.inner = inner; a.outer = outer; a.compute_cost = compute_cost; a.band_ldlt = h->band_ldlt;
+  a.inner = inner; a.outer = outer; a.compute_cost = compute_cost; a.band_ldlt = h->solver == SOLVER_BANDG ? 0 : h->band_ldlt; a.Hband = h->Hband.p; a.hband_stride = h->hband_stride;
   a.obst_scale = obst_cost_scale; a.via_scale = viapoint_cost_scale; a.alt_time = alternative_time_cost;
 #ifdef TEB_PROFILE
   a.dbg_H = h->dbg_H.p;
@@ -664,6 +691,7 @@ int finish_init(teb_amd_handle* h) {
   HIPCHK(hipMemcpyAsync(&err, h->err_flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->consumers_valid = false;
+  h->hsig_mode = 0;   // the bands change: signatures of an earlier teb_amd_compute_h_signatures call are stale
   if (err) return fail(TEB_AMD_ERR_CAPACITY, "initTrajectoryToGoal: the band needs more poses than max_poses");
   return TEB_AMD_OK;
 }
@@ -749,6 +777,7 @@ int teb_amd_update_and_prune(teb_amd_handle_t* h, int32_t b, const double* new_s
                      batch_of(h), b < 0 ? 0 : b, new_start ? 1 : 0, s[0], s[1], s[2], new_goal ? 1 : 0, g[0], g[1], g[2], min_samples);
   HIPCHK(hipGetLastError());
   h->consumers_valid = false;
+  h->hsig_mode = 0;   // the bands change: signatures of an earlier teb_amd_compute_h_signatures call are stale
   return TEB_AMD_OK;
 }
 
@@ -893,7 +922,7 @@ int teb_amd_compute_h_signatures(teb_amd_handle_t* h, double prescaler, double* 
   const int mode = h->cfg.include_dynamic_obstacles ? 3 : 2;   // homotopy_class_planner.hpp:50
   const int W = mode == 3 ? M : 2;
   if (width) *width = W;
-  h->hsig_mode = mode; h->hsig_B = B; h->hsig_M = M;
+  h->hsig_mode = mode; h->hsig_B = B; h->hsig_M = M; h->hsig_prescaler = prescaler;
   h->hsig_host.assign((size_t)B * (W > 0 ? W : 1), 0.0);
   if ((rc = launch_hsig(h, bt, B, prescaler, h->hsig.p))) return rc;
   if ((size_t)B * W > 0)
@@ -1086,25 +1115,31 @@ int teb_amd_explore_candidates(teb_amd_handle_t* h, const teb_amd_hcp_params_t* 
   ClassTable ct;
   ct.mode = mode; ct.W = W; ct.thr = p->h_signature_threshold; ct.max_in_best = p->max_number_plans_in_current_class;
   if (h->B > 0) {
-    if ((rc = teb_amd_compute_h_signatures(h, p->h_signature_prescaler, nullptr, nullptr))) return rc;
+    const bool fresh = h->hsig_mode == mode && h->hsig_B == h->B && h->hsig_M == M && h->hsig_prescaler == p->h_signature_prescaler;
+    if (!fresh && (rc = teb_amd_compute_h_signatures(h, p->h_signature_prescaler, nullptr, nullptr))) return rc;   // else: renew just did
     for (int b = 0; b < h->B; ++b) ct.classes.emplace_back(h->hsig_host.data() + (size_t)b * W, h->hsig_host.data() + (size_t)(b + 1) * W);
     if (best >= 0 && best < h->B) { h->best_class = ct.classes[best]; h->best_class_mode = mode; }
   }
   if (h->best_class_mode == mode && (int)h->best_class.size() == W) { ct.has_best = true; ct.best = h->best_class; }   // best_teb_eq_class_
   h->hsig_mode = 0;   // the batch is about to change: signatures have to be recomputed before the next filter call
   if (h->B >= slots) return TEB_AMD_OK;                                     // src/graph_search.cpp:99-100, 231-232
-  const double one3[3] = {0, 0, 0};
-  auto accept = [&](int cand_index) -> int {   // tebs_.push_back(candidate): scratch band -> next slot of the batch
-    const int slot = h->B;
-    int r = extend_batch(h, slot);              // default attributes of a new TebOptimalPlanner (fixed zero start / goal velocity)
+  // tebs_.push_back(candidate) for the accepted candidates of a chunk: scratch bands -> the next slots of the batch, one gather;
+  // default attributes of a new TebOptimalPlanner (fixed zero start / goal velocity), then setVelocityStart / setVelocityGoalFree
+  auto accept_all = [&](const std::vector<int>& cand) -> int {
+    if (cand.empty()) return TEB_AMD_OK;
+    const int slot0 = h->B, cnt = (int)cand.size();
+    int r = extend_batch(h, slot0 + cnt - 1);
     if (r) return r;
-    HIPCHK(hipMemcpyAsync(h->cand_map.p, &cand_index, sizeof(int), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(move_bands_kernel, dim3(1), dim3(kThreads), 0, h->stream, candidates_of(h), batch_of(h), h->cand_map.p, slot, 0);
+    HIPCHK(hipMemcpyAsync(h->cand_map.p, cand.data(), cnt * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(move_bands_kernel, dim3(cnt), dim3(kThreads), 0, h->stream, candidates_of(h), batch_of(h), h->cand_map.p, slot0, 0);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));   // cand_index lives on this stack frame
-    if (start_vel && (r = set_velocity(h, h->has_vs, h->vs, slot, 1, start_vel))) return r;
-    if (free_goal_vel && (r = set_velocity(h, h->has_vg, h->vg, slot, 0, nullptr))) return r;
-    (void)one3;
+    if (start_vel) {
+      std::vector<double> vv;
+      for (int k = 0; k < cnt; ++k) { vv.push_back(start_vel[0]); vv.push_back(start_vel[1]); vv.push_back(start_vel[2]); }
+      HIPCHK(hipMemcpyAsync(h->vs.p + 3 * slot0, vv.data(), vv.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    if (free_goal_vel) HIPCHK(hipMemsetAsync(h->has_vg.p + slot0, 0, cnt * sizeof(int), h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));   // the staging vectors live on this stack frame
     return TEB_AMD_OK;
   };
   std::vector<double> sig((size_t)kCandChunk * (W > 0 ? W : 1));
@@ -1129,7 +1164,7 @@ int teb_amd_explore_candidates(teb_amd_handle_t* h, const teb_amd_hcp_params_t* 
                          goal[0], goal[1], goal[2], 0.0, c.max_vel_x, c.min_samples, p->allow_init_with_backwards_motion, h->err_flag.p);
       HIPCHK(hipGetLastError());
       if ((rc = classify(1))) return rc;
-      if (ct.add_if_new(sig.data()) && (rc = accept(0))) return rc;
+      if (ct.add_if_new(sig.data()) && (rc = accept_all({0}))) return rc;
     }
     if (n_total) *n_total = h->B;
     return TEB_AMD_OK;
@@ -1236,10 +1271,12 @@ int teb_amd_explore_candidates(teb_amd_handle_t* h, const teb_amd_hcp_params_t* 
                        h->err_flag.p);
     HIPCHK(hipGetLastError());
     if ((rc = classify(count))) return rc;
-    for (int k = 0; k < count && h->B < slots; ++k) {
+    std::vector<int> accepted;
+    for (int k = 0; k < count && h->B + (int)accepted.size() < slots; ++k) {
       ++examined;
-      if (ct.add_if_new(sig.data() + (size_t)k * W) && (rc = accept(k))) return rc;
+      if (ct.add_if_new(sig.data() + (size_t)k * W)) accepted.push_back(k);
     }
+    if ((rc = accept_all(accepted))) return rc;
   }
   if (n_paths) *n_paths = (int32_t)std::min<int64_t>(examined, std::numeric_limits<int32_t>::max());
   if (n_total) *n_total = h->B;
@@ -1309,9 +1346,17 @@ int teb_amd_compact_bands(teb_amd_handle_t* h, const int32_t* keep, int32_t best
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
   }
+  if (h->hsig_mode != 0 && h->hsig_B == B) {   // the kept bands' signatures stay valid: same rows, new order
+    const int W = h->hsig_mode == 3 ? h->hsig_M : 2;
+    std::vector<double> moved((size_t)K * (W > 0 ? W : 1), 0.0);
+    for (int k = 0; k < K; ++k) std::copy(h->hsig_host.begin() + (size_t)map[k] * W, h->hsig_host.begin() + (size_t)(map[k] + 1) * W, moved.begin() + (size_t)k * W);
+    h->hsig_host.swap(moved);
+    h->hsig_B = K;
+  } else {
+    h->hsig_mode = 0;
+  }
   h->B = K;
   h->consumers_valid = false;
-  h->hsig_mode = 0;
   return TEB_AMD_OK;
 }
 
@@ -1409,6 +1454,7 @@ int teb_amd_restore_state(teb_amd_handle_t* h) {
   HIPCHK(hipMemcpyAsync(h->dt.p, h->snap_dt.p, BS, hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->n.p, h->snap_n.p, h->max_tebs * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
   h->consumers_valid = false;
+  h->hsig_mode = 0;   // the bands change: signatures of an earlier teb_amd_compute_h_signatures call are stale
   return TEB_AMD_OK;
 }
 
@@ -1429,7 +1475,7 @@ int teb_amd_capacity(teb_amd_handle_t* h, int32_t* lds_bytes, int32_t* max_poses
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, h->device));
     int S = kThreads * kMaxPoseIter;
-    while (S > 2 && lds_bytes_for(S, SOLVER_BAND) > h->lds_limit) --S;
+    while (S > 2 && lds_bytes_for(S, SOLVER_BANDG) > h->lds_limit) --S;   // band in HBM: 512 poses (two per lane)
     *max_poses_supported = S;
   }
   return TEB_AMD_OK;
@@ -1444,7 +1490,7 @@ int teb_amd_debug_linearize(teb_amd_handle_t* h, int32_t b, double weight_multip
   // run the kernel in debug mode on TEB b only: temporarily view the batch as starting at b
   OptArgs a;
   std::memset(&a, 0, sizeof a);
-  a.inner = 1; a.outer = 1; a.debug_linearize = 1; a.debug_weight_multiplier = weight_multiplier; a.band_ldlt = h->band_ldlt;
+  a.inner = 1; a.outer = 1; a.debug_linearize = 1; a.debug_weight_multiplier = weight_multiplier; a.band_ldlt = h->solver == SOLVER_BANDG ? 0 : h->band_ldlt; a.Hband = h->Hband.p; a.hband_stride = h->hband_stride;
   a.dbg_H = h->dbg_H.p; a.dbg_b = h->dbg_b.p; a.dbg_chi2 = h->dbg_chi2.p;
   SceneDev sc = scene_of(h);
   BatchDev bt = batch_of(h);

@@ -28,7 +28,7 @@ constexpr int kMaxPoseIter = 2;     // poses handled per thread: n <= kThreads *
 // LDS layout of one workgroup, computed on the host (offsets in doubles from the dynamic-LDS base).
 struct LdsPlan {
   int S;            // pose capacity
-  int solver;       // SOLVER_BAND / SOLVER_CR
+  int solver;       // SOLVER_BAND / SOLVER_CR / SOLVER_BANDG
   int off_state;    // sx sy sth sdt tdyn cs sn : 7*S
   int off_H;        // normal matrix (band or blocks)
   int off_b;        // 4S+8
@@ -93,6 +93,8 @@ struct OptArgs {
   int inner, outer, compute_cost;
   double obst_scale, via_scale;
   int alt_time;
+  double* Hband;         // SOLVER_BANDG: per-band normal matrix in band form in HBM, hband_stride doubles each
+  size_t hband_stride;
   int band_ldlt;         // SOLVER_BAND only: 1 = sequential banded LDL^T in LDS (v1), 0 = cyclic reduction on HBM-resident blocks
   int debug_linearize;   // test hook: stop after the first linearisation and dump H, b, chi2 categories
   double debug_weight_multiplier;

@@ -26,12 +26,14 @@ namespace tebamd {
 #define PROF_END(k)
 #endif
 
-// Two storage formats of the normal matrix (selected per handle by the pose capacity S):
-//   SOLVER_BAND : Hb[4S][11] lower band, solved by the sequential in-LDS LDL^T of wave 0 (any S up to 357)
+// Storage formats of the normal matrix (selected per handle by the pose capacity S and the obstacle cache):
+//   SOLVER_BAND : Hb[4S][11] lower band in LDS (S <= 343); solved by cyclic reduction on HBM-resident 8x8 blocks expanded from it
+//                 (or, TEB_AMD_BAND_SOLVE=ldlt, by the sequential in-LDS LDL^T of wave 0)
+//   SOLVER_BANDG: the same band in a per-band HBM buffer (S <= 512, or when the obstacle cache would not fit beside the LDS band)
 //   SOLVER_CR   : block-tridiagonal in 8x8 blocks (two 4-scalar pose groups per block row): D_j (full, symmetric)
 //                 and L_j (coupling to block row j-1), solved by block cyclic reduction with all 256 threads
-//                 (log2(n/2) levels instead of 4n sequential pivots). Needs 664*S bytes of LDS: S <= 245.
-enum { SOLVER_BAND = 0, SOLVER_CR = 1 };
+//                 (log2(n/2) levels instead of 4n sequential pivots). Needs ~680*S bytes of LDS: S <= 238.
+enum { SOLVER_BAND = 0, SOLVER_CR = 1, SOLVER_BANDG = 2 };   // BANDG: the band lives in HBM (bands too long for the LDS band: up to 512 poses)
 constexpr int kBlk = 66;   // padded stride (doubles) of one 8x8 block: spreads concurrent eliminations over LDS banks
 
 struct Lds {
@@ -43,6 +45,7 @@ struct Lds {
 
 __host__ __device__ inline int nb_for(int S) { return (4 * S + 7) / 8; }
 __host__ __device__ inline size_t hmat_doubles(int S, int solver) {  // (LDS-resident part)
+  if (solver == SOLVER_BANDG) return (size_t)4 * S + 256;   // only the scratch of autoResize (sweep output + split stack)
   return solver == SOLVER_CR ? (size_t)nb_for(S) * (2 * kBlk + 8) : (size_t)4 * S * kBand;
 }
 // host: lay out the LDS; ob_entries = obstacles to cache (0 = no cache). Returns total bytes.
@@ -63,13 +66,14 @@ __host__ inline LdsPlan make_lds_plan(int S, int solver, int ob_entries) {
 }
 __host__ inline size_t lds_bytes_for(int S, int solver) { return (size_t)make_lds_plan(S, solver, 0).total_bytes; }
 
-__device__ __forceinline__ Lds carve(double* base, const LdsPlan& p) {
+// gH: the band's slice of the HBM normal-matrix buffer (SOLVER_BANDG), else unused
+__device__ __forceinline__ Lds carve(double* base, const LdsPlan& p, double* gH = nullptr, bool hb_global = false) {
   Lds l;
   const int S = p.S;
   l.sx = base + p.off_state; l.sy = l.sx + S; l.sth = l.sy + S; l.sdt = l.sth + S; l.tdyn = l.sdt + S;
   l.cs = l.tdyn + S; l.sn = l.cs + S;
-  l.Hb = base + p.off_H;
-  l.Db = l.Hb; l.Lb = l.Db + (size_t)nb_for(S) * kBlk; l.fb = l.Lb + (size_t)nb_for(S) * kBlk;
+  l.Hb = hb_global ? gH : base + p.off_H;
+  l.Db = base + p.off_H; l.Lb = l.Db + (size_t)nb_for(S) * kBlk; l.fb = l.Lb + (size_t)nb_for(S) * kBlk;
   l.bv = base + p.off_b;
   l.dxv = base + p.off_dx;
   l.red = base + p.off_red;
@@ -314,7 +318,7 @@ __device__ __forceinline__ void scatter(const Accum& A, const Lds& l, int i, int
       bool fb = (rb < 3) || (rb >= last_pose);
       if (fb) continue;
       const double v = A.H[a * (a + 1) / 2 + b];
-      if (SOLVER == SOLVER_BAND) {
+      if (SOLVER != SOLVER_CR) {
         l.Hb[ra * kBand + (a - b)] += v;
       } else {
         const int jr = ra >> 3, jc = rb >> 3;   // window spans at most two consecutive block rows
@@ -332,7 +336,7 @@ __device__ __forceinline__ void scatter(const Accum& A, const Lds& l, int i, int
 // linear view of the live part of the normal matrix (band: Hb[0, Nt*11); blocks: Db[0, Nb*66) then Lb[0, Nb*66))
 template <int SOLVER>
 __device__ __forceinline__ double* hmat_ptr(const Lds& l, int q, int Nt) {
-  if (SOLVER == SOLVER_BAND) return l.Hb + q;
+  if (SOLVER != SOLVER_CR) return l.Hb + q;
   const int half = ((Nt + 7) >> 3) * kBlk;
   return q < half ? l.Db + q : l.Lb + (q - half);
 }
@@ -340,7 +344,7 @@ __device__ __forceinline__ double* hmat_ptr(const Lds& l, int q, int Nt) {
 // address of the diagonal entry of variable r
 template <int SOLVER>
 __device__ __forceinline__ double* diag_ptr(const Lds& l, int r) {
-  return SOLVER == SOLVER_BAND ? &l.Hb[r * kBand] : &l.Db[(r >> 3) * kBlk + (r & 7) * 9];
+  return SOLVER != SOLVER_CR ? &l.Hb[r * kBand] : &l.Db[(r >> 3) * kBlk + (r & 7) * 9];
 }
 
 // per-pose cos/sin cache: every cost term that needs the heading reads these instead of re-evaluating libm
@@ -353,7 +357,7 @@ template <int SOLVER, int JMODE>
 __device__ inline void linearize(const teb_amd_config_t& c, const SceneDev& sc, const TebCtx& t, const Lds& l,
                                  double* cats /*4, out on all threads*/) {
   const int n = t.n, Nt = 4 * n, tid = threadIdx.x;
-  const int hsz = (SOLVER == SOLVER_BAND) ? Nt * kBand : ((Nt + 7) >> 3) * 2 * kBlk;
+  const int hsz = (SOLVER != SOLVER_CR) ? Nt * kBand : ((Nt + 7) >> 3) * 2 * kBlk;
   for (int q = tid; q < hsz; q += kThreads) *hmat_ptr<SOLVER>(l, q, Nt) = 0;
   for (int q = tid; q < Nt + 8; q += kThreads) l.bv[q] = 0;
   refresh_trig(l, n);
@@ -680,12 +684,12 @@ __device__ __forceinline__ void cr_backward(const double* __restrict__ D, const 
 //                  blocks (+ lambda) are expanded into a per-band HBM buffer (L2-resident: ~70 doubles per pose) and the same
 //                  reduction runs there - log2(n/2) levels of round trips to L2 instead of 4n sequential pivots, and no
 //                  backup / restore of H since the band is never touched.
-template <bool GLOBAL>
-__device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, const SceneDev& sc, int n, double lambda, double* gbuf) {
+template <bool GLOBAL, bool HB_GLOBAL>
+__device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, const SceneDev& sc, int n, double lambda, double* gbuf, double* gH) {
   TEB_SOLVER_FMA
   extern __shared__ __attribute__((aligned(16))) double lds_base[];
   CRP_DECL
-  const Lds l = carve(lds_base, plan);
+  const Lds l = carve(lds_base, plan, gH, HB_GLOBAL);
   const int tid = threadIdx.x;
   const int Nt = 4 * n, Nb = (Nt + 7) >> 3;
   double* __restrict__ D = GLOBAL ? gbuf : l.Db;
@@ -1182,7 +1186,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
                     const LdsPlan plan) {
   extern __shared__ __attribute__((aligned(16))) double lds_base[];
   const int b = blockIdx.x, tid = threadIdx.x, S = bt.stride;
-  const Lds l = carve(lds_base, plan);
+  const Lds l = carve(lds_base, plan, SOLVER == SOLVER_BANDG ? args.Hband + (size_t)b * args.hband_stride : nullptr, SOLVER == SOLVER_BANDG);
   if (sc.fast_points) {   // stage the point-like obstacle table once: static list first, then the dynamic list
     const int tot = sc.n_static + sc.n_dyn;
     for (int k = tid; k < tot; k += kThreads) {
@@ -1305,7 +1309,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
             const int r = q / kBand, d = q % kBand, cc = r - d;
             double v = 0;
             if (cc >= 0) {
-              if (SOLVER == SOLVER_BAND) v = l.Hb[q];
+              if (SOLVER != SOLVER_CR) v = l.Hb[q];
               else if ((r >> 3) == (cc >> 3)) v = l.Db[(r >> 3) * kBlk + (r & 7) * 8 + (cc & 7)];
               else if ((r >> 3) == (cc >> 3) + 1) v = l.Lb[(r >> 3) * kBlk + (r & 7) * 8 + (cc & 7)];
             }
@@ -1326,8 +1330,8 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
         ni = 2;
       }
       PROF_START();
-      const int hsz = (SOLVER == SOLVER_BAND) ? Nt * kBand : ((Nt + 7) >> 3) * 2 * kBlk;
-      const bool keep_copy = !(SOLVER == SOLVER_BAND && !args.band_ldlt);   // the HBM-block reduction never touches the band
+      const int hsz = (SOLVER != SOLVER_CR) ? Nt * kBand : ((Nt + 7) >> 3) * 2 * kBlk;
+      const bool keep_copy = !(SOLVER != SOLVER_CR && !args.band_ldlt);   // the HBM-block reduction never touches the band
       if (keep_copy)
         for (int q = tid; q < hsz; q += kThreads) Hbk[q] = *hmat_ptr<SOLVER>(l, q, Nt);   // saved for rejected trials
       PROF_END(3);
@@ -1336,7 +1340,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       do {
         // --- damped solve
         PROF_START();
-        if (SOLVER == SOLVER_BAND) {
+        if (SOLVER != SOLVER_CR) {
           if (args.band_ldlt) {
             if (tid < 64) {
               bool ok = banded_ldlt_solve_wave0(l, Nt, lambda);
@@ -1344,10 +1348,10 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
             }
             __syncthreads();
           } else {
-            cr_solve_t<true>(plan, sc, n, lambda, Hbk);
+            cr_solve_t<true, SOLVER == SOLVER_BANDG>(plan, sc, n, lambda, Hbk, l.Hb);
           }
         } else {
-          cr_solve_t<false>(plan, sc, n, lambda, nullptr);
+          cr_solve_t<false, false>(plan, sc, n, lambda, nullptr, nullptr);
         }
         PROF_END(4);
         PROF_START();

@@ -129,6 +129,7 @@ class TebBatchSolver:
 
     def set_obstacles(self, obst):
         _chk(lib().teb_amd_set_obstacles(self._h, C.byref(obst.freeze())), "teb_amd_set_obstacles")
+        self._n_obst = len(obst)
 
     def set_via_points(self, via):
         vx = _abi.f64([v[0] for v in via]) if via else _abi.f64([0.0])
@@ -269,15 +270,19 @@ class TebBatchSolver:
         return bool(d.value)
 
     # -- equivalence classes of the resident bands (SURVEY 8f row f3, arithmetic core) ----------------------
-    def h_signatures(self, prescaler=1.0):
-        """[B, M] (HSignature3d, include_dynamic_obstacles) or [B, 2] (HSignature: re, im)."""
+    def h_signatures(self, prescaler=1.0, values=True):
+        """[B, M] (HSignature3d, include_dynamic_obstacles) or [B, 2] (HSignature: re, im); values=False: compute only (the
+        signatures stay in the handle for filter_equivalence_classes / explore_candidates)."""
         self._sync_count()
         w = C.c_int32(0)
-        _chk(lib().teb_amd_compute_h_signatures(self._h, prescaler, None, C.byref(w)), "teb_amd_compute_h_signatures")
-        out = np.zeros((self.count, max(w.value, 1)))
+        if not values:
+            _chk(lib().teb_amd_compute_h_signatures(self._h, prescaler, None, C.byref(w)), "teb_amd_compute_h_signatures")
+            return None
+        width = max(getattr(self, "_n_obst", 0), 2)
+        out = np.zeros((max(self.count, 1), width))
         _chk(lib().teb_amd_compute_h_signatures(self._h, prescaler, _abi._ptr(out, C.c_double), C.byref(w)),
              "teb_amd_compute_h_signatures")
-        return out[:, :w.value]
+        return out.ravel()[:self.count * w.value].reshape(self.count, w.value).copy()
 
     def filter_equivalence_classes(self, threshold=0.1, best=-1, max_number_plans_in_current_class=1):
         keep = np.zeros(self.count, np.int32); valid = np.zeros(self.count, np.int32); reas = np.zeros(self.count, np.int32)
@@ -394,7 +399,8 @@ class TebOptimalPlanner:
         self.cfg_ = cfg
         self.obstacles_ = obstacles if obstacles is not None else _abi.ObstacleTable()
         self.via_points_ = list(via_points or [])
-        self.max_poses = max_poses or min(cfg.trajectory.max_samples + 1, 352)
+        # capacity = whatever autoResize may produce (max_samples + 1 <= 512); pass a smaller max_poses for the faster LDS layouts
+        self.max_poses = max_poses or min(cfg.trajectory.max_samples + 1, 512)
         self.teb_ = _abi.TebBatchHost(1, self.max_poses)
         self.cost_ = float("nan")
         self.optimized_ = False
@@ -576,7 +582,7 @@ class HomotopyClassPlanner:
     def exploreEquivalenceClassesAndInitTebs(self, start, goal, dist_to_obst, start_vel=None, free_goal_vel=False):
         s, h = self.solver, self.cfg_.hcp
         if s.count > 0:
-            s.h_signatures(h.h_signature_prescaler)
+            s.h_signatures(h.h_signature_prescaler, values=False)
             keep, _, _ = s.filter_equivalence_classes(h.h_signature_threshold, self.best_teb_, h.max_number_plans_in_current_class)
             if h.delete_detours_backwards:
                 keep = s.filter_detours(keep, self.best_teb_)

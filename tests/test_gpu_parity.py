@@ -483,10 +483,11 @@ def test_empty_scene_and_minimal_and_ragged_bands(oracle):
     np.testing.assert_allclose(res.cost[:4], rres.cost[:4], rtol=1e-8)
 
 
-@pytest.mark.parametrize("n,solver", [(238, "cr"), (343, "band")])
+@pytest.mark.parametrize("n,solver", [(238, "cr"), (343, "band"), (344, "bandg"), (500, "bandg"), (512, "bandg")])
 def test_maximum_pose_capacities(oracle, n, solver):
     """S = 238 is the largest band the block-cyclic-reduction solver holds in LDS (without the obstacle cache), S = 343 the largest for
-    the banded solver."""
+    the band in LDS; longer bands (the reference's max_samples default is 500) keep the band form of the normal matrix in HBM, up to
+    512 poses (two per lane)."""
     cfg, obst, via, _ = scenes.scene_small_mixed(footprint="point")
     cfg.trajectory.teb_autosize = False
     cfg.trajectory.max_samples = 500
@@ -494,14 +495,34 @@ def test_maximum_pose_capacities(oracle, n, solver):
     batch = _straight_batch(cfg, [n, n - 7], n, rng)
     s = planner.make_solver(cfg, obst, via, batch)
     lds, cap = s.capacity()
-    assert cap >= n
+    assert cap >= n and cap == 512
     s.optimize(3, 2, True, cfg.hcp.selection_obst_cost_scale, cfg.hcp.selection_viapoint_cost_scale,
                cfg.hcp.selection_alternative_time_cost)
     res = s.results(); out = s.download(batch.copy()); s.close()
     ref, rres = oracle.optimize_batch(cfg, obst, via, batch, inner=3, outer=2)
     assert_full_parity(out, res, ref, rres, pos_tol=1e-7, rtol=1e-7)
-    with pytest.raises(planner.TebAmdError):                  # one more pose does not fit the LDS plan of the 343-pose handle
-        planner.TebBatchSolver(cfg, 1, 344, 4, 4, 1)
+    with pytest.raises(planner.TebAmdError) as e:             # two poses per lane: 513 poses do not fit
+        planner.TebBatchSolver(cfg, 1, 513, 4, 4, 1)
+    assert e.value.code == _abi.ERR_CAPACITY
+
+
+def test_long_band_with_autoresize_grows_past_the_lds_band(oracle):
+    """A 300-pose band whose time differences call for more samples: autoResize grows it past 343 poses inside the kernel (band form in
+    HBM), same result as the oracle."""
+    cfg, obst, via, _ = scenes.scene_small_mixed(footprint="point")
+    cfg.trajectory.max_samples = 500
+    rng = np.random.default_rng(77)
+    batch = _straight_batch(cfg, [300, 280], 512, rng)
+    for b in range(2):
+        k = int(batch.n[b])
+        batch.dt[b, :120] *= 1.6            # above dt_ref + dt_hysteresis: these intervals are split
+    s = planner.make_solver(cfg, obst, via, batch)
+    s.optimize(3, 2, True, cfg.hcp.selection_obst_cost_scale, cfg.hcp.selection_viapoint_cost_scale,
+               cfg.hcp.selection_alternative_time_cost)
+    res = s.results(); out = s.download(batch.copy()); s.close()
+    ref, rres = oracle.optimize_batch(cfg, obst, via, batch, inner=3, outer=2)
+    assert int(out.n.max()) > 343
+    assert_full_parity(out, res, ref, rres, pos_tol=1e-7, rtol=1e-7)
 
 
 def test_non_finite_input_is_reported_not_propagated(oracle):

@@ -21,7 +21,7 @@ for k in range(ticks):
     s.set_config(hc)
     hp.updateAllTEBs(start, goal, sv); t1 = time.perf_counter(); T["update"].append(t1 - t0)
     if s.count > 0:
-        s.h_signatures(h.h_signature_prescaler); t2 = time.perf_counter(); T["signatures"].append(t2 - t1)
+        s.h_signatures(h.h_signature_prescaler, values=False); t2 = time.perf_counter(); T["signatures"].append(t2 - t1)
         keep, _, _ = s.filter_equivalence_classes(h.h_signature_threshold, hp.best_teb_, h.max_number_plans_in_current_class)
         t3 = time.perf_counter(); T["filter"].append(t3 - t2)
         keep = s.filter_detours(keep, hp.best_teb_); t4 = time.perf_counter(); T["detours"].append(t4 - t3)
