@@ -294,6 +294,8 @@ typedef struct teb_amd_hcp_params {
   double  detours_orientation_tolerance;      /* hcp.detours_orientation_tolerance                                          */
   double  length_start_orientation_vector;    /* hcp.length_start_orientation_vector                                        */
   double  max_ratio_detours_duration_best_duration; /* hcp.max_ratio_detours_duration_best_duration                        */
+  int32_t global_plan_overwrite_orientation;  /* trajectory.global_plan_overwrite_orientation                               */
+  int32_t viapoints_all_candidates;           /* hcp.viapoints_all_candidates                                               */
 } teb_amd_hcp_params_t;
 void teb_amd_hcp_params_default(teb_amd_hcp_params_t* p);   /* the defaults of teb_config.h:330-360 */
 /*
@@ -309,12 +311,20 @@ void teb_amd_hcp_params_default(teb_amd_hcp_params_t* p);   /* the defaults of t
  * in draw order: per sample first the one scaled to the area width, then the one scaled to the area length (the order GCC gives
  * Eigen::Vector2d(distribution_x(g), distribution_y(g)), src/graph_search.cpp:274); NULL = the handle's own generator, the
  * default-seeded mt19937 + boost::random::uniform_real_distribution stream of the reference's member generator.
+ * n_plan > 0: the initial plan of plan(initial_plan, ...) (positions and yaw of its poses; start / goal are its first / last pose):
+ * it is tried as a candidate before the graph (addAndInitNewTeb(*initial_plan_, ...), src/homotopy_class_planner.cpp:326-329,
+ * 412-440: band via initTrajectoryToGoal(plan, ...), its class is remembered as initial_plan_eq_class_). *initial_plan_teb =
+ * getInitialPlanTEB() afterwards (:495-536): that band, else the first band of the remembered class, else -1 - the index to hand to
+ * teb_amd_select_best. Via-points (updateReferenceTrajectoryViaPoints, :286-315): new candidates start without them; they are
+ * enabled for all bands (viapoints_all_candidates) or, with an initial plan, for the bands of its class only.
  * *n_vertices / *n_paths (may be NULL): graph size and number of start-goal paths examined. max_paths > 0 bounds the enumeration
  * (the reference has no bound: without new classes it enumerates every simple path); TEB_AMD_OK is returned either way.
  */
 int  teb_amd_explore_candidates(teb_amd_handle_t* h, const teb_amd_hcp_params_t* p, const double* start, const double* goal,
                                 double dist_to_obst, const double* start_vel, int32_t free_goal_vel, int32_t best,
-                                const double* unit_samples, int64_t max_paths, int32_t* n_total, int32_t* n_vertices, int32_t* n_paths);
+                                const double* unit_samples, int64_t max_paths, int32_t* n_total, int32_t* n_vertices, int32_t* n_paths,
+                                int32_t n_plan, const double* plan_x, const double* plan_y, const double* plan_yaw,
+                                int32_t* initial_plan_teb);
 /* the graph of the last teb_amd_explore_candidates call: vertices (x, y) [n_vertices], adjacency bytes [n_vertices^2] (row = from) */
 int  teb_amd_get_exploration_graph(teb_amd_handle_t* h, double* vx, double* vy, unsigned char* adjacency, int32_t capacity_vertices,
                                    int32_t* n_vertices);
@@ -339,6 +349,9 @@ int  teb_amd_filter_detours(teb_amd_handle_t* h, const teb_amd_hcp_params_t* p, 
  * for bands whose history lives on the host (get: flags receives the current values). */
 int  teb_amd_set_optimized_flags(teb_amd_handle_t* h, const int32_t* flags);
 int  teb_amd_get_optimized_flags(teb_amd_handle_t* h, int32_t* flags);
+/* per-band attributes of the resident batch, each [B], any may be NULL: via-points attached (TebOptimalPlanner::via_points_ != NULL),
+ * vel_start_.first, vel_goal_.first */
+int  teb_amd_get_band_flags(teb_amd_handle_t* h, int32_t* via_points_enabled, int32_t* has_vel_start, int32_t* has_vel_goal);
 /* Device pointers (hipDeviceptr as void*) of the resident SoA strips: x, y, theta, dt, each
  * [max_tebs*max_poses] doubles, and n [max_tebs] int32. Valid until destroy.                          */
 int  teb_amd_device_state(teb_amd_handle_t* h, void** x, void** y, void** theta, void** dt, void** n,

@@ -281,7 +281,7 @@ def filter_equivalence_classes(mode, sig, threshold=0.1, best=-1, max_number_pla
 
 # ---- row f3 (candidate generation): createGraph + DepthFirst + addAndInitNewTeb --------------------------------------------------
 def explore_candidates(cfg, obst, batch, n_tebs, best, start, goal, dist_to_obst=None, unit_samples=None, skip_draws=0,
-                       vcap=4096, acap=1 << 20, max_paths=0, stale_best_sig=None):
+                       vcap=4096, acap=1 << 20, max_paths=0, stale_best_sig=None, initial_plan=None, stale_initial_sig=None, via_enabled=None):
     """Bands 0..n_tebs-1 of `batch` are tebs_ after renewAndAnalyzeOldTebs; returns dict(batch (copy, candidates appended), n_total,
     vertices [nv, 2], adjacency (list of lists, insertion order), n_paths)."""
     c = cfg.to_c()
@@ -298,15 +298,23 @@ def explore_candidates(cfg, obst, batch, n_tebs, best, start, goal, dist_to_obst
     f.restype = C.c_int
     f.argtypes = [C.POINTER(_abi.Config), C.POINTER(_abi.HcpParams), C.POINTER(_abi.Obstacles), C.POINTER(_abi.TebBatch), C.c_int32,
                   C.c_int32, _abi.p_f64, _abi.p_f64, C.c_double, _abi.p_f64, C.c_int64, C.c_int64, _abi.p_f64, _abi.p_i32, C.c_int32, _abi.p_f64, _abi.p_f64,
-                  _abi.p_i32, C.c_int32, _abi.p_i32, _abi.p_i32, _abi.p_i32]
+                  _abi.p_i32, C.c_int32, _abi.p_i32, _abi.p_i32, _abi.p_i32, C.c_int32, _abi.p_f64, _abi.p_f64, _abi.p_f64, _abi.p_f64,
+                  _abi.p_i32, _abi.p_i32]
+    plan = [None, None, None] if initial_plan is None else [np.ascontiguousarray(a, np.float64) for a in initial_plan]
+    sis = None if stale_initial_sig is None else np.ascontiguousarray(stale_initial_sig, np.float64)
+    ve = None if via_enabled is None else np.ascontiguousarray(via_enabled, np.int32).copy()
+    ipt = C.c_int32(-1)
     _check(f(C.byref(c), C.byref(p), C.byref(obst.freeze()), C.byref(bs), int(n_tebs), int(best), _P(st), _P(gl),
              float(dist_to_obst), _abi._ptr(us, C.c_double), int(skip_draws), int(max_paths),
              _abi._ptr(None if stale_best_sig is None else np.ascontiguousarray(stale_best_sig, np.float64), C.c_double), C.byref(nt), vcap, _P(vx), _P(vy), C.byref(nv), acap,
-             I(off), I(adj), C.byref(npth)), "explore_candidates")
+             I(off), I(adj), C.byref(npth), 0 if initial_plan is None else len(plan[0]), _abi._ptr(plan[0], C.c_double),
+             _abi._ptr(plan[1], C.c_double), _abi._ptr(plan[2], C.c_double), _abi._ptr(sis, C.c_double), C.byref(ipt), _abi._ptr(ve, C.c_int32)),
+           "explore_candidates")
     N = nv.value
     assert N <= vcap and off[N] <= acap
     return dict(batch=out, n_total=nt.value, vertices=np.stack([vx[:N], vy[:N]], 1),
-                adjacency=[adj[off[v]:off[v + 1]].tolist() for v in range(N)], n_paths=npth.value)
+                adjacency=[adj[off[v]:off[v + 1]].tolist() for v in range(N)], n_paths=npth.value, initial_plan_teb=ipt.value,
+                via_enabled=ve)
 
 
 def filter_detours(cfg, batch, keep, best, optimized):

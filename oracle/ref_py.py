@@ -245,7 +245,8 @@ def optimize_batch(cfg, obst, via, batch, inner=None, outer=None, compute_cost=T
 
 
 def explore_candidates(cfg, obst, batch, best, start, goal, dist_to_obst=None, start_vel=None, free_goal_vel=False, skip_draws=0,
-                       slots=None, vcap=4096, acap=1 << 20, optimized=None, stale_band=None):
+                       slots=None, vcap=4096, acap=1 << 20, optimized=None, stale_band=None, initial_plan=None, stale_initial_band=None, via=None,
+                       via_enabled=None):
     """The reference's HomotopyClassPlanner::exploreEquivalenceClassesAndInitTebs (renewAndAnalyzeOldTebs without detour deletion,
     then createGraph / DepthFirst / addAndInitNewTeb) with tebs_ = the bands of `batch` (may be None) and best_teb_ = band `best`.
     dict(batch, n_total, vertices, adjacency, has_vel_start, vel_start, has_vel_goal)."""
@@ -268,22 +269,31 @@ def explore_candidates(cfg, obst, batch, best, start, goal, dist_to_obst=None, s
     f.argtypes = [C.POINTER(A.Config), C.POINTER(A.HcpParams), C.POINTER(A.Obstacles), C.POINTER(A.TebBatch), C.c_int, A.p_f64, A.p_f64,
                   C.c_double, A.p_f64, C.c_int, C.c_long, A.p_i32, C.c_int, A.p_f64, A.p_f64, A.p_f64, A.p_f64, C.POINTER(A.TebBatch), A.p_i32, A.p_i32,
                   A.p_f64, A.p_i32, C.c_int, A.p_f64,
-                  A.p_f64, A.p_i32, C.c_int, A.p_i32, A.p_i32]
+                  A.p_f64, A.p_i32, C.c_int, A.p_i32, A.p_i32, C.c_int, A.p_f64, A.p_f64, A.p_f64, C.c_int, A.p_f64, A.p_f64, A.p_f64, A.p_f64,
+                  C.c_int, A.p_f64, A.p_f64, A.p_i32, A.p_i32, A.p_i32, A.p_f64]
     ins = batch.c_struct() if batch is not None else None
     sb = [np.ascontiguousarray(a, np.float64) for a in stale_band] if stale_band is not None else [np.zeros(0)] * 4
     sb[3] = np.append(sb[3], 0.0)
+    plan = [np.ascontiguousarray(a, np.float64) for a in initial_plan] if initial_plan is not None else [np.zeros(0)] * 3
+    si = [np.ascontiguousarray(a, np.float64) for a in stale_initial_band] if stale_initial_band is not None else [np.zeros(0)] * 4
+    si[3] = np.append(si[3], 0.0)
+    vxs = np.ascontiguousarray([v[0] for v in (via or [])], np.float64); vys = np.ascontiguousarray([v[1] for v in (via or [])], np.float64)
+    ipt = C.c_int32(-1); vout = np.zeros(slots, np.int32); seen = np.zeros(max(len(plan[0]), 1))
     rc = f(C.byref(c), C.byref(p), C.byref(obst.freeze()), C.byref(ins) if ins is not None else None, int(best), _P(st), _P(gl),
            float(dist_to_obst), _abi._ptr(sv, C.c_double), int(bool(free_goal_vel)), int(skip_draws),
            _abi._ptr(None if optimized is None else np.ascontiguousarray(optimized, np.int32), C.c_int32), len(sb[0]), _P(sb[0]), _P(sb[1]),
            _P(sb[2]), _P(sb[3]), C.byref(obs), C.byref(nt), I(hvs),
-           _P(vs), I(hvg), vcap, _P(vx), _P(vy), C.byref(nv), acap, I(off), I(adj))
+           _P(vs), I(hvg), vcap, _P(vx), _P(vy), C.byref(nv), acap, I(off), I(adj), len(plan[0]), _P(plan[0]), _P(plan[1]), _P(plan[2]),
+           len(si[0]), _P(si[0]), _P(si[1]), _P(si[2]), _P(si[3]), len(vxs), _P(vxs), _P(vys),
+           _abi._ptr(None if via_enabled is None else np.ascontiguousarray(via_enabled, np.int32), C.c_int32), C.byref(ipt), I(vout), _P(seen))
     assert rc == 0, rc
     N = nv.value
     return dict(batch=out, n_total=nt.value, vertices=np.stack([vx[:N], vy[:N]], 1),
-                adjacency=[adj[off[v]:off[v + 1]].tolist() for v in range(N)], has_vel_start=hvs, vel_start=vs, has_vel_goal=hvg)
+                adjacency=[adj[off[v]:off[v + 1]].tolist() for v in range(N)], has_vel_start=hvs, vel_start=vs, has_vel_goal=hvg,
+                initial_plan_teb=ipt.value, via_enabled=vout[:nt.value].copy(), plan_yaw_seen=seen[:len(plan[0])].copy())
 
 
-def hcp_plan_ticks(cfg, obst, starts, goals, start_vels=None, free_goal_vel=False, slots=8, stride=512):
+def hcp_plan_ticks(cfg, obst, starts, goals, start_vels=None, free_goal_vel=False, slots=8, stride=512, plans=None, via=None):
     """n_ticks x the reference's HomotopyClassPlanner::plan() on one planner object: list of dict(bands, best, costs) per tick."""
     from teb_local_planner_amd import _abi as A
     c = cfg.to_c()
@@ -297,13 +307,23 @@ def hcp_plan_ticks(cfg, obst, starts, goals, start_vels=None, free_goal_vel=Fals
     f = lib().ref_hcp_plan_ticks
     f.restype = C.c_int
     f.argtypes = [C.POINTER(A.Config), C.POINTER(A.HcpParams), C.POINTER(A.Obstacles), C.c_int, A.p_f64, A.p_f64, A.p_f64, C.c_int, C.c_int,
-                  C.POINTER(A.TebBatch), A.p_i32, A.p_i32, A.p_f64]
+                  C.POINTER(A.TebBatch), A.p_i32, A.p_i32, A.p_f64, A.p_i32, A.p_f64, A.p_f64, A.p_f64, A.p_f64, C.c_int, A.p_f64, A.p_f64, A.p_i32]
+    plans = plans or [None] * T
+    off = np.zeros(T + 1, np.int32)
+    for t in range(T):
+        off[t + 1] = off[t] + (0 if plans[t] is None else len(plans[t][0]))
+    cat = lambda k: np.ascontiguousarray(np.concatenate([np.asarray(pl[k], np.float64) for pl in plans if pl is not None] or [np.zeros(1)]))
+    px, py, pyaw = cat(0), cat(1), cat(2)
+    seen = np.zeros(len(pyaw)); ipt = np.zeros(T, np.int32)
+    vxs = np.ascontiguousarray([v[0] for v in (via or [])] or [0.0], np.float64); vys = np.ascontiguousarray([v[1] for v in (via or [])] or [0.0], np.float64)
     rc = f(C.byref(c), C.byref(p), C.byref(obst.freeze()), T, _P(st), _P(gl), _abi._ptr(sv, C.c_double), int(bool(free_goal_vel)), slots,
-           C.byref(obs), _abi._ptr(counts, C.c_int32), _abi._ptr(best, C.c_int32), _P(costs))
+           C.byref(obs), _abi._ptr(counts, C.c_int32), _abi._ptr(best, C.c_int32), _P(costs), _abi._ptr(off, C.c_int32), _P(px), _P(py), _P(pyaw),
+           _P(seen), len(via or []), _P(vxs), _P(vys), _abi._ptr(ipt, C.c_int32))
     assert rc == 0, rc
     res = []
     for t in range(T):
         assert counts[t] <= slots
         res.append(dict(bands=[out.get_teb(t * slots + k) for k in range(counts[t])], best=int(best[t]),
-                        costs=costs[t * slots:t * slots + counts[t]].copy()))
+                        costs=costs[t * slots:t * slots + counts[t]].copy(), initial_plan_teb=int(ipt[t]),
+                        plan_yaw_seen=seen[off[t]:off[t + 1]].copy()))
     return res

@@ -37,7 +37,10 @@ int ref_explore_candidates(const teb_amd_config_t* acfg, const teb_amd_hcp_param
                            const double* start_vel, int free_goal_vel, long skip_draws, const int32_t* optimized, int stale_n,
                            const double* stale_x, const double* stale_y, const double* stale_th, const double* stale_dt, teb_amd_teb_batch_t* out, int32_t* n_out,
                            int32_t* has_vs_out, double* vs_out, int32_t* has_vg_out, int vcap, double* vx, double* vy, int32_t* nv,
-                           int acap, int32_t* adj_off, int32_t* adj) {
+                           int acap, int32_t* adj_off, int32_t* adj, int n_plan, const double* plan_x, const double* plan_y,
+                           const double* plan_yaw, int stale_initial_n, const double* si_x, const double* si_y, const double* si_th,
+                           const double* si_dt, int n_via, const double* via_x, const double* via_y, const int32_t* via_in,
+                           int32_t* initial_plan_teb, int32_t* via_out, double* plan_yaw_seen) {
   TebConfig cfg;
   to_ref_config(*acfg, cfg);
   cfg.hcp.simple_exploration = p->simple_exploration;
@@ -60,9 +63,13 @@ int ref_explore_candidates(const teb_amd_config_t* acfg, const teb_amd_hcp_param
   ObstContainer obst;
   to_ref_obstacles(o, obst);
   HomotopyClassPlanner hcp;
-  hcp.initialize(cfg, &obst, TebVisualizationPtr(), NULL);
+  cfg.trajectory.global_plan_overwrite_orientation = p->global_plan_overwrite_orientation;
+  cfg.hcp.viapoints_all_candidates = p->viapoints_all_candidates;
+  ViaPointContainer via;
+  for (int k = 0; k < n_via; ++k) via.push_back(Eigen::Vector2d(via_x[k], via_y[k]));
+  hcp.initialize(cfg, &obst, TebVisualizationPtr(), n_via > 0 ? &via : NULL);
   for (int b = 0; in && b < in->count; ++b) {
-    TebOptimalPlannerPtr t(new TebOptimalPlanner(cfg, &obst));
+    TebOptimalPlannerPtr t(new TebOptimalPlanner(cfg, &obst, TebVisualizationPtr(), (via_in && via_in[b]) ? &via : NULL));
     const size_t so = (size_t)b * in->stride;
     band_in(t->teb(), in->n[b], in->x + so, in->y + so, in->theta + so, in->dt + so);
     t->optimized_ = optimized ? optimized[b] != 0 : true;
@@ -79,10 +86,30 @@ int ref_explore_candidates(const teb_amd_config_t* acfg, const teb_amd_hcp_param
     ProbRoadmapGraph* g = dynamic_cast<ProbRoadmapGraph*>(hcp.graph_search_.get());
     if (g) g->rnd_generator_.discard(skip_draws);
   }
+  TimedElasticBand stale_initial;   // initial_plan_eq_class_ left over from an earlier tick's initial plan
+  if (stale_initial_n > 0) {
+    band_in(stale_initial, stale_initial_n, si_x, si_y, si_th, si_dt);
+    hcp.initial_plan_eq_class_ = hcp.calculateEquivalenceClass(stale_initial.poses().begin(), stale_initial.poses().end(), getCplxFromVertexPosePtr,
+                                                               &obst, stale_initial.timediffs().begin(), stale_initial.timediffs().end());
+  }
+  std::vector<geometry_msgs::PoseStamped> plan(n_plan > 0 ? n_plan : 0);
+  for (int k = 0; k < n_plan; ++k) {
+    plan[k].pose.position.x = plan_x[k]; plan[k].pose.position.y = plan_y[k];
+    plan[k].pose.orientation = tf::createQuaternionMsgFromYaw(plan_yaw[k]);
+    plan_yaw_seen[k] = tf::getYaw(plan[k].pose.orientation);   // what initTrajectoryToGoal(plan, ...) reads back from the message
+  }
+  if (n_plan > 0) hcp.initial_plan_ = &plan;
   PoseSE2 s(start[0], start[1], start[2]), g(goal[0], goal[1], goal[2]);
   geometry_msgs::Twist tw;
   if (start_vel) { tw.linear.x = start_vel[0]; tw.linear.y = start_vel[1]; tw.angular.z = start_vel[2]; }
   hcp.exploreEquivalenceClassesAndInitTebs(s, g, dist_to_obst, start_vel ? &tw : NULL, free_goal_vel != 0);
+  hcp.updateReferenceTrajectoryViaPoints(cfg.hcp.viapoints_all_candidates);     // the next statement of plan(), :117
+  {
+    TebOptimalPlannerPtr ip = hcp.getInitialPlanTEB();                            // what selectBestTeb will see, :569
+    *initial_plan_teb = -1;
+    for (size_t b = 0; b < hcp.tebs_.size(); ++b) if (hcp.tebs_[b] == ip) *initial_plan_teb = (int)b;
+    for (size_t b = 0; b < hcp.tebs_.size() && (int)b < out->count; ++b) via_out[b] = hcp.tebs_[b]->via_points_ != NULL;
+  }
   const int nt = (int)hcp.tebs_.size();
   *n_out = nt;
   for (int b = 0; b < nt && b < out->count; ++b) {
@@ -111,7 +138,9 @@ int ref_explore_candidates(const teb_amd_config_t* acfg, const teb_amd_hcp_param
 // out: slots bands per tick (band k of tick t at out slot t*slots+k), counts [n_ticks], best [n_ticks], costs [n_ticks*slots].
 int ref_hcp_plan_ticks(const teb_amd_config_t* acfg, const teb_amd_hcp_params_t* p, const teb_amd_obstacles_t* o, int n_ticks,
                        const double* starts, const double* goals, const double* start_vels, int free_goal_vel, int slots,
-                       teb_amd_teb_batch_t* out, int32_t* counts, int32_t* best, double* costs) {
+                       teb_amd_teb_batch_t* out, int32_t* counts, int32_t* best, double* costs, const int32_t* plan_off,
+                       const double* plan_x, const double* plan_y, const double* plan_yaw, double* plan_yaw_seen, int n_via,
+                       const double* via_x, const double* via_y, int32_t* initial_plan_teb) {
   TebConfig cfg;
   to_ref_config(*acfg, cfg);
   cfg.hcp.simple_exploration = p->simple_exploration;
@@ -132,16 +161,37 @@ int ref_hcp_plan_ticks(const teb_amd_config_t* acfg, const teb_amd_hcp_params_t*
   cfg.hcp.selection_dropping_probability = 0.0;
   cfg.hcp.switching_blocking_period = 0.0;
   cfg.hcp.enable_multithreading = false;
-  cfg.hcp.viapoints_all_candidates = true;
+  cfg.hcp.viapoints_all_candidates = p->viapoints_all_candidates;
+  cfg.trajectory.global_plan_overwrite_orientation = p->global_plan_overwrite_orientation;
   ObstContainer obst;
   to_ref_obstacles(o, obst);
+  ViaPointContainer via;
+  for (int k = 0; k < n_via; ++k) via.push_back(Eigen::Vector2d(via_x[k], via_y[k]));
   HomotopyClassPlanner hcp;
-  hcp.initialize(cfg, &obst, TebVisualizationPtr(), NULL);
+  hcp.initialize(cfg, &obst, TebVisualizationPtr(), n_via > 0 ? &via : NULL);
+  std::vector<geometry_msgs::PoseStamped> plan;
   for (int t = 0; t < n_ticks; ++t) {
     PoseSE2 s(starts[3 * t], starts[3 * t + 1], starts[3 * t + 2]), g(goals[3 * t], goals[3 * t + 1], goals[3 * t + 2]);
     geometry_msgs::Twist tw;
     if (start_vels) { tw.linear.x = start_vels[3 * t]; tw.linear.y = start_vels[3 * t + 1]; tw.angular.z = start_vels[3 * t + 2]; }
-    hcp.plan(s, g, start_vels ? &tw : NULL, free_goal_vel != 0);
+    const int np = plan_off ? plan_off[t + 1] - plan_off[t] : 0;
+    if (np > 0) {   // plan(const std::vector<geometry_msgs::PoseStamped>& initial_plan, ...), :84-96
+      plan.assign(np, geometry_msgs::PoseStamped());
+      for (int k = 0; k < np; ++k) {
+        const int q = plan_off[t] + k;
+        plan[k].pose.position.x = plan_x[q]; plan[k].pose.position.y = plan_y[q];
+        plan[k].pose.orientation = tf::createQuaternionMsgFromYaw(plan_yaw[q]);
+        plan_yaw_seen[q] = tf::getYaw(plan[k].pose.orientation);
+      }
+      hcp.plan(plan, start_vels ? &tw : NULL, free_goal_vel != 0);
+    } else {
+      hcp.plan(s, g, start_vels ? &tw : NULL, free_goal_vel != 0);
+    }
+    {
+      TebOptimalPlannerPtr ip = hcp.getInitialPlanTEB();
+      initial_plan_teb[t] = -1;
+      for (size_t b = 0; b < hcp.tebs_.size(); ++b) if (hcp.tebs_[b] == ip) initial_plan_teb[t] = (int)b;
+    }
     const int nt = (int)hcp.tebs_.size();
     counts[t] = nt;
     best[t] = hcp.bestTebIdx();

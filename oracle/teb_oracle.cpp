@@ -2507,7 +2507,9 @@ int teb_oracle_explore_candidates(const teb_amd_config_t* cfg, const teb_amd_hcp
                                   teb_amd_teb_batch_t* batch, int32_t n_tebs, int32_t best, const double* start, const double* goal,
                                   double dist_to_obst, const double* unit_samples, int64_t skip_draws, int64_t max_paths,
                                   const double* stale_best_sig, int32_t* n_total, int32_t vcap, double* vx, double* vy, int32_t* nv,
-                                  int32_t acap, int32_t* adj_off, int32_t* adj, int32_t* n_paths) {
+                                  int32_t acap, int32_t* adj_off, int32_t* adj, int32_t* n_paths, int32_t n_plan, const double* plan_x,
+                                  const double* plan_y, const double* plan_yaw, const double* stale_initial_sig, int32_t* initial_plan_teb,
+                                  int32_t* via_enabled) {
   Scene s;
   int rc = load_scene(s, cfg, obst, 0, nullptr, nullptr);
   if (rc) return rc;
@@ -2523,6 +2525,18 @@ int teb_oracle_explore_candidates(const teb_amd_config_t* cfg, const teb_amd_hcp
   }
   if (best >= 0 && best < n_tebs) { ex.has_best = true; ex.best_class = ex.classes[best]; }
   else if (stale_best_sig) { ex.has_best = true; ex.best_class.v.assign(stale_best_sig, stale_best_sig + ex.W); }   // stale best_teb_eq_class_
+  // ---- addAndInitNewTeb(*initial_plan_, ...), src/homotopy_class_planner.cpp:326-329, 412-440
+  int initial_idx = -1;
+  bool have_initial_class = false;
+  ClassSig initial_class;
+  if (stale_initial_sig) { have_initial_class = true; initial_class.v.assign(stale_initial_sig, stale_initial_sig + ex.W); }
+  if (n_plan > 0 && (int)ex.tebs.size() < p->max_number_classes) {
+    Teb t;
+    init_trajectory_plan(t, n_plan, plan_x, plan_y, plan_yaw, cfg->max_vel_x, cfg->max_vel_theta, p->global_plan_overwrite_orientation != 0,
+                         cfg->min_samples, p->allow_init_with_backwards_motion != 0);
+    initial_class = ex.signature(t); have_initial_class = true;   // initial_plan_eq_class_
+    if (ex.add_class_if_new(initial_class)) { ex.tebs.push_back(t); initial_idx = (int)ex.tebs.size() - 1; }
+  }
   HcGraph g;
   const double thr = p->obstacle_heading_threshold;
   const V2 sp{start[0], start[1]}, gp{goal[0], goal[1]};
@@ -2539,6 +2553,19 @@ int teb_oracle_explore_candidates(const teb_amd_config_t* cfg, const teb_amd_hcp
       for (int w : g.adj[v]) { if (e < acap) adj[e] = w; ++e; }
     }
     if (N <= vcap && adj_off) adj_off[N] = e;
+    // getInitialPlanTEB (:495-536): the band made from the plan, else the first band whose class equals initial_plan_eq_class_
+    if (initial_idx < 0 && have_initial_class && ex.is_valid(initial_class))
+      for (int b = 0; b < (int)ex.classes.size(); ++b)
+        if (ex.is_equal(ex.classes[b], initial_class)) { initial_idx = b; break; }
+    if (initial_plan_teb) *initial_plan_teb = initial_idx;
+    // updateReferenceTrajectoryViaPoints (:286-315) given that via-points exist and weight_viapoint > 0: in = flags of the existing
+    // bands, new bands start at 0 (constructed without via-points)
+    if (via_enabled) {
+      for (int b = n_tebs; b < (int)ex.tebs.size(); ++b) via_enabled[b] = 0;
+      if (p->viapoints_all_candidates) { for (int b = 0; b < (int)ex.tebs.size(); ++b) via_enabled[b] = 1; }
+      else if (n_plan > 0)
+        for (int b = 0; b < (int)ex.tebs.size(); ++b) via_enabled[b] = have_initial_class && ex.is_equal(initial_class, ex.classes[b]);
+    }
     return (int)TEB_AMD_OK;
   };
   if ((int)ex.tebs.size() >= p->max_number_classes) return finish();   // src/graph_search.cpp:99-100, 231-232

@@ -140,13 +140,18 @@ int teb_oracle_filter_detours(const teb_amd_teb_batch_t* batch, const teb_amd_hc
                               int32_t* keep);
 /* ---- row f3, candidate generation: GraphSearchInterface::createGraph (src/graph_search.cpp:95-340), DepthFirst (:45-91),
  * addAndInitNewTeb (homotopy_class_planner.hpp:66-93) on bands 0..n_tebs-1 (= tebs_ after renewAndAnalyzeOldTebs); batch->count = slots.
+ * n_plan > 0: the initial plan, tried first (addAndInitNewTeb(*initial_plan_, ...), :326-329, 412-440); stale_initial_sig =
+ * initial_plan_eq_class_ of an earlier tick or NULL; *initial_plan_teb = getInitialPlanTEB(); via_enabled [slots] in/out (may be
+ * NULL) = updateReferenceTrajectoryViaPoints given via-points exist.
  * max_paths > 0 bounds the number of start-goal paths examined (test guard; the reference has no bound).
  * Graph out: vertices vx, vy [vcap], adjacency in insertion order as CSR (adj_off [nv+1], adj [acap]). */
 int teb_oracle_explore_candidates(const teb_amd_config_t* cfg, const teb_amd_hcp_params_t* p, const teb_amd_obstacles_t* obst,
                                   teb_amd_teb_batch_t* batch, int32_t n_tebs, int32_t best, const double* start, const double* goal,
                                   double dist_to_obst, const double* unit_samples, int64_t skip_draws, int64_t max_paths,
                                   const double* stale_best_sig, int32_t* n_total, int32_t vcap, double* vx, double* vy, int32_t* nv,
-                                  int32_t acap, int32_t* adj_off, int32_t* adj, int32_t* n_paths);
+                                  int32_t acap, int32_t* adj_off, int32_t* adj, int32_t* n_paths, int32_t n_plan, const double* plan_x,
+                                  const double* plan_y, const double* plan_yaw, const double* stale_initial_sig, int32_t* initial_plan_teb,
+                                  int32_t* via_enabled);
 
 #ifdef __cplusplus
 }

@@ -85,7 +85,8 @@ class HcpParams(C.Structure):
         ("max_number_classes", c_i32), ("max_number_plans_in_current_class", c_i32), ("h_signature_prescaler", c_f64),
         ("h_signature_threshold", c_f64), ("allow_init_with_backwards_motion", c_i32), ("delete_detours_backwards", c_i32),
         ("detours_orientation_tolerance", c_f64), ("length_start_orientation_vector", c_f64),
-        ("max_ratio_detours_duration_best_duration", c_f64),
+        ("max_ratio_detours_duration_best_duration", c_f64), ("global_plan_overwrite_orientation", c_i32),
+        ("viapoints_all_candidates", c_i32),
     ]
 
 

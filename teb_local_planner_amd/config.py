@@ -99,6 +99,7 @@ class TebConfig:
                 setattr(p, k, int(v) if isinstance(v, bool) else v)
         p.xy_goal_tolerance = self.goal_tolerance.xy_goal_tolerance
         p.allow_init_with_backwards_motion = int(self.trajectory.allow_init_with_backwards_motion)
+        p.global_plan_overwrite_orientation = int(self.trajectory.global_plan_overwrite_orientation)
         return p
 
     def to_c(self):

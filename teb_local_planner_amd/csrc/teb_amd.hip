@@ -183,6 +183,8 @@ struct teb_amd_handle {
   bool cand_ready = false, tmp_ready = false;
   std::vector<double> best_class;   // best_teb_eq_class_ (homotopy_class_planner.h): signature of the last best band; survives the band
   int best_class_mode = 0;          // 0 = none yet, 2 / 3 = HSignature / HSignature3d
+  std::vector<double> initial_class;   // initial_plan_eq_class_: signature of the band made from the last initial plan
+  int initial_class_mode = 0;
   std::mt19937 rnd_generator;   // ProbRoadmapGraph::rnd_generator_ (graph_search.h:211): default-seeded 32-bit Mersenne twister
 };
 
@@ -1002,6 +1004,7 @@ void teb_amd_hcp_params_default(teb_amd_hcp_params_t* p) {   // teb_config.h:352
   p->h_signature_prescaler = 1; p->h_signature_threshold = 0.1; p->allow_init_with_backwards_motion = 0;
   p->delete_detours_backwards = 1; p->detours_orientation_tolerance = M_PI / 2.0; p->length_start_orientation_vector = 0.4;   // :374-377
   p->max_ratio_detours_duration_best_duration = 3.0;
+  p->global_plan_overwrite_orientation = 1; p->viapoints_all_candidates = 1;   // :259, :370
 }
 
 namespace {
@@ -1098,10 +1101,14 @@ struct PathEnumerator {
 
 int teb_amd_explore_candidates(teb_amd_handle_t* h, const teb_amd_hcp_params_t* p, const double* start, const double* goal,
                                double dist_to_obst, const double* start_vel, int32_t free_goal_vel, int32_t best,
-                               const double* unit_samples, int64_t max_paths, int32_t* n_total, int32_t* n_vertices, int32_t* n_paths) {
+                               const double* unit_samples, int64_t max_paths, int32_t* n_total, int32_t* n_vertices, int32_t* n_paths,
+                               int32_t n_plan, const double* plan_x, const double* plan_y, const double* plan_yaw,
+                               int32_t* initial_plan_teb) {
   int rc = check_handle(h);
   if (rc) return rc;
   if (!p || !start || !goal) return fail(TEB_AMD_ERR_INVALID_ARG, "null argument");
+  if (n_plan > 0 && (!plan_x || !plan_y || !plan_yaw)) return fail(TEB_AMD_ERR_INVALID_ARG, "null initial plan");
+  if (initial_plan_teb) *initial_plan_teb = -1;
   if ((rc = ensure_candidate_buffers(h))) return rc;
   const teb_amd_config_t& c = h->cfg;
   const int M = h->M;
@@ -1122,7 +1129,7 @@ int teb_amd_explore_candidates(teb_amd_handle_t* h, const teb_amd_hcp_params_t* 
   }
   if (h->best_class_mode == mode && (int)h->best_class.size() == W) { ct.has_best = true; ct.best = h->best_class; }   // best_teb_eq_class_
   h->hsig_mode = 0;   // the batch is about to change: signatures have to be recomputed before the next filter call
-  if (h->B >= slots) return TEB_AMD_OK;                                     // src/graph_search.cpp:99-100, 231-232
+  const int n_old = h->B;
   // tebs_.push_back(candidate) for the accepted candidates of a chunk: scratch bands -> the next slots of the batch, one gather;
   // default attributes of a new TebOptimalPlanner (fixed zero start / goal velocity), then setVelocityStart / setVelocityGoalFree
   auto accept_all = [&](const std::vector<int>& cand) -> int {
@@ -1153,10 +1160,27 @@ int teb_amd_explore_candidates(teb_amd_handle_t* h, const teb_amd_hcp_params_t* 
     if (err) return fail(TEB_AMD_ERR_CAPACITY, "candidate band needs more poses than max_poses");
     return TEB_AMD_OK;
   };
+  h->consumers_valid = false;
+  // ---- the initial plan as a candidate: addAndInitNewTeb(*initial_plan_, ...), src/homotopy_class_planner.cpp:326-329, 412-440
+  int initial_idx = -1;   // initial_plan_teb_
+  if (n_plan > 0 && h->B < slots) {
+    if ((rc = stage(h, n_plan, plan_x, plan_y, plan_yaw))) return rc;
+    hipLaunchKernelGGL(init_plan_kernel, dim3(1), dim3(kThreads), 0, h->stream, candidates_of(h), 0, n_plan, h->stage_x.p, h->stage_y.p,
+                       h->stage_yaw.p, c.max_vel_x, c.max_vel_theta, p->global_plan_overwrite_orientation, c.min_samples,
+                       p->allow_init_with_backwards_motion, h->err_flag.p);
+    HIPCHK(hipGetLastError());
+    if ((rc = classify(1))) return rc;
+    h->initial_class.assign(sig.data(), sig.data() + W); h->initial_class_mode = mode;   // initial_plan_eq_class_
+    if (ct.add_if_new(sig.data())) {
+      if ((rc = accept_all({0}))) return rc;
+      initial_idx = h->B - 1;
+    }
+  }
+  auto body = [&]() -> int {
+  if (h->B >= slots) return TEB_AMD_OK;                                     // src/graph_search.cpp:99-100, 231-232
   const double sx = start[0], sy = start[1], gx = goal[0], gy = goal[1];
   double dfx = gx - sx, dfy = gy - sy;
   const double start_goal_dist = std::sqrt(dfx * dfx + dfy * dfy);
-  h->consumers_valid = false;
   if (start_goal_dist < p->xy_goal_tolerance) {                             // :104-113, :237-246
     if (h->B == 0) {                                                        // addAndInitNewTeb(start, goal, ...), hcp.cpp:358-384
       HIPCHK(hipMemsetAsync(h->err_flag.p, 0, sizeof(int), h->stream));
@@ -1166,7 +1190,6 @@ int teb_amd_explore_candidates(teb_amd_handle_t* h, const teb_amd_hcp_params_t* 
       if ((rc = classify(1))) return rc;
       if (ct.add_if_new(sig.data()) && (rc = accept_all({0}))) return rc;
     }
-    if (n_total) *n_total = h->B;
     return TEB_AMD_OK;
   }
   // ---- vertices (host: O(M) on the centroids kept from teb_amd_set_obstacles) ------------------------------------------------------
@@ -1279,7 +1302,26 @@ int teb_amd_explore_candidates(teb_amd_handle_t* h, const teb_amd_hcp_params_t* 
     if ((rc = accept_all(accepted))) return rc;
   }
   if (n_paths) *n_paths = (int32_t)std::min<int64_t>(examined, std::numeric_limits<int32_t>::max());
+  return TEB_AMD_OK;
+  };
+  if ((rc = body())) return rc;
   if (n_total) *n_total = h->B;
+  // ---- getInitialPlanTEB (:495-536): the band created from the initial plan, else the first band of the initial plan's class
+  const bool have_initial_class = h->initial_class_mode == mode && (int)h->initial_class.size() == W && ct.valid(h->initial_class.data());
+  if (initial_idx < 0 && have_initial_class)
+    for (int b = 0; b < h->B && b < (int)ct.classes.size(); ++b)
+      if (ct.equal(ct.classes[b].data(), h->initial_class.data())) { initial_idx = b; break; }
+  if (initial_plan_teb) *initial_plan_teb = initial_idx;
+  // ---- updateReferenceTrajectoryViaPoints (:286-315): new candidates are born without via-points (their constructor gets none);
+  //      all candidates get them (viapoints_all_candidates), or - with an initial plan - exactly those of the initial plan's class
+  if (h->B > n_old) HIPCHK(hipMemsetAsync(h->via_en.p + n_old, 0, (h->B - n_old) * sizeof(int), h->stream));
+  if (h->B > 0 && !((!p->viapoints_all_candidates && n_plan <= 0) || h->nvia <= 0 || c.weight_viapoint <= 0)) {
+    std::vector<int> ve(h->B, 1);
+    if (!p->viapoints_all_candidates)
+      for (int b = 0; b < h->B; ++b) ve[b] = have_initial_class && b < (int)ct.classes.size() && ct.equal(h->initial_class.data(), ct.classes[b].data());
+    HIPCHK(hipMemcpyAsync(h->via_en.p, ve.data(), h->B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
   return TEB_AMD_OK;
 }
 
@@ -1420,6 +1462,17 @@ int teb_amd_get_optimized_flags(teb_amd_handle_t* h, int32_t* flags) {
   if (!flags) return fail(TEB_AMD_ERR_INVALID_ARG, "null flags");
   if (h->B <= 0) return TEB_AMD_OK;
   HIPCHK(hipMemcpyAsync(flags, h->optimized.p, h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return TEB_AMD_OK;
+}
+
+int teb_amd_get_band_flags(teb_amd_handle_t* h, int32_t* via_points_enabled, int32_t* has_vel_start, int32_t* has_vel_goal) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (h->B <= 0) return TEB_AMD_OK;
+  if (via_points_enabled) HIPCHK(hipMemcpyAsync(via_points_enabled, h->via_en.p, h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (has_vel_start) HIPCHK(hipMemcpyAsync(has_vel_start, h->has_vs.p, h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (has_vel_goal) HIPCHK(hipMemcpyAsync(has_vel_goal, h->has_vg.p, h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return TEB_AMD_OK;
 }

@@ -409,7 +409,8 @@ void toAmdHcpParams(const TebConfig& cfg, teb_amd_hcp_params_t& p)
 bool TebAmdBatch::exploreEquivalenceClassesAndInitTebs(const TebConfig& cfg, ObstContainer* obstacles, const ViaPointContainer* via_points,
                                                        std::vector<TebOptimalPlannerAmdPtr>& tebs, int& best_index, const PoseSE2& start,
                                                        const PoseSE2& goal, double dist_to_obst, const geometry_msgs::Twist* start_vel,
-                                                       bool free_goal_vel)
+                                                       bool free_goal_vel, const std::vector<geometry_msgs::PoseStamped>* initial_plan,
+                                                       int* initial_plan_index)
 {
   if (!h_) return false;
   teb_amd_hcp_params_t hp;
@@ -423,6 +424,10 @@ bool TebAmdBatch::exploreEquivalenceClassesAndInitTebs(const TebConfig& cfg, Obs
   int rc = teb_amd_set_config(h_, &a);
   if (rc != TEB_AMD_OK && rc != TEB_AMD_ERR_INVALID_ARG) return check(rc, "teb_amd_set_config");
   if (!check(teb_amd_set_obstacles(h_, &ov), "teb_amd_set_obstacles")) return false;
+  std::vector<double> viax, viay;
+  if (via_points)
+    for (const Eigen::Vector2d& v : *via_points) { viax.push_back(v.x()); viay.push_back(v.y()); }
+  if (!check(teb_amd_set_via_points(h_, (int32_t)viax.size(), viax.data(), viay.data()), "teb_amd_set_via_points")) return false;
   // ---- renewAndAnalyzeOldTebs on the existing candidates
   int32_t n_kept = 0, new_best = -1;
   if (!tebs.empty())
@@ -451,9 +456,15 @@ bool TebAmdBatch::exploreEquivalenceClassesAndInitTebs(const TebConfig& cfg, Obs
   const double s[3] = { start.x(), start.y(), start.theta() }, g[3] = { goal.x(), goal.y(), goal.theta() };
   double sv[3] = { 0, 0, 0 };
   if (start_vel) { sv[0] = start_vel->linear.x; sv[1] = start_vel->linear.y; sv[2] = start_vel->angular.z; }
-  int32_t n_total = 0;
+  int32_t n_total = 0, ip_index = -1;
+  std::vector<double> px, py, pyaw;
+  if (initial_plan)
+    for (const geometry_msgs::PoseStamped& ps : *initial_plan)
+    { px.push_back(ps.pose.position.x); py.push_back(ps.pose.position.y); pyaw.push_back(tf::getYaw(ps.pose.orientation)); }
   if (!check(teb_amd_explore_candidates(h_, &hp, s, g, dist_to_obst, start_vel ? sv : NULL, free_goal_vel ? 1 : 0, best_index, NULL, 0,
-                                        &n_total, NULL, NULL), "teb_amd_explore_candidates")) return false;
+                                        &n_total, NULL, NULL, (int32_t)px.size(), px.data(), py.data(), pyaw.data(), &ip_index),
+             "teb_amd_explore_candidates")) return false;
+  if (initial_plan_index) *initial_plan_index = ip_index;
   const size_t old = tebs.size();
   for (int b = (int)old; b < n_total; ++b)
   {
@@ -461,6 +472,12 @@ bool TebAmdBatch::exploreEquivalenceClassesAndInitTebs(const TebConfig& cfg, Obs
     if (start_vel) c->setVelocityStart(*start_vel);
     if (free_goal_vel) c->setVelocityGoalFree();
     tebs.push_back(c);
+  }
+  if (n_total > 0)   // updateReferenceTrajectoryViaPoints: the flags the device applied, onto the planner objects
+  {
+    std::vector<int32_t> ve(n_total);
+    if (!check(teb_amd_get_band_flags(h_, ve.data(), NULL, NULL), "teb_amd_get_band_flags")) return false;
+    for (int b = 0; b < n_total; ++b) tebs[b]->setViaPoints(ve[b] ? via_points : NULL);
   }
   if (n_total > (int)old)   // bands of the new candidates (the old ones are unchanged)
   {

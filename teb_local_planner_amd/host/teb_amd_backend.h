@@ -118,8 +118,9 @@ public:
                               int* width = NULL);
 
   /**
-   * Replaces the body of HomotopyClassPlanner::exploreEquivalenceClassesAndInitTebs (src/homotopy_class_planner.cpp:318-340; not the
-   * initial-plan branch :326-335 nor randomlyDropTebs): renewAndAnalyzeOldTebs incl. deletePlansDetouringBackwards on the
+   * Replaces the body of HomotopyClassPlanner::exploreEquivalenceClassesAndInitTebs (src/homotopy_class_planner.cpp:318-340; not
+   * randomlyDropTebs), with initial_plan = initial_plan_ (or NULL) and *initial_plan_index = the index of getInitialPlanTEB() in `tebs`
+   * afterwards (for selectBestTeb), incl. updateReferenceTrajectoryViaPoints on the device-side attributes: renewAndAnalyzeOldTebs incl. deletePlansDetouringBackwards on the
    * candidates in `tebs` (erased ones leave the vector; the last best candidate, best_index, moves to the front), then
    * createGraph / DepthFirst / addAndInitNewTeb on the device; every new band arrives as a new TebOptimalPlannerAmd appended to
    * `tebs` (constructed like the reference's candidates: same cfg, obstacles, via-points; setVelocityStart / setVelocityGoalFree
@@ -128,7 +129,8 @@ public:
   bool exploreEquivalenceClassesAndInitTebs(const TebConfig& cfg, ObstContainer* obstacles, const ViaPointContainer* via_points,
                                             std::vector<TebOptimalPlannerAmdPtr>& tebs, int& best_index, const PoseSE2& start,
                                             const PoseSE2& goal, double dist_to_obst, const geometry_msgs::Twist* start_vel,
-                                            bool free_goal_vel);
+                                            bool free_goal_vel, const std::vector<geometry_msgs::PoseStamped>* initial_plan = NULL,
+                                            int* initial_plan_index = NULL);
 
   //! TebOptimalPlanner::getVelocityCommand (src/optimal_planner.cpp:1135-1168) of candidate `index`, from the device-resident band.
   bool getVelocityCommand(const TebConfig& cfg, int index, double& vx, double& vy, double& omega, int look_ahead_poses);

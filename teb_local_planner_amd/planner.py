@@ -79,12 +79,14 @@ def lib():
         L.teb_amd_compute_h_signatures.argtypes = [vp, d, _abi.p_f64, _abi.p_i32]
         L.teb_amd_filter_equivalence_classes.argtypes = [vp, d, i32, i32, _abi.p_i32, _abi.p_i32, _abi.p_i32]
         L.teb_amd_explore_candidates.argtypes = [vp, C.POINTER(_abi.HcpParams), _abi.p_f64, _abi.p_f64, d, _abi.p_f64, i32, i32,
-                                                 _abi.p_f64, C.c_int64, _abi.p_i32, _abi.p_i32, _abi.p_i32]
+                                                 _abi.p_f64, C.c_int64, _abi.p_i32, _abi.p_i32, _abi.p_i32, i32, _abi.p_f64, _abi.p_f64,
+                                                 _abi.p_f64, _abi.p_i32]
         L.teb_amd_get_exploration_graph.argtypes = [vp, _abi.p_f64, _abi.p_f64, C.POINTER(C.c_ubyte), i32, _abi.p_i32]
         L.teb_amd_compact_bands.argtypes = [vp, _abi.p_i32, i32, _abi.p_i32, _abi.p_i32]
         L.teb_amd_filter_detours.argtypes = [vp, C.POINTER(_abi.HcpParams), i32, _abi.p_i32]
         L.teb_amd_set_optimized_flags.argtypes = [vp, _abi.p_i32]
         L.teb_amd_get_optimized_flags.argtypes = [vp, _abi.p_i32]
+        L.teb_amd_get_band_flags.argtypes = [vp, _abi.p_i32, _abi.p_i32, _abi.p_i32]
         L.teb_amd_hcp_params_default.argtypes = [C.POINTER(_abi.HcpParams)]
         L.teb_amd_hcp_params_default.restype = None
         _LIB = L
@@ -302,6 +304,14 @@ class TebBatchSolver:
         _chk(lib().teb_amd_get_optimized_flags(self._h, _abi._ptr(f, C.c_int32)), "teb_amd_get_optimized_flags")
         return f[:self.count]
 
+    def band_flags(self):
+        """(via_points_enabled, has_vel_start, has_vel_goal), each [B]."""
+        self._sync_count()
+        v = np.zeros(max(self.count, 1), np.int32); a = v.copy(); g = v.copy()
+        I = lambda x: _abi._ptr(x, C.c_int32)
+        _chk(lib().teb_amd_get_band_flags(self._h, I(v), I(a), I(g)), "teb_amd_get_band_flags")
+        return v[:self.count], a[:self.count], g[:self.count]
+
     def filter_detours(self, keep, best, params=None):
         """deletePlansDetouringBackwards on the bands with keep != 0: returns the new keep array."""
         p = params if params is not None else self.cfg.hcp_params()
@@ -319,20 +329,23 @@ class TebBatchSolver:
         return nk.value, nb.value
 
     def explore_candidates(self, start, goal, dist_to_obst=None, start_vel=None, free_goal_vel=False, best=-1, unit_samples=None,
-                           max_paths=0, params=None):
+                           max_paths=0, params=None, initial_plan=None):
         """exploreEquivalenceClassesAndInitTebs after renewAndAnalyzeOldTebs on the resident batch: dict(n_total, n_vertices, n_paths)."""
         p = params if params is not None else self.cfg.hcp_params()
         st = _abi.f64(start); gl = _abi.f64(goal)
         sv = None if start_vel is None else _abi.f64(start_vel)
         us = None if unit_samples is None else _abi.f64(np.asarray(unit_samples).ravel())
         dist_to_obst = self.cfg.obstacles.min_obstacle_dist if dist_to_obst is None else dist_to_obst
-        nt = C.c_int32(0); nv = C.c_int32(0); npth = C.c_int32(0)
+        nt = C.c_int32(0); nv = C.c_int32(0); npth = C.c_int32(0); ipt = C.c_int32(-1)
+        plan = [None, None, None] if initial_plan is None else [_abi.f64(a) for a in initial_plan]      # (x, y, yaw) of the poses
         _chk(lib().teb_amd_explore_candidates(self._h, C.byref(p), _abi._ptr(st, C.c_double), _abi._ptr(gl, C.c_double),
                                               float(dist_to_obst), _abi._ptr(sv, C.c_double), int(bool(free_goal_vel)), int(best),
-                                              _abi._ptr(us, C.c_double), int(max_paths), C.byref(nt), C.byref(nv), C.byref(npth)),
+                                              _abi._ptr(us, C.c_double), int(max_paths), C.byref(nt), C.byref(nv), C.byref(npth),
+                                              0 if initial_plan is None else len(plan[0]), _abi._ptr(plan[0], C.c_double),
+                                              _abi._ptr(plan[1], C.c_double), _abi._ptr(plan[2], C.c_double), C.byref(ipt)),
              "teb_amd_explore_candidates")
         self.count = nt.value
-        return dict(n_total=nt.value, n_vertices=nv.value, n_paths=npth.value)
+        return dict(n_total=nt.value, n_vertices=nv.value, n_paths=npth.value, initial_plan_teb=ipt.value)
 
     def exploration_graph(self):
         """(vertices [N, 2], adjacency [N, N] uint8) of the last explore_candidates call."""
@@ -539,9 +552,9 @@ class TebOptimalPlanner:
 class HomotopyClassPlanner:
     """Batch view: owns the candidates resident on one GPU (reference homotopy_class_planner.h). Either constructed around a host
     batch (optimizeAllTEBs / selectBestTeb on given bands) or empty (batch=None): plan() then runs the reference's whole tick on the
-    device-resident bands - updateAllTEBs, exploreEquivalenceClassesAndInitTebs, optimizeAllTEBs, selectBestTeb
-    (src/homotopy_class_planner.cpp:107-125). Not mirrored: the initial-plan candidate (initial_plan_, :326-335), randomlyDropTebs
-    (off by default) and switching_blocking_period (0 by default)."""
+    device-resident bands - updateAllTEBs, exploreEquivalenceClassesAndInitTebs (incl. the initial-plan candidate), optimizeAllTEBs,
+    selectBestTeb (src/homotopy_class_planner.cpp:84-125). Not mirrored: randomlyDropTebs (off by default) and
+    switching_blocking_period (0 by default)."""
 
     def __init__(self, cfg, obstacles, via_points, batch=None, device=0, stream=None, max_tebs=None, max_poses=None):
         self.cfg_ = cfg
@@ -579,7 +592,7 @@ class HomotopyClassPlanner:
         self._goal = tuple(goal)
 
     # ---- :318-340 (renewAndAnalyzeOldTebs :214-254, deletePlansDetouringBackwards :766-817, createGraph) -------------------------
-    def exploreEquivalenceClassesAndInitTebs(self, start, goal, dist_to_obst, start_vel=None, free_goal_vel=False):
+    def exploreEquivalenceClassesAndInitTebs(self, start, goal, dist_to_obst, start_vel=None, free_goal_vel=False, initial_plan=None):
         s, h = self.solver, self.cfg_.hcp
         if s.count > 0:
             s.h_signatures(h.h_signature_prescaler, values=False)
@@ -587,15 +600,22 @@ class HomotopyClassPlanner:
             if h.delete_detours_backwards:
                 keep = s.filter_detours(keep, self.best_teb_)
             _, self.best_teb_ = s.compact_bands(keep, self.best_teb_)
-        self.last_exploration = s.explore_candidates(start, goal, dist_to_obst, start_vel, free_goal_vel, self.best_teb_)
+        self.last_exploration = s.explore_candidates(start, goal, dist_to_obst, start_vel, free_goal_vel, self.best_teb_,
+                                                     initial_plan=initial_plan)
+        self.initial_plan_teb_ = self.last_exploration["initial_plan_teb"]      # getInitialPlanTEB() of selectBestTeb
         return self.last_exploration["n_total"]
 
-    def plan(self, start, goal, start_vel=None, free_goal_vel=False):
-        """plan(const PoseSE2& start, const PoseSE2& goal, const geometry_msgs::Twist* start_vel, bool free_goal_vel), :107-125."""
+    def plan(self, start, goal, start_vel=None, free_goal_vel=False, initial_plan=None):
+        """plan(const PoseSE2& start, const PoseSE2& goal, const geometry_msgs::Twist* start_vel, bool free_goal_vel), :107-125;
+        initial_plan = (x, y, yaw) arrays: plan(const std::vector<geometry_msgs::PoseStamped>& initial_plan, ...), :84-96 (start / goal
+        are then its first / last pose)."""
+        if initial_plan is not None:
+            px, py, pyaw = initial_plan
+            start = (px[0], py[0], pyaw[0]); goal = (px[-1], py[-1], pyaw[-1])
         o = self.cfg_.optim
         self.solver.set_config(self.cfg_)
         self.updateAllTEBs(start, goal, start_vel)
-        self.exploreEquivalenceClassesAndInitTebs(start, goal, self.cfg_.obstacles.min_obstacle_dist, start_vel, free_goal_vel)
+        self.exploreEquivalenceClassesAndInitTebs(start, goal, self.cfg_.obstacles.min_obstacle_dist, start_vel, free_goal_vel, initial_plan)
         if self.solver.count == 0:
             self.best_teb_ = -1
             return True

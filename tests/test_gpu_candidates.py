@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
 sys.path.insert(0, HERE)
 import make_ref_golden as RG  # noqa: E402
-from test_reference_pinning import renew_on_host, stale_signature  # noqa: E402
+from test_reference_pinning import renew_on_host, stale_signature, plan_as_seen, kept_via_flags  # noqa: E402
 
 from teb_local_planner_amd import planner, _abi, scenes  # noqa: E402
 
@@ -28,10 +28,19 @@ TOL = 1e-12
 
 def _make(case, max_tebs=16, stride=256):
     cfg, obst, batch = case["cfg"], case["obst"], case["batch"]
-    s = planner.TebBatchSolver(cfg, max_tebs, stride, max(len(obst), 1), max(len(obst.vert_x), 1), 1)
+    via = case.get("via") or []
+    s = planner.TebBatchSolver(cfg, max_tebs, stride, max(len(obst), 1), max(len(obst.vert_x), 1), max(len(via), 1))
     s.set_obstacles(obst)
-    s.set_via_points([])
+    s.set_via_points(via)
+    if case.get("stale_initial_band") is not None:   # initial_plan_eq_class_ of an earlier tick: a one-candidate exploration with that
+        x, y, th, _ = case["stale_initial_band"]     # band's poses as the plan leaves its class in the handle and draws no samples
+        p1 = cfg.hcp_params(); p1.max_number_classes = 1
+        r0 = s.explore_candidates(case["start"], case["goal"], params=p1, initial_plan=(x, y, th))
+        assert r0["n_total"] == 1 and r0["initial_plan_teb"] == 0 and r0["n_vertices"] == 0
+        s.compact_bands(np.zeros(1, np.int32))
     if batch is not None:
+        if case.get("via_enabled") is not None:
+            batch = batch.copy(); batch.via_points_enabled[:] = case["via_enabled"]
         s.upload(batch)
         opt = case.get("optimized")
         if opt is None:
@@ -53,9 +62,10 @@ def _renew_on_device(s, case):
     return best
 
 
-def _explore(s, case, best):
+def _explore(s, case, best, ref=None):
+    plan = plan_as_seen(case, ref) if ref is not None else None
     return s.explore_candidates(case["start"], case["goal"], dist_to_obst=case.get("dist_to_obst"), start_vel=case.get("start_vel"),
-                                free_goal_vel=case.get("free_goal_vel", False), best=best)
+                                free_goal_vel=case.get("free_goal_vel", False), best=best, initial_plan=plan)
 
 
 def _bands(s, stride=256):
@@ -86,13 +96,19 @@ def test_explore_candidates_matches_oracle_and_reference_vectors(oracle, name):
         _explore(s, case, best)
         s.compact_bands(np.zeros(s.count, np.int32))
         assert s.count == 0
-    r = _explore(s, case, best)
+    r = _explore(s, case, best, ref)
     b, n_tebs, obest = renew_on_host(oracle, case)
     assert obest == best
     o = oracle.explore_candidates(case["cfg"], case["obst"], b, n_tebs, obest, case["start"], case["goal"],
                                   skip_draws=case.get("skip_draws", 0), dist_to_obst=case.get("dist_to_obst"),
-                                  stale_best_sig=stale_signature(oracle, case))
+                                  stale_best_sig=stale_signature(oracle, case), initial_plan=plan_as_seen(case, ref),
+                                  stale_initial_sig=stale_signature(oracle, case, "stale_initial_band"),
+                                  via_enabled=kept_via_flags(oracle, case, b.count))
     assert r["n_total"] == o["n_total"] == int(ref["n_total"]) == s.count
+    assert r["initial_plan_teb"] == o["initial_plan_teb"] == int(ref["initial_plan_teb"])
+    if case.get("via"):
+        np.testing.assert_array_equal(s.band_flags()[0], ref["via_enabled"])
+        np.testing.assert_array_equal(o["via_enabled"][:o["n_total"]], ref["via_enabled"])
     assert r["n_vertices"] == len(o["vertices"])
     if r["n_total"] > n_tebs or name == "max_two_classes":
         assert r["n_paths"] <= o["n_paths"] or o["n_paths"] == 0   # the device may stop inside a chunk exactly where the oracle stops
@@ -229,14 +245,18 @@ def test_whole_plan_ticks_match_the_reference_planner(name):
     costs within 1e-6 relative."""
     case = RG.hcp_tick_cases()[name]
     g = np.load(os.path.join(HERE, "golden", "ref_f3_hcp_ticks.npz"))
-    hcp = planner.HomotopyClassPlanner(case["cfg"], case["obst"], [], None, max_tebs=8, max_poses=256)
+    hcp = planner.HomotopyClassPlanner(case["cfg"], case["obst"], case.get("via") or [], None, max_tebs=8, max_poses=256)
     for t, (st, gl) in enumerate(zip(case["starts"], case["goals"])):
         sv = None if case["start_vels"] is None else case["start_vels"][t]
-        assert hcp.plan(st, gl, sv)
         pre = "%s__%d__" % (name, t)
         ref = {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)}
+        plan = None
+        if case.get("plans"):            # plan(initial_plan, ...): yaw as the reference reads it back from the pose messages
+            plan = (case["plans"][t][0], case["plans"][t][1], ref["plan_yaw_seen"])
+        assert hcp.plan(st, gl, sv, initial_plan=plan)
         bands = hcp.bands()
         assert len(bands) == len(ref["n"]) and hcp.best_teb_ == int(ref["best"]), (t, len(bands), hcp.best_teb_)
+        assert hcp.initial_plan_teb_ == int(ref["initial_plan_teb"])
         cost = np.array(hcp.results().cost[:len(bands)])
         assert np.abs(cost - ref["costs"]).max() <= 1e-6 * np.abs(ref["costs"]).max()
         for k, band in enumerate(bands):

@@ -313,13 +313,37 @@ def renew_on_host(oracle, case, slots=None):
     return out, len(kept), (0 if best >= 0 and keep[best] else -1)
 
 
-def stale_signature(oracle, case):
-    """Signature of case["stale_band"] (the class of a best band that no longer exists), or None."""
-    if case.get("stale_band") is None:
+def kept_via_flags(oracle, case, slots):
+    """via-point flags of the existing bands after renewAndAnalyzeOldTebs (they travel with their band), padded to `slots`."""
+    if not case.get("via"):
+        return None
+    flags = np.zeros(slots, np.int32)
+    if case["batch"] is not None:
+        given = case.get("via_enabled") or [1] * case["batch"].count
+        kept, n_tebs, _ = renew_on_host(oracle, case)
+        for k in range(n_tebs):
+            for j in range(case["batch"].count):
+                a, c = kept.get_teb(k), case["batch"].get_teb(j)
+                if len(a[0]) == len(c[0]) and np.array_equal(a[1], c[1]) and np.array_equal(a[3], c[3]):
+                    flags[k] = given[j]
+    return flags
+
+
+def plan_as_seen(case, ref):
+    """The initial plan with the yaw angles the reference reads back from the pose messages (yaw -> quaternion -> tf::getYaw)."""
+    if case.get("initial_plan") is None:
+        return None
+    px, py, _ = case["initial_plan"]
+    return px, py, ref["plan_yaw_seen"]
+
+
+def stale_signature(oracle, case, key="stale_band"):
+    """Signature of case[key] (the class of a best / initial-plan band that no longer exists), or None."""
+    if case.get(key) is None:
         return None
     cfg = case["cfg"]
     b = _abi.TebBatchHost(1, 256)
-    b.set_teb(0, *case["stale_band"])
+    b.set_teb(0, *case[key])
     return oracle.h_signatures(cfg, case["obst"], b, 3 if cfg.obstacles.include_dynamic_obstacles else 2, cfg.hcp.h_signature_prescaler)[0]
 
 
@@ -335,8 +359,13 @@ def test_f3_candidate_generation_matches_reference_graph_search(oracle, name):
         ref = {k[len(name) + 2:]: g[k] for k in g.files if k.startswith(name + "__")}
     b, n_tebs, best = renew_on_host(oracle, case)
     o = oracle.explore_candidates(case["cfg"], case["obst"], b, n_tebs, best, case["start"], case["goal"], skip_draws=case.get("skip_draws", 0),
-                                  dist_to_obst=case.get("dist_to_obst"), stale_best_sig=stale_signature(oracle, case))
+                                  dist_to_obst=case.get("dist_to_obst"), stale_best_sig=stale_signature(oracle, case),
+                                  initial_plan=plan_as_seen(case, ref), stale_initial_sig=stale_signature(oracle, case, "stale_initial_band"),
+                                  via_enabled=kept_via_flags(oracle, case, b.count))
     assert o["n_total"] == int(ref["n_total"])
+    assert o["initial_plan_teb"] == int(ref["initial_plan_teb"])
+    if case.get("via"):
+        np.testing.assert_array_equal(o["via_enabled"][:o["n_total"]], ref["via_enabled"])
     np.testing.assert_array_equal(o["vertices"], ref["vertices"])
     N = len(o["vertices"])
     adj = np.zeros((N, N), np.uint8)
