@@ -266,3 +266,38 @@ def test_whole_plan_ticks_match_the_reference_planner(name):
         ok, vx, vy, om = hcp.getVelocityCommand()
         assert ok and np.isfinite([vx, vy, om]).all()
     hcp.solver.close()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_randomized_candidate_generation_matches_oracle(oracle, seed):
+    """Random scenes (tests/random_explore_cases.py; the oracle is bit-equal to the reference's code on them,
+    tests/test_reference_pinning.py): same graph, same bands in the same order, same initial-plan index and via-point flags."""
+    from random_explore_cases import random_explore_case
+    case = random_explore_case(seed)
+    plan = case.get("initial_plan")
+    b = _abi.TebBatchHost(16, 256)
+    o = oracle.explore_candidates(case["cfg"], case["obst"], b, 0, -1, case["start"], case["goal"], dist_to_obst=case["dist_to_obst"],
+                                  initial_plan=plan, via_enabled=np.zeros(16, np.int32) if case.get("via") else None, max_paths=20000)
+    if o["n_paths"] >= 20000:
+        pytest.skip("path enumeration bounded")
+    s = _make(case)
+    r = s.explore_candidates(case["start"], case["goal"], dist_to_obst=case["dist_to_obst"], start_vel=case.get("start_vel"),
+                             free_goal_vel=case.get("free_goal_vel", False), initial_plan=plan)
+    assert r["n_total"] == o["n_total"] and r["initial_plan_teb"] == o["initial_plan_teb"] and r["n_vertices"] == len(o["vertices"])
+    V, A = s.exploration_graph()
+    if len(V):
+        assert np.abs(V - o["vertices"]).max() <= TOL
+        want = np.zeros_like(A)
+        for i, row in enumerate(o["adjacency"]):
+            want[i, row] = 1
+        np.testing.assert_array_equal(A, want)
+    got = _bands(s)
+    for k in range(r["n_total"]):
+        for u, v in zip(got[k], o["batch"].get_teb(k)):
+            assert len(u) == len(v) and np.abs(u - v).max(initial=0) <= TOL
+    if r["n_total"]:
+        ve, hvs, hvg = s.band_flags()
+        if case.get("via"):
+            np.testing.assert_array_equal(ve, o["via_enabled"][:o["n_total"]])
+        assert hvs.all() and (not hvg.any() if case.get("free_goal_vel") else hvg.all())
+    s.close()
