@@ -451,6 +451,16 @@ bool TebAmdBatch::exploreEquivalenceClassesAndInitTebs(const TebConfig& cfg, Obs
     for (int b : order) if (keep[b]) kept.push_back(tebs[b]);
     tebs.swap(kept);
   }
+  else
+  {   // tebs_.clear() (new planner, clearPlanner(), goal jump in updateAllTEBs): whatever the device still holds goes as well
+    int32_t count = 0;
+    if (!check(teb_amd_get_pose_counts(h_, NULL, &count), "teb_amd_get_pose_counts")) return false;
+    if (count > 0)
+    {
+      std::vector<int32_t> none(count, 0);
+      if (!check(teb_amd_compact_bands(h_, none.data(), -1, &n_kept, &new_best), "teb_amd_compact_bands")) return false;
+    }
+  }
   best_index = new_best;
   // ---- createGraph + DepthFirst + addAndInitNewTeb
   const double s[3] = { start.x(), start.y(), start.theta() }, g[3] = { goal.x(), goal.y(), goal.theta() };
@@ -498,6 +508,19 @@ bool TebAmdBatch::exploreEquivalenceClassesAndInitTebs(const TebConfig& cfg, Obs
       t.setPoseVertexFixed(n[b] - 1, true);
     }
   }
+  return true;
+}
+
+bool TebAmdBatch::signatures(const TebConfig& cfg, std::vector<double>& values, int& width)
+{
+  int32_t w = 0, count = 0;
+  values.clear(); width = 0;
+  if (!check(teb_amd_get_pose_counts(h_, NULL, &count), "teb_amd_get_pose_counts")) return false;
+  if (count <= 0) return true;
+  if (!check(teb_amd_compute_h_signatures(h_, cfg.hcp.h_signature_prescaler, NULL, &w), "teb_amd_compute_h_signatures")) return false;
+  values.assign((size_t)count * (w > 0 ? w : 1), 0.0);
+  if (!check(teb_amd_compute_h_signatures(h_, cfg.hcp.h_signature_prescaler, values.data(), &w), "teb_amd_compute_h_signatures")) return false;
+  width = w;
   return true;
 }
 

@@ -132,6 +132,10 @@ public:
                                             bool free_goal_vel, const std::vector<geometry_msgs::PoseStamped>* initial_plan = NULL,
                                             int* initial_plan_index = NULL);
 
+  //! H-signatures of the bands currently on the device (after exploreEquivalenceClassesAndInitTebs: the candidates in `tebs` order):
+  //! values [B * width], width = #obstacles (HSignature3d) or 2 (HSignature: re, im).
+  bool signatures(const TebConfig& cfg, std::vector<double>& values, int& width);
+
   //! TebOptimalPlanner::getVelocityCommand (src/optimal_planner.cpp:1135-1168) of candidate `index`, from the device-resident band.
   bool getVelocityCommand(const TebConfig& cfg, int index, double& vx, double& vy, double& omega, int look_ahead_poses);
 

@@ -1,0 +1,105 @@
+// teb_amd_hcp_backend.cpp — see teb_amd_hcp_backend.h. Written against the reference's HomotopyClassPlanner; cites refer to
+// src/homotopy_class_planner.cpp.
+#include <complex>
+#include <vector>
+// the two equivalence-class types keep their values private and offer no setter: the classes computed on the device are written into
+// objects of the reference's own types, so that everything that reads equivalence_classes_ keeps working
+#define private public
+#include <teb_local_planner/h_signature.h>
+#undef private
+#include "teb_amd_hcp_backend.h"
+
+namespace teb_local_planner {
+
+HomotopyClassPlannerAmd::HomotopyClassPlannerAmd(const TebConfig& cfg, ObstContainer* obstacles, TebVisualizationPtr visualization,
+                                                 const ViaPointContainer* via_points, int max_tebs, int max_poses, int max_obstacles,
+                                                 int max_obstacle_vertices, int max_via_points, int device)
+  : HomotopyClassPlanner(cfg, obstacles, visualization, via_points),
+    batch_(new TebAmdBatch(cfg, max_tebs, max_poses, max_obstacles, max_obstacle_vertices, max_via_points, device))
+{
+}
+
+bool HomotopyClassPlannerAmd::plan(const PoseSE2& start, const PoseSE2& goal, const geometry_msgs::Twist* start_vel, bool free_goal_vel)
+{
+  ROS_ASSERT_MSG(initialized_, "Call initialize() first.");
+  // Update old TEBs with new start, goal and velocity (:539-562)
+  updateAllTEBs(&start, &goal, start_vel);
+
+  // ---- exploreEquivalenceClassesAndInitTebs (:318-340) on the device ------------------------------------------------------------------
+  std::vector<TebOptimalPlannerAmdPtr> cand;
+  int best_index = -1;
+  for (std::size_t i = 0; i < tebs_.size(); ++i)
+  {
+    TebOptimalPlannerAmdPtr p = boost::dynamic_pointer_cast<TebOptimalPlannerAmd>(tebs_[i]);
+    if (!p) continue;   // a candidate created by foreign code: cannot be moved to the device
+    if (tebs_[i] == best_teb_) best_index = (int)cand.size();
+    cand.push_back(p);
+  }
+  int initial_index = -1;
+  if (!batch_->exploreEquivalenceClassesAndInitTebs(*cfg_, obstacles_, via_points_, cand, best_index, start, goal,
+                                                    cfg_->obstacles.min_obstacle_dist, start_vel, free_goal_vel, initial_plan_, &initial_index))
+    return false;
+  tebs_.clear();
+  for (const TebOptimalPlannerAmdPtr& p : cand) tebs_.push_back(p);
+  initial_plan_teb_ = initial_index >= 0 ? tebs_[initial_index] : TebOptimalPlannerPtr();
+  // equivalence_classes_: the reference's own class objects, filled with the signatures computed on the device
+  std::vector<double> values;
+  int width = 0;
+  equivalence_classes_.clear();
+  if (!tebs_.empty())
+  {
+    if (!batch_->signatures(*cfg_, values, width)) return false;
+    for (std::size_t b = 0; b < tebs_.size(); ++b)
+    {
+      if (cfg_->obstacles.include_dynamic_obstacles)
+      {
+        HSignature3d* H = new HSignature3d(*cfg_);
+        H->hsignature3d_.assign(values.begin() + b * width, values.begin() + (b + 1) * width);
+        equivalence_classes_.push_back(std::make_pair(EquivalenceClassPtr(H), false));
+      }
+      else
+      {
+        HSignature* H = new HSignature(*cfg_);
+        H->hsignature_ = std::complex<long double>(values[b * width], values[b * width + 1]);
+        equivalence_classes_.push_back(std::make_pair(EquivalenceClassPtr(H), false));
+      }
+    }
+    if (best_index >= 0) best_teb_eq_class_ = equivalence_classes_[best_index].first;
+    if (initial_index >= 0 && initial_plan_) initial_plan_eq_class_ = equivalence_classes_[initial_index].first;
+  }
+  // update via-points if activated: done on the device-side flags and mirrored onto the candidates by the call above (:286-315)
+
+  if (tebs_.empty())
+  {
+    best_teb_.reset();
+    initial_plan_ = nullptr;
+    return true;
+  }
+  // ---- optimizeAllTEBs (:466-493): one launch ------------------------------------------------------------------------------------------
+  {
+    std::vector<TebOptimalPlannerAmd*> raw;
+    for (const TebOptimalPlannerAmdPtr& p : cand) raw.push_back(p.get());
+    batch_->optimizeAllTEBs(raw, cfg_->optim.no_inner_iterations, cfg_->optim.no_outer_iterations, true, cfg_->hcp.selection_obst_cost_scale,
+                            cfg_->hcp.selection_viapoint_cost_scale, cfg_->hcp.selection_alternative_time_cost);
+  }
+  // ---- selectBestTeb (:564-667) -----------------------------------------------------------------------------------------------------------
+  {
+    int last_best = -1;
+    for (std::size_t i = 0; i < tebs_.size(); ++i) if (tebs_[i] == best_teb_) last_best = (int)i;
+    last_best_teb_ = last_best >= 0 ? best_teb_ : TebOptimalPlannerPtr();
+    const int sel = batch_->selectBestTeb(last_best, initial_index);
+    best_teb_ = sel >= 0 ? tebs_[sel] : TebOptimalPlannerPtr();
+    if (last_best_teb_ && best_teb_ != last_best_teb_)   // check if we are allowed to change (:648-663)
+    {
+      ros::Time now = ros::Time::now();
+      if ((now - last_eq_class_switching_time_).toSec() > cfg_->hcp.switching_blocking_period)
+        last_eq_class_switching_time_ = now;
+      else
+        best_teb_ = last_best_teb_;   // block switching
+    }
+  }
+  initial_plan_ = nullptr;   // any previous plan is useless regarding the h-signature (:123)
+  return true;
+}
+
+} // namespace teb_local_planner

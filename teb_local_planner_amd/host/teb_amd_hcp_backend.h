@@ -1,0 +1,42 @@
+// teb_amd_hcp_backend.h — HomotopyClassPlanner whose planning tick runs on the MI355X: the class a teb_local_planner maintainer
+// instantiates instead of HomotopyClassPlanner (src/teb_local_planner_ros.cpp creates it when enable_homotopy_class_planning is set).
+// plan() keeps the reference's sequence (src/homotopy_class_planner.cpp:107-125) and its members (tebs_, best_teb_, equivalence_classes_,
+// initial_plan_teb_, ...) stay meaningful for everything the class inherits unchanged (getVelocityCommand, isTrajectoryFeasible,
+// visualize, hasDiverged, ...):
+//   updateAllTEBs                         inherited (O(n) per candidate on the host objects)
+//   exploreEquivalenceClassesAndInitTebs  TebAmdBatch::exploreEquivalenceClassesAndInitTebs (signatures, class list, detours, graph,
+//                                         candidate bands, via-point flags on the device)
+//   optimizeAllTEBs                       TebAmdBatch::optimizeAllTEBs (one kernel launch for all candidates)
+//   selectBestTeb                         TebAmdBatch::selectBestTeb + the reference's switching_blocking_period rule
+// Not taken over: randomlyDropTebs (selection_dropping_probability, default 0): the inherited code would draw from std::random_device.
+// Built where the reference's headers exist (oracle/ref_shim/Makefile -> libteb_backend_check.so); exercised against the reference's
+// own HomotopyClassPlanner tick by tick in tests/test_reference_backend.py.
+#ifndef TEB_AMD_HCP_BACKEND_H_
+#define TEB_AMD_HCP_BACKEND_H_
+
+#include <teb_local_planner/homotopy_class_planner.h>
+
+#include "teb_amd_backend.h"
+
+namespace teb_local_planner {
+
+class HomotopyClassPlannerAmd : public HomotopyClassPlanner
+{
+public:
+  /** max_tebs >= hcp.max_number_classes; max_poses = pose capacity per candidate (trajectory.max_samples + 1 <= 512 covers autoResize). */
+  HomotopyClassPlannerAmd(const TebConfig& cfg, ObstContainer* obstacles = NULL, TebVisualizationPtr visualization = TebVisualizationPtr(),
+                          const ViaPointContainer* via_points = NULL, int max_tebs = 16, int max_poses = 512, int max_obstacles = 512,
+                          int max_obstacle_vertices = 4096, int max_via_points = 256, int device = 0);
+
+  using HomotopyClassPlanner::plan;   // plan(initial_plan, ...) and plan(tf::Pose, ...) forward to the virtual overload below
+  virtual bool plan(const PoseSE2& start, const PoseSE2& goal, const geometry_msgs::Twist* start_vel = NULL, bool free_goal_vel = false);
+
+  const std::string& lastError() const { return batch_->lastError(); }
+
+private:
+  boost::shared_ptr<TebAmdBatch> batch_;
+};
+
+} // namespace teb_local_planner
+
+#endif

@@ -224,3 +224,52 @@ def test_binding_explores_like_the_reference_planner(name):
     if case.get("free_goal_vel") and na.value:
         assert not flags[1:2 * na.value:2].any()      # setVelocityGoalFree() on every new candidate
     assert ab.value in (-1, 0)
+
+
+# ---- the drop-in class: HomotopyClassPlannerAmd vs the reference's HomotopyClassPlanner, tick by tick ---------------------------------------
+def _hcp_ticks(which, case, slots=8, stride=256):
+    L = _lib()
+    cfg = case["cfg"]
+    c = cfg.to_c(); p = cfg.hcp_params()
+    st = _abi.f64(case["starts"]).reshape(-1, 3); gl = _abi.f64(case["goals"]).reshape(-1, 3)
+    T = len(st)
+    sv = None if case.get("start_vels") is None else _abi.f64(case["start_vels"]).reshape(T, 3)
+    out = _abi.TebBatchHost(T * slots, stride)
+    obs = out.c_struct()
+    counts = np.zeros(T, np.int32); best = np.zeros(T, np.int32); ipt = np.zeros(T, np.int32); costs = np.zeros(T * slots); cmd = np.zeros((T, 4))
+    plans = case.get("plans") or [None] * T
+    off = np.zeros(T + 1, np.int32)
+    for t in range(T):
+        off[t + 1] = off[t] + (0 if plans[t] is None else len(plans[t][0]))
+    cat = lambda k: _abi.f64(np.concatenate([np.asarray(pl[k], np.float64) for pl in plans if pl is not None] or [np.zeros(1)]))
+    px, py, pyaw = cat(0), cat(1), cat(2)
+    via = case.get("via") or []
+    vx = _abi.f64([v[0] for v in via] or [0.0]); vy = _abi.f64([v[1] for v in via] or [0.0])
+    P = lambda a: C.cast(_abi._ptr(a, C.c_double), C.c_void_p) if a is not None else None
+    I = lambda a: C.cast(_abi._ptr(a, C.c_int32), C.c_void_p)
+    vp = lambda x: C.cast(C.pointer(x), C.c_void_p)
+    L.backend_check_hcp_ticks.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 8 + \
+        [C.c_int] + [C.c_void_p] * 4
+    rc = L.backend_check_hcp_ticks(which, vp(c), vp(p), vp(case["obst"].freeze()), T, P(st), P(gl), P(sv), 0, slots, vp(obs), I(counts), I(best),
+                                   P(costs), I(off), P(px), P(py), P(pyaw), len(via), P(vx), P(vy), I(ipt), P(cmd))
+    assert rc == 0, rc
+    return [dict(bands=[out.get_teb(t * slots + k) for k in range(counts[t])], best=int(best[t]), initial=int(ipt[t]),
+                 costs=costs[t * slots:t * slots + counts[t]].copy(), cmd=cmd[t].copy()) for t in range(T)]
+
+
+@pytest.mark.parametrize("name", sorted(RG.hcp_tick_cases()))
+def test_drop_in_planner_class_follows_the_reference_planner_tick_by_tick(name):
+    """HomotopyClassPlannerAmd (teb_local_planner_amd/host/teb_amd_hcp_backend.cpp: a HomotopyClassPlanner subclass whose plan() runs on the
+    MI355X) and the reference's HomotopyClassPlanner, each driven through the same sequence of plan() calls on its own planner object, in
+    one process, on identical TebConfig / ObstContainer / ViaPointContainer objects. Same candidates in the same order, same best
+    candidate and initial-plan candidate every tick; costs 1e-6 relative, states 2e-5, the inherited getVelocityCommand 1e-5."""
+    case = RG.hcp_tick_cases()[name]
+    ref = _hcp_ticks(0, case)
+    amd = _hcp_ticks(1, case)
+    for t, (r, a) in enumerate(zip(ref, amd)):
+        assert len(a["bands"]) == len(r["bands"]) and a["best"] == r["best"] and a["initial"] == r["initial"], (t, a["best"], r["best"])
+        assert np.abs(a["costs"] - r["costs"]).max() <= 1e-6 * np.abs(r["costs"]).max()
+        for k, (u, v) in enumerate(zip(a["bands"], r["bands"])):
+            assert len(u[0]) == len(v[0]), (t, k)
+            assert max(np.abs(x - y).max() for x, y in zip(u, v)) <= 2e-5, (t, k)
+        assert a["cmd"][0] == r["cmd"][0] == 1 and np.abs(a["cmd"][1:] - r["cmd"][1:]).max() <= 1e-5
