@@ -553,8 +553,8 @@ class HomotopyClassPlanner:
     """Batch view: owns the candidates resident on one GPU (reference homotopy_class_planner.h). Either constructed around a host
     batch (optimizeAllTEBs / selectBestTeb on given bands) or empty (batch=None): plan() then runs the reference's whole tick on the
     device-resident bands - updateAllTEBs, exploreEquivalenceClassesAndInitTebs (incl. the initial-plan candidate), optimizeAllTEBs,
-    selectBestTeb (src/homotopy_class_planner.cpp:84-125). Not mirrored: randomlyDropTebs (off by default) and
-    switching_blocking_period (0 by default)."""
+    selectBestTeb (src/homotopy_class_planner.cpp:84-125), incl. randomlyDropTebs (off by default; own random stream - the reference
+    seeds from std::random_device) and switching_blocking_period."""
 
     def __init__(self, cfg, obstacles, via_points, batch=None, device=0, stream=None, max_tebs=None, max_poses=None):
         self.cfg_ = cfg
@@ -599,6 +599,12 @@ class HomotopyClassPlanner:
             keep, _, _ = s.filter_equivalence_classes(h.h_signature_threshold, self.best_teb_, h.max_number_plans_in_current_class)
             if h.delete_detours_backwards:
                 keep = s.filter_detours(keep, self.best_teb_)
+            if h.selection_dropping_probability > 0:       # randomlyDropTebs (:539-560): every band but the best one, with that probability
+                if not hasattr(self, "_rng"):
+                    self._rng = np.random.default_rng()
+                drop = self._rng.random(len(keep)) <= h.selection_dropping_probability
+                drop[self.best_teb_] = False if self.best_teb_ >= 0 else drop[self.best_teb_]
+                keep = np.where(drop, 0, keep).astype(np.int32)
             _, self.best_teb_ = s.compact_bands(keep, self.best_teb_)
         self.last_exploration = s.explore_candidates(start, goal, dist_to_obst, start_vel, free_goal_vel, self.best_teb_,
                                                      initial_plan=initial_plan)
@@ -646,8 +652,18 @@ class HomotopyClassPlanner:
         self.solver.optimize(iter_innerloop, iter_outerloop, True, h.selection_obst_cost_scale,
                              h.selection_viapoint_cost_scale, h.selection_alternative_time_cost)
 
-    def selectBestTeb(self):
+    def selectBestTeb(self, now=None):
+        """selectBestTeb (:564-667). now [s]: wall clock for hcp.switching_blocking_period (:648-663: a switch to another candidate is
+        only allowed when more than that period has passed since the last switch); None = time.monotonic()."""
+        import time
+        last = self.best_teb_
         best, _ = self.solver.select_best(self.best_teb_, self.initial_plan_teb_)
+        if last >= 0 and best != last:
+            now = time.monotonic() if now is None else now
+            if now - getattr(self, "_last_switch", 0.0) > self.cfg_.hcp.switching_blocking_period:
+                self._last_switch = now
+            else:
+                best = last        # switching blocked
         self.best_teb_ = best
         return best
 
