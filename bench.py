@@ -206,7 +206,7 @@ def main():
             ticks = max(8, args.latency_reps)
             starts = [[0.05 * k, 0.0, 0.0] for k in range(ticks)]
             goals = [[16.0, 0.0, 0.0]] * ticks
-            hp = planner.HomotopyClassPlanner(hc, hob, [], None, max_tebs=8, max_poses=256)
+            hp = planner.HomotopyClassPlanner(hc, hob, [], None, max_tebs=8, max_poses=224)   # <= 238: normal matrix as blocks in LDS
             ts, nb = [], []
             for k in range(ticks):
                 t1 = time.perf_counter()
@@ -217,7 +217,7 @@ def main():
             hp.solver.close()
             lat["hcp_plan_tick_p50_ms"] = 1e3 * float(np.median(ts[1:]))
             lat["hcp_plan_tick"] = {"workload": "HomotopyClassPlanner::plan() ticks on one planner: 16 m straight task, 12 point obstacles, "
-                                                "roadmap graph (15 samples), max_number_classes 5, 4x5 iterations, teb_autosize on",
+                                                "roadmap graph (15 samples), max_number_classes 5, 4x5 iterations, teb_autosize on, pose capacity 224",
                                     "ticks": ticks, "first_tick_ms": 1e3 * ts[0], "bands_per_tick": [int(min(nb)), int(max(nb))]}
             try:
                 from oracle import ref_py

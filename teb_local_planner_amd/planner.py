@@ -565,7 +565,8 @@ class HomotopyClassPlanner:
             self.solver = make_solver(cfg, obstacles, via_points, batch, device=device, stream=stream, max_tebs=max_tebs,
                                       max_poses=max_poses)
         else:
-            self.solver = TebBatchSolver(cfg, max_tebs or max(cfg.hcp.max_number_classes, 1), max_poses or 256, max(len(obstacles), 1),
+            # pose capacity: 224 keeps the normal matrix as 8x8 blocks in LDS (the fastest layout, <= 238 poses); pass up to 512 for longer bands
+            self.solver = TebBatchSolver(cfg, max_tebs or max(cfg.hcp.max_number_classes, 1), max_poses or 224, max(len(obstacles), 1),
                                          max(len(obstacles.vert_x), 1), max(len(self.via_points_), 1), device=device, stream=stream)
             self.solver.set_obstacles(obstacles)
             self.solver.set_via_points(self.via_points_)

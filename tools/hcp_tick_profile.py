@@ -12,7 +12,7 @@ hob = _abi.ObstacleTable()
 for _ in range(12):
     hob.add_point(rng.uniform(1.5, 14.5), rng.uniform(-2.5, 2.5))
 ticks = 24
-hp = planner.HomotopyClassPlanner(hc, hob, [], None, max_tebs=8, max_poses=256)
+hp = planner.HomotopyClassPlanner(hc, hob, [], None, max_tebs=8, max_poses=int(os.environ.get("TICK_MAX_POSES", "224")))
 s, h = hp.solver, hc.hcp
 T = {k: [] for k in ("update", "signatures", "filter", "detours", "compact", "explore", "optimize", "select", "command", "total")}
 for k in range(ticks):
