@@ -318,7 +318,8 @@ void teb_amd_hcp_params_default(teb_amd_hcp_params_t* p);   /* the defaults of t
  * teb_amd_select_best. Via-points (updateReferenceTrajectoryViaPoints, :286-315): new candidates start without them; they are
  * enabled for all bands (viapoints_all_candidates) or, with an initial plan, for the bands of its class only.
  * *n_vertices / *n_paths (may be NULL): graph size and number of start-goal paths examined. max_paths > 0 bounds the enumeration
- * (the reference has no bound: without new classes it enumerates every simple path); TEB_AMD_OK is returned either way.
+ * to that many start-goal paths and 10000 x max_paths vertex expansions (the reference has no bound: without new classes it
+ * enumerates every simple path, and dead-end subtrees can be exponential in a large graph); TEB_AMD_OK is returned either way.
  */
 int  teb_amd_explore_candidates(teb_amd_handle_t* h, const teb_amd_hcp_params_t* p, const double* start, const double* goal,
                                 double dist_to_obst, const double* start_vel, int32_t free_goal_vel, int32_t best,

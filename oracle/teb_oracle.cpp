@@ -2405,6 +2405,7 @@ struct Explorer {
   int cap = 0;                       // slots available (the reference has no such bound; max_number_classes <= cap is required)
   int n_paths = 0;
   int64_t max_paths = 0;             // > 0: stop after this many start-goal paths (guard of the tests; the reference has none)
+  int64_t expansions = 0;
 
   ClassSig signature(const Teb& t) const {
     ClassSig c;
@@ -2461,7 +2462,7 @@ struct Explorer {
   // GraphSearchInterface::DepthFirst, src/graph_search.cpp:45-91
   void depth_first(const HcGraph& g, std::vector<int>& visited, int goal, double start_orientation, double goal_orientation) {
     if ((int)tebs.size() >= p->max_number_classes || (int)tebs.size() >= cap) return;
-    if (max_paths > 0 && n_paths >= max_paths) return;
+    if (max_paths > 0 && (n_paths >= max_paths || ++expansions > max_paths * 10000)) return;   // test guard (dead-end subtrees can be exponential)
     const int back = visited.back();
     for (int v : g.adj[back]) {
       if (std::find(visited.begin(), visited.end(), v) != visited.end()) continue;

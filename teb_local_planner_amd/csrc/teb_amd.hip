@@ -1071,11 +1071,13 @@ struct PathEnumerator {
   std::vector<Frame> stack;
   std::vector<int> visited;
   std::vector<char> on_path;
+  int64_t expansions = 0, max_expansions = 0;   // > 0: give up after that many vertex expansions (dead-end subtrees can be exponential)
   PathEnumerator(const std::vector<std::vector<int>>& a, int start, int goal_) : adj(&a), goal(goal_), on_path(a.size(), 0) {
     stack.push_back({start, 0, 0}); visited.push_back(start); on_path[start] = 1;
   }
   bool next(std::vector<int>& path) {
     while (!stack.empty()) {
+      if (max_expansions > 0 && ++expansions > max_expansions) return false;
       Frame& f = stack.back();
       const std::vector<int>& out = (*adj)[f.v];
       if (f.phase == 0) {       // first loop: the goal, if adjacent, closes one path
@@ -1251,7 +1253,6 @@ int teb_amd_explore_candidates(teb_amd_handle_t* h, const teb_amd_hcp_params_t* 
   vx.push_back(gx); vy.push_back(gy);
   const int N = (int)vx.size();
   if (n_vertices) *n_vertices = N;
-  if (N - 1 > h->stride) return fail(TEB_AMD_ERR_CAPACITY, "graph has more vertices than a band has poses (max_poses)");
   // ---- edges (device) -------------------------------------------------------------------------------------------------------------
   if (h->g_vx.n < (size_t)N) { h->g_vx.free(); h->g_vy.free(); HIPCHK(h->g_vx.alloc(N)); HIPCHK(h->g_vy.alloc(N)); }
   if (h->g_adj.n < (size_t)N * N) { h->g_adj.free(); HIPCHK(h->g_adj.alloc((size_t)N * N)); }
@@ -1270,6 +1271,7 @@ int teb_amd_explore_candidates(teb_amd_handle_t* h, const teb_amd_hcp_params_t* 
     for (int j = 0; j < N; ++j) if (adjm[(size_t)i * N + j]) adj[i].push_back(j);   // add_edge order of the double loop
   // ---- paths in depth-first order, a chunk at a time: init + signature on the device, first come first served on the host ----------
   PathEnumerator en(adj, 0, N - 1);
+  if (max_paths > 0) en.max_expansions = max_paths * 10000;
   std::vector<int> path, off;
   std::vector<double> px, py;
   int64_t examined = 0;
@@ -1279,6 +1281,7 @@ int teb_amd_explore_candidates(teb_amd_handle_t* h, const teb_amd_hcp_params_t* 
     int count = 0;
     while (count < kCandChunk && (max_paths <= 0 || examined + count < max_paths)) {
       if (!en.next(path)) { more = false; break; }
+      if ((int)path.size() > h->stride + 1) return fail(TEB_AMD_ERR_CAPACITY, "a start-goal path has more vertices than a band has poses (max_poses)");
       for (int v : path) { px.push_back(vx[v]); py.push_back(vy[v]); }
       off.push_back((int)px.size());
       ++count;
