@@ -112,7 +112,9 @@ extern "C" int backend_check_hcp_ticks(int which, const teb_amd_config_t* acfg, 
                                        int n_ticks, const double* starts, const double* goals, const double* start_vels, int free_goal_vel,
                                        int slots, teb_amd_teb_batch_t* out, int32_t* counts, int32_t* best, double* costs,
                                        const int32_t* plan_off, const double* plan_x, const double* plan_y, const double* plan_yaw, int n_via,
-                                       const double* via_x, const double* via_y, int32_t* initial_plan_teb, double* cmd /* [n_ticks*4] */) {
+                                       const double* via_x, const double* via_y, int32_t* initial_plan_teb, double* cmd /* [n_ticks*4] */,
+                                       int jacobian_mode) {
+  setAmdJacobianMode(jacobian_mode);
   TebConfig cfg;
   to_ref_config(*acfg, cfg);
   cfg.hcp.simple_exploration = p->simple_exploration;

@@ -168,6 +168,7 @@ struct teb_amd_handle {
   DevBuf<int> hs_pex;
   std::vector<double> hsig_host;
   int hsig_mode = 0, hsig_B = 0, hsig_M = 0;
+  bool hs_prod_valid = false;   // hs_pre / hs_pim / hs_pex hold the products of the current obstacle table
   double hsig_prescaler = 0;
   int consumers_la = 0, consumers_prevent = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -494,6 +495,7 @@ int teb_amd_set_obstacles(teb_amd_handle_t* h, const teb_amd_obstacles_t* o) {
   h->host_type = type;
   h->host_cx = cx; h->host_cy = cy;
   h->hsig_mode = 0;   // signatures depend on the obstacle table
+  h->hs_prod_valid = false;
   h->host_static = st;
   // point-like fast path: all obstacles Point/Circular, footprint Point/Circular, and the cache fits the LDS
   bool pointlike = (h->cfg.footprint_type == TEB_AMD_FOOTPRINT_POINT || h->cfg.footprint_type == TEB_AMD_FOOTPRINT_CIRCULAR);
@@ -900,10 +902,11 @@ int launch_hsig(teb_amd_handle* h, const BatchDev& bt, int B, double prescaler, 
       HIPCHK(hipGetLastError());
     }
   } else {
-    if (M > 0) {
+    if (M > 0 && !h->hs_prod_valid) {   // the band-independent factor of A_l: once per obstacle table (O(M^2))
       hipLaunchKernelGGL(hsig2d_prod_kernel, dim3((M + kThreads - 1) / kThreads), dim3(kThreads), 0, h->stream, sc, h->hs_pre.p,
                          h->hs_pim.p, h->hs_pex.p);
       HIPCHK(hipGetLastError());
+      h->hs_prod_valid = true;
     }
     hipLaunchKernelGGL(hsig2d_kernel, dim3(B), dim3(kThreads), 2 * (size_t)h->stride * sizeof(double), h->stream, sc, bt, prescaler,
                        h->hs_pre.p, h->hs_pim.p, h->hs_pex.p, out);

@@ -27,6 +27,16 @@
 
 namespace teb_local_planner {
 
+// TimedElasticBand::addPoseAndTimeDiff asserts dt > 0 (src/timed_elastic_band.cpp:100-105); the optimiser itself is not bound by that
+// (g2o updates the vertices in place, a time difference may end up <= 0 exactly as in the reference), so a band that comes back
+// from the device is rebuilt vertex by vertex without the assertion.
+static void appendPoseAndTimeDiff(TimedElasticBand& t, double x, double y, double theta, double dt)
+{
+  t.addPose(x, y, theta, false);
+  t.timediffs().push_back(new VertexTimeDiff(dt, false));
+}
+
+
 namespace {
 int g_jacobian_mode = TEB_AMD_JACOBIAN_ANALYTIC;
 }
@@ -232,8 +242,12 @@ int TebAmdBatch::optimizeAllTEBs(const std::vector<TebOptimalPlannerAmd*>& tebs,
   table.assign(first.obstacles_);
   teb_amd_obstacles_t ov = table.view();
   std::vector<double> viax, viay;
-  if (first.via_points_)
-    for (const Eigen::Vector2d& v : *first.via_points_) { viax.push_back(v.x()); viay.push_back(v.y()); }
+  // the via-point container is shared (HomotopyClassPlanner hands the same pointer to every candidate that has via-points at all:
+  // updateReferenceTrajectoryViaPoints, :286-315); candidates without via-points carry NULL and get their flag cleared below
+  const ViaPointContainer* shared_via = NULL;
+  for (TebOptimalPlannerAmd* t : tebs) if (t->via_points_) { shared_via = t->via_points_; break; }
+  if (shared_via)
+    for (const Eigen::Vector2d& v : *shared_via) { viax.push_back(v.x()); viay.push_back(v.y()); }
   // set_obstacles before set_config would be rejected when include_dynamic_obstacles / footprint changed: config first, then scene
   int rc = teb_amd_set_config(h_, &a);
   if (rc != TEB_AMD_OK && rc != TEB_AMD_ERR_INVALID_ARG) { check(rc, "teb_amd_set_config"); return 0; }
@@ -290,7 +304,7 @@ int TebAmdBatch::optimizeAllTEBs(const std::vector<TebOptimalPlannerAmd*>& tebs,
     {
       t.clearTimedElasticBand();
       t.addPose(x[o], y[o], th[o], true);                       // start pose is fixed
-      for (int i = 1; i < n[b]; ++i) t.addPoseAndTimeDiff(x[o + i], y[o + i], th[o + i], dt[o + i - 1]);
+      for (int i = 1; i < n[b]; ++i) appendPoseAndTimeDiff(t, x[o + i], y[o + i], th[o + i], dt[o + i - 1]);
       t.setPoseVertexFixed(n[b] - 1, true);                     // goal pose is fixed
     }
     p.lm_iterations_ = iters[b]; p.lm_trials_ = trials[b];
@@ -343,7 +357,7 @@ bool TebAmdBatch::downloadBands(const std::vector<TebOptimalPlannerAmd*>& tebs)
     const size_t o = (size_t)b * S;
     t.clearTimedElasticBand();
     t.addPose(x[o], y[o], th[o], true);
-    for (int i = 1; i < n[b]; ++i) t.addPoseAndTimeDiff(x[o + i], y[o + i], th[o + i], dt[o + i - 1]);
+    for (int i = 1; i < n[b]; ++i) appendPoseAndTimeDiff(t, x[o + i], y[o + i], th[o + i], dt[o + i - 1]);
     t.setPoseVertexFixed(n[b] - 1, true);
   }
   return true;
@@ -404,6 +418,8 @@ void toAmdHcpParams(const TebConfig& cfg, teb_amd_hcp_params_t& p)
   p.detours_orientation_tolerance = cfg.hcp.detours_orientation_tolerance;
   p.length_start_orientation_vector = cfg.hcp.length_start_orientation_vector;
   p.max_ratio_detours_duration_best_duration = cfg.hcp.max_ratio_detours_duration_best_duration;
+  p.global_plan_overwrite_orientation = cfg.trajectory.global_plan_overwrite_orientation;
+  p.viapoints_all_candidates = cfg.hcp.viapoints_all_candidates;
 }
 
 bool TebAmdBatch::exploreEquivalenceClassesAndInitTebs(const TebConfig& cfg, ObstContainer* obstacles, const ViaPointContainer* via_points,
@@ -504,7 +520,7 @@ bool TebAmdBatch::exploreEquivalenceClassesAndInitTebs(const TebConfig& cfg, Obs
       const size_t o = (size_t)b * S;
       t.clearTimedElasticBand();
       t.addPose(x[o], y[o], th[o], true);
-      for (int i = 1; i < n[b]; ++i) t.addPoseAndTimeDiff(x[o + i], y[o + i], th[o + i], dt[o + i - 1]);
+      for (int i = 1; i < n[b]; ++i) appendPoseAndTimeDiff(t, x[o + i], y[o + i], th[o + i], dt[o + i - 1]);
       t.setPoseVertexFixed(n[b] - 1, true);
     }
   }

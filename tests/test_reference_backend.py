@@ -227,7 +227,7 @@ def test_binding_explores_like_the_reference_planner(name):
 
 
 # ---- the drop-in class: HomotopyClassPlannerAmd vs the reference's HomotopyClassPlanner, tick by tick ---------------------------------------
-def _hcp_ticks(which, case, slots=8, stride=256):
+def _hcp_ticks(which, case, slots=8, stride=256, jacobian_mode=_abi.JACOBIAN_ANALYTIC):
     L = _lib()
     cfg = case["cfg"]
     c = cfg.to_c(); p = cfg.hcp_params()
@@ -249,9 +249,9 @@ def _hcp_ticks(which, case, slots=8, stride=256):
     I = lambda a: C.cast(_abi._ptr(a, C.c_int32), C.c_void_p)
     vp = lambda x: C.cast(C.pointer(x), C.c_void_p)
     L.backend_check_hcp_ticks.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 8 + \
-        [C.c_int] + [C.c_void_p] * 4
+        [C.c_int] + [C.c_void_p] * 4 + [C.c_int]
     rc = L.backend_check_hcp_ticks(which, vp(c), vp(p), vp(case["obst"].freeze()), T, P(st), P(gl), P(sv), 0, slots, vp(obs), I(counts), I(best),
-                                   P(costs), I(off), P(px), P(py), P(pyaw), len(via), P(vx), P(vy), I(ipt), P(cmd))
+                                   P(costs), I(off), P(px), P(py), P(pyaw), len(via), P(vx), P(vy), I(ipt), P(cmd), int(jacobian_mode))
     assert rc == 0, rc
     return [dict(bands=[out.get_teb(t * slots + k) for k in range(counts[t])], best=int(best[t]), initial=int(ipt[t]),
                  costs=costs[t * slots:t * slots + counts[t]].copy(), cmd=cmd[t].copy()) for t in range(T)]
@@ -273,3 +273,53 @@ def test_drop_in_planner_class_follows_the_reference_planner_tick_by_tick(name):
             assert len(u[0]) == len(v[0]), (t, k)
             assert max(np.abs(x - y).max() for x, y in zip(u, v)) <= 2e-5, (t, k)
         assert a["cmd"][0] == r["cmd"][0] == 1 and np.abs(a["cmd"][1:] - r["cmd"][1:]).max() <= 1e-5
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_drop_in_planner_class_on_random_scenes(seed):
+    """Three plan() ticks on random scenes (tests/random_explore_cases.py: every obstacle class, both graph types, random planner
+    parameters, optionally an initial plan with a via-point every tick): HomotopyClassPlannerAmd (g2o-numeric Jacobians, like the
+    reference) against the reference's planner.
+    Candidate count, order and poses every tick; the best candidate whenever the reference's own choice is not a near-tie."""
+    from random_explore_cases import random_explore_case
+    base = random_explore_case(seed)
+    cfg = base["cfg"]
+    cfg.optim.no_inner_iterations = 3; cfg.optim.no_outer_iterations = 2
+    st, gl = np.array(base["start"]), np.array(base["goal"])
+    d = (gl[:2] - st[:2]) / np.linalg.norm(gl[:2] - st[:2])
+    starts = [[st[0] + 0.1 * k * d[0], st[1] + 0.1 * k * d[1], st[2]] for k in range(3)]
+    case = dict(cfg=cfg, obst=base["obst"], starts=starts, goals=[list(gl)] * 3, start_vels=[[0.0, 0, 0], [0.2, 0, 0], [0.25, 0, 0.02]],
+                via=base.get("via"))
+    if base.get("initial_plan") is not None:
+        px, py, pyaw = base["initial_plan"]
+        case["plans"] = []
+        for k in range(3):      # the global plan re-anchored at the current start
+            x = px.copy(); y = py.copy(); yaw = pyaw.copy()
+            x[0], y[0] = starts[k][0], starts[k][1]
+            case["plans"].append((x, y, yaw))
+    ref = _hcp_ticks(0, case, slots=10)
+    amd = _hcp_ticks(1, case, slots=10, jacobian_mode=_abi.JACOBIAN_G2O_NUMERIC)   # the reference's own linearisation scheme on the device
+    # yardstick: the reference against itself with the start poses moved by 1e-9 m - candidates that start inside the obstacle penalty
+    # zone (key points lie 0.25 m from point obstacles) amplify such noise by many orders of magnitude; a band is compared as tightly
+    # as the reference reproduces itself (x 20, at least 2e-5), and not at all from the tick on where it does not reproduce itself
+    moved = dict(case); moved["starts"] = [[s_[0] + 1e-9, s_[1], s_[2]] for s_ in starts]
+    if case.get("plans"):
+        moved["plans"] = [(np.concatenate([[x[0] + 1e-9], x[1:]]), y, yaw) for (x, y, yaw) in case["plans"]]
+    ref2 = _hcp_ticks(0, moved, slots=10)
+    compared = 0
+    for t, (r, a, r2) in enumerate(zip(ref, amd, ref2)):
+        if len(r2["bands"]) != len(r["bands"]) or any(len(u[0]) != len(v[0]) for u, v in zip(r["bands"], r2["bands"])):
+            break                                   # the reference's own tick bifurcates under 1e-9 m: later ticks are not comparable
+        noise = [max(np.abs(x - y).max() for x, y in zip(u, v)) for u, v in zip(r["bands"], r2["bands"])]
+        if max(noise, default=0.0) > 1e-3:
+            break
+        assert len(a["bands"]) == len(r["bands"]) and a["initial"] == r["initial"], (t, len(a["bands"]), len(r["bands"]))
+        for k, (u, v) in enumerate(zip(a["bands"], r["bands"])):
+            assert len(u[0]) == len(v[0]), (t, k)
+            tol = max(2e-5, 20 * noise[k])
+            assert max(np.abs(x - y).max() for x, y in zip(u, v)) <= tol, (t, k, max(np.abs(x - y).max() for x, y in zip(u, v)), tol)
+            compared += 1
+        c = np.sort(r["costs"])
+        near_tie = len(c) > 1 and (c[1] - c[0]) <= 1e-3 * abs(c[0])
+        if not near_tie and r2["best"] == r["best"]:
+            assert a["best"] == r["best"], (t, a["best"], r["best"], r["costs"])

@@ -7,6 +7,7 @@ from teb_local_planner_amd import scenes, planner, _abi
 
 hc = scenes.scene_c4(B=1, n=200)[0]
 hc.hcp.max_number_classes = 5
+hc.obstacles.include_dynamic_obstacles = os.environ.get("TICK_2D") is None      # TICK_2D=1: HSignature (2-D) instead of HSignature3d
 rng = np.random.default_rng(5)
 hob = _abi.ObstacleTable()
 for _ in range(12):
