@@ -301,3 +301,57 @@ def test_randomized_candidate_generation_matches_oracle(oracle, seed):
             np.testing.assert_array_equal(ve, o["via_enabled"][:o["n_total"]])
         assert hvs.all() and (not hvg.any() if case.get("free_goal_vel") else hvg.all())
     s.close()
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_whole_plan_ticks_on_random_scenes_against_the_reference_planner(seed):
+    """Three device-resident plan() ticks on random scenes (every obstacle class, both graph types, random planner parameters, optionally
+    an initial plan with a via-point every tick) against the reference's own HomotopyClassPlanner run live through oracle/_ref (built where
+    /root/reference exists; the binary travels). Device in the reference's linearisation mode (g2o-numeric). A band is compared as tightly
+    as the reference reproduces itself when its start poses move by 1e-9 m (x 20, at least 2e-5), and not at all from the tick on where it
+    does not reproduce itself; the best candidate is compared unless the reference's own choice is a near-tie."""
+    from random_explore_cases import random_explore_case
+    from oracle import ref_py
+    if not ref_py.available():
+        pytest.skip("oracle/_ref/libteb_ref.so not built")
+    base = random_explore_case(seed)
+    cfg = base["cfg"]
+    cfg.optim.no_inner_iterations = 3; cfg.optim.no_outer_iterations = 2
+    cfg.jacobian_mode = _abi.JACOBIAN_G2O_NUMERIC
+    st, gl = np.array(base["start"]), np.array(base["goal"])
+    d = (gl[:2] - st[:2]) / np.linalg.norm(gl[:2] - st[:2])
+    starts = [[st[0] + 0.1 * k * d[0], st[1] + 0.1 * k * d[1], st[2]] for k in range(3)]
+    vels = [[0.0, 0, 0], [0.2, 0, 0], [0.25, 0, 0.02]]
+    plans = None
+    if base.get("initial_plan") is not None:
+        px, py, pyaw = base["initial_plan"]
+        plans = []
+        for k in range(3):
+            x = px.copy(); y = py.copy(); x[0], y[0] = starts[k][0], starts[k][1]
+            plans.append((x, y, pyaw.copy()))
+    via = base.get("via")
+    ref = ref_py.hcp_plan_ticks(cfg, base["obst"], starts, [list(gl)] * 3, vels, slots=10, stride=256, plans=plans, via=via)
+    moved_plans = None if plans is None else [(np.concatenate([[x[0] + 1e-9], x[1:]]), y, yaw) for (x, y, yaw) in plans]
+    ref2 = ref_py.hcp_plan_ticks(cfg, base["obst"], [[s_[0] + 1e-9, s_[1], s_[2]] for s_ in starts], [list(gl)] * 3, vels, slots=10, stride=256,
+                                 plans=moved_plans, via=via)
+    hcp = planner.HomotopyClassPlanner(cfg, base["obst"], via or [], None, max_tebs=10, max_poses=256)
+    for t in range(3):
+        r, r2 = ref[t], ref2[t]
+        plan = None if plans is None else (plans[t][0], plans[t][1], r["plan_yaw_seen"])
+        assert hcp.plan(starts[t], list(gl), vels[t], initial_plan=plan)
+        if len(r2["bands"]) != len(r["bands"]) or any(len(u[0]) != len(v[0]) for u, v in zip(r["bands"], r2["bands"])):
+            break
+        noise = [max(np.abs(x - y).max() for x, y in zip(u, v)) for u, v in zip(r["bands"], r2["bands"])]
+        if max(noise, default=0.0) > 1e-3:
+            break
+        bands = hcp.bands()
+        assert len(bands) == len(r["bands"]) and hcp.initial_plan_teb_ == r["initial_plan_teb"], (t, len(bands), len(r["bands"]))
+        for k, (u, v) in enumerate(zip(bands, r["bands"])):
+            assert len(u[0]) == len(v[0]), (t, k)
+            tol = max(2e-5, 20 * noise[k])
+            assert max(np.abs(x - y).max() for x, y in zip(u, v)) <= tol, (t, k, max(np.abs(x - y).max() for x, y in zip(u, v)), tol)
+        c = np.sort(r["costs"])
+        near_tie = len(c) > 1 and (c[1] - c[0]) <= 1e-3 * abs(c[0])
+        if not near_tie and r2["best"] == r["best"]:
+            assert hcp.best_teb_ == r["best"], (t, hcp.best_teb_, r["best"], r["costs"])
+    hcp.solver.close()
