@@ -234,3 +234,35 @@ def test_planner_mirror_plan_ticks_like_the_reference_plan(oracle):
         start = [float(want[0][1]), float(want[1][1]), float(want[2][1])]      # the robot advanced to the second pose
         vel = tuple(wc["cmd"])
     assert tick == 3
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_randomized_strip_functions_match_oracle(oracle, seed):
+    """Random inputs (tests/random_strip_cases.py; the oracle is bit-equal to the reference's code on them,
+    tests/test_reference_pinning.py): the three initTrajectoryToGoal overloads, updateAndPruneTEB and the read-outs on the device."""
+    from random_strip_cases import random_strip_case, band_for_readout
+    c = random_strip_case(seed)
+    s = planner.TebBatchSolver(c["cfg"], 2, 512, 4, 4, 1)
+    s.init_trajectory_line(0, *c["line"])
+    _close(_band(s, 0, 512), oracle.init_trajectory_line(*c["line"]))
+    s.init_trajectory_plan(0, *c["plan"])
+    _close(_band(s, 0, 512), oracle.init_trajectory_plan(*c["plan"]))
+    px, py, mvx, mvt, acc, so, go, ms, gb = c["path"]
+    s.init_trajectory_path(0, px, py, mvx, mvt, acc, so, go, ms, gb)
+    _close(_band(s, 0, 512), oracle.init_trajectory_path(*c["path"]))
+    b = band_for_readout(oracle, c)
+    s.upload(b)
+    la, prevent, _, _ = c["consumer"]
+    want = oracle.consumers(c["cfg"], b, 0, la, prevent)
+    ok, cmd = s.velocity_command(0, la, prevent)
+    assert ok == want["ok"] and np.abs(cmd - want["cmd"]).max() <= TOL
+    assert np.abs(s.velocity_profile(0) - want["profile"]).max() <= TOL
+    tr = s.full_trajectory(0)
+    assert np.abs(tr - want["trajectory"]).max() <= TOL
+    np.testing.assert_array_equal(tr[:, 6], want["trajectory"][:, 6])
+    band = b.get_teb(0)
+    if len(band[0]) >= c["prune"][2]:
+        s.update_and_prune(*c["prune"], b=0)
+        for u, v in zip(_band(s, 0, 512), oracle.update_and_prune(*band, *c["prune"])):
+            np.testing.assert_array_equal(u, v)
+    s.close()
