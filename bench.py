@@ -52,6 +52,9 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     distributed = world > 1
+    if distributed:   # plan latencies, secondary configurations and the CPU baseline are N = 1 items (contract: rank 0 at N = 1 only)
+        args.latency_reps = 0
+        args.no_cpu_baseline = True
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
