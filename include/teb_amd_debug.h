@@ -35,6 +35,8 @@ int teb_amd_debug_distance(teb_amd_handle_t* h, int32_t nq, const int32_t* obst_
  * [0] autoResize [1] association+via+time stamps [2] linearise [3] H backup [4] damped solve
  * [5] update+chi2 evaluation [6] accept/reject (+H restore) */
 int teb_amd_debug_profile(teb_amd_handle_t* h, double* cycles8);
+/* -DTEB_PROFILE builds: clock64() cycles of every band's workgroup in the last optimize_batch launch, [B] */
+int teb_amd_debug_profile_bands(teb_amd_handle_t* h, double* cycles_per_band);
 
 /* Streams n_doubles fp64 values global->global (8 B per lane, coalesced; reads and writes n_doubles*8 bytes each)
  * `repeats` times: a known byte count to calibrate rocprofv3 FETCH_SIZE / WRITE_SIZE against. */

@@ -1657,6 +1657,20 @@ int teb_amd_debug_profile(teb_amd_handle_t* h, double* cycles8) {
 #endif
 }
 
+int teb_amd_debug_profile_bands(teb_amd_handle_t* h, double* cycles_per_band) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+#ifdef TEB_PROFILE
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if ((size_t)16 + h->B > h->dbg_H.n) return fail(TEB_AMD_ERR_CAPACITY, "debug buffer too small");
+  HIPCHK(hipMemcpy(cycles_per_band, h->dbg_H.p + 16, h->B * sizeof(double), hipMemcpyDeviceToHost));
+  return TEB_AMD_OK;
+#else
+  (void)cycles_per_band;
+  return fail(TEB_AMD_ERR_UNSUPPORTED, "library built without -DTEB_PROFILE");
+#endif
+}
+
 int teb_amd_debug_stream(teb_amd_handle_t* h, int64_t n_doubles, int32_t repeats) {
   int rc = check_handle(h);
   if (rc) return rc;

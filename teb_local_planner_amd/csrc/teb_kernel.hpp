@@ -17,7 +17,7 @@
 namespace tebamd {
 
 #ifdef TEB_PROFILE
-#define PROF_DECL long long prof_t0 = 0, prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF_DECL long long prof_t0 = 0, prof_wg_t0 = clock64(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define PROF_START() prof_t0 = clock64()
 #define PROF_END(k) prof_acc[k] += clock64() - prof_t0
 #else
@@ -1455,6 +1455,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   }
   nonfinite = __syncthreads_or(nonfinite);
 #ifdef TEB_PROFILE
+  if (tid == 0 && args.dbg_H) args.dbg_H[16 + b] = (double)(clock64() - prof_wg_t0);   // whole-kernel cycles of this band's workgroup
   if (tid == 0 && b == 0 && args.dbg_H) {
     prof_acc[7] = (long long)l.ired[12] + 1000000000LL * l.ired[13];   // autoResize: cycles inside the sequential sweeps + 1e9 * #sweeps
     for (int q = 0; q < 8; ++q) args.dbg_H[q] = (double)prof_acc[q];

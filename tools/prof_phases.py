@@ -47,4 +47,14 @@ for which in sys.argv[1:] or ["c4", "c2", "c5"]:
     print("   autoResize detail: %d sequential sweeps, %.0f cycles inside them" % (int(cyc[7] // 1e9), cyc[7] % 1e9))
     tot = cyc[:7].sum()
     print("   total cycles %.0f -> implied counter rate %.1f MHz" % (tot, tot / (ms * 1e3)))
+    per = np.zeros(batch.count)
+    Lb.teb_amd_debug_profile_bands.argtypes = [C.c_void_p, _abi.p_f64]
+    if Lb.teb_amd_debug_profile_bands(s._h, _abi._ptr(per, C.c_double)) == 0 and batch.count > 1:
+        n_after = s.pose_counts()
+        q = np.percentile(per, [0, 25, 50, 75, 100]) / per.max()
+        print("   per-band workgroup time / slowest: min %.2f  p25 %.2f  p50 %.2f  p75 %.2f  max 1.00; mean %.2f (= CU utilisation of the launch)" % (q[0], q[1], q[2], q[3], per.mean() / per.max()))
+        long_ = n_after > 256
+        if long_.any() and (~long_).any():
+            print("   bands > 256 poses: %d, mean time %.2f of the slowest; bands <= 256 poses: mean %.2f" % (int(long_.sum()), per[long_].mean() / per.max(), per[~long_].mean() / per.max()))
+        print("   correlation of time with pose count: %.2f" % np.corrcoef(per, n_after)[0, 1])
     s.close()
