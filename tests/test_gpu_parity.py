@@ -506,6 +506,23 @@ def test_maximum_pose_capacities(oracle, n, solver):
     assert e.value.code == _abi.ERR_CAPACITY
 
 
+@pytest.mark.parametrize("n", [300, 400])
+def test_numeric_jacobians_on_long_bands(oracle, n):
+    """The g2o-numeric instantiations of the band layouts (LDS band at 300 poses, HBM band at 400) against the oracle in the same mode."""
+    cfg, obst, via, _ = scenes.scene_small_mixed(footprint="point")
+    cfg.trajectory.teb_autosize = False
+    cfg.trajectory.max_samples = 500
+    cfg.jacobian_mode = _abi.JACOBIAN_G2O_NUMERIC
+    rng = np.random.default_rng(n)
+    batch = _straight_batch(cfg, [n, n - 11], n, rng)
+    s = planner.make_solver(cfg, obst, via, batch)
+    s.optimize(2, 2, True, cfg.hcp.selection_obst_cost_scale, cfg.hcp.selection_viapoint_cost_scale,
+               cfg.hcp.selection_alternative_time_cost)
+    res = s.results(); out = s.download(batch.copy()); s.close()
+    ref, rres = oracle.optimize_batch(cfg, obst, via, batch, inner=2, outer=2)
+    assert_full_parity(out, res, ref, rres, pos_tol=1e-7, rtol=1e-7)
+
+
 def test_long_band_with_autoresize_grows_past_the_lds_band(oracle):
     """A 300-pose band whose time differences call for more samples: autoResize grows it past 343 poses inside the kernel (band form in
     HBM), same result as the oracle."""
