@@ -300,13 +300,13 @@ def test_reference_style_planner_objects(oracle):
     assert p.optimizeTEB(5, 4) is False
 
 
-@pytest.mark.parametrize("solver", ["cr", "band", "band_ldlt"])
+@pytest.mark.parametrize("solver", ["cr", "band", "band_ldlt", "bandg"])
 def test_both_damped_solvers_match_the_oracle(oracle, solver, monkeypatch):
     """The three damped solves - block cyclic reduction on the LDS-resident blocks ("cr"), the same reduction on HBM-resident
     blocks expanded from the LDS band (what long bands use: "band"), and the sequential banded LDL^T ("band_ldlt", kept as a
     cross-check) - solve the same system: identical accept / reject decisions, trajectories within 1e-8. Even and odd pose
     counts (block padding)."""
-    monkeypatch.setenv("TEB_AMD_SOLVER", "band" if solver.startswith("band") else "cr")
+    monkeypatch.setenv("TEB_AMD_SOLVER", "bandg" if solver == "bandg" else ("band" if solver.startswith("band") else "cr"))   # "bandg": band in HBM
     if solver == "band_ldlt":
         monkeypatch.setenv("TEB_AMD_BAND_SOLVE", "ldlt")
     for n0 in (24, 25):
@@ -583,3 +583,23 @@ def test_randomized_scenes_full_parity(oracle, seed):
         checked += 1
     if checked == batch.count:
         assert best[0] == oracle.select_best(cfg, rres.cost)[0]
+
+
+@pytest.mark.parametrize("layout", ["band", "bandg"])
+@pytest.mark.parametrize("seed", range(0, 80, 5))
+def test_randomized_scenes_do_not_depend_on_the_layout(seed, layout, monkeypatch):
+    """The three layouts of the normal matrix (8x8 blocks in LDS, band in LDS, band in HBM) run the same arithmetic up to the order of
+    the block reduction: on random scenes (all options of the path toggled at random) the forced band layouts give the pose counts,
+    LM iteration / trial counts and status of the default layout and poses within 1e-8."""
+    cfg, obst, via, batch = _random_case(seed)
+    out0, res0, _ = run_gpu(cfg, obst, via, batch)
+    monkeypatch.setenv("TEB_AMD_SOLVER", layout)
+    out1, res1, _ = run_gpu(cfg, obst, via, batch)
+    np.testing.assert_array_equal(res0.status, res1.status)
+    np.testing.assert_array_equal(out0.n, out1.n)
+    np.testing.assert_array_equal(res0.lm_iterations, res1.lm_iterations)
+    for b in range(batch.count):
+        if res0.status[b] != _abi.TEB_OK:
+            continue
+        for u, v in zip(out0.get_teb(b), out1.get_teb(b)):
+            assert np.abs(u - v).max() <= 1e-8, (seed, b, np.abs(u - v).max())
