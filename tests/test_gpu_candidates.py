@@ -8,6 +8,7 @@ What is compared, and how tightly:
   * graph edges (N^2 * M collision tests on the device, no transcendental function): identical;
   * number of bands and every band: the device evaluates atan2 / sqrt where the reference does: <= 1e-12 absolute;
   * the order in which classes are discovered (= band order): identical."""
+import ctypes as C
 import os
 import sys
 
@@ -355,3 +356,30 @@ def test_whole_plan_ticks_on_random_scenes_against_the_reference_planner(seed):
         if not near_tie and r2["best"] == r["best"]:
             assert hcp.best_teb_ == r["best"], (t, hcp.best_teb_, r["best"], r["costs"])
     hcp.solver.close()
+
+
+def test_argument_errors_are_reported_not_ignored():
+    case = RG.explore_cases()["keypoint_points_2d"]
+    s = _make(case, max_tebs=2)
+    L = planner.lib()
+    p = case["cfg"].hcp_params()
+    st = _abi.f64(case["start"]); gl = _abi.f64(case["goal"])
+    P = lambda a: _abi._ptr(a, C.c_double)
+    nt = C.c_int32(0)
+    # NULL parameter block / start pose, initial plan announced but not given
+    assert L.teb_amd_explore_candidates(s._h, None, P(st), P(gl), 0.5, None, 0, -1, None, 0, C.byref(nt), None, None, 0, None, None, None, None) == _abi.ERR_INVALID_ARG
+    assert L.teb_amd_explore_candidates(s._h, C.byref(p), None, P(gl), 0.5, None, 0, -1, None, 0, C.byref(nt), None, None, 0, None, None, None, None) == _abi.ERR_INVALID_ARG
+    assert L.teb_amd_explore_candidates(s._h, C.byref(p), P(st), P(gl), 0.5, None, 0, -1, None, 0, C.byref(nt), None, None, 5, None, None, None, None) == _abi.ERR_INVALID_ARG
+    assert b"initial plan" in L.teb_amd_last_error()
+    assert L.teb_amd_compact_bands(s._h, None, -1, None, None) == _abi.ERR_INVALID_ARG
+    assert L.teb_amd_filter_detours(s._h, None, -1, None) == _abi.ERR_INVALID_ARG
+    # max_tebs bounds the number of candidates even when max_number_classes is larger; nothing is written past the batch
+    r = _explore(s, case, -1)
+    assert r["n_total"] == 2 == s.count
+    # a path with more vertices than a band has poses is a capacity error, not a truncated band
+    t = planner.TebBatchSolver(case["cfg"], 4, 2, 4, 4, 1)
+    t.set_obstacles(case["obst"]); t.set_via_points([])
+    with pytest.raises(planner.TebAmdError) as e:
+        t.explore_candidates(case["start"], case["goal"])
+    assert e.value.code == _abi.ERR_CAPACITY
+    s.close(); t.close()
