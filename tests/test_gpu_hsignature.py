@@ -108,3 +108,29 @@ def test_3d_signature_kernels_return_identical_bits(oracle):
             s.close()
     finally:
         os.environ.pop("TEB_AMD_HSIG3D", None)
+
+
+@pytest.mark.parametrize("seed", range(0, 80, 4))
+@pytest.mark.parametrize("mode", [2, 3])
+def test_randomized_h_signatures_match_oracle(oracle, mode, seed):
+    """Random scenes (tests/random_cases.py; the oracle is bit-equal to the reference's code on them): signatures and class decisions on
+    the device, both 3-D kernels."""
+    from random_cases import random_case
+    cfg, obst, via, batch = random_case(seed)
+    s = _solver(cfg, obst, batch, mode)
+    want = oracle.h_signatures(cfg, obst, batch, mode, 1.0)
+    try:
+        for kern in (("wide", "small") if mode == 3 else ("",)):
+            if kern:
+                os.environ["TEB_AMD_HSIG3D"] = kern
+            sig = s.h_signatures(1.0)
+            if mode == 3:
+                assert np.abs(sig - want).max(initial=0) <= 4 * np.finfo(float).eps * max(1.0, np.abs(want).max(initial=0)), (kern, np.abs(sig - want).max())
+            else:
+                assert np.abs(sig - want).max() <= 1e-10 * max(np.abs(want).max(), 1e-300)
+            got = s.filter_equivalence_classes(0.1, -1, 1)
+            for u, v in zip(got, oracle.filter_equivalence_classes(mode, want, 0.1, -1, 1)):
+                np.testing.assert_array_equal(u, v)
+    finally:
+        os.environ.pop("TEB_AMD_HSIG3D", None)
+    s.close()
