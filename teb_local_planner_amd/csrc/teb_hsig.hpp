@@ -23,10 +23,11 @@ __global__ void __launch_bounds__(kThreads) hsig3d_kernel(const SceneDev sc, con
   const int n = bt.n[b];
   double* lx = hs_lds; double* ly = hs_lds + S; double* lt = hs_lds + 2 * S;
   const size_t so = (size_t)b * S;
-  for (int i = threadIdx.x; i < n; i += kThreads) { lx[i] = bt.x[so + i]; ly[i] = bt.y[so + i]; }
-  if (threadIdx.x == 0) {   // next_transition_time += dt, left to right (:313-320)
+  for (int i = threadIdx.x; i < n; i += kThreads) { lx[i] = bt.x[so + i]; ly[i] = bt.y[so + i]; lt[i] = (i < n - 1) ? bt.dt[so + i] : 0.0; }
+  __syncthreads();
+  if (threadIdx.x == 0) {   // next_transition_time += dt, left to right (:313-320); the time differences were staged in parallel
     double t = 0;
-    for (int i = 0; i < n; ++i) { lt[i] = t; if (i < n - 1) t += bt.dt[so + i]; }
+    for (int i = 0; i < n; ++i) { const double d = lt[i]; lt[i] = t; t += d; }
   }
   __syncthreads();
   const int l = blockIdx.x * kThreads + threadIdx.x;
@@ -82,10 +83,11 @@ __global__ void __launch_bounds__(kThreads) hsig3d_small_kernel(const SceneDev s
   const int n = bt.n[b];
   double* lx = hs_lds; double* ly = hs_lds + S; double* lt = hs_lds + 2 * S;
   const size_t so = (size_t)b * S;
-  for (int i = threadIdx.x; i < n; i += kThreads) { lx[i] = bt.x[so + i]; ly[i] = bt.y[so + i]; }
-  if (threadIdx.x == 0) {
+  for (int i = threadIdx.x; i < n; i += kThreads) { lx[i] = bt.x[so + i]; ly[i] = bt.y[so + i]; lt[i] = (i < n - 1) ? bt.dt[so + i] : 0.0; }
+  __syncthreads();
+  if (threadIdx.x == 0) {   // next_transition_time += dt, left to right (:313-320); the time differences were staged in parallel
     double t = 0;
-    for (int i = 0; i < n; ++i) { lt[i] = t; if (i < n - 1) t += bt.dt[so + i]; }
+    for (int i = 0; i < n; ++i) { const double d = lt[i]; lt[i] = t; t += d; }
   }
   __syncthreads();
   const int o = threadIdx.x % kHsTile, s = threadIdx.x / kHsTile;
