@@ -232,8 +232,10 @@ void teb_amd_config_default(teb_amd_config_t* cfg);   /* TebConfig::TebConfig(),
  * create: one solver per GPU / host thread. device = HIP ordinal. stream = hipStream_t (as void*) to
  * launch on, or NULL for the handle's own stream. Fails (never falls back to CPU) when no gfx950 device.
  * max_poses = pose capacity of every band (trajectory.max_samples + 1 covers whatever autoResize can produce); up to 512
- * (teb_amd_capacity). The kernel layout follows from it: normal matrix as 8x8 blocks in LDS up to 238 poses (208 beside a
- * 500-obstacle cache) - the fastest -, as a band in LDS up to 343, as a band in HBM beyond; results do not depend on the layout.
+ * (teb_amd_capacity). Layouts: normal matrix as 8x8 blocks in LDS up to 238 poses (208 beside a 500-obstacle cache) - the
+ * fastest -, as a band in LDS up to 343, as a band in HBM beyond. Each launch uses the fastest layout that holds the current
+ * bands with 12.5 % room to grow and is repeated in the capacity's own layout if autoResize outgrows that (TEB_AMD_FIXED_LAYOUT=1:
+ * always the capacity's layout); results do not depend on the layout.
  */
 int  teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_poses,
                     int32_t max_obstacles, int32_t max_obstacle_vertices, int32_t max_via_points,

@@ -152,7 +152,9 @@ struct teb_amd_handle {
   DevBuf<double> o_ax, o_ay, o_bx, o_by, o_rad, o_vx, o_vy, o_cx, o_cy, o_pvx, o_pvy, viax, viay;
   // batch
   DevBuf<int> n, has_vs, has_vg, rotdir, via_en, status, optimized, iters, trials, assoc_cnt, assoc, assoc_ovf, via_pose, legacy_idx;
-  DevBuf<double> x, y, th, dt, vs, vg, chi2, cost, lambda, Hbackup, Hband;
+  DevBuf<double> x, y, th, dt, vs, vg, chi2, cost, lambda, Hbackup, Hband, ob_x, ob_y, ob_th, ob_dt;   // ob_*: strips before an optimistic launch
+  DevBuf<int> ob_n;
+  bool opt_backup_ready = false;
   size_t hband_stride = 0;
   // snapshot
   DevBuf<int> snap_n;
@@ -249,18 +251,82 @@ opt_kernel_t opt_kernel(int solver, int jmode) {
          : solver == SOLVER_BAND ? teb_optimize_kernel<SOLVER_BAND, TEB_AMD_JACOBIAN_ANALYTIC>
                                  : teb_optimize_kernel<SOLVER_BANDG, TEB_AMD_JACOBIAN_ANALYTIC>;
 }
+void launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const BatchDev& bt, const OptArgs& a, int solver, const LdsPlan& plan) {
+  hipLaunchKernelGGL(opt_kernel(solver, h->cfg.jacobian_mode), dim3(grid), dim3(kThreads), plan.total_bytes, h->stream,
+                     h->cfg, sc, bt, a, plan);
+}
 void launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const BatchDev& bt, const OptArgs& a) {
-  hipLaunchKernelGGL(opt_kernel(h->solver, h->cfg.jacobian_mode), dim3(grid), dim3(kThreads), h->plan.total_bytes, h->stream,
-                     h->cfg, sc, bt, a, h->plan);
+  launch_opt(h, grid, sc, bt, a, h->solver, h->plan);
+}
+
+// largest pose capacity whose LDS plan (with the obstacle cache of this scene, if it is in use) fits
+int max_capacity_of(teb_amd_handle* h, int solver, int upto) {
+  const int ob = h->fast_points ? h->M : 0;
+  int S = upto;
+  while (S > 8 && (size_t)make_lds_plan(S, solver, ob).total_bytes > h->lds_limit) --S;
+  return (size_t)make_lds_plan(S, solver, ob).total_bytes <= h->lds_limit ? S : 0;
 }
 
 int launch(teb_amd_handle* h, const OptArgs& args) {
   if (h->B <= 0) return fail(TEB_AMD_ERR_INVALID_ARG, "no TEBs uploaded");
   SceneDev sc = scene_of(h);
   BatchDev bt = batch_of(h);
+  // The layout of the normal matrix follows the pose capacity of the handle (blocks in LDS <= 238 poses, band in LDS <= 343, band in
+  // HBM beyond), the faster layouts only hold shorter bands. A handle created for long bands that currently holds short ones is
+  // launched in the fastest layout that leaves the bands 12.5 % room to grow (autoResize); should a band outgrow it all the same, the
+  // launch is repeated from the saved strips in the handle's own layout. Results do not depend on the layout (same arithmetic up to
+  // the order of the block reduction). TEB_AMD_FIXED_LAYOUT=1 switches this off.
+  int eff_solver = h->solver;
+  LdsPlan eff_plan = h->plan;
+  bool optimistic = false;
+  if (h->solver != SOLVER_CR && !args.debug_linearize && !getenv("TEB_AMD_FIXED_LAYOUT") && !getenv("TEB_AMD_SOLVER")) {
+    std::vector<int> n(h->B);
+    HIPCHK(hipMemcpyAsync(n.data(), h->n.p, h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int nmax = 0;
+    for (int v : n) nmax = std::max(nmax, v);
+    const int need = nmax + nmax / 8 + 4;   // 12.5 % room to grow; a band that needs more triggers the repeat below
+    const int ob = h->fast_points ? h->M : 0;
+    const int s_cr = max_capacity_of(h, SOLVER_CR, std::min(h->stride, 238));
+    const int s_band = h->solver == SOLVER_BANDG ? max_capacity_of(h, SOLVER_BAND, std::min(h->stride, 343)) : 0;
+    if (s_cr > 0 && need <= s_cr) { eff_solver = SOLVER_CR; eff_plan = make_lds_plan(s_cr, SOLVER_CR, ob); optimistic = true; }
+    else if (s_band > 0 && need <= s_band) { eff_solver = SOLVER_BAND; eff_plan = make_lds_plan(s_band, SOLVER_BAND, ob); optimistic = true; }
+  }
+  if (optimistic) {   // strips as they are now, for the repeat
+    if (!h->opt_backup_ready) {
+      const size_t BS = (size_t)h->max_tebs * h->stride;
+      HIPCHK(h->ob_x.alloc(BS)); HIPCHK(h->ob_y.alloc(BS)); HIPCHK(h->ob_th.alloc(BS)); HIPCHK(h->ob_dt.alloc(BS)); HIPCHK(h->ob_n.alloc(h->max_tebs));
+      h->opt_backup_ready = true;
+    }
+    const size_t bytes = (size_t)h->B * h->stride * sizeof(double);
+    HIPCHK(hipMemcpyAsync(h->ob_x.p, h->x.p, bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->ob_y.p, h->y.p, bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->ob_th.p, h->th.p, bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->ob_dt.p, h->dt.p, bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->ob_n.p, h->n.p, h->B * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+  }
   HIPCHK(hipMemsetAsync(h->assoc_ovf.p, 0, sizeof(int) * h->max_tebs, h->stream));
   HIPCHK(hipEventRecord(h->ev0, h->stream));
-  launch_opt(h, h->B, sc, bt, args);
+  launch_opt(h, h->B, sc, bt, args, eff_solver, eff_plan);
+  if (optimistic) {
+    HIPCHK(hipGetLastError());
+    std::vector<int> ovf(h->B);
+    HIPCHK(hipMemcpyAsync(ovf.data(), h->assoc_ovf.p, h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    bool outgrown = false;
+    for (int v : ovf) outgrown = outgrown || (v & 2);
+    if (outgrown) {
+      const size_t bytes = (size_t)h->B * h->stride * sizeof(double);
+      HIPCHK(hipMemcpyAsync(h->x.p, h->ob_x.p, bytes, hipMemcpyDeviceToDevice, h->stream));
+      HIPCHK(hipMemcpyAsync(h->y.p, h->ob_y.p, bytes, hipMemcpyDeviceToDevice, h->stream));
+      HIPCHK(hipMemcpyAsync(h->th.p, h->ob_th.p, bytes, hipMemcpyDeviceToDevice, h->stream));
+      HIPCHK(hipMemcpyAsync(h->dt.p, h->ob_dt.p, bytes, hipMemcpyDeviceToDevice, h->stream));
+      HIPCHK(hipMemcpyAsync(h->n.p, h->ob_n.p, h->B * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+      HIPCHK(hipMemsetAsync(h->assoc_ovf.p, 0, sizeof(int) * h->max_tebs, h->stream));
+      HIPCHK(hipEventRecord(h->ev0, h->stream));
+      launch_opt(h, h->B, sc, bt, args);
+    }
+  }
   h->consumers_valid = false;
   h->hsig_mode = 0;   // the bands change: signatures of an earlier teb_amd_compute_h_signatures call are stale
   HIPCHK(hipGetLastError());
@@ -396,9 +462,10 @@ int teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_po
   A(h->hsig.alloc((size_t)max_tebs * (Mo > 2 ? Mo : 2))); A(h->hs_pre.alloc(Mo)); A(h->hs_pim.alloc(Mo)); A(h->hs_pex.alloc(Mo));
   if (ok && hipEventCreate(&h->ev0) != hipSuccess) ok = false;
   if (ok && hipEventCreate(&h->ev1) != hipSuccess) ok = false;
-  for (int jm : {TEB_AMD_JACOBIAN_ANALYTIC, TEB_AMD_JACOBIAN_G2O_NUMERIC})
-    if (ok && hipFuncSetAttribute(reinterpret_cast<const void*>(opt_kernel(solver, jm)),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit) != hipSuccess) ok = false;
+  for (int sv : {SOLVER_BAND, SOLVER_CR, SOLVER_BANDG})   // every layout may be launched (teb_amd_set_obstacles / per-launch choice)
+    for (int jm : {TEB_AMD_JACOBIAN_ANALYTIC, TEB_AMD_JACOBIAN_G2O_NUMERIC})
+      if (ok && hipFuncSetAttribute(reinterpret_cast<const void*>(opt_kernel(sv, jm)),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit) != hipSuccess) ok = false;
   if (ok && hipMemset(h->cost.p, 0, sizeof(double) * max_tebs) != hipSuccess) ok = false;
   if (ok && hipMemset(h->chi2.p, 0, sizeof(double) * max_tebs) != hipSuccess) ok = false;
   if (ok && hipMemset(h->iters.p, 0, sizeof(int) * max_tebs) != hipSuccess) ok = false;   // hasDiverged: "no statistics yet"
@@ -419,7 +486,7 @@ void teb_amd_destroy(teb_amd_handle_t* h) {
   for (auto* q : ib) q->free();
   DevBuf<double>* db[] = {&h->o_ax, &h->o_ay, &h->o_bx, &h->o_by, &h->o_rad, &h->o_vx, &h->o_vy, &h->o_cx, &h->o_cy, &h->o_pvx,
                           &h->o_pvy, &h->viax, &h->viay, &h->x, &h->y, &h->th, &h->dt, &h->vs, &h->vg, &h->chi2, &h->cost,
-                          &h->lambda, &h->Hbackup, &h->Hband, &h->snap_x, &h->snap_y, &h->snap_th, &h->snap_dt, &h->dbg_H,
+                          &h->lambda, &h->Hbackup, &h->Hband, &h->ob_x, &h->ob_y, &h->ob_th, &h->ob_dt, &h->snap_x, &h->snap_y, &h->snap_th, &h->snap_dt, &h->dbg_H,
                           &h->dbg_b, &h->dbg_chi2, &h->sel_cost, &h->stage_x, &h->stage_y, &h->stage_yaw, &h->out_cmd, &h->out_prof, &h->out_traj, &h->hsig, &h->hs_pre, &h->hs_pim};
   for (auto* q : db) q->free();
   DevBuf<double>* gb[] = {&h->g_vx, &h->g_vy, &h->cand_x, &h->cand_y, &h->cand_th, &h->cand_dt, &h->cand_sig, &h->cand_px, &h->cand_py,
@@ -427,6 +494,7 @@ void teb_amd_destroy(teb_amd_handle_t* h) {
   for (auto* q : gb) q->free();
   DevBuf<int>* gi[] = {&h->cand_n, &h->cand_off, &h->cand_map, &h->tmp_n, &h->tmp_i};
   for (auto* q : gi) q->free();
+  h->ob_n.free();
   h->g_adj.free();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);

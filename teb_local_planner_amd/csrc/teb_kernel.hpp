@@ -1237,7 +1237,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       int ovf = 0;
       PROF_START();
       // sweep output + split stack (4 S + 256 doubles) live in the LDS region of the normal matrix, which is rebuilt afterwards
-      n = autoresize(c, l, n, plan.off_state, plan.off_H, S, fast_mode, &ovf);
+      n = autoresize(c, l, n, plan.off_state, plan.off_H, plan.S, fast_mode, &ovf);   // plan.S: LDS strip spacing = pose capacity of this launch
       PROF_END(0);
       if (ovf) { status = TEB_AMD_TEB_FAILED; if (tid == 0) bt.assoc_overflow[b] |= 2; break; }
     }

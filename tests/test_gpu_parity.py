@@ -603,3 +603,44 @@ def test_randomized_scenes_do_not_depend_on_the_layout(seed, layout, monkeypatch
             continue
         for u, v in zip(out0.get_teb(b), out1.get_teb(b)):
             assert np.abs(u - v).max() <= 1e-8, (seed, b, np.abs(u - v).max())
+
+
+def test_layout_is_chosen_per_launch_and_repeated_when_a_band_outgrows_it(oracle, monkeypatch):
+    """A handle created for 501 poses (band in HBM) that holds a 194-pose band is launched with the blocks in LDS: same result as a
+    208-pose handle to 1e-8, at its speed. A band that outgrows the optimistic capacity inside the kernel (autoResize doubles it) makes
+    the library repeat the launch from the saved strips in the handle's own layout: bit-identical to TEB_AMD_FIXED_LAYOUT=1."""
+    cfg, obst, via, batch = scenes.scene_c2(stride=208)
+    def run(cap, b=batch):
+        hb = _abi.TebBatchHost(b.count, cap)
+        for k in range(b.count):
+            hb.set_teb(k, *b.get_teb(k))
+        s = planner.make_solver(cfg, obst, via, hb)
+        s.optimize(5, 4, True, 100.0, 1.0, False); s.synchronize()
+        ms = s.last_kernel_ms(); res = s.results(); out = s.download(hb.copy()); s.close()
+        return out, res, ms
+    small, rs, ms_small = run(208)
+    big, rb, ms_big = run(501)
+    monkeypatch.setenv("TEB_AMD_FIXED_LAYOUT", "1")
+    fixed, rf, ms_fixed = run(501)
+    monkeypatch.delenv("TEB_AMD_FIXED_LAYOUT")
+    assert small.n[0] == big.n[0] == fixed.n[0] and rs.lm_iterations[0] == rb.lm_iterations[0] == rf.lm_iterations[0]
+    for u, v, w in zip(small.get_teb(0), big.get_teb(0), fixed.get_teb(0)):
+        assert np.abs(u - v).max() <= 1e-8 and np.abs(u - w).max() <= 1e-8
+    assert ms_big < 0.85 * ms_fixed, (ms_small, ms_big, ms_fixed)          # the per-launch choice is what makes the difference
+    # outgrowing: 150 poses whose time differences call for a split of every interval -> ~300 poses > the optimistic block capacity
+    rng = np.random.default_rng(3)
+    grow = _abi.TebBatchHost(1, 501)
+    x, y, th, dt = scenes.sine_band(150, 30.0, 0.2, 1.0, cfg.robot.max_vel_x)
+    grow.set_teb(0, x, y, th, dt * 0 + 0.75)
+    cfg.trajectory.max_samples = 500
+    def run_grow():
+        s = planner.make_solver(cfg, obst, via, grow)
+        s.optimize(3, 2, True, 100.0, 1.0, False); s.synchronize()
+        res = s.results(); out = s.download(grow.copy()); s.close()
+        return out, res
+    a, ra = run_grow()
+    monkeypatch.setenv("TEB_AMD_FIXED_LAYOUT", "1")
+    b, rb2 = run_grow()
+    assert a.n[0] == b.n[0] > 238 and ra.status[0] == rb2.status[0] == _abi.TEB_OK
+    for u, v in zip(a.get_teb(0), b.get_teb(0)):
+        np.testing.assert_array_equal(u, v)
