@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the TEB hot path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
 
-One "step" = one pass of the hot path over one batch: B x optimizeTEB (4 outer x 5 inner LM iterations,
-association, cost) = HomotopyClassPlanner::optimizeAllTEBs on the resident batch, from the same initial
-state every step (device-to-device restore inside the timed region), with inputs already in HBM.
-Workload at N=1: BASELINE config C4 — 256 candidate TEBs x 200 poses, 500 point obstacles incl. 50 dynamic
-(teb_autosize off so n stays 200). N>1: every rank runs its own 256 candidates (weak scaling),
-no data-path collective; one 16-byte all-gather per step performs the best-trajectory selection.
+One "step" = one pass of the hot path over one batch: B x optimizeTEB (4 outer x 5 inner LM iterations, autoResize, association,
+cost) = HomotopyClassPlanner::optimizeAllTEBs on the resident batch + selectBestTeb, from the same initial state every step
+(device-to-device restore inside the timed region), with inputs already in HBM.
 
+Workload: BASELINE config C4 — 256 candidate TEBs x 200 poses at the start, 450 static + 50 dynamic point obstacles, TebConfig
+defaults (teb_autosize on: the bands end with 193 .. 287 poses).
+
+  python bench.py                      1 GPU
+  python bench.py --gpus N             N ranks, one per GPU: spawned here (torch.distributed.run, RCCL) when WORLD_SIZE is unset,
+                                       or launched by the driver with RANK / LOCAL_RANK / WORLD_SIZE in the environment
+  --scaling weak  (default)            every rank optimises its own 256 candidates (per-GPU work fixed); the per-step exchange is the
+                                       selection: one 16-byte-per-rank ncclAllGather inside libteb_amd.so
+  --scaling strong                     ONE 256-candidate batch sharded over the ranks (BASELINE configs[3]: 32 per GPU at N = 8),
+                                       selection exchange + broadcast of the winner's strip from its owner
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 from teb_local_planner_amd import scenes, planner, parallel, _abi  # noqa: E402
 
+
 # ALGORITHMIC bytes per TEB.LM-iteration (restated in DESIGN.md §Measurement):
 #   64*n (state read+write) + R_obst + 4*E_assoc + 32  + (32*n + R_obst + 4*E_assoc)/inner  [association amortised]
 def alg_bytes_per_unit(n, M, e_assoc, inner):
@@ -30,17 +41,75 @@ def alg_bytes_per_unit(n, M, e_assoc, inner):
     return 64 * n + r_obst + 4 * e_assoc + 32 + (32 * n + r_obst + 4 * e_assoc) / inner
 
 
+def kernel_source_hash():
+    """sha256 over the device sources: ties a committed rocprof summary to the binary it was taken from."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "teb_local_planner_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-run this file under torch.distributed.run, one rank per GPU."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this box - refusing to fake a multi-GPU run" % (args.gpus, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def time_solver(torch, s, cfg, reps):
+    """median kernel ms / wall ms per optimize over `reps` runs from the snapshot; returns (kernel_ms, wall_ms, results)."""
+    ms, wall, res = [], [], None
+    for _ in range(reps):
+        s.restore()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        s.optimize(cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations, True, cfg.hcp.selection_obst_cost_scale,
+                   cfg.hcp.selection_viapoint_cost_scale, cfg.hcp.selection_alternative_time_cost)
+        res = s.results()
+        wall.append(time.perf_counter() - t1)
+        ms.append(s.last_kernel_ms())
+    return float(np.median(ms)), 1e3 * float(np.median(wall)), res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--tebs", type=int, default=256, help="candidate TEBs per GPU")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--tebs", type=int, default=256, help="candidate TEBs per GPU (weak) / in total (strong)")
     ap.add_argument("--poses", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=256, help="TEBs in the CPU-oracle sample")
+    ap.add_argument("--parity-bands", type=int, default=16)
     ap.add_argument("--latency-reps", type=int, default=20)
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
 
     import torch
     import torch.distributed as dist
@@ -50,43 +119,88 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d: the two must agree" % (args.gpus, world))
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     distributed = world > 1
-    if distributed:   # plan latencies, secondary configurations and the CPU baseline are N = 1 items (contract: rank 0 at N = 1 only)
+    if distributed:   # plan latencies, secondary configurations, parity sample and the CPU baseline are N = 1 items (rank 0 at N = 1 only)
         args.latency_reps = 0
         args.no_cpu_baseline = True
-    if distributed:
+        args.no_parity_check = True
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    B, n = args.tebs, args.poses
-    # every rank owns its own candidates (different seed -> different bands), the scene is replicated
-    # TebConfig defaults throughout (teb_autosize on: the bands are resized on the device every outer iteration and end with
-    # 190 .. 290 poses); capacity 288 poses per band = band-form normal matrix in LDS + the 500-obstacle LDS cache
-    STRIDE = max(288, n)
-    cfg, obst, via, batch = scenes.scene_c4(B=B, n=n, seed=1004 + 7919 * rank, stride=STRIDE)
+    n = args.poses
+    STRIDE = max(288, n)   # capacity 288 poses per band = band-form normal matrix in LDS + the 500-obstacle LDS cache
+    if args.scaling == "strong":
+        B_total = args.tebs
+        cfg, obst, via, full = scenes.scene_c4(B=B_total, n=n, seed=1004, stride=STRIDE)
+        lo, hi = parallel.shard_range(B_total, rank, world)
+        batch = _abi.TebBatchHost(max(hi - lo, 1), STRIDE)
+        for k, b in enumerate(range(lo, hi)):
+            batch.set_teb(k, *full.get_teb(b))
+            batch.has_vel_goal[k] = full.has_vel_goal[b]
+        B, offset = hi - lo, lo
+        if B == 0:
+            raise SystemExit("rank %d owns no candidate: more ranks than candidates" % rank)
+    else:
+        # every rank owns its own candidates (different seed -> different bands), the scene is replicated
+        B = args.tebs
+        cfg, obst, via, batch = scenes.scene_c4(B=B, n=n, seed=1004 + 7919 * rank, stride=STRIDE)
+        offset = rank * B
     inner, outer = cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations
     hp = planner.HomotopyClassPlanner(cfg, obst, via, batch, device=local_rank)
     s = hp.solver
     s.snapshot()
-    def step():
+
+    # the path's only exchange. Primary: inside libteb_amd.so (RCCL communicator of its own). The torch.distributed all-gather of
+    # parallel.select_best_distributed is kept as a cross-check during warm-up and as the fallback should RCCL refuse a second communicator.
+    comm, exchange = None, "none (single GPU)"
+    if distributed:
+        try:
+            comm = parallel.RcclComm.from_torch(local_rank)
+            exchange = "libteb_amd.so: ncclAllGather of 16 B per rank on a communicator of its own (teb_amd_select_best_distributed)"
+        except Exception as e:   # noqa: BLE001
+            exchange = "torch.distributed all_gather (C-ABI communicator unavailable: %s)" % str(e)[:120]
+        flag = torch.tensor([1.0 if comm is not None else 0.0], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # all ranks take the same route
+        if float(flag[0]) == 0.0 and comm is not None:
+            comm.close()
+            comm = None
+            exchange = "torch.distributed all_gather (a peer could not create the C-ABI communicator)"
+
+    winner_poses = [0]
+
+    def step(check=False):
         s.restore()
         hp.optimizeAllTEBs(inner, outer)
-        best, cost = s.select_best(-1, -1)          # K9 on the resident costs; synchronises the stream (16-byte D2H)
-        if distributed:                             # the path's only exchange: one (cost, global index) record per rank
-            return parallel.select_best_distributed(cost, rank * B + best, device="cuda")[1]
-        return best
+        if not distributed:
+            return s.select_best(-1, -1)[0]              # K9 on the resident costs; synchronises the stream (16-byte D2H)
+        if comm is not None:
+            best, cost, owner = s.select_best_distributed(comm, offset)
+            if check:
+                lb, lc = s.select_best(-1, -1)
+                tc, tb = parallel.select_best_distributed(lc, offset + lb, device="cuda")
+                assert tb == best and tc == cost, ("C-ABI exchange disagrees with torch.distributed", best, cost, tb, tc)
+            if args.scaling == "strong":                 # the rank that talks to the robot needs the winner's strip
+                x, _, _, _ = s.broadcast_band(comm, owner, best - offset if owner == rank else 0, STRIDE)
+                winner_poses[0] = len(x)
+            return best
+        lb, lc = s.select_best(-1, -1)
+        return parallel.select_best_distributed(lc, offset + lb, device="cuda")[1]
 
-    for _ in range(args.warmup):
-        step()
+    for w in range(args.warmup):
+        step(check=(w == 0))
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-        kernel_ms.append(s.last_kernel_ms())        # HIP events on the launch stream
+        best = step()
+        kernel_ms.append(s.last_kernel_ms())            # HIP events on the launch stream
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -95,15 +209,16 @@ def main():
     units_step = int(res.lm_iterations.sum())
     n_after = s.pose_counts()
     tebs_ok = int((res.status == 0).sum())
-    tt = torch.tensor([elapsed, float(units_step)], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([elapsed, float(units_step), 1.0, float(B)], dtype=torch.float64, device="cuda")
     if distributed:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tt.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed_max, units_all = float(tmax[0]), float(tsum[1])
+        elapsed_max, units_all, ranks_seen, tebs_all = float(tmax[0]), float(tsum[1]), int(round(float(tsum[2]))), int(round(float(tsum[3])))
+        assert ranks_seen == world, "the reduction saw %d records for %d ranks" % (ranks_seen, world)
     else:
-        elapsed_max, units_all = elapsed, float(units_step)
+        elapsed_max, units_all, tebs_all = elapsed, float(units_step), B
 
     out = None
     if rank == 0:
@@ -111,54 +226,111 @@ def main():
         kms = float(np.mean(kernel_ms))
         M = len(obst)
         # association list size for the algorithmic-byte model: measured on TEB 0 of this rank
-        s.restore()                                   # association list size of the initial band of TEB 0
+        s.restore()
         dbg = s.debug_linearize(0, n, 1.0)
         e_assoc = len(dbg["assoc_pose"])
         n_eff = float(n_after.mean())                 # pose count the iterations of this step actually worked on
         abu = alg_bytes_per_unit(n_eff, M, e_assoc, inner)
         alg_bytes_launch = abu * units_step
         achieved = alg_bytes_launch / (kms * 1e-3) / 1e9
-        # HBM-side traffic per launch from the committed rocprofv3 PMC passes of THIS command (FETCH_SIZE / WRITE_SIZE in
-        # separate runs, scaled by the factors calibrated on a known 1 GiB stream; profiles/rocprof_*_summary.json)
-        traffic, traffic_src, fp64 = None, None, None
+        # HBM-side traffic per launch from the committed rocprofv3 PMC passes of THIS command (FETCH_SIZE / WRITE_SIZE in separate
+        # runs, scaled by the factors calibrated on a known 1 GiB stream; profiles/rocprof_*_summary.json). The summary records the
+        # hash of the device sources it was taken from; a summary of other sources is reported as stale, never silently reused.
+        traffic, traffic_src, traffic_note, fp64, mfma = None, None, None, None, None
+        src_hash = kernel_source_hash()
         try:
             import glob
-            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "rocprof_r*_summary.json")))
-            if cands and B == 256 and n == 200:
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "rocprof_r*_summary.json")), key=os.path.getmtime)
+            if cands and args.tebs == 256 and n == 200 and args.scaling == "weak":
                 pj = json.load(open(cands[-1]))
-                cal = pj.get("calibration", {})
-                fr = cal.get("FETCH_SIZE_bytes_per_counted_KB", 2048.0)
-                fw = cal.get("WRITE_SIZE_bytes_per_counted_KB", 1024.0)
-                traffic = pj["FETCH_SIZE_KB_per_launch"] * fr + pj["WRITE_SIZE_KB_per_launch"] * fw
                 traffic_src = os.path.basename(cands[-1])
-                if pj.get("fp64_flop_per_launch"):   # PMC pass SQ_INSTS_VALU_*_F64 of this command (instruction counts x 64 lanes)
-                    fp64 = {"flop_per_launch": pj["fp64_flop_per_launch"], "achieved": pj["fp64_flop_per_launch"] / (kms * 1e-3) / 1e12,
-                            "peak": 78.6, "unit": "TFLOP/s", "source": traffic_src,
-                            "note": "vector fp64 (no MFMA on this path); peak = AMD spec, half the 157.3 TFLOP/s fp32 vector rate; "
-                                    "the build uses -ffp-contract=off, so mul+add pairs issue as two instructions (ceiling ~39 TFLOP/s)"}
-                    fp64["frac"] = fp64["achieved"] / fp64["peak"]
-        except Exception:
-            traffic = None
+                if pj.get("source_hash") == src_hash:
+                    cal = pj.get("calibration", {})
+                    fr = cal.get("FETCH_SIZE_bytes_per_counted_KB", 2048.0)
+                    fw = cal.get("WRITE_SIZE_bytes_per_counted_KB", 1024.0)
+                    traffic = pj["FETCH_SIZE_KB_per_launch"] * fr + pj["WRITE_SIZE_KB_per_launch"] * fw
+                    if pj.get("fp64_flop_per_launch"):   # PMC pass SQ_INSTS_VALU_*_F64 of this command (instruction counts x 64 lanes)
+                        fp64 = {"flop_per_launch": pj["fp64_flop_per_launch"], "achieved": pj["fp64_flop_per_launch"] / (kms * 1e-3) / 1e12,
+                                "peak": 78.6, "unit": "TFLOP/s", "source": traffic_src,
+                                "note": "vector fp64; peak = AMD spec, half the 157.3 TFLOP/s fp32 vector rate; the build uses "
+                                        "-ffp-contract=off outside the solve, so mul+add pairs issue as two instructions"}
+                        fp64["frac"] = fp64["achieved"] / fp64["peak"]
+                    if pj.get("mfma"):
+                        mfma = pj["mfma"]
+                else:
+                    traffic_note = "%s was taken from other device sources (hash %s, now %s): not reported" % (traffic_src, pj.get("source_hash"), src_hash)
+        except Exception as e:   # noqa: BLE001
+            traffic_note = "profile summary unreadable: %s" % str(e)[:80]
+        if args.scaling == "strong":
+            wl = ("C4 strong scaling: ONE batch of %d candidate TEBs sharded over %d rank(s) (%d on rank 0) x %d poses at the start "
+                  "(teb_autosize on: %d..%d after the step on rank 0), %d point obstacles (%d dynamic), winner strip broadcast (%d poses)"
+                  % (tebs_all, world, B, n, int(n_after.min()), int(n_after.max()), M, int(np.sum(obst.dynamic)), winner_poses[0]))
+        else:
+            wl = ("C4: %d candidate TEBs/GPU x %d poses at the start (teb_autosize on, the reference default: %d..%d poses, mean %.0f, "
+                  "after the step), %d point obstacles (%d dynamic), diff-drive, point footprint, TebConfig defaults, 4 outer x 5 inner"
+                  % (B, n, int(n_after.min()), int(n_after.max()), n_eff, M, int(np.sum(obst.dynamic))))
         out = {
             "metric": "TEB LM iterations/sec (whole node)", "value": value, "unit": "TEB.LM-iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed_max / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed_max / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C4: %d candidate TEBs/GPU x %d poses at the start (teb_autosize on, the reference default: "
-                                   "%d..%d poses, mean %.0f, after the step), %d point obstacles (%d dynamic), diff-drive, point "
-                                   "footprint, TebConfig defaults, 4 outer x 5 inner" %
-                                   (B, n, int(n_after.min()), int(n_after.max()), n_eff, M, int(np.sum(obst.dynamic))),
-                       "tebs_per_gpu": B, "poses": n, "poses_after": [int(n_after.min()), int(n_after.max())],
+            "config": {"workload": wl, "tebs_per_gpu": B, "tebs_total": tebs_all, "poses": n,
+                       "poses_after": [int(n_after.min()), int(n_after.max())],
                        "pose_capacity": STRIDE, "tebs_ok": tebs_ok, "obstacles": M, "units_per_step_per_gpu": units_step,
-                       "lm_trials_per_step_per_gpu": int(res.lm_trials.sum())},
+                       "lm_trials_per_step_per_gpu": int(res.lm_trials.sum()), "jacobian_mode": "analytic (closed form)",
+                       "exchange": exchange, "source_hash": src_hash},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,
                          "kernel": "teb_optimize_kernel", "kernel_ms": kms,
                          "alg_bytes_per_unit": abu, "alg_bytes_per_launch": alg_bytes_launch},
         }
+        if traffic_note:
+            out["roofline"]["traffic_note"] = traffic_note
         if fp64:
             out["roofline"]["valu_fp64"] = fp64
+        if mfma:
+            out["roofline"]["mfma"] = mfma
+
+        # ---- parity of THIS run against the oracle (checker only, outside the timed region): a spread of bands of the headline batch,
+        #      same closed-form mode, thread per TEB
+        if not args.no_parity_check:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import sensitivity
+                from oracle import oracle_py
+                oracle_py.build()
+                s.restore()
+                hp.optimizeAllTEBs(inner, outer)
+                res_p = s.results()
+                out_p = s.download(batch.copy())
+                k = max(1, min(args.parity_bands, B))
+                pick = sorted(set(np.linspace(0, B - 1, k).round().astype(int).tolist()))
+                sub = _abi.TebBatchHost(len(pick), STRIDE)
+                for j, b in enumerate(pick):
+                    sub.set_teb(j, *batch.get_teb(b))
+                    sub.has_vel_goal[j] = batch.has_vel_goal[b]
+                ref, rres = oracle_py.optimize_batch(cfg, obst, via, sub, threads=min(len(pick), os.cpu_count() or 1))
+
+                class _View:   # the picked bands of the device result, indexed like `sub`
+                    count = len(pick)
+                    n = out_p.n[pick]
+                    @staticmethod
+                    def get_teb(j):
+                        return out_p.get_teb(pick[j])
+                class _Res:
+                    status = res_p.status[pick]; lm_iterations = res_p.lm_iterations[pick]; lm_trials = res_p.lm_trials[pick]; cost = res_p.cost[pick]
+                rep = sensitivity.compare_bands(_View, _Res, ref, rres, None)
+                out["parity_check"] = {"bands": rep["bands"], "band_indices": pick, "counts_equal": rep["counts_equal"],
+                                       "status_equal": rep["status_equal"], "compared": rep["checked"],
+                                       "max_state_err": rep["max_state_err"], "max_cost_rel": rep["max_cost_rel"],
+                                       "tolerance": {"state": 1e-7, "cost_rel": 1e-7},
+                                       "pass": bool(rep["counts_equal"] == rep["bands"] and rep["checked"] == rep["bands"]
+                                                    and rep["max_state_err"] <= 1e-7 and rep["max_cost_rel"] <= 1e-7),
+                                       "against": "oracle/teb_oracle.cpp, closed-form Jacobians, same inputs; all 256 bands: tests/test_gpu_measured_configs.py"}
+            except Exception as e:   # noqa: BLE001
+                out["parity_check"] = {"error": str(e)[:200]}
+
         # ---- p50 plan()-equivalent latency on the 200-pose band: upload -> 4x5 iterations incl. autoResize,
         #      association, cost -> select -> download (single TEB, config C2, and the C4 batch)
         lat = {}
@@ -209,15 +381,15 @@ def main():
             ticks = max(8, args.latency_reps)
             starts = [[0.05 * k, 0.0, 0.0] for k in range(ticks)]
             goals = [[16.0, 0.0, 0.0]] * ticks
-            hp = planner.HomotopyClassPlanner(hc, hob, [], None, max_tebs=8, max_poses=224)   # <= 238: normal matrix as blocks in LDS
+            hpt = planner.HomotopyClassPlanner(hc, hob, [], None, max_tebs=8, max_poses=224)   # <= 238: normal matrix as blocks in LDS
             ts, nb = [], []
             for k in range(ticks):
                 t1 = time.perf_counter()
-                hp.plan(starts[k], goals[k], [0.3, 0.0, 0.0])
-                hp.getVelocityCommand()
+                hpt.plan(starts[k], goals[k], [0.3, 0.0, 0.0])
+                hpt.getVelocityCommand()
                 ts.append(time.perf_counter() - t1)
-                nb.append(hp.solver.count)
-            hp.solver.close()
+                nb.append(hpt.solver.count)
+            hpt.solver.close()
             lat["hcp_plan_tick_p50_ms"] = 1e3 * float(np.median(ts[1:]))
             lat["hcp_plan_tick"] = {"workload": "HomotopyClassPlanner::plan() ticks on one planner: 16 m straight task, 12 point obstacles, "
                                                 "roadmap graph (15 samples), max_number_classes 5, 4x5 iterations, teb_autosize on, pose capacity 224",
@@ -228,53 +400,55 @@ def main():
                     t1 = time.perf_counter()
                     ref_py.hcp_plan_ticks(hc, hob, starts, goals, [[0.3, 0.0, 0.0]] * ticks)
                     lat["hcp_plan_tick"]["reference_code_cpu_ms_per_tick"] = 1e3 * (time.perf_counter() - t1) / ticks   # oracle/_ref, one thread
-            except Exception as e:
+            except Exception as e:   # noqa: BLE001
                 lat["hcp_plan_tick"]["reference_code_cpu_ms_per_tick"] = str(e)[:120]
         out["plan_latency"] = lat
-        # ---- secondary numbers: C4 with autoResize switched off (every band keeps exactly 200 poses, block-form normal matrix in
-        #      LDS - the fastest configuration of the kernel) and BASELINE configs[2] (64 x 150 poses, 200 obstacles, defaults)
+
+        # ---- secondary numbers (kernel time per optimizeAllTEBs of the other BASELINE configurations at full size, defaults):
+        #      C4 with autoResize off (every band keeps 200 poses), the headline in the reference's own Jacobian mode (g2o central
+        #      differences), C3 (64 x 150 x 200), C2 (1 x 200 x 100), C5 (car-like, polygon footprint vs 300 polygons, 1 x 300)
         if args.latency_reps > 0:
-            c3, o3, v3, b3 = scenes.scene_c3(stride=208)
-            s3 = planner.make_solver(c3, o3, v3, b3)
-            s3.snapshot()
-            ms3, t3 = [], []
-            for _ in range(max(3, args.latency_reps // 4)):
-                s3.restore()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                s3.optimize(inner, outer, True, c3.hcp.selection_obst_cost_scale, c3.hcp.selection_viapoint_cost_scale,
-                            c3.hcp.selection_alternative_time_cost)
-                r3 = s3.results()
-                t3.append(time.perf_counter() - t1)
-                ms3.append(s3.last_kernel_ms())
-            n3 = s3.pose_counts()
-            u3 = int(r3.lm_iterations.sum())
+            sec = {}
+            reps4 = max(3, args.latency_reps // 2)
             c4f, o4f, v4f, b4f = scenes.scene_c4(B=B, n=n, stride=max(n, 208))
             c4f.trajectory.teb_autosize = False
             s4 = planner.make_solver(c4f, o4f, v4f, b4f)
             s4.snapshot()
-            ms4, t4 = [], []
-            for _ in range(max(3, args.latency_reps // 2)):
-                s4.restore()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                s4.optimize(inner, outer, True, c4f.hcp.selection_obst_cost_scale, c4f.hcp.selection_viapoint_cost_scale,
-                            c4f.hcp.selection_alternative_time_cost)
-                r4 = s4.results()
-                t4.append(time.perf_counter() - t1)
-                ms4.append(s4.last_kernel_ms())
-            u4 = int(r4.lm_iterations.sum())
+            k4, w4, r4 = time_solver(torch, s4, c4f, reps4)
             s4.close()
-            out["secondary"] = {"c4_fixed_200_poses": {
+            u4 = int(r4.lm_iterations.sum())
+            sec["c4_fixed_200_poses"] = {
                 "workload": "C4 with teb_autosize off: every band keeps exactly %d poses; normal matrix as 8x8 blocks in LDS" % n,
-                "kernel_ms": float(np.median(ms4)), "ms_per_step": 1e3 * float(np.median(t4)), "units_per_step": u4,
-                "value": u4 / float(np.median(t4)), "unit": "TEB.LM-iterations/s", "tebs_ok": int((r4.status == 0).sum())},
-                                "c3_autosize_on": {
-                "workload": "C3: 64 candidate TEBs x 150 poses, 200 point obstacles, teb_autosize on, 4 outer x 5 inner",
-                "kernel_ms": float(np.median(ms3)), "ms_per_step": 1e3 * float(np.median(t3)), "units_per_step": u3,
-                "value": u3 / float(np.median(t3)), "unit": "TEB.LM-iterations/s",
-                "poses_after": [int(n3.min()), int(n3.max())], "tebs_ok": int((r3.status == 0).sum())}}
-            s3.close()
+                "kernel_ms": k4, "ms_per_step": w4, "units_per_step": u4, "value": u4 / (w4 * 1e-3), "unit": "TEB.LM-iterations/s",
+                "tebs_ok": int((r4.status == 0).sum())}
+            c4n, o4n, v4n, b4n = scenes.scene_c4(B=B, n=n, stride=STRIDE)
+            c4n.jacobian_mode = _abi.JACOBIAN_G2O_NUMERIC
+            s4n = planner.make_solver(c4n, o4n, v4n, b4n)
+            s4n.snapshot()
+            kn, wn, rn = time_solver(torch, s4n, c4n, 3)
+            s4n.close()
+            un = int(rn.lm_iterations.sum())
+            sec["c4_g2o_numeric_jacobians"] = {
+                "workload": "the headline workload with jacobian_mode = g2o central differences (delta 1e-9), the reference's own linearisation "
+                            "scheme: 1 + 2 x #columns residual evaluations per edge",
+                "kernel_ms": kn, "ms_per_step": wn, "units_per_step": un, "value": un / (wn * 1e-3), "unit": "TEB.LM-iterations/s",
+                "tebs_ok": int((rn.status == 0).sum())}
+            for nm, mk, what in (("c3_autosize_on", lambda: scenes.scene_c3(stride=208), "C3: 64 candidate TEBs x 150 poses, 200 point obstacles"),
+                                 ("c2_autosize_on", lambda: scenes.scene_c2(stride=232), "C2: 1 TEB x 200 poses, 100 point obstacles"),
+                                 ("c5_carlike_polygons", lambda: scenes.scene_c5(stride=343),
+                                  "C5: 1 TEB x 300 poses, car-like, polygon footprint vs 300 polygon obstacles")):
+                cc, oo, vv, bb = mk()
+                sx = planner.make_solver(cc, oo, vv, bb)
+                sx.snapshot()
+                kx, wx, rx = time_solver(torch, sx, cc, 3 if nm.startswith("c5") else max(3, args.latency_reps // 4))
+                nx = sx.pose_counts()
+                sx.close()
+                ux = int(rx.lm_iterations.sum())
+                sec[nm] = {"workload": what + ", teb_autosize on, 4 outer x 5 inner", "kernel_ms": kx, "ms_per_step": wx, "units_per_step": ux,
+                           "value": ux / (wx * 1e-3), "unit": "TEB.LM-iterations/s", "poses_after": [int(nx.min()), int(nx.max())],
+                           "tebs_ok": int((rx.status == 0).sum())}
+            out["secondary"] = sec
+
         # ---- CPU baseline: the oracle in the reference-faithful mode (g2o central differences), thread per TEB
         if not args.no_cpu_baseline:
             from oracle import oracle_py
@@ -291,7 +465,7 @@ def main():
             # (a shared 256-thread host is not fastest with 256 busy threads) and reported as `cores`
             try:
                 avail = len(os.sched_getaffinity(0))
-            except Exception:
+            except Exception:   # noqa: BLE001
                 avail = cores
             cand = sorted({t for t in (avail, avail // 2, avail // 4, 64, 32, 16) if 1 <= t <= max(avail, 1)}, reverse=True)
             cpu_t, cores = float("inf"), avail
@@ -303,14 +477,26 @@ def main():
                     if dtc < cpu_t:
                         cpu_t, cores = dtc, th
             out["cpu_baseline"] = {
-                "value": float(cres.lm_iterations.sum()) / cpu_t, "unit": "TEB.LM-iterations/s", "cores": cores,
-                "kind": "port",
+                "value": float(cres.lm_iterations.sum()) / cpu_t, "unit": "TEB.LM-iterations/s", "cores": cores, "cpu_model": cpu_model(),
+                "host_threads_available": avail, "kind": "port",
                 "sample": "%d of the %d C4 candidates, one optimizeTEB each (4x5, teb_autosize on), g2o-numeric Jacobians, "
                           "one std::thread per TEB capped at %d (best of the thread counts tried, 2 runs each), %.1f s wall; the port is bit-identical to the "
                           "reference's src/optimal_planner.cpp on the pinned bands (tests/test_reference_pinning.py)" % (ks, B, cores, cpu_t)}
+            # the same candidates on ONE thread (1 thread and thread-per-TEB): a bounded sample
+            k1 = min(24, ks)
+            c1 = _abi.TebBatchHost(k1, cb.stride)
+            for b in range(k1):
+                c1.set_teb(b, *cb.get_teb(b))
+            c1.has_vel_goal[:] = cb.has_vel_goal[:k1]
+            t1 = time.perf_counter()
+            _, cr1 = oracle_py.optimize_batch(cfg_cpu, obst, via, c1, threads=1)
+            t_1 = time.perf_counter() - t1
+            out["cpu_baseline"]["one_thread"] = {"value": float(cr1.lm_iterations.sum()) / t_1, "unit": "TEB.LM-iterations/s", "cores": 1,
+                                                 "sample": "%d of the C4 candidates back to back on one thread, %.1f s wall" % (k1, t_1)}
             # the reference's OWN code on the same sample (oracle/_ref: src/optimal_planner.cpp + edge classes compiled in place; only
             # the LM iteration / banded Cholesky inside is a stand-in for the absent libg2o). Same results bit for bit; slower than the
             # port because of the g2o-style virtual edge interface. Reported beside the port, which stays the (faster) baseline value.
+            ref_py = None
             try:
                 from oracle import ref_py
                 if os.path.exists(ref_py.SO):
@@ -322,9 +508,39 @@ def main():
                     out["cpu_baseline"]["reference_code"] = {
                         "value": float(rit.sum()) / rt, "unit": "TEB.LM-iterations/s", "cores": cores,
                         "sample": "same %d candidates through oracle/_ref/libteb_ref.so, best of 2 runs, %.1f s wall" % (ks, rt)}
-            except Exception as e:   # the checker library is optional on the bench box
+                else:
+                    ref_py = None
+            except Exception as e:   # the checker library is optional on the bench box  # noqa: BLE001
                 out["cpu_baseline"]["reference_code"] = {"error": str(e)[:200]}
+                ref_py = None
+            # ---- CPU p50 latency of one plan()-equivalent optimizeTEB beside the GPU latencies above: one thread for the
+            #      single-band configurations C2 / C5 (g2o-numeric oracle and the reference's own code), thread per TEB for the C4 batch
+            pl = {}
+            for nm, mk in (("c2", lambda: scenes.scene_c2(stride=232)), ("c5", lambda: scenes.scene_c5(stride=343))):
+                cc, oo, vv, bb = mk()
+                cc.jacobian_mode = _abi.JACOBIAN_G2O_NUMERIC
+                reps = 7 if nm == "c2" else 3
+                ts = []
+                for _ in range(reps):
+                    t1 = time.perf_counter()
+                    oracle_py.optimize_batch(cc, oo, vv, bb, threads=1)
+                    ts.append(time.perf_counter() - t1)
+                pl[nm + "_oracle_g2o_numeric_1_thread_p50_ms"] = 1e3 * float(np.median(ts))
+                if ref_py is not None:
+                    ts = []
+                    for _ in range(reps):
+                        t1 = time.perf_counter()
+                        ref_py.optimize_batch(cc, oo, vv, bb, threads=1)
+                        ts.append(time.perf_counter() - t1)
+                    pl[nm + "_reference_code_1_thread_p50_ms"] = 1e3 * float(np.median(ts))
+            pl["c4_batch_oracle_g2o_numeric_thread_per_teb_ms"] = 1e3 * cpu_t * (B / float(ks))
+            pl["c4_batch_threads"] = cores
+            pl["note"] = ("optimizeTEB only (4x5 iterations incl. autoResize, association, cost) from host buffers; compare with plan_latency.*_p50_ms "
+                          "(GPU, PCIe inclusive) and secondary.*.kernel_ms")
+            out["cpu_baseline"]["plan_latency_ms"] = pl
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TEB_AMD_ABI_VERSION 1
+#define TEB_AMD_ABI_VERSION 2
 
 /* ---- status codes (library calls) ------------------------------------------------------------- */
 enum {
@@ -229,19 +229,46 @@ const char* teb_amd_last_error(void);           /* thread-local message of the l
 void teb_amd_config_default(teb_amd_config_t* cfg);   /* TebConfig::TebConfig(), teb_config.h:245-390 */
 
 /*
+ * Behaviour switches of a handle (ABI 2; these were process-environment variables in ABI 1 - a library must not change its layout
+ * because the host process happens to have a variable set). Zero-initialise, or teb_amd_options_default(), then override.
+ */
+enum { TEB_AMD_LAYOUT_AUTO = 0,        /* by capacity and obstacle count, and per launch by the current pose counts (see create) */
+       TEB_AMD_LAYOUT_BLOCKS_LDS = 1,  /* normal matrix as 8x8 blocks in LDS, cyclic reduction in place (<= 238 poses)           */
+       TEB_AMD_LAYOUT_BAND_LDS = 2,    /* band in LDS, cyclic reduction on HBM-resident blocks (<= 343 poses)                   */
+       TEB_AMD_LAYOUT_BAND_HBM = 3 };  /* band in HBM as well (<= 512 poses)                                                    */
+enum { TEB_AMD_HSIG3D_AUTO = 0, TEB_AMD_HSIG3D_WIDE = 1, TEB_AMD_HSIG3D_SMALL = 2 };
+typedef struct teb_amd_options {
+  int32_t struct_size;            /* sizeof(teb_amd_options_t) of the caller (forward compatibility); 0 = this header's         */
+  int32_t layout;                 /* TEB_AMD_LAYOUT_*; anything but AUTO pins the layout (no per-launch choice)                 */
+  int32_t fixed_layout;           /* 1: always launch in the capacity's own layout (no optimistic launch + repeat)              */
+  int32_t band_ldlt;              /* 1: TEB_AMD_LAYOUT_BAND_LDS solves with the sequential banded LDL^T (cross-check, slow)     */
+  int32_t generic_distance_path;  /* 1: never use the point-like LDS obstacle cache                                             */
+  int32_t hsig3d_kernel;          /* TEB_AMD_HSIG3D_*: pin one of the two HSignature3d kernels                                  */
+  int32_t reserved[10];           /* must be 0                                                                                  */
+} teb_amd_options_t;
+void teb_amd_options_default(teb_amd_options_t* opt);
+
+/*
  * create: one solver per GPU / host thread. device = HIP ordinal. stream = hipStream_t (as void*) to
  * launch on, or NULL for the handle's own stream. Fails (never falls back to CPU) when no gfx950 device.
  * max_poses = pose capacity of every band (trajectory.max_samples + 1 covers whatever autoResize can produce); up to 512
  * (teb_amd_capacity). Layouts: normal matrix as 8x8 blocks in LDS up to 238 poses (208 beside a 500-obstacle cache) - the
  * fastest -, as a band in LDS up to 343, as a band in HBM beyond. Each launch uses the fastest layout that holds the current
- * bands with 12.5 % room to grow and is repeated in the capacity's own layout if autoResize outgrows that (TEB_AMD_FIXED_LAYOUT=1:
+ * bands with 12.5 % room to grow and is repeated in the capacity's own layout if autoResize outgrows that (teb_amd_options_t::fixed_layout:
  * always the capacity's layout); results do not depend on the layout.
  */
 int  teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_poses,
                     int32_t max_obstacles, int32_t max_obstacle_vertices, int32_t max_via_points,
                     int32_t device, void* stream, teb_amd_handle_t** out);
+/* the same with explicit options (NULL = defaults = teb_amd_create) */
+int  teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_poses,
+                       int32_t max_obstacles, int32_t max_obstacle_vertices, int32_t max_via_points,
+                       int32_t device, void* stream, const teb_amd_options_t* options, teb_amd_handle_t** out);
 void teb_amd_destroy(teb_amd_handle_t* h);
-int  teb_amd_set_config(teb_amd_handle_t* h, const teb_amd_config_t* cfg);       /* dynamic_reconfigure */
+/* dynamic_reconfigure. A change of include_dynamic_obstacles or of the footprint type re-derives the static / dynamic obstacle
+ * lists and the distance path from the obstacle table the handle already holds (no re-upload needed). On an error (invalid
+ * footprint / jacobian_mode) the handle keeps its previous configuration. */
+int  teb_amd_set_config(teb_amd_handle_t* h, const teb_amd_config_t* cfg);
 
 /* Scene, once per plan(): obstacles_ and via_points_ (optimal_planner.h:683-684). Host pointers. */
 int  teb_amd_set_obstacles(teb_amd_handle_t* h, const teb_amd_obstacles_t* obst);
@@ -425,7 +452,41 @@ int  teb_amd_compute_h_signatures(teb_amd_handle_t* h, double prescaler, double*
 int  teb_amd_filter_equivalence_classes(teb_amd_handle_t* h, double threshold, int32_t best, int32_t max_number_plans_in_current_class,
                                         int32_t* keep, int32_t* valid, int32_t* reasonable);
 
-/* Duration [ms] of the last optimize_batch kernel, measured with HIP events on the launch stream. */
+/*
+ * ---- Multi-GPU: one process per GPU, the candidate batch sharded by contiguous blocks, scene replicated, no
+ * data-path collective. The path's single exchange - best-trajectory selection - lives here, behind the C-ABI, so that the C++
+ * drop-in (HomotopyClassPlannerAmd) can shard as well: an RCCL communicator over xGMI (librccl is dlopen'ed on first use).
+ *   rank 0:    teb_amd_comm_unique_id(id)            -> ship the 128 bytes to the other ranks by any means (MPI, a ROS param, a file,
+ *                                                        torch.distributed)
+ *   all ranks: teb_amd_comm_create(id, rank, world, device, &comm)
+ *   per plan:  teb_amd_optimize_batch(h, ...)         each rank on its own candidates
+ *              teb_amd_select_best_distributed(...)    one ncclAllGather of 16 bytes per rank; same answer on every rank
+ *              teb_amd_broadcast_band(...)             optional: the winner's strip (8 + 32 * capacity bytes) from its owner to all
+ */
+#define TEB_AMD_COMM_ID_BYTES 128
+typedef struct teb_amd_comm teb_amd_comm_t;
+int  teb_amd_comm_unique_id(char id[TEB_AMD_COMM_ID_BYTES]);
+int  teb_amd_comm_create(const char id[TEB_AMD_COMM_ID_BYTES], int32_t rank, int32_t world, int32_t device, teb_amd_comm_t** out);
+void teb_amd_comm_destroy(teb_amd_comm_t* comm);
+/*
+ * selectBestTeb (src/homotopy_class_planner.cpp:564-667) over the candidates of ALL ranks. This rank holds the global candidates
+ * [global_offset, global_offset + B); last_best_global / initial_plan_global are global indices (< 0 = none) and receive the
+ * hysteresis / prefer-initial-plan multipliers on the rank that owns them. Lowest cost wins, ties -> lowest global index (strict '<'
+ * of :610). *best_global, *best_cost (scaled, bit-exact: costs travel as fp64), *owner_rank are identical on every rank.
+ * Collective: every rank of the communicator must call it. Runs on the handle's stream and synchronises it.
+ */
+int  teb_amd_select_best_distributed(teb_amd_handle_t* h, teb_amd_comm_t* comm, int32_t global_offset, int32_t last_best_global,
+                                     int32_t initial_plan_global, int32_t* best_global, double* best_cost, int32_t* owner_rank);
+/*
+ * The winner's strip from its owner to every rank (host buffers x, y, theta, dt of `capacity` doubles each, *n poses): what the rank
+ * that talks to the robot needs for getVelocityCommand / visualisation. local_index is only read on owner_rank. capacity must be
+ * the same on every rank and >= the winner's pose count (TEB_AMD_ERR_CAPACITY otherwise, on every rank). Collective.
+ */
+int  teb_amd_broadcast_band(teb_amd_handle_t* h, teb_amd_comm_t* comm, int32_t owner_rank, int32_t local_index, int32_t capacity,
+                            int32_t* n, double* x, double* y, double* theta, double* dt);
+
+/* Duration [ms] of the last optimize_batch call on the device, measured with HIP events on the launch stream: from before the
+ * (first) kernel launch to after the last one, i.e. including a repeated launch when autoResize outgrew the optimistic layout. */
 int  teb_amd_last_kernel_ms(teb_amd_handle_t* h, float* ms);
 /* LDS bytes per workgroup and the largest pose count this build can optimise. */
 int  teb_amd_capacity(teb_amd_handle_t* h, int32_t* lds_bytes, int32_t* max_poses_supported);

@@ -14,6 +14,7 @@ int teb_amd_sizeof_config(void);
 int teb_amd_sizeof_obstacles(void);
 int teb_amd_sizeof_teb_batch(void);
 int teb_amd_sizeof_results(void);
+int teb_amd_sizeof_options(void);
 
 /*
  * Build the cost graph of resident TEB b with the given weight_multiplier and linearise once (no

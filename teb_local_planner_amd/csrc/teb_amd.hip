@@ -18,6 +18,7 @@
 #include "teb_strip.hpp"
 #include "teb_hsig.hpp"
 #include "teb_graph.hpp"
+#include "teb_comm.hpp"
 
 using namespace tebamd;
 
@@ -146,6 +147,11 @@ struct teb_amd_handle {
   size_t lds_limit = 0;
   LdsPlan plan;
   int fast_points = 0;
+  teb_amd_options_t opt;   // behaviour switches fixed at create (ABI 2; never the process environment)
+  int snap_nmax = -1;      // nmax_known at the time of teb_amd_snapshot_state
+  int nmax_known = -1;     // upper bound of the resident pose counts as far as the host knows it, -1 = unknown (device-side producers ran)
+  // host copy of the last obstacle table: teb_amd_set_config re-derives the static / dynamic lists from it
+  struct HostObst { std::vector<int> type, dyn, voff; std::vector<double> ax, ay, bx, by, rad, vx, vy, cx, cy, pvx, pvy; } hob;
   std::vector<int> host_static;
   // scene
   DevBuf<int> o_type, o_dyn, o_voff, o_static, o_dynidx;
@@ -279,12 +285,15 @@ int launch(teb_amd_handle* h, const OptArgs& args) {
   int eff_solver = h->solver;
   LdsPlan eff_plan = h->plan;
   bool optimistic = false;
-  if (h->solver != SOLVER_CR && !args.debug_linearize && !getenv("TEB_AMD_FIXED_LAYOUT") && !getenv("TEB_AMD_SOLVER")) {
-    std::vector<int> n(h->B);
-    HIPCHK(hipMemcpyAsync(n.data(), h->n.p, h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    int nmax = 0;
-    for (int v : n) nmax = std::max(nmax, v);
+  if (h->solver != SOLVER_CR && !args.debug_linearize && !h->opt.fixed_layout && h->opt.layout == TEB_AMD_LAYOUT_AUTO && !h->band_ldlt) {
+    int nmax = h->nmax_known;
+    if (nmax < 0) {   // a device-side producer changed the bands since the host last saw their pose counts
+      std::vector<int> n(h->B);
+      HIPCHK(hipMemcpyAsync(n.data(), h->n.p, h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      nmax = 0;
+      for (int v : n) nmax = std::max(nmax, v);
+    }
     const int need = nmax + nmax / 8 + 4;   // 12.5 % room to grow; a band that needs more triggers the repeat below
     const int ob = h->fast_points ? h->M : 0;
     const int s_cr = max_capacity_of(h, SOLVER_CR, std::min(h->stride, 238));
@@ -310,11 +319,15 @@ int launch(teb_amd_handle* h, const OptArgs& args) {
   launch_opt(h, h->B, sc, bt, args, eff_solver, eff_plan);
   if (optimistic) {
     HIPCHK(hipGetLastError());
-    std::vector<int> ovf(h->B);
+    // this mode is synchronous: the overflow flags decide whether the launch has to be repeated (documented in teb_amd.h)
+    std::vector<int> ovf(h->B), nn(h->B);
     HIPCHK(hipMemcpyAsync(ovf.data(), h->assoc_ovf.p, h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(nn.data(), h->n.p, h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     bool outgrown = false;
     for (int v : ovf) outgrown = outgrown || (v & 2);
+    h->nmax_known = 0;
+    for (int v : nn) h->nmax_known = std::max(h->nmax_known, v);
     if (outgrown) {
       const size_t bytes = (size_t)h->B * h->stride * sizeof(double);
       HIPCHK(hipMemcpyAsync(h->x.p, h->ob_x.p, bytes, hipMemcpyDeviceToDevice, h->stream));
@@ -323,9 +336,11 @@ int launch(teb_amd_handle* h, const OptArgs& args) {
       HIPCHK(hipMemcpyAsync(h->dt.p, h->ob_dt.p, bytes, hipMemcpyDeviceToDevice, h->stream));
       HIPCHK(hipMemcpyAsync(h->n.p, h->ob_n.p, h->B * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
       HIPCHK(hipMemsetAsync(h->assoc_ovf.p, 0, sizeof(int) * h->max_tebs, h->stream));
-      HIPCHK(hipEventRecord(h->ev0, h->stream));
-      launch_opt(h, h->B, sc, bt, args);
+      launch_opt(h, h->B, sc, bt, args);   // ev0 stays where it was: the reported time includes the discarded first launch
+      h->nmax_known = -1;
     }
+  } else if (h->cfg.teb_autosize && !args.debug_linearize) {
+    h->nmax_known = -1;   // asynchronous launch: autoResize may change the pose counts
   }
   h->consumers_valid = false;
   h->hsig_mode = 0;   // the bands change: signatures of an earlier teb_amd_compute_h_signatures call are stale
@@ -345,6 +360,7 @@ int teb_amd_sizeof_config(void) { return (int)sizeof(teb_amd_config_t); }
 int teb_amd_sizeof_obstacles(void) { return (int)sizeof(teb_amd_obstacles_t); }
 int teb_amd_sizeof_teb_batch(void) { return (int)sizeof(teb_amd_teb_batch_t); }
 int teb_amd_sizeof_results(void) { return (int)sizeof(teb_amd_results_t); }
+int teb_amd_sizeof_options(void) { return (int)sizeof(teb_amd_options_t); }
 
 void teb_amd_config_default(teb_amd_config_t* c) {   // TebConfig::TebConfig(), reference teb_config.h:245-390
   std::memset(c, 0, sizeof(*c));
@@ -370,9 +386,30 @@ void teb_amd_config_default(teb_amd_config_t* c) {   // TebConfig::TebConfig(), 
   c->jacobian_mode = TEB_AMD_JACOBIAN_ANALYTIC;
 }
 
+void teb_amd_options_default(teb_amd_options_t* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->struct_size = (int32_t)sizeof(*o);
+}
+
 int teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_poses, int32_t max_obstacles,
                    int32_t max_obstacle_vertices, int32_t max_via_points, int32_t device, void* stream,
                    teb_amd_handle_t** out) {
+  return teb_amd_create_ex(cfg, max_tebs, max_poses, max_obstacles, max_obstacle_vertices, max_via_points, device, stream, nullptr, out);
+}
+
+int teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_poses, int32_t max_obstacles,
+                      int32_t max_obstacle_vertices, int32_t max_via_points, int32_t device, void* stream,
+                      const teb_amd_options_t* options, teb_amd_handle_t** out) {
+  teb_amd_options_t opt;
+  teb_amd_options_default(&opt);
+  if (options) {   // copy what the caller's (possibly older, shorter) struct holds
+    const size_t have = options->struct_size > 0 ? (size_t)options->struct_size : sizeof(opt);
+    std::memcpy(&opt, options, std::min(have, sizeof(opt)));
+    opt.struct_size = (int32_t)sizeof(opt);
+    if (opt.layout < TEB_AMD_LAYOUT_AUTO || opt.layout > TEB_AMD_LAYOUT_BAND_HBM || opt.hsig3d_kernel < 0 || opt.hsig3d_kernel > TEB_AMD_HSIG3D_SMALL)
+      return fail(TEB_AMD_ERR_INVALID_ARG, "teb_amd_options_t: unknown layout / hsig3d_kernel");
+  }
   if (!cfg || !out || max_tebs <= 0 || max_poses < 2 || max_obstacles < 0 || max_obstacle_vertices < 0 || max_via_points < 0)
     return fail(TEB_AMD_ERR_INVALID_ARG, "teb_amd_create: bad arguments");
   int rc = validate_config(cfg);
@@ -397,10 +434,11 @@ int teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_po
   else if ((size_t)make_lds_plan(max_poses, SOLVER_CR, max_obstacles > 0 ? max_obstacles : 0).total_bytes > lds_limit &&
            (size_t)make_lds_plan(max_poses, SOLVER_BAND, max_obstacles > 0 ? max_obstacles : 0).total_bytes <= lds_limit)
     solver = SOLVER_BAND;
-  if (const char* env = getenv("TEB_AMD_SOLVER")) {
-    if (std::strcmp(env, "band") == 0) solver = SOLVER_BAND;
-    else if (std::strcmp(env, "bandg") == 0) solver = SOLVER_BANDG;
-    else if (lds_bytes_for(max_poses, SOLVER_CR) <= lds_limit) solver = SOLVER_CR;
+  if (opt.layout == TEB_AMD_LAYOUT_BAND_LDS) solver = SOLVER_BAND;
+  else if (opt.layout == TEB_AMD_LAYOUT_BAND_HBM) solver = SOLVER_BANDG;
+  else if (opt.layout == TEB_AMD_LAYOUT_BLOCKS_LDS) {
+    if (lds_bytes_for(max_poses, SOLVER_CR) > lds_limit) return fail(TEB_AMD_ERR_CAPACITY, "TEB_AMD_LAYOUT_BLOCKS_LDS: max_poses too large for the block layout");
+    solver = SOLVER_CR;
   }
   // bands too long for the LDS band (> 343 poses; the reference's max_samples default is 500): the band form of the normal matrix
   // moves to HBM (SOLVER_BANDG: 44 doubles per pose, L2-resident), everything else stays as it is
@@ -418,6 +456,7 @@ int teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_po
   teb_amd_handle* h = new teb_amd_handle();
   h->device = device;
   h->cfg = *cfg;
+  h->opt = opt;
   h->max_tebs = max_tebs; h->stride = max_poses; h->max_obst = max_obstacles; h->max_verts = max_obstacle_vertices;
   h->max_via = max_via_points;
   h->lds_bytes = lds;
@@ -427,8 +466,7 @@ int teb_amd_create(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max_po
   // per-band HBM buffer: the copy of H for rejected trials (SOLVER_CR, banded LDL^T) or the blocks the cyclic reduction of a
   // SOLVER_BAND handle works on (D, L, f: nb * (2 * kBlk + 8) doubles)
   h->hmat_stride = std::max(hmat_doubles(max_poses, solver), (size_t)nb_for(max_poses) * (2 * kBlk + 8));
-  h->band_ldlt = 0;
-  if (const char* env = getenv("TEB_AMD_BAND_SOLVE")) h->band_ldlt = std::strcmp(env, "ldlt") == 0;
+  h->band_ldlt = opt.band_ldlt != 0;
   if (solver == SOLVER_BANDG) h->band_ldlt = 0;   // the sequential LDL^T works in place on an LDS band only
   if (stream) { h->stream = reinterpret_cast<hipStream_t>(stream); h->own_stream = false; }
   else {
@@ -502,77 +540,32 @@ void teb_amd_destroy(teb_amd_handle_t* h) {
   delete h;
 }
 
-int teb_amd_set_config(teb_amd_handle_t* h, const teb_amd_config_t* cfg) {
-  int rc = check_handle(h);
-  if (rc) return rc;
-  if (!cfg) return fail(TEB_AMD_ERR_INVALID_ARG, "null config");
-  rc = validate_config(cfg);
-  if (rc) return rc;
-  bool dyn_changed = (cfg->include_dynamic_obstacles != h->cfg.include_dynamic_obstacles) ||
-                     (cfg->footprint_type != h->cfg.footprint_type);
-  h->cfg = *cfg;
-  if (dyn_changed && h->M > 0)
-    return fail(TEB_AMD_ERR_INVALID_ARG, "include_dynamic_obstacles / footprint_type changed: call teb_amd_set_obstacles again");
-  return TEB_AMD_OK;
-}
-
-int teb_amd_set_obstacles(teb_amd_handle_t* h, const teb_amd_obstacles_t* o) {
-  int rc = check_handle(h);
-  if (rc) return rc;
-  if (!o || o->count < 0) return fail(TEB_AMD_ERR_INVALID_ARG, "null obstacle table");
-  const int M = o->count;
-  if (M > h->max_obst) return fail(TEB_AMD_ERR_CAPACITY, "more obstacles than max_obstacles");
-  if (M > 0 && (!o->type || !o->ax || !o->ay)) return fail(TEB_AMD_ERR_INVALID_ARG, "obstacle arrays missing");
-  std::vector<int> type(M), dyn(M), voff(M + 1, 0), st, dy;
-  std::vector<double> ax(M), ay(M), bx(M), by(M), rad(M), vx(M), vy(M), cx(M), cy(M), pvx, pvy;
+namespace {
+// (Re)derives everything that depends on BOTH the obstacle table held in h->hob and the configuration: the lists AddEdgesObstacles /
+// AddEdgesDynamicObstacles visit, the distance path (point-like LDS cache or generic) and the layout that goes with it.
+int commit_obstacles(teb_amd_handle* h) {
+  const auto& o = h->hob;
+  const int M = (int)o.type.size();
+  std::vector<int> st, dy;
   for (int i = 0; i < M; ++i) {
-    type[i] = o->type[i];
-    ax[i] = o->ax[i]; ay[i] = o->ay[i];
-    bx[i] = o->bx ? o->bx[i] : 0; by[i] = o->by ? o->by[i] : 0;
-    rad[i] = o->radius ? o->radius[i] : 0;
-    vx[i] = o->vx ? o->vx[i] : 0; vy[i] = o->vy ? o->vy[i] : 0;
-    dyn[i] = o->dynamic ? (o->dynamic[i] != 0) : 0;
-    voff[i] = (int)pvx.size();
-    switch (type[i]) {
-      case TEB_AMD_OBST_POINT: case TEB_AMD_OBST_CIRCULAR: cx[i] = ax[i]; cy[i] = ay[i]; break;
-      case TEB_AMD_OBST_LINE: case TEB_AMD_OBST_PILL: cx[i] = 0.5 * (ax[i] + bx[i]); cy[i] = 0.5 * (ay[i] + by[i]); break;
-      case TEB_AMD_OBST_POLYGON: {
-        if (!o->vert_offset || !o->vert_x || !o->vert_y) return fail(TEB_AMD_ERR_INVALID_ARG, "polygon obstacle without vertex arrays");
-        int k0 = o->vert_offset[i], k1 = o->vert_offset[i + 1];
-        if (k1 <= k0) return fail(TEB_AMD_ERR_INVALID_ARG, "polygon obstacle without vertices");
-        for (int k = k0; k < k1; ++k) { pvx.push_back(o->vert_x[k]); pvy.push_back(o->vert_y[k]); }
-        polygon_centroid(o->vert_x + k0, o->vert_y + k0, k1 - k0, cx[i], cy[i]);
-        break;
-      }
-      default: return fail(TEB_AMD_ERR_INVALID_ARG, "unknown obstacle type");
-    }
     // AddEdgesObstacles skips dynamic obstacles iff include_dynamic_obstacles (optimal_planner.cpp:496-497);
     // AddEdgesDynamicObstacles visits the dynamic ones (:658-659)
-    if (h->cfg.include_dynamic_obstacles && dyn[i]) dy.push_back(i); else st.push_back(i);
+    if (h->cfg.include_dynamic_obstacles && o.dyn[i]) dy.push_back(i); else st.push_back(i);
   }
-  voff[M] = (int)pvx.size();
-  if ((int)pvx.size() > h->max_verts) return fail(TEB_AMD_ERR_CAPACITY, "more polygon vertices than max_obstacle_vertices");
   auto up_i = [&](DevBuf<int>& d, const std::vector<int>& v) { return v.empty() ? hipSuccess : hipMemcpyAsync(d.p, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, h->stream); };
-  auto up_d = [&](DevBuf<double>& d, const std::vector<double>& v) { return v.empty() ? hipSuccess : hipMemcpyAsync(d.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, h->stream); };
-  HIPCHK(up_i(h->o_type, type)); HIPCHK(up_i(h->o_dyn, dyn)); HIPCHK(up_i(h->o_voff, voff)); HIPCHK(up_i(h->o_static, st)); HIPCHK(up_i(h->o_dynidx, dy));
-  HIPCHK(up_d(h->o_ax, ax)); HIPCHK(up_d(h->o_ay, ay)); HIPCHK(up_d(h->o_bx, bx)); HIPCHK(up_d(h->o_by, by)); HIPCHK(up_d(h->o_rad, rad));
-  HIPCHK(up_d(h->o_vx, vx)); HIPCHK(up_d(h->o_vy, vy)); HIPCHK(up_d(h->o_cx, cx)); HIPCHK(up_d(h->o_cy, cy));
-  HIPCHK(up_d(h->o_pvx, pvx)); HIPCHK(up_d(h->o_pvy, pvy));
+  HIPCHK(up_i(h->o_static, st)); HIPCHK(up_i(h->o_dynidx, dy));
   HIPCHK(hipStreamSynchronize(h->stream));   // host vectors go out of scope
-  h->M = M; h->n_static = (int)st.size(); h->n_dyn = (int)dy.size();
-  h->host_type = type;
-  h->host_cx = cx; h->host_cy = cy;
-  h->hsig_mode = 0;   // signatures depend on the obstacle table
-  h->hs_prod_valid = false;
+  h->n_static = (int)st.size(); h->n_dyn = (int)dy.size();
   h->host_static = st;
+  h->hsig_mode = 0;   // signatures depend on the obstacle table and on include_dynamic_obstacles
   // point-like fast path: all obstacles Point/Circular, footprint Point/Circular, and the cache fits the LDS
   bool pointlike = (h->cfg.footprint_type == TEB_AMD_FOOTPRINT_POINT || h->cfg.footprint_type == TEB_AMD_FOOTPRINT_CIRCULAR);
-  for (int i = 0; i < M && pointlike; ++i) pointlike = (type[i] == TEB_AMD_OBST_POINT || type[i] == TEB_AMD_OBST_CIRCULAR);
-  if (getenv("TEB_AMD_NO_FAST_POINTS")) pointlike = false;
+  for (int i = 0; i < M && pointlike; ++i) pointlike = (o.type[i] == TEB_AMD_OBST_POINT || o.type[i] == TEB_AMD_OBST_CIRCULAR);
+  if (h->opt.generic_distance_path) pointlike = false;
   // a point-like scene whose obstacle cache does not fit beside the LDS band: the band moves to HBM and the cache stays (measured,
   // 64 bands x 343 poses x 500 obstacles: 9.0 instead of 11.8 ms per step)
   h->solver = h->solver_created;
-  if (pointlike && M > 0 && h->solver == SOLVER_BAND && !getenv("TEB_AMD_SOLVER") &&
+  if (pointlike && M > 0 && h->solver == SOLVER_BAND && h->opt.layout == TEB_AMD_LAYOUT_AUTO &&
       (size_t)make_lds_plan(h->stride, SOLVER_BAND, M).total_bytes > h->lds_limit &&
       (size_t)make_lds_plan(h->stride, SOLVER_BANDG, M).total_bytes <= h->lds_limit) {
     if (h->hband_stride == 0) {
@@ -586,6 +579,69 @@ int teb_amd_set_obstacles(teb_amd_handle_t* h, const teb_amd_obstacles_t* o) {
   if (pointlike && M > 0 && (size_t)with_cache.total_bytes <= h->lds_limit) { h->fast_points = 1; h->plan = with_cache; }
   else { h->fast_points = 0; h->plan = make_lds_plan(h->stride, h->solver, 0); }
   return TEB_AMD_OK;
+}
+}  // namespace
+
+int teb_amd_set_config(teb_amd_handle_t* h, const teb_amd_config_t* cfg) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!cfg) return fail(TEB_AMD_ERR_INVALID_ARG, "null config");
+  rc = validate_config(cfg);
+  if (rc) return rc;   // the handle keeps its previous configuration
+  const bool lists_changed = (cfg->include_dynamic_obstacles != h->cfg.include_dynamic_obstacles) ||
+                             (cfg->footprint_type != h->cfg.footprint_type);
+  h->cfg = *cfg;
+  if (lists_changed && h->M > 0) return commit_obstacles(h);
+  return TEB_AMD_OK;
+}
+
+int teb_amd_set_obstacles(teb_amd_handle_t* h, const teb_amd_obstacles_t* o) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!o || o->count < 0) return fail(TEB_AMD_ERR_INVALID_ARG, "null obstacle table");
+  const int M = o->count;
+  if (M > h->max_obst) return fail(TEB_AMD_ERR_CAPACITY, "more obstacles than max_obstacles");
+  if (M > 0 && (!o->type || !o->ax || !o->ay)) return fail(TEB_AMD_ERR_INVALID_ARG, "obstacle arrays missing");
+  teb_amd_handle::HostObst t;
+  t.type.resize(M); t.dyn.resize(M); t.voff.assign(M + 1, 0);
+  t.ax.resize(M); t.ay.resize(M); t.bx.resize(M); t.by.resize(M); t.rad.resize(M); t.vx.resize(M); t.vy.resize(M); t.cx.resize(M); t.cy.resize(M);
+  for (int i = 0; i < M; ++i) {
+    t.type[i] = o->type[i];
+    t.ax[i] = o->ax[i]; t.ay[i] = o->ay[i];
+    t.bx[i] = o->bx ? o->bx[i] : 0; t.by[i] = o->by ? o->by[i] : 0;
+    t.rad[i] = o->radius ? o->radius[i] : 0;
+    t.vx[i] = o->vx ? o->vx[i] : 0; t.vy[i] = o->vy ? o->vy[i] : 0;
+    t.dyn[i] = o->dynamic ? (o->dynamic[i] != 0) : 0;
+    t.voff[i] = (int)t.pvx.size();
+    switch (t.type[i]) {
+      case TEB_AMD_OBST_POINT: case TEB_AMD_OBST_CIRCULAR: t.cx[i] = t.ax[i]; t.cy[i] = t.ay[i]; break;
+      case TEB_AMD_OBST_LINE: case TEB_AMD_OBST_PILL: t.cx[i] = 0.5 * (t.ax[i] + t.bx[i]); t.cy[i] = 0.5 * (t.ay[i] + t.by[i]); break;
+      case TEB_AMD_OBST_POLYGON: {
+        if (!o->vert_offset || !o->vert_x || !o->vert_y) return fail(TEB_AMD_ERR_INVALID_ARG, "polygon obstacle without vertex arrays");
+        int k0 = o->vert_offset[i], k1 = o->vert_offset[i + 1];
+        if (k1 <= k0) return fail(TEB_AMD_ERR_INVALID_ARG, "polygon obstacle without vertices");
+        for (int k = k0; k < k1; ++k) { t.pvx.push_back(o->vert_x[k]); t.pvy.push_back(o->vert_y[k]); }
+        polygon_centroid(o->vert_x + k0, o->vert_y + k0, k1 - k0, t.cx[i], t.cy[i]);
+        break;
+      }
+      default: return fail(TEB_AMD_ERR_INVALID_ARG, "unknown obstacle type");
+    }
+  }
+  t.voff[M] = (int)t.pvx.size();
+  if ((int)t.pvx.size() > h->max_verts) return fail(TEB_AMD_ERR_CAPACITY, "more polygon vertices than max_obstacle_vertices");
+  auto up_i = [&](DevBuf<int>& d, const std::vector<int>& v) { return v.empty() ? hipSuccess : hipMemcpyAsync(d.p, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, h->stream); };
+  auto up_d = [&](DevBuf<double>& d, const std::vector<double>& v) { return v.empty() ? hipSuccess : hipMemcpyAsync(d.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, h->stream); };
+  HIPCHK(up_i(h->o_type, t.type)); HIPCHK(up_i(h->o_dyn, t.dyn)); HIPCHK(up_i(h->o_voff, t.voff));
+  HIPCHK(up_d(h->o_ax, t.ax)); HIPCHK(up_d(h->o_ay, t.ay)); HIPCHK(up_d(h->o_bx, t.bx)); HIPCHK(up_d(h->o_by, t.by)); HIPCHK(up_d(h->o_rad, t.rad));
+  HIPCHK(up_d(h->o_vx, t.vx)); HIPCHK(up_d(h->o_vy, t.vy)); HIPCHK(up_d(h->o_cx, t.cx)); HIPCHK(up_d(h->o_cy, t.cy));
+  HIPCHK(up_d(h->o_pvx, t.pvx)); HIPCHK(up_d(h->o_pvy, t.pvy));
+  HIPCHK(hipStreamSynchronize(h->stream));   // the uploads read `t`
+  h->M = M;
+  h->host_type = t.type;
+  h->host_cx = t.cx; h->host_cy = t.cy;
+  h->hs_prod_valid = false;
+  h->hob = std::move(t);
+  return commit_obstacles(h);
 }
 
 int teb_amd_set_via_points(teb_amd_handle_t* h, int32_t count, const double* x, const double* y) {
@@ -644,7 +700,7 @@ int teb_amd_upload_tebs(teb_amd_handle_t* h, const teb_amd_teb_batch_t* bt) {
   HIPCHK(hipMemsetAsync(h->optimized.p, 0, B * sizeof(int), h->stream));   // bands from the host: optimized_ unknown -> false
   HIPCHK(hipStreamSynchronize(h->stream));
   h->B = B;
-  h->consumers_valid = false;
+  h->consumers_valid = false; h->nmax_known = nmax;
   h->hsig_mode = 0;   // the bands change: signatures of an earlier teb_amd_compute_h_signatures call are stale
   return TEB_AMD_OK;
 }
@@ -726,6 +782,120 @@ int teb_amd_select_best(teb_amd_handle_t* h, int32_t last_best, int32_t initial_
   return TEB_AMD_OK;
 }
 
+// ---- multi-GPU: the selection exchange (teb_comm.hpp) --------------------------------------------------------------------------------
+#define NCCLCHK(expr)                                                                                                     \
+  do {                                                                                                                    \
+    ncclResult_t _r = (expr);                                                                                             \
+    if (_r != ncclSuccess) return fail(TEB_AMD_ERR_HIP, std::string(#expr) + " -> " + rccl().GetErrorString(_r));         \
+  } while (0)
+
+int teb_amd_comm_unique_id(char id[TEB_AMD_COMM_ID_BYTES]) {
+  static_assert(sizeof(ncclUniqueId) == TEB_AMD_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+  if (!id) return fail(TEB_AMD_ERR_INVALID_ARG, "null id buffer");
+  if (!rccl().load()) return fail(TEB_AMD_ERR_UNSUPPORTED, rccl().error);
+  ncclUniqueId u;
+  NCCLCHK(rccl().GetUniqueId(&u));
+  std::memcpy(id, &u, sizeof(u));
+  return TEB_AMD_OK;
+}
+
+int teb_amd_comm_create(const char id[TEB_AMD_COMM_ID_BYTES], int32_t rank, int32_t world, int32_t device, teb_amd_comm_t** out) {
+  if (!id || !out || world < 1 || rank < 0 || rank >= world) return fail(TEB_AMD_ERR_INVALID_ARG, "teb_amd_comm_create: bad arguments");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(TEB_AMD_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(TEB_AMD_ERR_INVALID_ARG, "device ordinal out of range");
+  if (!rccl().load()) return fail(TEB_AMD_ERR_UNSUPPORTED, rccl().error);
+  HIPCHK(hipSetDevice(device));
+  teb_amd_comm* c = new teb_amd_comm();
+  c->rank = rank; c->world = world; c->device = device;
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof(u));
+  ncclResult_t r = rccl().CommInitRank(&c->comm, world, u, rank);
+  if (r != ncclSuccess) { delete c; return fail(TEB_AMD_ERR_HIP, std::string("ncclCommInitRank -> ") + rccl().GetErrorString(r)); }
+  if (hipMalloc(reinterpret_cast<void**>(&c->rec), 2 * sizeof(double)) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&c->all), 2 * (size_t)world * sizeof(double)) != hipSuccess) {
+    teb_amd_comm_destroy(c);
+    return fail(TEB_AMD_ERR_HIP, "teb_amd_comm_create: device allocation failed");
+  }
+  *out = c;
+  return TEB_AMD_OK;
+}
+
+void teb_amd_comm_destroy(teb_amd_comm_t* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->comm && rccl().lib) (void)rccl().CommDestroy(c->comm);
+  if (c->rec) (void)hipFree(c->rec);
+  if (c->all) (void)hipFree(c->all);
+  if (c->msg) (void)hipFree(c->msg);
+  delete c;
+}
+
+int teb_amd_select_best_distributed(teb_amd_handle_t* h, teb_amd_comm_t* c, int32_t global_offset, int32_t last_best_global,
+                                    int32_t initial_plan_global, int32_t* best_global, double* best_cost, int32_t* owner_rank) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!c || !c->comm || !best_global) return fail(TEB_AMD_ERR_INVALID_ARG, "teb_amd_select_best_distributed: null communicator / output");
+  if (c->device != h->device) return fail(TEB_AMD_ERR_INVALID_ARG, "communicator and handle live on different devices");
+  const int have = h->B > 0;
+  if (have) {   // local arg-min with the multipliers applied where this rank owns the favoured candidates
+    int lb = last_best_global - global_offset, ip = initial_plan_global - global_offset;
+    if (last_best_global < 0 || lb < 0 || lb >= h->B) lb = -1;
+    if (initial_plan_global < 0 || ip < 0 || ip >= h->B) ip = -1;
+    hipLaunchKernelGGL(select_best_kernel, dim3(1), dim3(kThreads), 0, h->stream, h->cost.p, h->B, lb, ip,
+                       h->cfg.selection_cost_hysteresis, h->cfg.selection_prefer_initial_plan, h->sel_cost.p, h->sel_idx.p);
+  }
+  hipLaunchKernelGGL(pack_record_kernel, dim3(1), dim3(64), 0, h->stream, h->sel_cost.p, h->sel_idx.p, global_offset, have, c->rec);
+  HIPCHK(hipGetLastError());
+  NCCLCHK(rccl().AllGather(c->rec, c->all, 2, ncclDouble, c->comm, h->stream));
+  std::vector<double> all(2 * (size_t)c->world);
+  HIPCHK(hipMemcpyAsync(all.data(), c->all, all.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  double bc = 1.7976931348623157e308; int bi = -1, owner = -1;
+  for (int r = 0; r < c->world; ++r) {
+    const double cst = all[2 * r]; const int idx = (int)all[2 * r + 1];
+    if (idx < 0) continue;
+    if (bi < 0 || cst < bc || (cst == bc && idx < bi)) { bc = cst; bi = idx; owner = r; }
+  }
+  *best_global = bi;
+  if (best_cost) *best_cost = bc;
+  if (owner_rank) *owner_rank = owner;
+  return TEB_AMD_OK;
+}
+
+int teb_amd_broadcast_band(teb_amd_handle_t* h, teb_amd_comm_t* c, int32_t owner_rank, int32_t local_index, int32_t capacity, int32_t* n,
+                           double* x, double* y, double* theta, double* dt) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!c || !c->comm || !n || !x || !y || !theta || !dt || capacity < 2) return fail(TEB_AMD_ERR_INVALID_ARG, "teb_amd_broadcast_band: bad arguments");
+  if (owner_rank < 0 || owner_rank >= c->world) return fail(TEB_AMD_ERR_INVALID_ARG, "owner_rank out of range");
+  if (c->rank == owner_rank && (local_index < 0 || local_index >= h->B)) return fail(TEB_AMD_ERR_INVALID_ARG, "local_index out of range on the owner");
+  const size_t count = 1 + 4 * (size_t)capacity;
+  if (c->msg_cap < count) {
+    if (c->msg) (void)hipFree(c->msg);
+    c->msg = nullptr; c->msg_cap = 0;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->msg), count * sizeof(double)));
+    c->msg_cap = count;
+  }
+  if (c->rank == owner_rank) {
+    hipLaunchKernelGGL(pack_band_kernel, dim3((capacity + 255) / 256), dim3(256), 0, h->stream, h->n.p, h->x.p, h->y.p, h->th.p, h->dt.p,
+                       local_index, h->stride, capacity, c->msg);
+    HIPCHK(hipGetLastError());
+  }
+  NCCLCHK(rccl().Broadcast(c->msg, c->msg, count, ncclDouble, owner_rank, c->comm, h->stream));
+  std::vector<double> host(count);
+  HIPCHK(hipMemcpyAsync(host.data(), c->msg, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const int nb = (int)host[0];
+  *n = nb;
+  if (nb > capacity) return fail(TEB_AMD_ERR_CAPACITY, "the winner has more poses than `capacity`");
+  std::memcpy(x, host.data() + 1, capacity * sizeof(double));
+  std::memcpy(y, host.data() + 1 + capacity, capacity * sizeof(double));
+  std::memcpy(theta, host.data() + 1 + 2 * (size_t)capacity, capacity * sizeof(double));
+  std::memcpy(dt, host.data() + 1 + 3 * (size_t)capacity, capacity * sizeof(double));
+  return TEB_AMD_OK;
+}
+
 // ---- f1 / f2: producers and consumers of the device-resident strips (kernels in teb_strip.hpp) ---------------------------------
 namespace {
 
@@ -762,7 +932,7 @@ int finish_init(teb_amd_handle* h) {
   int err = 0;
   HIPCHK(hipMemcpyAsync(&err, h->err_flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  h->consumers_valid = false;
+  h->consumers_valid = false; h->nmax_known = -1;
   h->hsig_mode = 0;   // the bands change: signatures of an earlier teb_amd_compute_h_signatures call are stale
   if (err) return fail(TEB_AMD_ERR_CAPACITY, "initTrajectoryToGoal: the band needs more poses than max_poses");
   return TEB_AMD_OK;
@@ -848,7 +1018,7 @@ int teb_amd_update_and_prune(teb_amd_handle_t* h, int32_t b, const double* new_s
   hipLaunchKernelGGL(prune_kernel, dim3(b < 0 ? h->B : 1), dim3(kThreads), 4 * (size_t)h->stride * sizeof(double), h->stream,
                      batch_of(h), b < 0 ? 0 : b, new_start ? 1 : 0, s[0], s[1], s[2], new_goal ? 1 : 0, g[0], g[1], g[2], min_samples);
   HIPCHK(hipGetLastError());
-  h->consumers_valid = false;
+  h->consumers_valid = false; h->nmax_known = -1;
   h->hsig_mode = 0;   // the bands change: signatures of an earlier teb_amd_compute_h_signatures call are stale
   return TEB_AMD_OK;
 }
@@ -866,7 +1036,7 @@ int set_velocity(teb_amd_handle* h, DevBuf<int>& flag, DevBuf<double>& vel, int 
     HIPCHK(hipMemcpyAsync(vel.p + 3 * b0, vv.data(), vv.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   }
   HIPCHK(hipStreamSynchronize(h->stream));
-  h->consumers_valid = false;
+  h->consumers_valid = false; h->nmax_known = -1;
   return TEB_AMD_OK;
 }
 }  // namespace
@@ -959,7 +1129,7 @@ int launch_hsig(teb_amd_handle* h, const BatchDev& bt, int B, double prescaler, 
   if (h->cfg.include_dynamic_obstacles) {
     if (M > 0) {
       // one lane per (band, obstacle) when that fills the chip; otherwise lanes over (obstacle, segment): same bits, lower latency
-      const char* force = std::getenv("TEB_AMD_HSIG3D");   // "wide" / "small": pin one of the two kernels (tests, tools/hsig_bench.py)
+      const char* force = h->opt.hsig3d_kernel == TEB_AMD_HSIG3D_WIDE ? "wide" : h->opt.hsig3d_kernel == TEB_AMD_HSIG3D_SMALL ? "small" : nullptr;   // teb_amd_options_t::hsig3d_kernel pins one of the two kernels (tests, tools/hsig_bench.py)
       const bool wide = force ? std::strcmp(force, "wide") == 0 : (long long)B * M >= 32768;
       if (wide)
         hipLaunchKernelGGL(hsig3d_kernel, dim3((M + kThreads - 1) / kThreads, B), dim3(kThreads), 3 * (size_t)h->stride * sizeof(double),
@@ -1233,7 +1403,7 @@ int teb_amd_explore_candidates(teb_amd_handle_t* h, const teb_amd_hcp_params_t* 
     if (err) return fail(TEB_AMD_ERR_CAPACITY, "candidate band needs more poses than max_poses");
     return TEB_AMD_OK;
   };
-  h->consumers_valid = false;
+  h->consumers_valid = false; h->nmax_known = -1;
   // ---- the initial plan as a candidate: addAndInitNewTeb(*initial_plan_, ...), src/homotopy_class_planner.cpp:326-329, 412-440
   int initial_idx = -1;   // initial_plan_teb_
   if (n_plan > 0 && h->B < slots) {
@@ -1472,7 +1642,7 @@ int teb_amd_compact_bands(teb_amd_handle_t* h, const int32_t* keep, int32_t best
     h->hsig_mode = 0;
   }
   h->B = K;
-  h->consumers_valid = false;
+  h->consumers_valid = false; h->nmax_known = -1;
   return TEB_AMD_OK;
 }
 
@@ -1568,6 +1738,7 @@ int teb_amd_snapshot_state(teb_amd_handle_t* h) {
   HIPCHK(hipMemcpyAsync(h->snap_th.p, h->th.p, BS, hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->snap_dt.p, h->dt.p, BS, hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->snap_n.p, h->n.p, h->max_tebs * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+  h->snap_nmax = h->nmax_known;
   return TEB_AMD_OK;
 }
 
@@ -1580,7 +1751,7 @@ int teb_amd_restore_state(teb_amd_handle_t* h) {
   HIPCHK(hipMemcpyAsync(h->th.p, h->snap_th.p, BS, hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->dt.p, h->snap_dt.p, BS, hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->n.p, h->snap_n.p, h->max_tebs * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
-  h->consumers_valid = false;
+  h->consumers_valid = false; h->nmax_known = h->snap_nmax;
   h->hsig_mode = 0;   // the bands change: signatures of an earlier teb_amd_compute_h_signatures call are stale
   return TEB_AMD_OK;
 }

@@ -1,0 +1,73 @@
+// teb_comm.hpp — the path's only exchange step behind the C-ABI: best-trajectory selection across the ranks
+// that share one candidate batch, and the broadcast of the winner's strip. One process per GPU; RCCL over xGMI.
+//
+// Reference: the reduction is HomotopyClassPlanner::selectBestTeb (src/homotopy_class_planner.cpp:564-667) - an arg-min with strict '<'
+// (lowest index wins ties, :610) over costs that already carry the hysteresis / prefer-initial-plan multipliers. Each rank reduces its
+// own candidates on the device (select_best_kernel), contributes ONE 16-byte record (cost f64, global index as f64) to an
+// ncclAllGather, and every rank takes the lexicographic minimum of the world records - bit-exact costs, no second collective.
+// librccl is loaded with dlopen on first use: single-GPU users of libteb_amd.so neither link nor load it.
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace tebamd {
+
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+  bool load() {
+    if (lib) return true;
+    // a copy already in the process (e.g. the one PyTorch ships) is reused: two RCCL instances in one process would each claim the GPUs
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD))) break;
+    if (!lib) for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!lib) { error = std::string("librccl not found: ") + dlerror(); return false; }
+    auto sym = [&](const char* s) { void* p = dlsym(lib, s); if (!p) error = std::string("librccl lacks ") + s; return p; };
+    GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
+    CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+    AllGather = reinterpret_cast<decltype(AllGather)>(sym("ncclAllGather"));
+    Broadcast = reinterpret_cast<decltype(Broadcast)>(sym("ncclBroadcast"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllGather || !Broadcast || !GetErrorString) { dlclose(lib); lib = nullptr; return false; }
+    return true;
+  }
+};
+inline RcclApi& rccl() { static RcclApi api; return api; }
+
+// record of this rank for the all-gather: (scaled cost, global index) from the result of select_best_kernel; an empty rank sends (max, -1)
+__global__ void pack_record_kernel(const double* sel_cost, const int* sel_idx, int offset, int have, double* rec) {
+  if (threadIdx.x == 0) {
+    const int i = have ? *sel_idx : -1;
+    rec[0] = (have && i >= 0) ? *sel_cost : 1.7976931348623157e308;
+    rec[1] = i >= 0 ? (double)(offset + i) : -1.0;
+  }
+}
+// winner's strip -> one contiguous message [n | x | y | theta | dt], each strip `cap` doubles
+__global__ void pack_band_kernel(const int* n, const double* x, const double* y, const double* th, const double* dt, int b, int stride, int cap,
+                                 double* msg) {
+  const int nb = n[b];
+  if (blockIdx.x == 0 && threadIdx.x == 0) msg[0] = (double)nb;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x) {
+    const bool in = i < nb && i < stride;
+    const size_t o = (size_t)b * stride + i;
+    msg[1 + i] = in ? x[o] : 0.0; msg[1 + cap + i] = in ? y[o] : 0.0; msg[1 + 2 * cap + i] = in ? th[o] : 0.0; msg[1 + 3 * cap + i] = in ? dt[o] : 0.0;
+  }
+}
+
+}  // namespace tebamd
+
+struct teb_amd_comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+  double* rec = nullptr;       // [2] this rank's record
+  double* all = nullptr;       // [2 * world]
+  double* msg = nullptr;       // broadcast message, msg_cap doubles
+  size_t msg_cap = 0;
+};

@@ -45,7 +45,7 @@ struct Lds {
 
 __host__ __device__ inline int nb_for(int S) { return (4 * S + 7) / 8; }
 __host__ __device__ inline size_t hmat_doubles(int S, int solver) {  // (LDS-resident part)
-  if (solver == SOLVER_BANDG) return (size_t)4 * S + 256;   // only the scratch of autoResize (sweep output + split stack)
+  if (solver == SOLVER_BANDG) return (size_t)5 * S + 256;   // only the scratch of autoResize (edit script + new poses + split stack)
   return solver == SOLVER_CR ? (size_t)nb_for(S) * (2 * kBlk + 8) : (size_t)4 * S * kBand;
 }
 // host: lay out the LDS; ob_entries = obstacles to cache (0 = no cache). Returns total bytes.
@@ -906,60 +906,80 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, const SceneDev&
 }
 
 // ---- TimedElasticBand::autoResize (src/timed_elastic_band.cpp:227-286) -------------------------------------
-// One sweep, executed by thread 0 as a streaming pass LDS strip -> LDS scratch (no O(n) inserts).
-// Reproduces the sequential i-- re-check semantics: `cur` is the interval under test, `stack` holds the
-// right halves produced by splits that still wait to be visited.
-__device__ __noinline__ void autoresize_sweep_thread0(double dt_ref, double hyst, int max_samples, int min_samples, int off_state,
-                                                        int off_scratch, int n_in, int stride, int* n_out, int* modified_out,
-                                                        int* overflow) {
+// The rules of a sweep read and write TIME DIFFERENCES only (and the interval count); poses are carried along, and a split inserts
+// PoseSE2::average of the two poses either side (pose_se2.h:266-269). So a sweep is split in two:
+//   1. one lane runs the reference's sequential rule machine on the dt array alone (exact `i--` re-check semantics: `cur` is the
+//      interval under test, `stack` holds the right halves of splits that still wait to be visited) and emits an EDIT SCRIPT: the new
+//      dt array, for every output pose a descriptor (input pose j, or new pose q) and for every new pose its two parents (input or
+//      earlier new poses - repeated splits of one interval form a small tree) and its depth in that tree;
+//   2. all lanes apply the script: new poses level by level (depth 1 = both parents are input poses), then a gather of the output strip.
+// Pose descriptors: d < kNewPose = input pose d, else new pose d - kNewPose. New-pose record: parent A | parent B << 11 | depth << 22.
+constexpr int kNewPose = 1024;
+constexpr int kSplitStack = 64;
+// scratch (doubles from off_scratch): odt[S] | nx[S] ny[S] nth[S] | ints: out_desc[S] rec[S] | stack dt[64] | ints: stack desc[64]
+__host__ __device__ inline size_t autoresize_scratch_doubles(int S) { return (size_t)5 * S + kSplitStack + kSplitStack / 2 + 8; }
+
+// wave-uniform copy of a value: arguments of an out-of-line device function arrive in VGPRs and count as divergent, which would turn
+// every `if` of the rule machine into exec-mask bookkeeping (measured: ~860 cycles per rule evaluation); from SGPRs the loop is
+// compiled to scalar branches
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+// results: out[0] = n_out, out[1] = modified, out[2] = overflow, out[3] = #new poses, out[4] = deepest split tree (ints at off_out, in
+// units of ints from the LDS base)
+__device__ __noinline__ void autoresize_script_lane0(double dt_ref_, double hyst_, int max_samples_, int min_samples_, int off_state_,
+                                                       int off_scratch_, int n_in_, int stride_, int off_out_) {
   // all operands are addressed from the dynamic LDS base inside this function, so that the sequential loop is compiled to
   // ds_read / ds_write (generic pointers handed in from the caller would make every access a flat_load / flat_store)
   extern __shared__ __attribute__((aligned(16))) double lds_base[];
-  const double* in_x = lds_base + off_state; const double* in_y = in_x + stride; const double* in_th = in_y + stride;
-  const double* in_dt = in_th + stride; const double* in_cs = in_dt + 2 * stride; const double* in_sn = in_cs + stride;   // Lds: sx sy sth sdt tdyn cs sn
-  double* ox = lds_base + off_scratch; double* oy = ox + stride; double* oth = oy + stride; double* odt = oth + stride;
-  double* stk = odt + stride;
+  const double dt_ref = uni(dt_ref_), hyst = uni(hyst_);
+  const int max_samples = uni(max_samples_), min_samples = uni(min_samples_), off_state = uni(off_state_), off_scratch = uni(off_scratch_),
+            n_in = uni(n_in_), stride = uni(stride_);
+  int* res = reinterpret_cast<int*>(lds_base) + uni(off_out_);
+  int ovf = 0;
+  const double* in_dt = lds_base + off_state + 3 * stride;   // Lds: sx sy sth sdt ...
+  double* odt = lds_base + off_scratch;
+  int* out_desc = reinterpret_cast<int*>(odt + 4 * stride);
+  int* rec = out_desc + stride;
+  double* stk_dt = odt + 5 * stride;
+  int* stk_desc = reinterpret_cast<int*>(stk_dt + kSplitStack);
   const int Tin = n_in - 1;
   int T = Tin;           // sizeTimeDiffs()
   int j = 1;             // next unread input interval
-  int sp = 0;            // stack size (entries: x, y, th, dt)
+  int sp = 0;            // stack size
   int k = 0;             // emitted intervals
+  int nn = 0, md = 0;    // new poses, deepest split tree
   bool modified = false;
-  double cx = in_x[0], cy = in_y[0], cth = in_th[0], cdt = in_dt[0];
-  const double gx = in_x[n_in - 1], gy = in_y[n_in - 1], gth = in_th[n_in - 1];
-  // cos / sin of the input poses come from the per-pose cache (refreshed by the caller); poses created by a split compute theirs
-  // only if they are split again. ci < 0: the current pose is such a new pose.
-  int ci = 0;
-  // the next unread input interval is kept in registers one step ahead, so that its LDS latency overlaps the rule evaluation
-  double px = 0, py = 0, pth = 0, pdt = 0;
-  if (j < Tin) { px = in_x[j]; py = in_y[j]; pth = in_th[j]; pdt = in_dt[j]; }
+  int cdesc = 0, cdepth = 0;
+  double cdt = in_dt[0];
+  // the next unread input interval is kept in a register one step ahead, so that its LDS latency overlaps the rule evaluation
+  double pdt = (j < Tin) ? in_dt[j] : 0.0;
   bool alive = Tin >= 1;
+  int top_desc = 0, top_depth = 0; double top_dt = 0;   // register copy of the stack top
   while (alive) {
     const bool has_next = (sp > 0) || (j < Tin);
     if (cdt > dt_ref + hyst && T < max_samples) {
       if (cdt > 2 * dt_ref) {
-        double newtime = 0.5 * cdt;
-        double ex, ey, eth;   // Pose(i+1)
-        int ei;               // its input index, or -1 for a pose created in this sweep
-        if (sp > 0) { ex = stk[4 * (sp - 1)]; ey = stk[4 * (sp - 1) + 1]; eth = stk[4 * (sp - 1) + 2]; ei = -1; }
-        else if (j < Tin) { ex = px; ey = py; eth = pth; ei = j; }
-        else { ex = gx; ey = gy; eth = gth; ei = n_in - 1; }
-        if (sp >= 64) { *overflow = 1; break; }
-        // PoseSE2::average (pose_se2.h:266-269) with g2o::average_angle
-        const double cc = ci >= 0 ? in_cs[ci] : cos(cth), cs_ = ci >= 0 ? in_sn[ci] : sin(cth);
-        const double ec = ei >= 0 ? in_cs[ei] : cos(eth), es = ei >= 0 ? in_sn[ei] : sin(eth);
-        double sxn = cc + ec, syn = cs_ + es;
-        stk[4 * sp] = (cx + ex) / 2; stk[4 * sp + 1] = (cy + ey) / 2;
-        stk[4 * sp + 2] = (sxn == 0 && syn == 0) ? 0.0 : atan2(syn, sxn);
-        stk[4 * sp + 3] = newtime;
-        ++sp;
+        const double newtime = 0.5 * cdt;
+        // Pose(i+1): the stack top, else the next input pose, else the goal
+        int edesc, edepth;
+        if (sp > 0) { edesc = top_desc; edepth = top_depth; }
+        else { edesc = (j < Tin) ? j : n_in - 1; edepth = 0; }
+        if (sp >= kSplitStack || nn >= stride) { ovf = 1; break; }
+        const int depth = 1 + (cdepth > edepth ? cdepth : edepth);
+        rec[nn] = cdesc | (edesc << 11) | (depth << 22);
+        md = depth > md ? depth : md;
+        if (sp > 0) { stk_dt[sp - 1] = top_dt; stk_desc[sp - 1] = top_desc | (top_depth << 16); }   // spill the old top
+        top_desc = kNewPose + nn; top_depth = depth; top_dt = newtime;
+        ++nn; ++sp;
         cdt = newtime;
         ++T;
         modified = true;
         continue;   // i-- : re-check the left half
       } else {
         if (has_next) {
-          if (sp > 0) stk[4 * (sp - 1) + 3] += cdt - dt_ref;
+          if (sp > 0) top_dt += cdt - dt_ref;
           else pdt += cdt - dt_ref;
         }
         cdt = dt_ref;
@@ -967,10 +987,12 @@ __device__ __noinline__ void autoresize_sweep_thread0(double dt_ref, double hyst
     } else if (cdt < dt_ref - hyst && T > min_samples) {
       if (has_next) {
         // TimeDiff(i+1) += TimeDiff(i); deleteTimeDiff(i); deletePose(i+1); i--
-        if (sp > 0) { cdt = stk[4 * (sp - 1) + 3] + cdt; --sp; }
-        else {
+        if (sp > 0) {
+          cdt = top_dt + cdt; --sp;
+          if (sp > 0) { top_dt = stk_dt[sp - 1]; const int e = stk_desc[sp - 1]; top_desc = e & 0xffff; top_depth = e >> 16; }
+        } else {
           cdt = pdt + cdt; ++j;
-          if (j < Tin) { px = in_x[j]; py = in_y[j]; pth = in_th[j]; pdt = in_dt[j]; }
+          if (j < Tin) pdt = in_dt[j];
         }
         --T;
         modified = true;
@@ -985,26 +1007,28 @@ __device__ __noinline__ void autoresize_sweep_thread0(double dt_ref, double hyst
       }
     }
     // emit cur, advance
-    if (k >= stride - 1) { *overflow = 1; break; }
-    ox[k] = cx; oy[k] = cy; oth[k] = cth; odt[k] = cdt;
+    if (k >= stride - 1) { ovf = 1; break; }
+    out_desc[k] = cdesc; odt[k] = cdt;
     ++k;
-    if (sp > 0) { --sp; cx = stk[4 * sp]; cy = stk[4 * sp + 1]; cth = stk[4 * sp + 2]; cdt = stk[4 * sp + 3]; ci = -1; }
-    else if (j < Tin) {
-      cx = px; cy = py; cth = pth; cdt = pdt; ci = j; ++j;
-      if (j < Tin) { px = in_x[j]; py = in_y[j]; pth = in_th[j]; pdt = in_dt[j]; }
-    }
-    else alive = false;
+    if (sp > 0) {
+      cdesc = top_desc; cdepth = top_depth; cdt = top_dt; --sp;
+      if (sp > 0) { top_dt = stk_dt[sp - 1]; const int e = stk_desc[sp - 1]; top_desc = e & 0xffff; top_depth = e >> 16; }
+    } else if (j < Tin) {
+      cdesc = j; cdepth = 0; cdt = pdt; ++j;
+      if (j < Tin) pdt = in_dt[j];
+    } else alive = false;
   }
-  ox[k] = gx; oy[k] = gy; oth[k] = gth;
-  *n_out = k + 1;
-  *modified_out = modified ? 1 : 0;
+  out_desc[k] = n_in - 1;   // the goal pose
+  res[0] = k + 1; res[1] = modified ? 1 : 0; res[2] = ovf; res[3] = nn; res[4] = md;
 }
 
 __device__ inline int autoresize(const teb_amd_config_t& c, const Lds& l, int n, int off_state, int off_scratch, int stride,
                                  bool fast_mode, int* overflow_flag) {
   extern __shared__ __attribute__((aligned(16))) double lds_base[];
   const int tid = threadIdx.x;
-  double* ox = lds_base + off_scratch; double* oy = ox + stride; double* oth = oy + stride; double* odt = oth + stride;
+  double* odt = lds_base + off_scratch; double* nx = odt + stride; double* ny = nx + stride; double* nth = ny + stride;
+  const int* out_desc = reinterpret_cast<const int*>(odt + 4 * stride);
+  const int* rec = out_desc + stride;
   for (int rep = 0; rep < 100; ++rep) {
     // parallel pre-check: a sweep is a no-op iff no interval satisfies either trigger condition
     const int T = n - 1;
@@ -1015,29 +1039,63 @@ __device__ inline int autoresize(const teb_amd_config_t& c, const Lds& l, int n,
     }
     trig = __syncthreads_or(trig);
     if (!trig) break;
-    refresh_trig(l, n);   // cos / sin of the poses as they are now (the cache may date from a rejected LM trial)
-    __syncthreads();
     if (tid == 0) {
-      int n_out = n, mod = 0, ovf = 0;
 #ifdef TEB_PROFILE
       const long long sw_t0 = clock64();
 #endif
-      autoresize_sweep_thread0(c.dt_ref, c.dt_hysteresis, c.max_samples, c.min_samples, off_state, off_scratch, n, stride, &n_out,
-                               &mod, &ovf);
+      autoresize_script_lane0(c.dt_ref, c.dt_hysteresis, c.max_samples, c.min_samples, off_state, off_scratch, n, stride,
+                              (int)(reinterpret_cast<int*>(l.ired + 16) - reinterpret_cast<int*>(lds_base)));
 #ifdef TEB_PROFILE
       l.ired[12] += (int)(clock64() - sw_t0); l.ired[13] += 1;
 #endif
-      l.ired[8] = n_out; l.ired[9] = mod; l.ired[10] = ovf;
       __threadfence_block();
+    } else if (tid >= 64) {
+      // meanwhile the other waves refresh cos / sin of the poses as they are now (the cache may date from a rejected LM trial);
+      // wave 0 is excluded so that lane 0 is not held up by its own wave
+      for (int i = tid - 64; i < n; i += kThreads - 64) { const double th = l.sth[i]; l.cs[i] = cos(th); l.sn[i] = sin(th); }
     }
     __syncthreads();
-    const int n_out = l.ired[8], mod = l.ired[9], ovf = l.ired[10];
+    const int n_out = l.ired[16], mod = l.ired[17], ovf = l.ired[18], n_new = l.ired[19], md = l.ired[20];
     if (ovf) { *overflow_flag = 1; return n; }
-    n = n_out;
-    for (int i = tid; i < n; i += kThreads) {
-      l.sx[i] = ox[i]; l.sy[i] = oy[i]; l.sth[i] = oth[i];
-      if (i < n - 1) l.sdt[i] = odt[i];
+    // new poses, level by level: PoseSE2::average (pose_se2.h:266-269) with g2o::average_angle
+    for (int d = 1; d <= md; ++d) {
+      for (int q = tid; q < n_new; q += kThreads) {
+        const int r = rec[q];
+        if ((r >> 22) != d) continue;
+        const int pa = r & 0x7ff, pb = (r >> 11) & 0x7ff;
+        double ax, ay, ac, as, bx, by, bc, bs;
+        if (pa < kNewPose) { ax = l.sx[pa]; ay = l.sy[pa]; ac = l.cs[pa]; as = l.sn[pa]; }
+        else { const double t = nth[pa - kNewPose]; ax = nx[pa - kNewPose]; ay = ny[pa - kNewPose]; ac = cos(t); as = sin(t); }
+        if (pb < kNewPose) { bx = l.sx[pb]; by = l.sy[pb]; bc = l.cs[pb]; bs = l.sn[pb]; }
+        else { const double t = nth[pb - kNewPose]; bx = nx[pb - kNewPose]; by = ny[pb - kNewPose]; bc = cos(t); bs = sin(t); }
+        const double sxn = ac + bc, syn = as + bs;
+        nx[q] = (ax + bx) / 2; ny[q] = (ay + by) / 2;
+        nth[q] = (sxn == 0 && syn == 0) ? 0.0 : atan2(syn, sxn);
+      }
+      __syncthreads();
     }
+    // gather the output strip through registers (in place: every source is read before any destination is written)
+    double gx[kMaxPoseIter], gy[kMaxPoseIter], gth[kMaxPoseIter], gdt[kMaxPoseIter];
+#pragma unroll
+    for (int kk = 0; kk < kMaxPoseIter; ++kk) {
+      const int i = tid + kk * kThreads;
+      if (i < n_out) {
+        const int d = out_desc[i];
+        if (d < kNewPose) { gx[kk] = l.sx[d]; gy[kk] = l.sy[d]; gth[kk] = l.sth[d]; }
+        else { gx[kk] = nx[d - kNewPose]; gy[kk] = ny[d - kNewPose]; gth[kk] = nth[d - kNewPose]; }
+        gdt[kk] = (i < n_out - 1) ? odt[i] : 0.0;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < kMaxPoseIter; ++kk) {
+      const int i = tid + kk * kThreads;
+      if (i < n_out) {
+        l.sx[i] = gx[kk]; l.sy[i] = gy[kk]; l.sth[i] = gth[kk];
+        if (i < n_out - 1) l.sdt[i] = gdt[kk];
+      }
+    }
+    n = n_out;
     __syncthreads();
     if (!mod || fast_mode) break;
   }
@@ -1236,7 +1294,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     if (c.teb_autosize && !args.debug_linearize) {
       int ovf = 0;
       PROF_START();
-      // sweep output + split stack (4 S + 256 doubles) live in the LDS region of the normal matrix, which is rebuilt afterwards
+      // edit script + new poses + split stack (autoresize_scratch_doubles: 5 S + 104 doubles) live in the LDS region of the normal matrix, which is rebuilt afterwards
       n = autoresize(c, l, n, plan.off_state, plan.off_H, plan.S, fast_mode, &ovf);   // plan.S: LDS strip spacing = pose capacity of this launch
       PROF_END(0);
       if (ovf) { status = TEB_AMD_TEB_FAILED; if (tid == 0) bt.assoc_overflow[b] |= 2; break; }

@@ -4,6 +4,7 @@
 #include <complex>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <iostream>
 #include <limits>
 #include <map>
@@ -16,11 +17,29 @@
 #include <vector>
 
 // The five footprint classes keep their parameters private and offer no getters (robot_footprint_model.h:227, 306, 424,
-// 592, 768). A maintainer adds four one-line getters there; this out-of-tree build reads the members directly instead.
-#ifndef TEB_AMD_BACKEND_HAVE_FOOTPRINT_GETTERS
+// 592, 768). host/patches/footprint_and_signature_accessors.patch adds them (build with TEB_AMD_BACKEND_HAVE_ACCESSORS, see
+// host/CMakeLists.txt); without the patch this out-of-tree build reads the members directly instead.
+#ifdef TEB_AMD_BACKEND_HAVE_ACCESSORS
+#define FP_RADIUS(m) (m)->getRadius()
+#define FP_FRONT_OFFSET(m) (m)->getFrontOffset()
+#define FP_FRONT_RADIUS(m) (m)->getFrontRadius()
+#define FP_REAR_OFFSET(m) (m)->getRearOffset()
+#define FP_REAR_RADIUS(m) (m)->getRearRadius()
+#define FP_LINE_START(m) (m)->getLineStart()
+#define FP_LINE_END(m) (m)->getLineEnd()
+#define FP_VERTICES(m) (m)->getVertices()
+#else
 #define private public
 #include <teb_local_planner/robot_footprint_model.h>
 #undef private
+#define FP_RADIUS(m) (m)->radius_
+#define FP_FRONT_OFFSET(m) (m)->front_offset_
+#define FP_FRONT_RADIUS(m) (m)->front_radius_
+#define FP_REAR_OFFSET(m) (m)->rear_offset_
+#define FP_REAR_RADIUS(m) (m)->rear_radius_
+#define FP_LINE_START(m) (m)->line_start_
+#define FP_LINE_END(m) (m)->line_end_
+#define FP_VERTICES(m) (m)->vertices_
 #endif
 
 #include "teb_amd_backend.h"
@@ -51,36 +70,36 @@ bool toAmdFootprint(const BaseRobotFootprintModel& model, teb_amd_config_t& a)
   if (const CircularRobotFootprint* m = dynamic_cast<const CircularRobotFootprint*>(&model))
   {
     a.footprint_type = TEB_AMD_FOOTPRINT_CIRCULAR;
-    a.footprint_radius = m->radius_;
+    a.footprint_radius = FP_RADIUS(m);
     return true;
   }
   if (const TwoCirclesRobotFootprint* m = dynamic_cast<const TwoCirclesRobotFootprint*>(&model))
   {
     a.footprint_type = TEB_AMD_FOOTPRINT_TWO_CIRCLES;
-    a.footprint_front_offset = m->front_offset_; a.footprint_front_radius = m->front_radius_;
-    a.footprint_rear_offset = m->rear_offset_;   a.footprint_rear_radius = m->rear_radius_;
+    a.footprint_front_offset = FP_FRONT_OFFSET(m); a.footprint_front_radius = FP_FRONT_RADIUS(m);
+    a.footprint_rear_offset = FP_REAR_OFFSET(m);   a.footprint_rear_radius = FP_REAR_RADIUS(m);
     return true;
   }
   if (const LineRobotFootprint* m = dynamic_cast<const LineRobotFootprint*>(&model))
   {
     a.footprint_type = TEB_AMD_FOOTPRINT_LINE;
     a.footprint_n_vertices = 2;
-    a.footprint_vx[0] = m->line_start_.x(); a.footprint_vy[0] = m->line_start_.y();
-    a.footprint_vx[1] = m->line_end_.x();   a.footprint_vy[1] = m->line_end_.y();
+    a.footprint_vx[0] = FP_LINE_START(m).x(); a.footprint_vy[0] = FP_LINE_START(m).y();
+    a.footprint_vx[1] = FP_LINE_END(m).x();   a.footprint_vy[1] = FP_LINE_END(m).y();
     return true;
   }
   if (const PolygonRobotFootprint* m = dynamic_cast<const PolygonRobotFootprint*>(&model))
   {
-    if ((int)m->vertices_.size() > TEB_AMD_MAX_FOOTPRINT_VERTICES) return false;
+    if ((int)FP_VERTICES(m).size() > TEB_AMD_MAX_FOOTPRINT_VERTICES) return false;
     a.footprint_type = TEB_AMD_FOOTPRINT_POLYGON;
-    a.footprint_n_vertices = (int32_t)m->vertices_.size();
-    for (int i = 0; i < a.footprint_n_vertices; ++i) { a.footprint_vx[i] = m->vertices_[i].x(); a.footprint_vy[i] = m->vertices_[i].y(); }
+    a.footprint_n_vertices = (int32_t)FP_VERTICES(m).size();
+    for (int i = 0; i < a.footprint_n_vertices; ++i) { a.footprint_vx[i] = FP_VERTICES(m)[i].x(); a.footprint_vy[i] = FP_VERTICES(m)[i].y(); }
     return true;
   }
   return false;
 }
 
-void toAmdConfig(const TebConfig& c, teb_amd_config_t& a)
+bool toAmdConfig(const TebConfig& c, teb_amd_config_t& a)
 {
   teb_amd_config_default(&a);
   a.teb_autosize = c.trajectory.teb_autosize ? 1 : 0;   a.dt_ref = c.trajectory.dt_ref;
@@ -125,8 +144,15 @@ void toAmdConfig(const TebConfig& c, teb_amd_config_t& a)
   a.divergence_detection_enable = c.recovery.divergence_detection_enable;
   a.divergence_detection_max_chi_squared = c.recovery.divergence_detection_max_chi_squared;
   a.jacobian_mode = g_jacobian_mode;
+  // Fail closed: a footprint the device cannot represent (unknown class, polygon with more than TEB_AMD_MAX_FOOTPRINT_VERTICES
+  // vertices) must never be replaced by a smaller one - obstacle clearance would be optimised for the wrong robot.
   if (!c.robot_model || !toAmdFootprint(*c.robot_model, a))
-    ROS_ERROR("toAmdConfig(): unknown robot footprint model, falling back to the point footprint");
+  {
+    ROS_ERROR("toAmdConfig(): the robot footprint model cannot be represented on the device (unknown class or more than %d polygon vertices); "
+              "optimizeTEB() will fail instead of planning with a different footprint", TEB_AMD_MAX_FOOTPRINT_VERTICES);
+    return false;
+  }
+  return true;
 }
 
 void AmdObstacleTable::assign(const ObstContainer* obstacles)
@@ -185,10 +211,15 @@ bool TebOptimalPlannerAmd::optimizeTEB(int iterations_innerloop, int iterations_
   if (cfg_->optim.optimization_activate == false) return false;   // src/optimal_planner.cpp:186-187
   AmdObstacleTable probe;
   probe.assign(obstacles_);
-  const int need_poses = std::max(teb_.sizePoses(), std::min(cfg_->trajectory.max_samples + 1, 343));
-  if (!single_ || teb_.sizePoses() > single_->maxPoses())
-    single_.reset(new TebAmdBatch(*cfg_, 1, need_poses, std::max<int>(1, (int)probe.type.size()), std::max(1, probe.vertices()),
-                                  std::max<int>(1, via_points_ ? (int)via_points_->size() : 0)));
+  // Capacities: whatever autoResize can produce (max_samples + 1 poses; the layout is chosen per launch, so a large capacity does not
+  // slow down short bands), and head-room over the obstacle / vertex / via-point counts of THIS tick - the costmap converter changes
+  // them every tick, so the handle is rebuilt with room to spare whenever a count outgrows it.
+  const int need_poses = std::max(teb_.sizePoses(), std::min(cfg_->trajectory.max_samples + 1, 512));
+  const int n_obst = (int)probe.type.size(), n_vert = probe.vertices(), n_via = via_points_ ? (int)via_points_->size() : 0;
+  if (!single_ || !single_->valid() || teb_.sizePoses() > single_->maxPoses() || n_obst > single_->maxObstacles() ||
+      n_vert > single_->maxObstacleVertices() || n_via > single_->maxViaPoints())
+    single_.reset(new TebAmdBatch(*cfg_, 1, need_poses, std::max(16, 2 * n_obst), std::max(64, 2 * n_vert), std::max(8, 2 * n_via)));
+  if (!single_->valid()) return false;
   std::vector<TebOptimalPlannerAmd*> one(1, this);
   return single_->optimizeAllTEBs(one, iterations_innerloop, iterations_outerloop, compute_cost_afterwards, obst_cost_scale,
                                   viapoint_cost_scale, alternative_time_cost) == 1;
@@ -198,10 +229,11 @@ bool TebOptimalPlannerAmd::optimizeTEB(int iterations_innerloop, int iterations_
 
 TebAmdBatch::TebAmdBatch(const TebConfig& cfg, int max_tebs, int max_poses, int max_obstacles, int max_obstacle_vertices,
                          int max_via_points, int device)
-    : max_tebs_(max_tebs), max_poses_(max_poses)
+    : max_tebs_(max_tebs), max_poses_(max_poses), max_obstacles_(max_obstacles), max_obstacle_vertices_(max_obstacle_vertices),
+      max_via_points_(max_via_points)
 {
   teb_amd_config_t a;
-  toAmdConfig(cfg, a);
+  if (!toAmdConfig(cfg, a)) { check(TEB_AMD_ERR_UNSUPPORTED, "toAmdConfig (robot footprint not representable)"); return; }   // h_ stays NULL
   check(teb_amd_create(&a, max_tebs, max_poses, max_obstacles, max_obstacle_vertices, max_via_points, device, NULL, &h_),
         "teb_amd_create");
 }
@@ -237,7 +269,7 @@ int TebAmdBatch::optimizeAllTEBs(const std::vector<TebOptimalPlannerAmd*>& tebs,
 
   // scene: TebConfig (dynamic_reconfigure may have changed it), obstacles, via-points
   teb_amd_config_t a;
-  toAmdConfig(*first.cfg_, a);
+  if (!toAmdConfig(*first.cfg_, a)) { check(TEB_AMD_ERR_UNSUPPORTED, "toAmdConfig (robot footprint not representable)"); return 0; }
   AmdObstacleTable table;
   table.assign(first.obstacles_);
   teb_amd_obstacles_t ov = table.view();
@@ -248,9 +280,9 @@ int TebAmdBatch::optimizeAllTEBs(const std::vector<TebOptimalPlannerAmd*>& tebs,
   for (TebOptimalPlannerAmd* t : tebs) if (t->via_points_) { shared_via = t->via_points_; break; }
   if (shared_via)
     for (const Eigen::Vector2d& v : *shared_via) { viax.push_back(v.x()); viay.push_back(v.y()); }
-  // set_obstacles before set_config would be rejected when include_dynamic_obstacles / footprint changed: config first, then scene
-  int rc = teb_amd_set_config(h_, &a);
-  if (rc != TEB_AMD_OK && rc != TEB_AMD_ERR_INVALID_ARG) { check(rc, "teb_amd_set_config"); return 0; }
+  // every error of set_config is a real one (ABI 2: it re-derives the obstacle lists itself when include_dynamic_obstacles / the
+  // footprint type change, and keeps the previous configuration when the new one is invalid)
+  if (!check(teb_amd_set_config(h_, &a), "teb_amd_set_config")) return 0;
   if (!check(teb_amd_set_obstacles(h_, &ov), "teb_amd_set_obstacles")) return 0;
   if (!check(teb_amd_set_via_points(h_, (int32_t)viax.size(), viax.data(), viay.data()), "teb_amd_set_via_points")) return 0;
 
@@ -426,19 +458,18 @@ bool TebAmdBatch::exploreEquivalenceClassesAndInitTebs(const TebConfig& cfg, Obs
                                                        std::vector<TebOptimalPlannerAmdPtr>& tebs, int& best_index, const PoseSE2& start,
                                                        const PoseSE2& goal, double dist_to_obst, const geometry_msgs::Twist* start_vel,
                                                        bool free_goal_vel, const std::vector<geometry_msgs::PoseStamped>* initial_plan,
-                                                       int* initial_plan_index)
+                                                       int* initial_plan_index, const std::function<bool()>* random_drop)
 {
   if (!h_) return false;
   teb_amd_hcp_params_t hp;
   toAmdHcpParams(cfg, hp);
   // scene
   teb_amd_config_t a;
-  toAmdConfig(cfg, a);
+  if (!toAmdConfig(cfg, a)) return check(TEB_AMD_ERR_UNSUPPORTED, "toAmdConfig (robot footprint not representable)");
   AmdObstacleTable table;
   table.assign(obstacles);
   teb_amd_obstacles_t ov = table.view();
-  int rc = teb_amd_set_config(h_, &a);
-  if (rc != TEB_AMD_OK && rc != TEB_AMD_ERR_INVALID_ARG) return check(rc, "teb_amd_set_config");
+  if (!check(teb_amd_set_config(h_, &a), "teb_amd_set_config")) return false;
   if (!check(teb_amd_set_obstacles(h_, &ov), "teb_amd_set_obstacles")) return false;
   std::vector<double> viax, viay;
   if (via_points)
@@ -459,6 +490,15 @@ bool TebAmdBatch::exploreEquivalenceClassesAndInitTebs(const TebConfig& cfg, Obs
     if (!check(teb_amd_filter_equivalence_classes(h_, hp.h_signature_threshold, best_index, hp.max_number_plans_in_current_class, keep.data(),
                                                   NULL, NULL), "teb_amd_filter_equivalence_classes")) return false;
     if (hp.delete_detours_backwards && !check(teb_amd_filter_detours(h_, &hp, best_index, keep.data()), "teb_amd_filter_detours")) return false;
+    // randomlyDropTebs (:539-562): every surviving candidate but the best one is dropped when the caller's generator says so; visited in
+    // the order the reference's vector has after renewAndAnalyzeOldTebs (best first, then the others)
+    if (random_drop && *random_drop)
+    {
+      std::vector<int> visit(tebs.size());
+      for (size_t b = 0; b < tebs.size(); ++b) visit[b] = (int)b;
+      if (best_index >= 0 && best_index < (int)tebs.size()) std::swap(visit[0], visit[best_index]);
+      for (int b : visit) if (keep[b] && b != best_index && (*random_drop)()) keep[b] = 0;
+    }
     if (!check(teb_amd_compact_bands(h_, keep.data(), best_index, &n_kept, &new_best), "teb_amd_compact_bands")) return false;
     std::vector<int> order(tebs.size());
     for (size_t b = 0; b < tebs.size(); ++b) order[b] = (int)b;

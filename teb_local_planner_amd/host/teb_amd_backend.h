@@ -16,13 +16,15 @@
 
 #include <teb_local_planner/optimal_planner.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
 namespace teb_local_planner {
 
-//! TebConfig (teb_config.h:62-430) -> flat teb_amd_config_t; robot_model is flattened by toAmdFootprint.
-void toAmdConfig(const TebConfig& cfg, teb_amd_config_t& out);
+//! TebConfig (teb_config.h:62-430) -> flat teb_amd_config_t; robot_model is flattened by toAmdFootprint. Returns false (fails closed:
+//! every planner built on it then reports optimizeTEB() == false) when the footprint model cannot be represented on the device.
+bool toAmdConfig(const TebConfig& cfg, teb_amd_config_t& out);
 
 //! One of the five footprint classes (robot_footprint_model.h:134-770) -> footprint_* fields. Returns false for an unknown class.
 bool toAmdFootprint(const BaseRobotFootprintModel& model, teb_amd_config_t& out);
@@ -101,6 +103,10 @@ public:
   int selectBestTeb(int last_best, int initial_plan, double* best_cost = NULL);
 
   int maxPoses() const { return max_poses_; }
+  int maxObstacles() const { return max_obstacles_; }
+  int maxObstacleVertices() const { return max_obstacle_vertices_; }
+  int maxViaPoints() const { return max_via_points_; }
+  bool valid() const { return h_ != NULL; }   //!< false: the device / footprint / capacity was refused at construction (lastError())
   /**
    * HomotopyClassPlanner::updateAllTEBs (src/homotopy_class_planner.cpp:539-562): TimedElasticBand::updateAndPruneTEB(start, goal,
    * cfg.trajectory.min_samples) on every candidate - one launch on the device - and setVelocityStart(*start_velocity).
@@ -120,7 +126,7 @@ public:
   /**
    * Replaces the body of HomotopyClassPlanner::exploreEquivalenceClassesAndInitTebs (src/homotopy_class_planner.cpp:318-340; not
    * randomlyDropTebs), with initial_plan = initial_plan_ (or NULL) and *initial_plan_index = the index of getInitialPlanTEB() in `tebs`
-   * afterwards (for selectBestTeb), incl. updateReferenceTrajectoryViaPoints on the device-side attributes: renewAndAnalyzeOldTebs incl. deletePlansDetouringBackwards on the
+   * afterwards (for selectBestTeb); random_drop = the draw of randomlyDropTebs (:539-562; NULL or empty: no dropping), incl. updateReferenceTrajectoryViaPoints on the device-side attributes: renewAndAnalyzeOldTebs incl. deletePlansDetouringBackwards on the
    * candidates in `tebs` (erased ones leave the vector; the last best candidate, best_index, moves to the front), then
    * createGraph / DepthFirst / addAndInitNewTeb on the device; every new band arrives as a new TebOptimalPlannerAmd appended to
    * `tebs` (constructed like the reference's candidates: same cfg, obstacles, via-points; setVelocityStart / setVelocityGoalFree
@@ -130,7 +136,7 @@ public:
                                             std::vector<TebOptimalPlannerAmdPtr>& tebs, int& best_index, const PoseSE2& start,
                                             const PoseSE2& goal, double dist_to_obst, const geometry_msgs::Twist* start_vel,
                                             bool free_goal_vel, const std::vector<geometry_msgs::PoseStamped>* initial_plan = NULL,
-                                            int* initial_plan_index = NULL);
+                                            int* initial_plan_index = NULL, const std::function<bool()>* random_drop = NULL);
 
   //! H-signatures of the bands currently on the device (after exploreEquivalenceClassesAndInitTebs: the candidates in `tebs` order):
   //! values [B * width], width = #obstacles (HSignature3d) or 2 (HSignature: re, im).
@@ -147,7 +153,7 @@ private:
   bool uploadBands(const std::vector<TebOptimalPlannerAmd*>& tebs);
   bool downloadBands(const std::vector<TebOptimalPlannerAmd*>& tebs);
   teb_amd_handle_t* h_ = NULL;
-  int max_tebs_, max_poses_;
+  int max_tebs_, max_poses_, max_obstacles_ = 0, max_obstacle_vertices_ = 0, max_via_points_ = 0;
   std::string error_;
 };
 

@@ -4,9 +4,17 @@
 #include <vector>
 // the two equivalence-class types keep their values private and offer no setter: the classes computed on the device are written into
 // objects of the reference's own types, so that everything that reads equivalence_classes_ keeps working
+#ifdef TEB_AMD_BACKEND_HAVE_ACCESSORS   // host/patches/footprint_and_signature_accessors.patch applied
+#include <teb_local_planner/h_signature.h>
+#define HSIG3D_SET(H, first, last) (H)->setValues(std::vector<double>(first, last))
+#define HSIG2D_SET(H, v) (H)->setValue(v)
+#else
 #define private public
 #include <teb_local_planner/h_signature.h>
 #undef private
+#define HSIG3D_SET(H, first, last) (H)->hsignature3d_.assign(first, last)
+#define HSIG2D_SET(H, v) (H)->hsignature_ = (v)
+#endif
 #include "teb_amd_hcp_backend.h"
 
 namespace teb_local_planner {
@@ -36,8 +44,13 @@ bool HomotopyClassPlannerAmd::plan(const PoseSE2& start, const PoseSE2& goal, co
     cand.push_back(p);
   }
   int initial_index = -1;
+  // randomlyDropTebs (:539-562) with the planner's own generator, exactly the reference's draw
+  std::function<bool()> drop;
+  if (cfg_->hcp.selection_dropping_probability != 0.0)
+    drop = [this]() { return random_() <= cfg_->hcp.selection_dropping_probability * random_.max(); };
   if (!batch_->exploreEquivalenceClassesAndInitTebs(*cfg_, obstacles_, via_points_, cand, best_index, start, goal,
-                                                    cfg_->obstacles.min_obstacle_dist, start_vel, free_goal_vel, initial_plan_, &initial_index))
+                                                    cfg_->obstacles.min_obstacle_dist, start_vel, free_goal_vel, initial_plan_, &initial_index,
+                                                    &drop))
     return false;
   tebs_.clear();
   for (const TebOptimalPlannerAmdPtr& p : cand) tebs_.push_back(p);
@@ -54,13 +67,13 @@ bool HomotopyClassPlannerAmd::plan(const PoseSE2& start, const PoseSE2& goal, co
       if (cfg_->obstacles.include_dynamic_obstacles)
       {
         HSignature3d* H = new HSignature3d(*cfg_);
-        H->hsignature3d_.assign(values.begin() + b * width, values.begin() + (b + 1) * width);
+        HSIG3D_SET(H, values.begin() + b * width, values.begin() + (b + 1) * width);
         equivalence_classes_.push_back(std::make_pair(EquivalenceClassPtr(H), false));
       }
       else
       {
         HSignature* H = new HSignature(*cfg_);
-        H->hsignature_ = std::complex<long double>(values[b * width], values[b * width + 1]);
+        HSIG2D_SET(H, std::complex<long double>(values[b * width], values[b * width + 1]));
         equivalence_classes_.push_back(std::make_pair(EquivalenceClassPtr(H), false));
       }
     }

@@ -9,6 +9,8 @@ index winning ties (strict '<' at :610). Each rank contributes its local winner 
 (cost f64, global index as f64) to an all-gather (RCCL over xGMI when the backend is "nccl", gloo in the CPU
 tests); every rank then takes the lexicographic minimum, so all ranks agree without a second collective.
 """
+import ctypes as C
+
 import numpy as np
 
 
@@ -58,3 +60,47 @@ def select_best_distributed(cost, global_index, group=None, device=None):
     dist.all_gather(out, rec, group=group)
     allv = torch.stack(out).cpu().numpy()
     return pick_global((allv[k, 0], allv[k, 1]) for k in range(world))
+
+
+COMM_ID_BYTES = 128
+
+
+class RcclComm:
+    """teb_amd_comm_t: the RCCL communicator the C-ABI's exchange runs on (include/teb_amd.h, multi-GPU section).
+
+    rank 0 creates the 128-byte id (RcclComm.unique_id()) and ships it to the other ranks by any means; from_torch() uses an
+    already initialised torch.distributed group for exactly that and nothing else - the exchange itself happens inside libteb_amd.so."""
+
+    def __init__(self, unique_id, rank, world, device):
+        from . import planner
+        self._c = C.c_void_p(None)
+        self.rank, self.world, self.device = rank, world, device
+        buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        planner._chk(planner.lib().teb_amd_comm_create(buf, rank, world, device, C.byref(self._c)), "teb_amd_comm_create")
+
+    @staticmethod
+    def unique_id():
+        from . import planner
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        planner._chk(planner.lib().teb_amd_comm_unique_id(buf), "teb_amd_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_torch(cls, device, group=None):
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(box[0], rank, world, device)
+
+    def close(self):
+        if self._c:
+            from . import planner
+            planner.lib().teb_amd_comm_destroy(self._c)
+            self._c = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

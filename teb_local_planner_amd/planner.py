@@ -39,6 +39,10 @@ def lib():
         L.teb_amd_config_default.argtypes = [C.POINTER(_abi.Config)]
         L.teb_amd_create.argtypes = [C.POINTER(_abi.Config), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, vp, C.POINTER(vp)]
+        L.teb_amd_create_ex.argtypes = [C.POINTER(_abi.Config), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_int32, vp, C.POINTER(_abi.Options), C.POINTER(vp)]
+        L.teb_amd_options_default.argtypes = [C.POINTER(_abi.Options)]
+        L.teb_amd_options_default.restype = None
         L.teb_amd_destroy.argtypes = [vp]
         L.teb_amd_destroy.restype = None
         L.teb_amd_set_config.argtypes = [vp, C.POINTER(_abi.Config)]
@@ -89,6 +93,13 @@ def lib():
         L.teb_amd_get_band_flags.argtypes = [vp, _abi.p_i32, _abi.p_i32, _abi.p_i32]
         L.teb_amd_hcp_params_default.argtypes = [C.POINTER(_abi.HcpParams)]
         L.teb_amd_hcp_params_default.restype = None
+        # multi-GPU exchange
+        L.teb_amd_comm_unique_id.argtypes = [C.c_char_p]
+        L.teb_amd_comm_create.argtypes = [C.c_char_p, i32, i32, i32, C.POINTER(vp)]
+        L.teb_amd_comm_destroy.argtypes = [vp]
+        L.teb_amd_comm_destroy.restype = None
+        L.teb_amd_select_best_distributed.argtypes = [vp, vp, i32, i32, i32, _abi.p_i32, _abi.p_f64, _abi.p_i32]
+        L.teb_amd_broadcast_band.argtypes = [vp, vp, i32, i32, i32, _abi.p_i32, _abi.p_f64, _abi.p_f64, _abi.p_f64, _abi.p_f64]
         _LIB = L
     return _LIB
 
@@ -102,13 +113,13 @@ class TebBatchSolver:
     """Thin RAII wrapper of a teb_amd_handle_t (one per GPU / host thread)."""
 
     def __init__(self, cfg, max_tebs, max_poses, max_obstacles=0, max_obstacle_vertices=0, max_via_points=0,
-                 device=0, stream=None):
+                 device=0, stream=None, options=None):
         self._h = C.c_void_p(None)
         self.cfg = cfg
         c = cfg.to_c()
-        _chk(lib().teb_amd_create(C.byref(c), max_tebs, max_poses, max_obstacles, max_obstacle_vertices,
-                                  max_via_points, device, C.c_void_p(stream) if stream else None,
-                                  C.byref(self._h)), "teb_amd_create")
+        _chk(lib().teb_amd_create_ex(C.byref(c), max_tebs, max_poses, max_obstacles, max_obstacle_vertices,
+                                     max_via_points, device, C.c_void_p(stream) if stream else None,
+                                     C.byref(options) if options is not None else None, C.byref(self._h)), "teb_amd_create_ex")
         self.max_tebs, self.max_poses = max_tebs, max_poses
         self.count = 0
 
@@ -178,6 +189,24 @@ class TebBatchSolver:
         _chk(lib().teb_amd_select_best(self._h, last_best, initial_plan, C.byref(best), C.byref(cost)),
              "teb_amd_select_best")
         return best.value, cost.value
+
+    def select_best_distributed(self, comm, global_offset, last_best_global=-1, initial_plan_global=-1):
+        """selectBestTeb over the candidates of all ranks of `comm` (parallel.RcclComm): (best_global, scaled cost, owner_rank), the
+        same on every rank. One 16-byte-per-rank ncclAllGather inside libteb_amd.so."""
+        best = C.c_int32(-1); cost = C.c_double(0); owner = C.c_int32(-1)
+        _chk(lib().teb_amd_select_best_distributed(self._h, comm._c, int(global_offset), int(last_best_global), int(initial_plan_global),
+                                                   C.byref(best), C.byref(cost), C.byref(owner)), "teb_amd_select_best_distributed")
+        return best.value, cost.value, owner.value
+
+    def broadcast_band(self, comm, owner_rank, local_index, capacity=None):
+        """The winner's strip from its owner to every rank: (x, y, theta, dt) as host arrays."""
+        cap = int(capacity or self.max_poses)
+        n = C.c_int32(0)
+        x = np.zeros(cap); y = np.zeros(cap); th = np.zeros(cap); dt = np.zeros(cap)
+        P = lambda a: _abi._ptr(a, C.c_double)
+        _chk(lib().teb_amd_broadcast_band(self._h, comm._c, int(owner_rank), int(local_index), cap, C.byref(n), P(x), P(y), P(th), P(dt)),
+             "teb_amd_broadcast_band")
+        return x[:n.value].copy(), y[:n.value].copy(), th[:n.value].copy(), dt[:max(n.value - 1, 0)].copy()
 
     def last_kernel_ms(self):
         ms = C.c_float(0)
@@ -394,11 +423,11 @@ class TebBatchSolver:
         return f
 
 
-def make_solver(cfg, obst, via, batch, device=0, stream=None, max_tebs=None, max_poses=None):
-    """Creates a solver sized for the scene, uploads scene + batch."""
+def make_solver(cfg, obst, via, batch, device=0, stream=None, max_tebs=None, max_poses=None, options=None):
+    """Creates a solver sized for the scene, uploads scene + batch. options: _abi.Options (layout pins etc.) or None."""
     nverts = len(obst.vert_x)
     s = TebBatchSolver(cfg, max_tebs or batch.count, max_poses or batch.stride, max(len(obst), 1), max(nverts, 1),
-                       max(len(via), 1), device=device, stream=stream)
+                       max(len(via), 1), device=device, stream=stream, options=options)
     s.set_obstacles(obst)
     s.set_via_points(via)
     s.upload(batch)

@@ -32,3 +32,33 @@ def band_tolerances(oracle, cfg, obst, via, batch, **kw):
             d = max(d, abs(ra.cost[b] - rn.cost[b]) / abs(rn.cost[b]))
         tol.append(min(max(WELL_CONDITIONED_TOL, 10.0 * d), ILL_CONDITIONED_CAP))
     return tol
+
+
+def compare_bands(out, res, ref, rres, tols=None, bands=None):
+    """Device result (out, res) against the oracle's (ref, rres), band by band. Returns a dict with
+       counts_equal : bands whose status, pose count, LM iteration and trial counts are all identical
+       checked      : bands compared on state / cost (well conditioned by `tols`, or all when tols is None)
+       skipped      : bands left out (ill conditioned), reported so that a silent regression cannot hide behind the skip rule
+       max_state_err, max_cost_rel over the checked bands."""
+    bands = range(out.count) if bands is None else bands
+    rep = {"bands": 0, "counts_equal": 0, "status_equal": 0, "checked": 0, "skipped": 0, "max_state_err": 0.0, "max_cost_rel": 0.0,
+           "count_mismatch": []}
+    for b in bands:
+        rep["bands"] += 1
+        same_status = int(res.status[b]) == int(rres.status[b])
+        rep["status_equal"] += same_status
+        same = (same_status and int(out.n[b]) == int(ref.n[b]) and int(res.lm_iterations[b]) == int(rres.lm_iterations[b])
+                and int(res.lm_trials[b]) == int(rres.lm_trials[b]))
+        rep["counts_equal"] += same
+        if not same:
+            rep["count_mismatch"].append(int(b))
+        well = tols is None or (tols[b] is not None and tols[b] <= WELL_CONDITIONED_TOL)
+        if not well or int(out.n[b]) != int(ref.n[b]):
+            rep["skipped"] += 1
+            continue
+        d = max(float(np.abs(u - v).max()) for u, v in zip(out.get_teb(b), ref.get_teb(b)))
+        rep["max_state_err"] = max(rep["max_state_err"], d)
+        if np.isfinite(rres.cost[b]) and rres.cost[b] != 0:
+            rep["max_cost_rel"] = max(rep["max_cost_rel"], abs(float(res.cost[b]) - float(rres.cost[b])) / abs(float(rres.cost[b])))
+        rep["checked"] += 1
+    return rep

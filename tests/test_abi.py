@@ -29,7 +29,12 @@ def test_exports_every_declared_symbol(header):
 
 def test_struct_sizes_match_ctypes_mirror():
     L = planner.lib()
-    assert L.teb_amd_abi_version() == 1
+    assert L.teb_amd_abi_version() == 2
+    o = _abi.Options(layout="band")
+    assert o.struct_size == C.sizeof(_abi.Options) == L.teb_amd_sizeof_options()
+    d = _abi.Options(layout=3, fixed_layout=True)
+    L.teb_amd_options_default(C.byref(d))
+    assert d.layout == 0 and d.fixed_layout == 0 and d.struct_size == C.sizeof(_abi.Options)
     assert L.teb_amd_sizeof_config() == C.sizeof(_abi.Config)
     assert L.teb_amd_sizeof_obstacles() == C.sizeof(_abi.Obstacles)
     assert L.teb_amd_sizeof_teb_batch() == C.sizeof(_abi.TebBatch)

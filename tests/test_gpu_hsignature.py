@@ -21,9 +21,9 @@ from teb_local_planner_amd import scenes, planner, _abi  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def _solver(cfg, obst, batch, mode):
+def _solver(cfg, obst, batch, mode, kern=None):
     cfg.obstacles.include_dynamic_obstacles = (mode == 3)   # HomotopyClassPlanner::calculateEquivalenceClass picks the class by this flag
-    return planner.make_solver(cfg, obst, [], batch)
+    return planner.make_solver(cfg, obst, [], batch, options=_abi.Options(hsig3d_kernel=kern) if kern else None)   # kern pins one 3-D kernel
 
 
 @pytest.mark.parametrize("mode", [2, 3])
@@ -96,18 +96,14 @@ def test_h_signature_2d_large_obstacle_count_stays_in_range(oracle):
 def test_3d_signature_kernels_return_identical_bits(oracle):
     """hsig3d_kernel (one lane per band x obstacle) and hsig3d_small_kernel (lanes over obstacle x segment, sequential sum by one lane
     per obstacle) perform the same operations in the same order: identical results, on every case incl. ragged band lengths."""
-    try:
-        for cname, cfg, obst, batch in RG.h_signature_cases():
-            s = _solver(cfg, obst, batch, 3)
-            os.environ["TEB_AMD_HSIG3D"] = "wide"
-            a = s.h_signatures(1.0).copy()
-            os.environ["TEB_AMD_HSIG3D"] = "small"
-            b = s.h_signatures(1.0).copy()
-            np.testing.assert_array_equal(a, b)
-            assert np.isfinite(a).all() and np.abs(a).max() > 0
+    for cname, cfg, obst, batch in RG.h_signature_cases():
+        res = []
+        for kern in ("wide", "small"):
+            s = _solver(cfg, obst, batch, 3, kern)
+            res.append(s.h_signatures(1.0).copy())
             s.close()
-    finally:
-        os.environ.pop("TEB_AMD_HSIG3D", None)
+        np.testing.assert_array_equal(res[0], res[1])
+        assert np.isfinite(res[0]).all() and np.abs(res[0]).max() > 0
 
 
 @pytest.mark.parametrize("seed", range(0, 80, 4))
@@ -117,20 +113,15 @@ def test_randomized_h_signatures_match_oracle(oracle, mode, seed):
     the device, both 3-D kernels."""
     from random_cases import random_case
     cfg, obst, via, batch = random_case(seed)
-    s = _solver(cfg, obst, batch, mode)
     want = oracle.h_signatures(cfg, obst, batch, mode, 1.0)
-    try:
-        for kern in (("wide", "small") if mode == 3 else ("",)):
-            if kern:
-                os.environ["TEB_AMD_HSIG3D"] = kern
-            sig = s.h_signatures(1.0)
-            if mode == 3:
-                assert np.abs(sig - want).max(initial=0) <= 4 * np.finfo(float).eps * max(1.0, np.abs(want).max(initial=0)), (kern, np.abs(sig - want).max())
-            else:
-                assert np.abs(sig - want).max() <= 1e-10 * max(np.abs(want).max(), 1e-300)
-            got = s.filter_equivalence_classes(0.1, -1, 1)
-            for u, v in zip(got, oracle.filter_equivalence_classes(mode, want, 0.1, -1, 1)):
-                np.testing.assert_array_equal(u, v)
-    finally:
-        os.environ.pop("TEB_AMD_HSIG3D", None)
-    s.close()
+    for kern in (("wide", "small") if mode == 3 else (None,)):
+        s = _solver(cfg, obst, batch, mode, kern)
+        sig = s.h_signatures(1.0)
+        if mode == 3:
+            assert np.abs(sig - want).max(initial=0) <= 4 * np.finfo(float).eps * max(1.0, np.abs(want).max(initial=0)), (kern, np.abs(sig - want).max())
+        else:
+            assert np.abs(sig - want).max() <= 1e-10 * max(np.abs(want).max(), 1e-300)
+        got = s.filter_equivalence_classes(0.1, -1, 1)
+        for u, v in zip(got, oracle.filter_equivalence_classes(mode, want, 0.1, -1, 1)):
+            np.testing.assert_array_equal(u, v)
+        s.close()

@@ -26,10 +26,10 @@ from test_golden_oracle import check_against_golden  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def run_gpu(cfg, obst, via, batch, inner=None, outer=None, compute_cost=True):
+def run_gpu(cfg, obst, via, batch, inner=None, outer=None, compute_cost=True, options=None):
     inner = cfg.optim.no_inner_iterations if inner is None else inner
     outer = cfg.optim.no_outer_iterations if outer is None else outer
-    s = planner.make_solver(cfg, obst, via, batch)
+    s = planner.make_solver(cfg, obst, via, batch, options=options)
     s.optimize(inner, outer, compute_cost, cfg.hcp.selection_obst_cost_scale, cfg.hcp.selection_viapoint_cost_scale,
                cfg.hcp.selection_alternative_time_cost)
     res = s.results()
@@ -301,19 +301,18 @@ def test_reference_style_planner_objects(oracle):
 
 
 @pytest.mark.parametrize("solver", ["cr", "band", "band_ldlt", "bandg"])
-def test_both_damped_solvers_match_the_oracle(oracle, solver, monkeypatch):
+def test_both_damped_solvers_match_the_oracle(oracle, solver):
     """The three damped solves - block cyclic reduction on the LDS-resident blocks ("cr"), the same reduction on HBM-resident
     blocks expanded from the LDS band (what long bands use: "band"), and the sequential banded LDL^T ("band_ldlt", kept as a
     cross-check) - solve the same system: identical accept / reject decisions, trajectories within 1e-8. Even and odd pose
     counts (block padding)."""
-    monkeypatch.setenv("TEB_AMD_SOLVER", "bandg" if solver == "bandg" else ("band" if solver.startswith("band") else "cr"))   # "bandg": band in HBM
-    if solver == "band_ldlt":
-        monkeypatch.setenv("TEB_AMD_BAND_SOLVE", "ldlt")
+    opt = _abi.Options(layout="bandg" if solver == "bandg" else ("band" if solver.startswith("band") else "cr"),   # "bandg": band in HBM
+                       band_ldlt=(solver == "band_ldlt"))
     for n0 in (24, 25):
         cfg, obst, via, batch = scenes.scene_small_mixed(footprint="polygon", n=n0)
         for autosize in (True, False):
             cfg.trajectory.teb_autosize = autosize
-            out, res, best = run_gpu(cfg, obst, via, batch)
+            out, res, best = run_gpu(cfg, obst, via, batch, options=opt)
             ref, rres = oracle.optimize_batch(cfg, obst, via, batch)
             assert_full_parity(out, res, ref, rres)
 
@@ -332,11 +331,10 @@ def test_solver_fails_like_cholesky_on_indefinite_system(oracle):
 
 @pytest.mark.parametrize("fast", [True, False])
 @pytest.mark.parametrize("footprint", ["point", "circular"])
-def test_pointlike_fast_path_equals_generic_path(oracle, fast, footprint, monkeypatch):
+def test_pointlike_fast_path_equals_generic_path(oracle, fast, footprint):
     """Point/Circular obstacles + Point/Circular footprint take the LDS-resident specialised distance path;
-    TEB_AMD_NO_FAST_POINTS forces the generic one. Both must match the oracle (incl. the velocity-obstacle-ratio edge)."""
-    if not fast:
-        monkeypatch.setenv("TEB_AMD_NO_FAST_POINTS", "1")
+    teb_amd_options_t::generic_distance_path forces the generic one. Both must match the oracle (incl. the velocity-obstacle-ratio edge)."""
+    opt = None if fast else _abi.Options(generic_distance_path=True)
     cfg, obst0, via, batch = scenes.scene_small_mixed(footprint=footprint, stride=192)
     obst = _abi.ObstacleTable()
     rng = np.random.default_rng(4)
@@ -348,7 +346,7 @@ def test_pointlike_fast_path_equals_generic_path(oracle, fast, footprint, monkey
         else:
             obst.add_point(p[0], p[1], vel=vel)
     cfg.optim.weight_velocity_obstacle_ratio = 2.0
-    s = planner.make_solver(cfg, obst, via, batch)
+    s = planner.make_solver(cfg, obst, via, batch, options=opt)
     for b in range(batch.count):
         G = s.debug_linearize(b, int(batch.n[b]), 2.0)
         R = oracle.linearize(cfg, obst, via, batch, b, 2.0)
@@ -358,7 +356,7 @@ def test_pointlike_fast_path_equals_generic_path(oracle, fast, footprint, monkey
         np.testing.assert_array_equal(G["assoc_pose"], ap)
         np.testing.assert_array_equal(G["assoc_obst"], ao)
     s.close()
-    out, res, best = run_gpu(cfg, obst, via, batch)
+    out, res, best = run_gpu(cfg, obst, via, batch, options=opt)
     ref, rres = oracle.optimize_batch(cfg, obst, via, batch)
     assert_full_parity(out, res, ref, rres)
 
@@ -369,6 +367,9 @@ def test_pointlike_fast_path_equals_generic_path(oracle, fast, footprint, monkey
 # Jacobian entries - the same noise the reference has between two compilers ("Compiler note").
 sys.path.insert(0, os.path.join(HERE, "golden"))
 import make_ref_golden as RG  # noqa: E402
+
+# bands compared / bands seen, per skip rule; the floors are asserted by test_skip_rules_have_a_floor at the end of this file
+_SKIP_STATS = {"reference_code": [0, 0], "randomized": [0, 0]}
 
 NUMERIC_CASES = ["edges_point", "edges_two_circles", "edges_line", "edges_polygon_carlike_arc", "edges_optional",
                  "edges_holonomic", "c1", "c1_velocities", "c2_small", "c3_small", "c5_small", "divergence_detection", "legacy_association"]
@@ -415,6 +416,8 @@ def test_optimizeTEB_matches_reference_code(oracle, name, mode):
         assert d <= tols[b], (name, b, d, tols[b])
         assert abs(res.cost[b] - g["cost"][b]) <= tols[b] * abs(g["cost"][b]), (name, b, res.cost[b], g["cost"][b])
         checked += 1
+    _SKIP_STATS["reference_code"][0] += checked
+    _SKIP_STATS["reference_code"][1] += min(batch.count, RG.MAX_TEBS)
     assert checked >= 1
 
 
@@ -560,41 +563,39 @@ from random_cases import random_case as _random_case  # noqa: E402
 
 @pytest.mark.parametrize("seed", range(80))
 def test_randomized_scenes_full_parity(oracle, seed):
-    """Same closed-form mode on both sides: pose counts, status, LM iteration / trial counts identical, poses <= 1e-7, on every
-    band that is well conditioned by the yardstick of tests/sensitivity.py. A few percent of these random bands are not: the
-    averaged heading of a pose inserted by autoResize differs by one ulp between the device's and the host's atan2, and the
-    oracle itself - run on the two inputs - then ends 2e-2 apart (measured: seed 32; tools/fuzz_probe6.py). Those bands are
-    compared on status only."""
+    """Same closed-form mode on both sides, EVERY band (no skip rule): status, pose counts, LM iteration / trial counts identical; poses
+    and time differences <= 1e-7 on bands that are well conditioned by the yardstick of tests/sensitivity.py and <= 1e-6 on the others
+    (bands that start in collision amplify last-bit differences of the device's libm; observed on MI355X over the 240 bands of the 80
+    seeds, tools/random_parity_probe.py: 190 below 1e-12, 231 below 1e-10, the worst 5e-8); cost rel to the same bounds."""
     import sensitivity
     cfg, obst, via, batch = _random_case(seed)
     tols = sensitivity.band_tolerances(oracle, cfg, obst, via, batch)
     out, res, best = run_gpu(cfg, obst, via, batch)
     ref, rres = oracle.optimize_batch(cfg, obst, via, batch)
     np.testing.assert_array_equal(res.status, rres.status)
-    checked = 0
     for b in range(batch.count):
-        if tols[b] is None or tols[b] > sensitivity.WELL_CONDITIONED_TOL:
-            continue
+        well = tols[b] is not None and tols[b] <= sensitivity.WELL_CONDITIONED_TOL
+        bound = 1e-7 if well else 1e-6
         assert out.n[b] == ref.n[b], (seed, b)
         assert res.lm_iterations[b] == rres.lm_iterations[b] and res.lm_trials[b] == rres.lm_trials[b], (seed, b)
         for u, v in zip(out.get_teb(b), ref.get_teb(b)):
-            assert np.abs(u - v).max() <= 1e-7, (seed, b, np.abs(u - v).max())
-        assert abs(res.cost[b] - rres.cost[b]) <= 1e-7 * abs(rres.cost[b])
-        checked += 1
-    if checked == batch.count:
-        assert best[0] == oracle.select_best(cfg, rres.cost)[0]
+            assert np.abs(u - v).max() <= bound, (seed, b, np.abs(u - v).max())
+        if np.isfinite(rres.cost[b]):
+            assert abs(res.cost[b] - rres.cost[b]) <= bound * abs(rres.cost[b])
+        _SKIP_STATS["randomized"][0] += 1
+    _SKIP_STATS["randomized"][1] += batch.count
+    assert best[0] == oracle.select_best(cfg, rres.cost)[0]
 
 
 @pytest.mark.parametrize("layout", ["band", "bandg"])
 @pytest.mark.parametrize("seed", range(0, 80, 5))
-def test_randomized_scenes_do_not_depend_on_the_layout(seed, layout, monkeypatch):
+def test_randomized_scenes_do_not_depend_on_the_layout(seed, layout):
     """The three layouts of the normal matrix (8x8 blocks in LDS, band in LDS, band in HBM) run the same arithmetic up to the order of
     the block reduction: on random scenes (all options of the path toggled at random) the forced band layouts give the pose counts,
     LM iteration / trial counts and status of the default layout and poses within 1e-8."""
     cfg, obst, via, batch = _random_case(seed)
     out0, res0, _ = run_gpu(cfg, obst, via, batch)
-    monkeypatch.setenv("TEB_AMD_SOLVER", layout)
-    out1, res1, _ = run_gpu(cfg, obst, via, batch)
+    out1, res1, _ = run_gpu(cfg, obst, via, batch, options=_abi.Options(layout=layout))
     np.testing.assert_array_equal(res0.status, res1.status)
     np.testing.assert_array_equal(out0.n, out1.n)
     np.testing.assert_array_equal(res0.lm_iterations, res1.lm_iterations)
@@ -605,24 +606,22 @@ def test_randomized_scenes_do_not_depend_on_the_layout(seed, layout, monkeypatch
             assert np.abs(u - v).max() <= 1e-8, (seed, b, np.abs(u - v).max())
 
 
-def test_layout_is_chosen_per_launch_and_repeated_when_a_band_outgrows_it(oracle, monkeypatch):
+def test_layout_is_chosen_per_launch_and_repeated_when_a_band_outgrows_it(oracle):
     """A handle created for 501 poses (band in HBM) that holds a 194-pose band is launched with the blocks in LDS: same result as a
     208-pose handle to 1e-8, at its speed. A band that outgrows the optimistic capacity inside the kernel (autoResize doubles it) makes
-    the library repeat the launch from the saved strips in the handle's own layout: bit-identical to TEB_AMD_FIXED_LAYOUT=1."""
+    the library repeat the launch from the saved strips in the handle's own layout: bit-identical to a handle with teb_amd_options_t::fixed_layout."""
     cfg, obst, via, batch = scenes.scene_c2(stride=208)
-    def run(cap, b=batch):
+    def run(cap, b=batch, fixed=False):
         hb = _abi.TebBatchHost(b.count, cap)
         for k in range(b.count):
             hb.set_teb(k, *b.get_teb(k))
-        s = planner.make_solver(cfg, obst, via, hb)
+        s = planner.make_solver(cfg, obst, via, hb, options=_abi.Options(fixed_layout=fixed))
         s.optimize(5, 4, True, 100.0, 1.0, False); s.synchronize()
         ms = s.last_kernel_ms(); res = s.results(); out = s.download(hb.copy()); s.close()
         return out, res, ms
     small, rs, ms_small = run(208)
     big, rb, ms_big = run(501)
-    monkeypatch.setenv("TEB_AMD_FIXED_LAYOUT", "1")
-    fixed, rf, ms_fixed = run(501)
-    monkeypatch.delenv("TEB_AMD_FIXED_LAYOUT")
+    fixed, rf, ms_fixed = run(501, fixed=True)
     assert small.n[0] == big.n[0] == fixed.n[0] and rs.lm_iterations[0] == rb.lm_iterations[0] == rf.lm_iterations[0]
     for u, v, w in zip(small.get_teb(0), big.get_teb(0), fixed.get_teb(0)):
         assert np.abs(u - v).max() <= 1e-8 and np.abs(u - w).max() <= 1e-8
@@ -633,14 +632,28 @@ def test_layout_is_chosen_per_launch_and_repeated_when_a_band_outgrows_it(oracle
     x, y, th, dt = scenes.sine_band(150, 30.0, 0.2, 1.0, cfg.robot.max_vel_x)
     grow.set_teb(0, x, y, th, dt * 0 + 0.75)
     cfg.trajectory.max_samples = 500
-    def run_grow():
-        s = planner.make_solver(cfg, obst, via, grow)
+    def run_grow(fixed=False):
+        s = planner.make_solver(cfg, obst, via, grow, options=_abi.Options(fixed_layout=fixed))
         s.optimize(3, 2, True, 100.0, 1.0, False); s.synchronize()
-        res = s.results(); out = s.download(grow.copy()); s.close()
-        return out, res
-    a, ra = run_grow()
-    monkeypatch.setenv("TEB_AMD_FIXED_LAYOUT", "1")
-    b, rb2 = run_grow()
+        ms = s.last_kernel_ms(); res = s.results(); out = s.download(grow.copy()); s.close()
+        return out, res, ms
+    a, ra, ms_a = run_grow()
+    b, rb2, ms_b = run_grow(fixed=True)
+    assert ms_a > ms_b          # teb_amd_last_kernel_ms covers the discarded optimistic launch as well as the repeated one
     assert a.n[0] == b.n[0] > 238 and ra.status[0] == rb2.status[0] == _abi.TEB_OK
     for u, v in zip(a.get_teb(0), b.get_teb(0)):
         np.testing.assert_array_equal(u, v)
+
+
+def test_skip_rules_have_a_floor():
+    """The comparison with the reference-code vectors leaves out bands on which even the CPU oracle's two Jacobian modes end with
+    different pose counts; the randomized comparison skips nothing. Neither rule may hide a regression: at least 90 % of the bands
+    seen were actually compared (observed on MI355X: reference-code vectors 60 of 62, randomized scenes 240 of 240). Runs after them
+    (file order); skipped when they were deselected."""
+    for name, (checked, seen) in _SKIP_STATS.items():
+        print("%s: %d of %d bands compared, %d skipped as ill conditioned" % (name, checked, seen, seen - checked))
+    if all(seen == 0 for _, seen in _SKIP_STATS.values()):
+        pytest.skip("the parametrised comparisons did not run in this session")
+    for name, (checked, seen) in _SKIP_STATS.items():
+        if seen:
+            assert checked >= 0.9 * seen, (name, checked, seen)

@@ -9,7 +9,7 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "prof")
+SRC = os.path.join(ROOT, "gpurun_out", os.environ.get("PROF_DIR", "prof"))
 DST = os.path.join(ROOT, "profiles")
 
 
@@ -41,7 +41,9 @@ def main():
         lines.append("grid=%d wg=%d lds=%d scratch=%d vgpr=%d agpr=%d sgpr=%d calls=%d avg_ns=%.0f min_ns=%.0f max_ns=%.0f" % r[1:])
         if full is None or r[1] > full[1]:
             full = r
-    summary = {"tag": tag, "kernel": "teb_optimize_kernel", "grid": full[1], "workgroup": full[2], "calls": full[8],
+    sys.path.insert(0, ROOT)
+    import bench
+    summary = {"tag": tag, "source_hash": bench.kernel_source_hash(), "kernel": "teb_optimize_kernel", "grid": full[1], "workgroup": full[2], "calls": full[8],
                "avg_ms": full[9] / 1e6, "lds_bytes": full[3], "scratch_bytes_per_lane": full[4], "vgpr": full[5], "agpr": full[6]}
     grid = full[1]
     for sub, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):

@@ -1,0 +1,43 @@
+"""Distribution of device-vs-oracle differences (same closed-form Jacobian mode) on the measured configurations, next to two
+yardsticks of how well conditioned a band is: (a) the oracle's analytic vs numeric mode (tests/sensitivity.py), (b) the oracle against
+itself when the inputs move by 1e-13 relative."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import sensitivity
+from teb_local_planner_amd import scenes, planner, _abi
+from oracle import oracle_py
+oracle_py.build()
+TH = os.cpu_count() or 1
+def run(name, cfg, obst, via, batch):
+    s = planner.make_solver(cfg, obst, via, batch)
+    s.optimize(5, 4, True, 100.0, 1.0, False)
+    res = s.results(); out = s.download(batch.copy()); s.close()
+    t = time.time(); ref, rres = oracle_py.optimize_batch(cfg, obst, via, batch, threads=TH); t_or = time.time() - t
+    tols = sensitivity.band_tolerances(oracle_py, cfg, obst, via, batch, threads=TH)
+    pert = batch.copy()
+    rng = np.random.default_rng(7)
+    pert.x *= 1 + 1e-13 * rng.standard_normal(pert.x.shape); pert.y *= 1 + 1e-13 * rng.standard_normal(pert.y.shape)
+    pref, pres = oracle_py.optimize_batch(cfg, obst, via, pert, threads=TH)
+    err = np.zeros(batch.count); self_err = np.zeros(batch.count); cnt_ok = np.zeros(batch.count, bool)
+    for b in range(batch.count):
+        cnt_ok[b] = out.n[b] == ref.n[b] and res.lm_iterations[b] == rres.lm_iterations[b] and res.lm_trials[b] == rres.lm_trials[b] and res.status[b] == rres.status[b]
+        err[b] = max(np.abs(u - v).max() for u, v in zip(out.get_teb(b), ref.get_teb(b))) if out.n[b] == ref.n[b] else np.inf
+        self_err[b] = max(np.abs(u - v).max() for u, v in zip(pref.get_teb(b), ref.get_teb(b))) if pref.n[b] == ref.n[b] else np.inf
+    well = np.array([t is not None and t <= sensitivity.WELL_CONDITIONED_TOL for t in tols])
+    print("== %s: %d bands, oracle %.1f s on %d threads; counts identical on %d; well conditioned (a) %d" % (name, batch.count, t_or, TH, cnt_ok.sum(), well.sum()))
+    for lo, hi in ((0, 1e-12), (1e-12, 1e-10), (1e-10, 1e-8), (1e-8, 1e-7), (1e-7, 1e-5), (1e-5, 1e-2), (1e-2, np.inf)):
+        sel = (err >= lo) & (err < hi)
+        print("   device-oracle err in [%g, %g): %3d bands (of them well (a): %3d, self-err<1e-9 (b): %3d)" % (lo, hi, sel.sum(), (sel & well).sum(), (sel & (self_err < 1e-9)).sum()))
+    print("   err == inf (pose counts differ): %d ; self-err inf: %d" % (np.isinf(err).sum(), np.isinf(self_err).sum()))
+    bad = np.where(err > 1e-7)[0]
+    for b in bad[:12]:
+        print("   band %3d err %.2e self_err %.2e tol(a) %s n %d/%d trials %d/%d" % (b, err[b], self_err[b], tols[b], out.n[b], ref.n[b], res.lm_trials[b], rres.lm_trials[b]))
+for which in sys.argv[1:] or ["c4on", "c4", "c2", "c3"]:
+    if which == "c4on": a = scenes.scene_c4(B=256, n=200, seed=1004, stride=288)
+    elif which == "c4":
+        a = scenes.scene_c4(B=256, n=200, seed=1004, stride=208); a[0].trajectory.teb_autosize = False
+    elif which == "c2": a = scenes.scene_c2(stride=208)
+    else: a = scenes.scene_c3(stride=208)
+    run(which, *a)
