@@ -42,6 +42,9 @@ int teb_amd_debug_profile_bands(teb_amd_handle_t* h, double* cycles_per_band);
 /* Streams n_doubles fp64 values global->global (8 B per lane, coalesced; reads and writes n_doubles*8 bytes each)
  * `repeats` times: a known byte count to calibrate rocprofv3 FETCH_SIZE / WRITE_SIZE against. */
 int teb_amd_debug_stream(teb_amd_handle_t* h, int64_t n_doubles, int32_t repeats);
+/* Operand maps of v_mfma_f64_16x16x4_f64 as used by the MFMA Schur update (builds with -DTEB_AMD_MFMA_SCHUR; others return
+ * TEB_AMD_ERR_UNSUPPORTED): C [16x16] = A [16x8, row-major] * B [8x16]; *cycles_per_mfma = clock ticks per issue on one wave. */
+int teb_amd_debug_mfma_selftest(teb_amd_handle_t* h, const double* A, const double* B, double* C, int32_t reps, double* cycles_per_mfma);
 
 /* per-TEB flags of the last launch: bit0 association list overflow, bit1 autoResize capacity overflow */
 int teb_amd_debug_assoc_overflow(teb_amd_handle_t* h, int32_t* flags);

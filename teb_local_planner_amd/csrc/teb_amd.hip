@@ -465,7 +465,7 @@ int teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max
   h->plan = make_lds_plan(max_poses, solver, 0);
   // per-band HBM buffer: the copy of H for rejected trials (SOLVER_CR, banded LDL^T) or the blocks the cyclic reduction of a
   // SOLVER_BAND handle works on (D, L, f: nb * (2 * kBlk + 8) doubles)
-  h->hmat_stride = std::max(hmat_doubles(max_poses, solver), (size_t)nb_for(max_poses) * (2 * kBlk + 8));
+  h->hmat_stride = std::max(hbm_scratch_doubles(max_poses, SOLVER_BAND), hbm_scratch_doubles(max_poses, solver));   // every layout may be launched
   h->band_ldlt = opt.band_ldlt != 0;
   if (solver == SOLVER_BANDG) h->band_ldlt = 0;   // the sequential LDL^T works in place on an LDS band only
   if (stream) { h->stream = reinterpret_cast<hipStream_t>(stream); h->own_stream = false; }
@@ -1907,6 +1907,33 @@ int teb_amd_debug_profile_bands(teb_amd_handle_t* h, double* cycles_per_band) {
 #else
   (void)cycles_per_band;
   return fail(TEB_AMD_ERR_UNSUPPORTED, "library built without -DTEB_PROFILE");
+#endif
+}
+
+// debug: checks the operand maps of v_mfma_f64_16x16x4_f64 that cr_forward_mfma relies on (C = A B, A 16x8 row-major, B 8x16, C 16x16)
+// and times reps x 4 independent issues on one wave. Builds without -DTEB_AMD_MFMA_SCHUR return TEB_AMD_ERR_UNSUPPORTED.
+int teb_amd_debug_mfma_selftest(teb_amd_handle_t* h, const double* A, const double* B, double* C, int32_t reps, double* cycles_per_mfma) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+#ifdef TEB_AMD_MFMA_SCHUR
+  if (!A || !B || !C) return fail(TEB_AMD_ERR_INVALID_ARG, "null matrices");
+  double *dA = nullptr, *dB = nullptr, *dC = nullptr; long long* dT = nullptr;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&dA), 128 * sizeof(double))); HIPCHK(hipMalloc(reinterpret_cast<void**>(&dB), 128 * sizeof(double)));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&dC), 256 * sizeof(double))); HIPCHK(hipMalloc(reinterpret_cast<void**>(&dT), 2 * sizeof(long long)));
+  HIPCHK(hipMemcpyAsync(dA, A, 128 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(dB, B, 128 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, h->stream, dA, dB, dC, reps, dT);
+  HIPCHK(hipGetLastError());
+  long long t[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(C, dC, 256 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(t, dT, sizeof(t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (cycles_per_mfma) *cycles_per_mfma = reps > 0 ? (double)t[0] / (4.0 * reps) : 0.0;
+  (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dT);
+  return TEB_AMD_OK;
+#else
+  (void)A; (void)B; (void)C; (void)reps; (void)cycles_per_mfma;
+  return fail(TEB_AMD_ERR_UNSUPPORTED, "this build has no MFMA Schur update (-DTEB_AMD_MFMA_SCHUR)");
 #endif
 }
 

@@ -46,7 +46,17 @@ struct Lds {
 __host__ __device__ inline int nb_for(int S) { return (4 * S + 7) / 8; }
 __host__ __device__ inline size_t hmat_doubles(int S, int solver) {  // (LDS-resident part)
   if (solver == SOLVER_BANDG) return (size_t)5 * S + 256;   // only the scratch of autoResize (edit script + new poses + split stack)
-  return solver == SOLVER_CR ? (size_t)nb_for(S) * (2 * kBlk + 8) : (size_t)4 * S * kBand;
+  if (solver == SOLVER_CR) return (size_t)nb_for(S) * (2 * kBlk + 8);
+  const size_t band = (size_t)4 * S * kBand, compact = (size_t)((nb_for(S) + 1) / 2) * (2 * kBlk + 8);   // hybrid solve: even block rows in LDS
+  return band > compact ? band : compact;
+}
+// per-band HBM scratch of the solves: SOLVER_CR keeps a copy of H there; SOLVER_BAND / BANDG the 8x8 blocks (D, L, f) the reduction
+// works on (the hybrid solve only reads them)
+__host__ __device__ inline size_t hbm_scratch_doubles(int S, int solver) {
+  const size_t nb = (size_t)nb_for(S);
+  const size_t blocks = nb * (2 * kBlk + 8);
+  const size_t own = hmat_doubles(S, solver);
+  return own > blocks ? own : blocks;
 }
 // host: lay out the LDS; ob_entries = obstacles to cache (0 = no cache). Returns total bytes.
 __host__ inline LdsPlan make_lds_plan(int S, int solver, int ob_entries) {
@@ -595,7 +605,8 @@ __device__ __forceinline__ bool cr_forward(double* __restrict__ D, double* __res
           for (int k = 0; k < 8; ++k) s2 += Lp[c * 8 + k] * wf[k];
         }
       }
-      __syncthreads();   // every read of this round is done
+      // No barrier before the writes: within a level the eliminated rows i = s (2 e + 1) and the blocks read for them (D_i, L_i,
+      // L_{i+s}, f_i) belong to exactly one 8-lane group, and the survivors' D / f are only written (never read) in this level.
       if (act) {
         double* Dm = D + (i - s) * kBlk;
         double* Di = D + i * kBlk;
@@ -624,6 +635,137 @@ __device__ __forceinline__ bool cr_forward(double* __restrict__ D, double* __res
   }
   return ok;
 }
+#ifdef TEB_AMD_MFMA_SCHUR
+// ---- the same forward step with the Schur update on the matrix cores (north_star: "MFMA only on the dense Schur block") -----------
+// Per elimination the update of the neighbours is ONE 16 x 16 x 8 fp64 contraction
+//     C = [L_i | U_i]^T  [W_L | W_U],   W = P_i [L_i | U_i]     (U_i = L_{i+s}^T)
+//     C(0:8, 0:8) = L_i^T W_L  -> D_{i-s} -= .     C(8:16, 0:8) = U_i^T W_L -> L_{i+s} := -.     C(8:16, 8:16) = U_i^T W_U -> D_{i+s} -= .
+// i.e. two v_mfma_f64_16x16x4_f64 per elimination (the quadrant C(0:8, 8:16) is the transpose of C(8:16, 0:8) and is dropped: 75 % of
+// the MACs are useful). A wave serves its 8 eliminations one after the other; the factorisation of D_i and the three triangular solves
+// stay per-lane VALU code (8 lanes per elimination, as in cr_forward). What the matrix instruction buys is not rate (on gfx950 the fp64
+// matrix rate equals the fp64 vector rate) but operand traffic: a lane loads 2 + 2 operand values per elimination instead of streaming
+// the whole of L_i and L_{i+s} (128 values) for its column of the product. Lane l holds A(m = l & 15, k = l >> 4),
+// B(k = l >> 4, n = l & 15) and C(m = (l >> 4) + 4 r, n = l & 15), r = 0..3 (checked on the device by teb_amd_debug_mfma_selftest).
+typedef double v4d __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bool cr_forward_mfma(double* __restrict__ D, double* __restrict__ L, double* __restrict__ f, int Nb, int s_lo,
+                                                int s_hi) {
+  TEB_SOLVER_FMA
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int grp = tid >> 3, c = tid & 7;
+  const int am = lane & 15, ak = lane >> 4, an = am & 7;
+  const bool left = am < 8;
+  bool ok = true;
+  for (int s = s_lo; s < s_hi; s <<= 1) {
+    const int E = (Nb - 1 - s) / (2 * s) + 1;
+    for (int e0 = 0; e0 < E; e0 += kThreads / 8) {
+      const int e = e0 + grp;
+      const bool act = e < E;
+      const int i = s * (2 * e + 1);
+      const bool hasU = act && (i + s < Nb);
+      // A operands of the 8 eliminations of this wave, fetched before anything overwrites L_i / L_{i+s}
+      double A0[8], A1[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int eq = e0 + 8 * wv + q, iq = s * (2 * eq + 1);
+        const bool v = left ? (eq < E) : (eq < E && iq + s < Nb);
+        const double* src = left ? L + iq * kBlk + am : L + (iq + s) * kBlk + an * 8;   // L_i[k][m]  |  L_{i+s}[m - 8][k]
+        const int st = left ? 8 : 1;
+        A0[q] = v ? src[ak * st] : 0.0;
+        A1[q] = v ? src[(ak + 4) * st] : 0.0;
+      }
+      double wL[8], wU[8], wf[8];
+      double s1 = 0, s2 = 0;
+      if (act) {
+        double* Di = D + i * kBlk;
+        double* Li = L + i * kBlk;
+        const double* Lp = L + (i + s) * kBlk;   // U_i^T, valid iff hasU
+        Ldl8 F;
+        F.load(Di);
+        ok = F.factor() && ok;
+        double cl[8], cu[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          cl[k] = wL[k] = Li[k * 8 + c];
+          cu[k] = wU[k] = hasU ? Lp[c * 8 + k] : 0.0;
+          wf[k] = f[i * 8 + k];
+        }
+        F.solve3(wL, wU, wf);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s1 += cl[k] * wf[k]; s2 += cu[k] * wf[k]; }   // (L_i^T P f_i)[c], (L_{i+s} P f_i)[c]
+        // W_L, W_U take the slots of the eliminated row: operands of the matrix instruction below, and of the back substitution later
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { Di[k * 8 + c] = wL[k]; Li[k * 8 + c] = wU[k]; }
+      }
+      // same wave: LDS operations complete in order, so the operand loads below see the stores above; no other wave touches these slots
+      v4d C[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int eq = e0 + 8 * wv + q, iq = s * (2 * eq + 1);
+        C[q] = v4d{0.0, 0.0, 0.0, 0.0};
+        if (eq < E) {
+          const double* W = (left ? D : L) + iq * kBlk + an;   // W_L | W_U, entry (k, n)
+          const double b0 = W[ak * 8], b1 = W[(ak + 4) * 8];
+          C[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[q], b0, C[q], 0, 0, 0);
+          C[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[q], b1, C[q], 0, 0, 0);
+        }
+      }
+      // phase 1: D_{i-s} -= C(0:8, 0:8), L_{i+s} := -C(8:16, 0:8)   (lanes n < 8)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int eq = e0 + 8 * wv + q, iq = s * (2 * eq + 1);
+        if (eq < E && left) {
+          double* Dm = D + (iq - s) * kBlk;
+          Dm[ak * 8 + am] -= C[q][0];
+          Dm[(ak + 4) * 8 + am] -= C[q][1];
+          if (iq + s < Nb) {
+            double* Lq = L + (iq + s) * kBlk;
+            Lq[ak * 8 + am] = -C[q][2];
+            Lq[(ak + 4) * 8 + am] = -C[q][3];
+          }
+        }
+      }
+      if (act) { f[(i - s) * 8 + c] -= s1; f[i * 8 + c] = wf[c]; }
+      __syncthreads();
+      // phase 2: D_{i+s} -= C(8:16, 8:16)   (lanes n >= 8)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int eq = e0 + 8 * wv + q, iq = s * (2 * eq + 1);
+        if (eq < E && !left && iq + s < Nb) {
+          double* Dp = D + (iq + s) * kBlk;
+          Dp[ak * 8 + an] -= C[q][2];
+          Dp[(ak + 4) * 8 + an] -= C[q][3];
+        }
+      }
+      if (hasU) f[(i + s) * 8 + c] -= s2;
+      __syncthreads();
+    }
+  }
+  return ok;
+}
+// A(16 x 8) B(8 x 16) with the operand maps used above -> C (16 x 16); also times `reps` dependent-free issues per wave (clock64 ticks)
+__global__ void mfma_selftest_kernel(const double* A, const double* B, double* Cout, int reps, long long* ticks) {
+  const int lane = threadIdx.x & 63, am = lane & 15, ak = lane >> 4;
+  const double a0 = A[am * 8 + ak], a1 = A[am * 8 + ak + 4], b0 = B[ak * 16 + am], b1 = B[(ak + 4) * 16 + am];
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) Cout[(ak + 4 * r) * 16 + am] = acc[r];
+  v4d t0 = {0, 0, 0, 0}, t1 = t0, t2 = t0, t3 = t0;
+  const long long c0 = clock64();
+  for (int it = 0; it < reps; ++it) {   // four independent accumulators: issue-bound, not latency-bound
+    t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, t0, 0, 0, 0);
+    t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, t1, 0, 0, 0);
+    t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, t2, 0, 0, 0);
+    t3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, t3, 0, 0, 0);
+  }
+  const long long c1 = clock64();
+  if (threadIdx.x == 0 && blockIdx.x == 0) { ticks[0] = c1 - c0; ticks[1] = (long long)(t0[0] + t1[1] + t2[2] + t3[3]); }
+}
+#define TEB_CR_FORWARD cr_forward_mfma
+#else
+#define TEB_CR_FORWARD cr_forward
+#endif
+
 // x_0 = D_0^{-1} f_0 of the last surviving row
 __device__ __forceinline__ bool cr_top(const double* __restrict__ D, double* __restrict__ f) {
   TEB_SOLVER_FMA
@@ -748,7 +890,7 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, const SceneDev&
       for (int q = tid; q < Nc * 8; q += kThreads) fc[q] = f[(size_t)(q >> 3) * s0 * 8 + (q & 7)];
       __syncthreads();
       CRP(2);
-      ok = cr_forward(Dc, Lc, fc, Nc, 1, Nc) && ok;
+      ok = cr_forward(Dc, Lc, fc, Nc, 1, Nc) && ok;   // (the MFMA build keeps the vector code for this layout, SOLVER_BANDG)
       ok = cr_top(Dc, fc) && ok;
       __syncthreads();
       int stop = 1;
@@ -780,6 +922,9 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, const SceneDev&
     CRP(5);
     return;
   }
+#ifdef TEB_AMD_MFMA_SCHUR
+  bool ok = cr_forward_mfma(D, L, f, Nb, 1, Nb);
+#else
   // 8 lanes per elimination: lane c owns column c of L_i, of U_i and (redundantly) f_i; 32 eliminations per round
   const int grp = tid >> 3, c = tid & 7;
   bool ok = true;
@@ -831,8 +976,7 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, const SceneDev&
         }
       }
       CRP(1);
-      __syncthreads();   // every read of this round is done
-      CRP(2);
+      CRP(2);   // (no barrier here: see cr_forward)
       if (act) {
         double* Dm = D + (i - s) * kBlk;
         double* Di = D + i * kBlk;
@@ -860,6 +1004,7 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, const SceneDev&
       CRP(3);
     }
   }
+#endif
   // the last surviving block row: x_0 = D_0^{-1} f_0
   if (tid < 8) {
     double v[8];
@@ -903,6 +1048,176 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, const SceneDev&
   for (int q = tid; q < Nt; q += kThreads) l.dxv[q] = f[q];
   __syncthreads();
   CRP(5);
+}
+
+// ---- damped solve (K6 v4, "hybrid"): for bands whose block layout does not fit the LDS (SOLVER_BAND) ------------------------------------
+// The normal matrix is linearised into the LDS band. ONCE per LM iteration its 8x8 blocks are expanded into the band's HBM scratch
+// (read-only from then on, lambda-free); the band region of the LDS is dead until the next linearisation. Every damped trial then runs
+//   level 0: the odd block rows are eliminated straight from the HBM blocks (+ lambda on the fly; loads only, no read-modify-write on
+//            HBM) INTO a compact system of the even rows built in the former band region of the LDS (35 S <= 44 S doubles),
+//            their (W_L, W_U, P f) records stay in registers;
+//   levels >= 1, top solve, back substitution of the even rows: the in-LDS block cyclic reduction (cr_forward / cr_top / cr_backward);
+//   back substitution of the odd rows from those records.
+// Same arithmetic as cr_solve_t (an exact re-indexing: compact row j' = row 2 j'); no backup / restore of H, no obstacle-cache reload.
+// gbuf: D [Nb * kBlk] | L [Nb * kBlk]
+template <bool HB_GLOBAL>
+__device__ __forceinline__ void cr_expand_blocks(const Lds& l, int n, double* __restrict__ gbuf) {
+  const int tid = threadIdx.x;
+  const int Nt = 4 * n, Nb = (Nt + 7) >> 3;
+  double* __restrict__ D = gbuf;
+  double* __restrict__ L = gbuf + (size_t)Nb * kBlk;
+  const double* Hb = l.Hb;
+  for (int q = tid; q < Nb * 128; q += kThreads) {
+    const int j = q >> 7, w = q & 127, a = (w & 63) >> 3, bcol = w & 7;
+    const int r = 8 * j + a;
+    double v = 0;
+    if (w < 64) {            // D_j[a][bcol]
+      const int cc = 8 * j + bcol;
+      if (r < Nt && cc < Nt) v = (cc <= r) ? Hb[r * kBand + (r - cc)] : Hb[cc * kBand + (cc - r)];
+      else if (r == cc) v = 1.0;
+      D[j * kBlk + a * 8 + bcol] = v;
+    } else {                 // L_j[a][bcol] = H[8j+a][8(j-1)+bcol]
+      const int d = 8 + a - bcol;
+      if (j >= 1 && r < Nt && d < kBand) v = Hb[r * kBand + d];
+      L[j * kBlk + a * 8 + bcol] = v;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+}
+
+constexpr int kHybridRounds = 3;   // level-0 rounds of 32 eliminations: block rows <= 172 (343 poses) -> <= 86 odd rows
+__device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, double lambda, double* gbuf) {
+  TEB_SOLVER_FMA
+  extern __shared__ __attribute__((aligned(16))) double lds_base[];
+  const Lds l = carve(lds_base, plan);
+  const int tid = threadIdx.x;
+  const int Nt = 4 * n, Nb = (Nt + 7) >> 3, Nc = (Nb + 1) >> 1, E = Nb >> 1;
+  const double* __restrict__ Dg = gbuf;
+  const double* __restrict__ Lg = gbuf + (size_t)Nb * kBlk;
+  double* __restrict__ Dc = lds_base + plan.off_H;
+  double* __restrict__ Lc = Dc + Nc * kBlk;
+  double* __restrict__ fc = Lc + Nc * kBlk;
+  // compact system = the even block rows (+ lambda); their couplings are filled in by the eliminations
+  for (int q = tid; q < Nc * 64; q += kThreads) {
+    const int j = q >> 6, w = q & 63;
+    double v = Dg[(size_t)(2 * j) * kBlk + w];
+    if ((w >> 3) == (w & 7)) v += lambda;
+    Dc[j * kBlk + w] = v;
+    Lc[j * kBlk + w] = 0.0;
+  }
+  for (int q = tid; q < Nc * 8; q += kThreads) {
+    const int src = 16 * (q >> 3) + (q & 7);
+    fc[q] = src < Nt ? l.bv[src] : 0.0;
+  }
+  if (tid == 0) l.ired[0] = 1;
+  __syncthreads();
+  // level 0: 8 lanes per elimination of an odd row i = 2 e + 1 (lane c owns column c of L_i, of U_i = L_{i+1}^T and, redundantly, f_i).
+  // The records W_L = P L_i, W_U = P U_i, P f_i of the eliminated rows stay in the registers of the lanes that computed them (column c
+  // each) until the back substitution at the end: nothing but the read-only blocks crosses the LDS boundary during a solve.
+  const int grp = tid >> 3, c = tid & 7;
+  bool ok = true;
+  double kL[kHybridRounds][8], kU[kHybridRounds][8], kf[kHybridRounds];
+#pragma unroll
+  for (int rr = 0; rr < kHybridRounds; ++rr) {
+    const int e = rr * (kThreads / 8) + grp;
+    const bool act = e < E;
+    const int i = 2 * e + 1;
+    const bool hasU = act && (i + 1 < Nb);
+    double wL[8], wU[8], wf[8], o1[8], o2[8], o3[8];
+    double s1 = 0, s2 = 0;
+    if (rr * (kThreads / 8) < E) {   // (uniform) this round has eliminations at all
+      if (act) {
+        const double* Di = Dg + (size_t)i * kBlk;
+        const double* Li = Lg + (size_t)i * kBlk;
+        const double* Lp = Lg + (size_t)(i + 1) * kBlk;   // U_i^T, valid iff hasU
+        Ldl8 F;
+        F.load(Di);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) F.a[Ldl8::idx(k, k)] += lambda;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          wL[k] = Li[k * 8 + c];
+          wU[k] = hasU ? Lp[c * 8 + k] : 0.0;
+          wf[k] = (8 * i + k < Nt) ? l.bv[8 * i + k] : 0.0;
+        }
+        ok = F.factor() && ok;
+        F.solve3(wL, wU, wf);
+#pragma unroll
+        for (int aa = 0; aa < 8; ++aa) { o1[aa] = 0; o2[aa] = 0; o3[aa] = 0; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+          for (int aa = 0; aa < 8; ++aa) o1[aa] += Li[k * 8 + aa] * wL[k];
+          s1 += Li[k * 8 + c] * wf[k];
+        }
+        if (hasU) {
+#pragma unroll
+          for (int aa = 0; aa < 8; ++aa) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const double lp = Lp[aa * 8 + k];
+              o2[aa] -= lp * wL[k];
+              o3[aa] += lp * wU[k];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) s2 += Lp[c * 8 + k] * wf[k];
+        }
+        // fold into the compact rows e (= row i - 1) and e + 1 (= row i + 1); two phases: neighbouring eliminations share a row
+#pragma unroll
+        for (int aa = 0; aa < 8; ++aa) Dc[e * kBlk + aa * 8 + c] -= o1[aa];
+        fc[e * 8 + c] -= s1;
+        if (hasU) {
+#pragma unroll
+          for (int aa = 0; aa < 8; ++aa) Lc[(e + 1) * kBlk + aa * 8 + c] = o2[aa];
+        }
+      }
+      __syncthreads();
+      if (hasU) {
+#pragma unroll
+        for (int aa = 0; aa < 8; ++aa) Dc[(e + 1) * kBlk + aa * 8 + c] -= o3[aa];
+        fc[(e + 1) * 8 + c] -= s2;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { kL[rr][k] = act ? wL[k] : 0.0; kU[rr][k] = act ? wU[k] : 0.0; }
+    kf[rr] = act ? wf[c] : 0.0;
+  }
+  // levels >= 1 on the compact system in LDS
+  ok = TEB_CR_FORWARD(Dc, Lc, fc, Nc, 1, Nc) && ok;
+  ok = cr_top(Dc, fc) && ok;
+  if (!ok) l.ired[0] = 0;
+  __syncthreads();
+  int stop = 1;
+  while (stop * 2 < Nc) stop *= 2;
+  if (Nc > 1) cr_backward(Dc, Lc, fc, Nc, stop, 1);
+  // x of the even rows, then the odd rows from the records in registers: x_i = P f_i - W_L x_{i-1} - W_U x_{i+1}; lane c holds column c of
+  // W_L and W_U, so the 8 lanes of a group add up their column contributions (butterfly over c), then lane r keeps component r
+  for (int q = tid; q < Nc * 8; q += kThreads) {
+    const int dst = 16 * (q >> 3) + (q & 7);
+    if (dst < Nt) l.dxv[dst] = fc[q];
+  }
+#pragma unroll
+  for (int rr = 0; rr < kHybridRounds; ++rr) {
+    const int e = rr * (kThreads / 8) + grp;
+    const bool act = e < E;
+    const int i = 2 * e + 1;
+    const double xm = act ? fc[e * 8 + c] : 0.0;
+    const double xp = (act && i + 1 < Nb) ? fc[(e + 1) * 8 + c] : 0.0;
+    double mine = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      double t = kL[rr][r] * xm + kU[rr][r] * xp;
+      t += __shfl_xor(t, 1, 64);
+      t += __shfl_xor(t, 2, 64);
+      t += __shfl_xor(t, 4, 64);
+      mine = (c == r) ? t : mine;
+    }
+    if (act && 8 * i + c < Nt) l.dxv[8 * i + c] = kf[rr] - mine;
+  }
+  __syncthreads();
 }
 
 // ---- TimedElasticBand::autoResize (src/timed_elastic_band.cpp:227-286) -------------------------------------
@@ -1389,16 +1704,17 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       }
       PROF_START();
       const int hsz = (SOLVER != SOLVER_CR) ? Nt * kBand : ((Nt + 7) >> 3) * 2 * kBlk;
-      const bool keep_copy = !(SOLVER != SOLVER_CR && !args.band_ldlt);   // the HBM-block reduction never touches the band
+      const bool keep_copy = !(SOLVER != SOLVER_CR && !args.band_ldlt);   // the HBM-block reductions never touch the band
       if (keep_copy)
         for (int q = tid; q < hsz; q += kThreads) Hbk[q] = *hmat_ptr<SOLVER>(l, q, Nt);   // saved for rejected trials
+      if (SOLVER == SOLVER_BAND && !args.band_ldlt) cr_expand_blocks<false>(l, n, Hbk);   // hybrid solve: blocks to HBM once per iteration
       PROF_END(3);
       double rho = 0;
       int qmax = 0;
       do {
         // --- damped solve
         PROF_START();
-        if (SOLVER != SOLVER_CR) {
+        if constexpr (SOLVER == SOLVER_BAND) {
           if (args.band_ldlt) {
             if (tid < 64) {
               bool ok = banded_ldlt_solve_wave0(l, Nt, lambda);
@@ -1406,8 +1722,10 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
             }
             __syncthreads();
           } else {
-            cr_solve_t<true, SOLVER == SOLVER_BANDG>(plan, sc, n, lambda, Hbk, l.Hb);
+            cr_solve_hybrid(plan, n, lambda, Hbk);
           }
+        } else if constexpr (SOLVER == SOLVER_BANDG) {
+          cr_solve_t<true, true>(plan, sc, n, lambda, Hbk, l.Hb);
         } else {
           cr_solve_t<false, false>(plan, sc, n, lambda, nullptr, nullptr);
         }
