@@ -247,6 +247,41 @@ def consumers(cfg, batch, b, look_ahead_poses=1, prevent_look_ahead_poses_near_g
 
 
 # ---- row f3 (arithmetic core): H-signatures and equivalence classes ------------------------------------------------------------
+class Costmap:
+    """uint8 grid of a costmap_2d::Costmap2D: cells[my, mx]; 254 lethal, 253 inscribed, 255 no information."""
+
+    def __init__(self, cells, resolution, origin_x, origin_y):
+        self.cells = np.ascontiguousarray(cells, dtype=np.uint8)
+        self.size_y, self.size_x = self.cells.shape
+        self.resolution, self.origin_x, self.origin_y = float(resolution), float(origin_x), float(origin_y)
+
+
+def footprint_cost(costmap, x, y, theta, footprint):
+    """base_local_planner::CostmapModel::footprintCost restated on the grid (oracle/grid_costmap.h)."""
+    L = lib()
+    L.teb_oracle_footprint_cost.restype = C.c_double
+    fx = _abi.f64([p[0] for p in footprint]); fy = _abi.f64([p[1] for p in footprint])
+    return L.teb_oracle_footprint_cost(costmap.cells.ctypes.data_as(C.c_void_p), costmap.size_x, costmap.size_y, C.c_double(costmap.resolution),
+                                       C.c_double(costmap.origin_x), C.c_double(costmap.origin_y), C.c_double(x), C.c_double(y), C.c_double(theta),
+                                       len(footprint), _abi._ptr(fx, C.c_double), _abi._ptr(fy, C.c_double))
+
+
+def is_trajectory_feasible(batch, b, costmap, footprint, inscribed_radius, min_resolution_collision_check_angular=3.141592653589793,
+                           look_ahead_idx=-1, feasibility_check_lookahead_distance=-1.0):
+    """TebOptimalPlanner::isTrajectoryFeasible (src/optimal_planner.cpp:1250-1308): (feasible, number of footprint tests passed before the
+    failing one or -1)."""
+    bs = batch.c_struct()
+    fx = _abi.f64([p[0] for p in footprint]); fy = _abi.f64([p[1] for p in footprint])
+    ok = C.c_int32(0); first = C.c_int32(-1)
+    _check(lib().teb_oracle_is_trajectory_feasible(C.byref(bs), int(b), costmap.cells.ctypes.data_as(C.c_void_p), costmap.size_x, costmap.size_y,
+                                                   C.c_double(costmap.resolution), C.c_double(costmap.origin_x), C.c_double(costmap.origin_y),
+                                                   len(footprint), _abi._ptr(fx, C.c_double), _abi._ptr(fy, C.c_double),
+                                                   C.c_double(inscribed_radius), C.c_double(min_resolution_collision_check_angular),
+                                                   int(look_ahead_idx), C.c_double(feasibility_check_lookahead_distance), C.byref(ok),
+                                                   C.byref(first)), "teb_oracle_is_trajectory_feasible")
+    return bool(ok.value), first.value
+
+
 def h_signatures(cfg, obst, batch, mode, prescaler=1.0):
     """mode 2: HSignature -> [B, 2]; mode 3: HSignature3d -> [B, M]."""
     c = cfg.to_c()

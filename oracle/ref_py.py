@@ -213,6 +213,24 @@ def consumers(cfg, batch, b, look_ahead_poses=1, prevent_look_ahead_poses_near_g
     return dict(cmd=cmd, ok=bool(ok.value), profile=prof, trajectory=traj)
 
 
+def is_trajectory_feasible(batch, b, costmap, footprint, inscribed_radius, min_resolution_collision_check_angular=3.141592653589793,
+                           look_ahead_idx=-1, feasibility_check_lookahead_distance=-1.0):
+    """The reference's own TebOptimalPlanner::isTrajectoryFeasible (src/optimal_planner.cpp:1250-1308) over the grid CostmapModel of
+    oracle/grid_costmap.h: (feasible, number of footprint tests passed before the failing one or -1)."""
+    x, y, th, dt = batch.get_teb(b)
+    n = len(x)
+    dtp = np.zeros(n); dtp[:n - 1] = dt
+    fx = _abi.f64([p[0] for p in footprint]); fy = _abi.f64([p[1] for p in footprint])
+    ok = C.c_int32(0); first = C.c_int32(-1)
+    assert lib().ref_is_trajectory_feasible(n, _P(_abi.f64(x)), _P(_abi.f64(y)), _P(_abi.f64(th)), _P(dtp),
+                                            costmap.cells.ctypes.data_as(C.c_void_p), costmap.size_x, costmap.size_y,
+                                            C.c_double(costmap.resolution), C.c_double(costmap.origin_x), C.c_double(costmap.origin_y),
+                                            len(footprint), _P(fx), _P(fy), C.c_double(inscribed_radius),
+                                            C.c_double(min_resolution_collision_check_angular), int(look_ahead_idx),
+                                            C.c_double(feasibility_check_lookahead_distance), C.byref(ok), C.byref(first)) == 0
+    return bool(ok.value), first.value
+
+
 def h_signatures(cfg, obst, batch, mode, prescaler=1.0, threshold=0.1):
     """The reference's HSignature (mode 2) / HSignature3d (mode 3) on every band: dict(sig, equal [B,B], valid, reasonable)."""
     c = cfg.to_c()

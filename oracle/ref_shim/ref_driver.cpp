@@ -7,6 +7,7 @@
 // recording SparseOptimizer stand-in of shim_g2o.h (the LM iteration itself is restated there, libg2o being absent).
 // What is NOT (external, absent): libg2o, Eigen, ROS, Boost -> ./shim_*.h.
 #include "ref_common.h"
+#include "../grid_costmap.h"
 
 #include <atomic>
 #include <thread>
@@ -335,6 +336,40 @@ int ref_consumers(const teb_amd_config_t* acfg, int n, const double* x, const do
     o[0] = tr[i].pose.position.x; o[1] = tr[i].pose.position.y; o[2] = tf::getYaw(tr[i].pose.orientation);
     o[3] = tr[i].velocity.linear.x; o[4] = tr[i].velocity.linear.y; o[5] = tr[i].velocity.angular.z; o[6] = tr[i].time_from_start.toSec();
   }
+  return 0;
+}
+
+// ---- row f4: the reference's own TebOptimalPlanner::isTrajectoryFeasible (src/optimal_planner.cpp:1250-1308) with a CostmapModel
+// whose footprintCost is the grid restatement of oracle/grid_costmap.h (base_local_planner is absent from this image)
+namespace {
+struct GridCostmapModel : public base_local_planner::CostmapModel {
+  gridcostmap::Grid g;
+  int tests = 0, failed_at = -1;
+  double footprintCost(double x, double y, double theta, const std::vector<geometry_msgs::Point>& spec, double, double) override {
+    std::vector<double> fx, fy;
+    for (const geometry_msgs::Point& p : spec) { fx.push_back(p.x); fy.push_back(p.y); }
+    const double c = gridcostmap::footprint_cost(g, x, y, theta, (int)spec.size(), fx.data(), fy.data());
+    if (c == -1 && failed_at < 0) failed_at = tests;
+    ++tests;
+    return c;
+  }
+};
+}  // namespace
+int ref_is_trajectory_feasible(int n, const double* x, const double* y, const double* th, const double* dt, const uint8_t* cells, int size_x,
+                               int size_y, double resolution, double origin_x, double origin_y, int nf, const double* fx, const double* fy,
+                               double inscribed_radius, double min_resolution_collision_check_angular, int look_ahead_idx,
+                               double feasibility_check_lookahead_distance, int32_t* feasible, int32_t* first_infeasible) {
+  TebConfig cfg;
+  cfg.trajectory.min_resolution_collision_check_angular = min_resolution_collision_check_angular;
+  PlannerProbe pl(cfg, nullptr, TebVisualizationPtr(), nullptr);
+  const double zero[3] = {0, 0, 0};
+  fill_planner(pl, n, x, y, th, dt, 1, zero, 1, zero, TEB_AMD_ROT_NONE);
+  GridCostmapModel model;
+  model.g = gridcostmap::Grid{cells, size_x, size_y, resolution, origin_x, origin_y};
+  std::vector<geometry_msgs::Point> spec(nf);
+  for (int i = 0; i < nf; ++i) { spec[i].x = fx[i]; spec[i].y = fy[i]; spec[i].z = 0; }
+  *feasible = pl.isTrajectoryFeasible(&model, spec, inscribed_radius, 0.0, look_ahead_idx, feasibility_check_lookahead_distance) ? 1 : 0;
+  if (first_infeasible) *first_infeasible = model.failed_at;
   return 0;
 }
 

@@ -24,6 +24,7 @@
  *                                                numeric mode in tests/test_oracle_jacobians.py.
  */
 #include "teb_oracle.h"
+#include "grid_costmap.h"
 
 #include <cfloat>
 #include <algorithm>
@@ -2123,6 +2124,60 @@ int teb_oracle_full_trajectory(const teb_amd_config_t* cfg, const teb_amd_teb_ba
     curr_time += t.dt[i];
   }
   put(n - 1, t.vg[0], t.vg[1], t.vg[2], curr_time);
+  return TEB_AMD_OK;
+}
+
+// ================================================================================================================
+// SURVEY section 8(f) row f4, arithmetic part: isTrajectoryFeasible on a costmap grid.
+// ================================================================================================================
+double teb_oracle_footprint_cost(const uint8_t* cells, int32_t size_x, int32_t size_y, double resolution, double origin_x, double origin_y,
+                                 double x, double y, double theta, int32_t nf, const double* fx, const double* fy) {
+  return gridcostmap::footprint_cost(gridcostmap::Grid{cells, size_x, size_y, resolution, origin_x, origin_y}, x, y, theta, nf, fx, fy);
+}
+
+// TebOptimalPlanner::isTrajectoryFeasible, src/optimal_planner.cpp:1250-1308
+int teb_oracle_is_trajectory_feasible(const teb_amd_teb_batch_t* batch, int32_t b, const uint8_t* cells, int32_t size_x, int32_t size_y,
+                                      double resolution, double origin_x, double origin_y, int32_t nf, const double* fx, const double* fy,
+                                      double inscribed_radius, double min_resolution_collision_check_angular, int32_t look_ahead_idx,
+                                      double feasibility_check_lookahead_distance, int32_t* feasible, int32_t* first_infeasible) {
+  Teb t;
+  teb_from_batch(batch, b, t);
+  const int n = t.n();
+  int tests = 0;
+  auto cost = [&](double x, double y, double th) {
+    return teb_oracle_footprint_cost(cells, size_x, size_y, resolution, origin_x, origin_y, x, y, th, nf, fx, fy);
+  };
+  auto fail = [&]() { *feasible = 0; if (first_infeasible) *first_infeasible = tests; return TEB_AMD_OK; };
+  if (look_ahead_idx < 0 || look_ahead_idx >= n) look_ahead_idx = n - 1;
+  if (feasibility_check_lookahead_distance > 0) {
+    for (int i = 1; i < n; ++i) {
+      const double pose_distance = std::hypot(t.x[i] - t.x[0], t.y[i] - t.y[0]);
+      if (pose_distance > feasibility_check_lookahead_distance) { look_ahead_idx = i - 1; break; }
+    }
+  }
+  for (int i = 0; i <= look_ahead_idx; ++i) {
+    if (cost(t.x[i], t.y[i], t.th[i]) == -1) return fail();
+    ++tests;
+    if (i < look_ahead_idx) {
+      const double delta_rot = normalize_theta(normalize_theta(t.th[i + 1]) - normalize_theta(t.th[i]));
+      const double ddx = t.x[i + 1] - t.x[i], ddy = t.y[i + 1] - t.y[i];
+      const double dnorm = std::sqrt(ddx * ddx + ddy * ddy);   // Eigen::Vector2d::norm()
+      if (fabs(delta_rot) > min_resolution_collision_check_angular || dnorm > inscribed_radius) {
+        const int n_additional_samples = (int)std::max(std::ceil(fabs(delta_rot) / min_resolution_collision_check_angular),
+                                                       std::ceil(dnorm / inscribed_radius)) - 1;
+        double px = t.x[i], py = t.y[i], pth = t.th[i];
+        for (int step = 0; step < n_additional_samples; ++step) {
+          px = px + ddx / (n_additional_samples + 1.0);
+          py = py + ddy / (n_additional_samples + 1.0);
+          pth = normalize_theta(pth + delta_rot / (n_additional_samples + 1.0));
+          if (cost(px, py, pth) == -1) return fail();
+          ++tests;
+        }
+      }
+    }
+  }
+  *feasible = 1;
+  if (first_infeasible) *first_infeasible = -1;
   return TEB_AMD_OK;
 }
 

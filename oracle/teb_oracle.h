@@ -118,6 +118,22 @@ int teb_oracle_velocity_profile(const teb_amd_config_t* cfg, const teb_amd_teb_b
 /* getFullTrajectory (:1198-1247): out[n*7] = (x, y, theta, vx, vy, omega, time_from_start). */
 int teb_oracle_full_trajectory(const teb_amd_config_t* cfg, const teb_amd_teb_batch_t* batch, int32_t b, double* out);
 
+/* ---- row f4, arithmetic part: TebOptimalPlanner::isTrajectoryFeasible (src/optimal_planner.cpp:1250-1308) ------------------------
+ * on a uint8 costmap grid. The footprint test is base_local_planner::CostmapModel::footprintCost of the ROS navigation stack
+ * (base_local_planner/src/costmap_model.cpp, an un-vendored dependency of the reference: package.xml <depend>base_local_planner</depend>,
+ * no version pin; restated from the published noetic sources): footprint vertices rotated / translated to the pose, every edge
+ * rasterised with base_local_planner::LineIterator (Bresenham), cell costs LETHAL_OBSTACLE 254 -> -1, NO_INFORMATION 255 -> -2,
+ * off the map -> -3, fewer than 3 vertices -> the centre cell alone (253 counts as lethal there). The reference treats ONLY -1 as a
+ * collision (:1269, :1292). cells[my * size_x + mx]; world (wx, wy) -> cell ((int)((wx - origin_x) / resolution), ...).
+ * *first_infeasible (may be NULL) = number of footprint tests that passed before the failing one, -1 if feasible. */
+double teb_oracle_footprint_cost(const uint8_t* cells, int32_t size_x, int32_t size_y, double resolution, double origin_x, double origin_y,
+                                 double x, double y, double theta, int32_t n_footprint, const double* fx, const double* fy);
+int teb_oracle_is_trajectory_feasible(const teb_amd_teb_batch_t* batch, int32_t b, const uint8_t* cells, int32_t size_x, int32_t size_y,
+                                      double resolution, double origin_x, double origin_y, int32_t n_footprint, const double* fx,
+                                      const double* fy, double inscribed_radius, double min_resolution_collision_check_angular,
+                                      int32_t look_ahead_idx, double feasibility_check_lookahead_distance, int32_t* feasible,
+                                      int32_t* first_infeasible);
+
 /* ---- row f3, arithmetic core: equivalence classes (h_signature.h) ---------------------------------------------------------- */
 /* HSignature::calculateHSignature, h_signature.h:96-188 -> re_im[2] (long double inside, like the reference) */
 int teb_oracle_h_signature_2d(const teb_amd_config_t* cfg, const teb_amd_obstacles_t* obst, const teb_amd_teb_batch_t* batch, int32_t b,

@@ -1889,6 +1889,10 @@ int teb_amd_debug_profile(teb_amd_handle_t* h, double* cycles8) {
   HIPCHK(hipMemcpyFromSymbol(crp, HIP_SYMBOL(tebamd::g_cr_prof), sizeof crp));
   fprintf(stderr, "[cr_solve cycles, workgroup 0, cumulative] prologue %lld compute %lld barrier0 %lld writes+2 barriers %lld top %lld backsub %lld\n",
           crp[0], crp[1], crp[2], crp[3], crp[4], crp[5]);
+  long long evp[8];
+  HIPCHK(hipMemcpyFromSymbol(evp, HIP_SYMBOL(tebamd::g_ev_prof), sizeof evp));
+  fprintf(stderr, "[eval_index cycles, thread 0 of workgroup 0, cumulative] evaluate: static %lld dynamic %lld chain %lld | linearise: static %lld dynamic %lld chain %lld\n",
+          evp[0], evp[1], evp[2], evp[3], evp[4], evp[5]);
   return TEB_AMD_OK;
 #else
   (void)cycles8;

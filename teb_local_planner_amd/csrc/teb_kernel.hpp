@@ -26,6 +26,14 @@ namespace tebamd {
 #define PROF_END(k)
 #endif
 
+#ifdef TEB_PROFILE
+__device__ long long g_ev_prof[8];   // thread 0 of workgroup 0: evaluate {static, dynamic, chain}, linearise {static, dynamic, chain}, trig, scatter
+#define EVP_DECL long long evp_t0 = clock64(), evp_t1;
+#define EVP(k) do { evp_t1 = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) g_ev_prof[k] += evp_t1 - evp_t0; evp_t0 = evp_t1; } while (0)
+#else
+#define EVP_DECL
+#define EVP(k)
+#endif
 // Storage formats of the normal matrix (selected per handle by the pose capacity S and the obstacle cache):
 //   SOLVER_BAND : Hb[4S][11] lower band in LDS (S <= 343); solved by cyclic reduction on HBM-resident 8x8 blocks expanded from it
 //                 (or, TEB_AMD_BAND_SOLVE=ldlt, by the sequential in-LDS LDL^T of wave 0)
@@ -177,11 +185,64 @@ struct TebCtx {
     }                                                                                                                 \
   } while (0)
 
+// Lanes per pose. A pass over the poses has kThreads lanes; when it holds at most kThreads / 2 poses (short bands, and the second pass
+// of a band with more than kThreads poses, which would otherwise cost a full pass for a handful of poses) G = 2, 4 or 8 adjacent lanes
+// share a pose: slice sl of nsl takes a contiguous chunk of the dynamic-obstacle list (the bulk of the per-pose work), slice 0 also
+// everything else of the pose. Partial sums are combined with lane shuffles (fixed tree: deterministic).
+__device__ __forceinline__ int lanes_per_pose(int poses_left) {
+  int G = 1;
+  while (G < 8 && 2 * G * poses_left <= kThreads) G *= 2;
+  return G;
+}
+
+// Far-field culling of the dynamic-obstacle edges, exact: beyond max(min_obstacle_dist + penalty_epsilon, dynamic_obstacle_inflation_dist)
+// both residuals of EdgeDynamicObstacle and their Jacobians are exactly zero (penalties.h:75-87), so an obstacle farther than that from
+// the pose (+ a relative guard band of 1e-12 against the rounding of the distance; + 1e-6 m in the numeric mode, whose residuals are
+// evaluated 1e-9 away) adds nothing but zeros. dyn_near_mask is pass 1: the squared distance of the obstacles [kb, ke) (at most 64) of
+// the dynamic list at the pose's time stamp, 6 operations each in independent chains, one bit per obstacle. It runs BEFORE the window
+// accumulator of the pose is live, so that its unrolled chains do not compete with it for registers. Pass 2 (eval_index): each lane
+// walks the set bits of its own mask in list order and evaluates only those edges (fp64 sqrt, divisions, penalties: > 100 operations
+// each) - same operations, same order, same bits as the full loop, which spent > 95 % of its time adding zeros.
+template <int MODE>
+__device__ __forceinline__ unsigned long long dyn_near_mask(const teb_amd_config_t& c, const SceneDev& sc, const Lds& l, int i, int kb, int ke) {
+  const double far_d = fmax(c.min_obstacle_dist + c.penalty_epsilon, c.dynamic_obstacle_inflation_dist) +
+                       (c.footprint_type == TEB_AMD_FOOTPRINT_CIRCULAR ? c.footprint_radius : 0.0);
+  const double x = l.sx[i], y = l.sy[i], ti = l.tdyn[i];
+  unsigned long long near = 0;
+#pragma unroll 4   // independent chains: at one wave per SIMD only instruction-level parallelism hides the fp64 latency
+  for (int k = kb; k < ke; ++k) {
+    const int p = sc.n_static + k;
+    // pos_ + t*centroid_velocity_ (obstacles.h:382-385)
+    const double ddx = x - (l.obx[p] + ti * l.obvx[p]), ddy = y - (l.oby[p] + ti * l.obvy[p]);
+    const double d2 = ddx * ddx + ddy * ddy;
+    const double thr = (far_d + l.obr[p]) * (1.0 + 1e-12) + (MODE == 2 ? 1e-6 : 0.0);
+    if (!(d2 >= thr * thr) || thr <= 0) near |= 1ull << (k - kb);   // non-finite distances count as near
+  }
+  return near;
+}
+// the chunk of the dynamic-obstacle list of slice sl of nsl (multiples of 4)
+__device__ __forceinline__ void dyn_chunk(const SceneDev& sc, int sl, int nsl, int& d_lo, int& d_hi) {
+  const int dchunk = nsl > 1 ? (((sc.n_dyn + nsl - 1) / nsl + 3) & ~3) : sc.n_dyn;
+  d_lo = sl * dchunk < sc.n_dyn ? sl * dchunk : sc.n_dyn;
+  d_hi = d_lo + dchunk < sc.n_dyn ? d_lo + dchunk : sc.n_dyn;
+}
+// mask of the first 64 obstacles of the slice for pose i (0 when the pose has no dynamic-obstacle edges or the scene is not point-like)
+template <int MODE>
+__device__ __forceinline__ unsigned long long dyn_near_first(const teb_amd_config_t& c, const SceneDev& sc, const Lds& l, int i, int sl, int nsl) {
+  if (!(sc.fast_points && i >= 1 && c.include_dynamic_obstacles && c.weight_obstacle != 0)) return 0;
+  int d_lo, d_hi;
+  dyn_chunk(sc, sl, nsl, d_lo, d_hi);
+  return dyn_near_mask<MODE>(c, sc, l, i, d_lo, d_lo + 64 < d_hi ? d_lo + 64 : d_hi);
+}
+
 template <int MODE>
 __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const SceneDev& sc, const TebCtx& t,
-                                           const Lds& l, int i, Accum& A) {
+                                           const Lds& l, int i, Accum& A, unsigned long long near_first, int sl = 0, int nsl = 1) {
   constexpr bool JAC = (MODE == 1);
   const int n = t.n;
+  const bool first = (sl == 0);
+  int d_lo, d_hi;
+  dyn_chunk(sc, sl, nsl, d_lo, d_hi);
   Win w;
   w.x0 = l.sx[i]; w.y0 = l.sy[i]; w.t0 = l.sth[i]; w.d0 = l.sdt[i];
   w.x1 = l.sx[i + 1]; w.y1 = l.sy[i + 1]; w.t1 = l.sth[i + 1];
@@ -193,7 +254,8 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
 
   // ---- unary edges of pose i (AddEdgesObstacles :444-548, AddEdgesDynamicObstacles :646-673, AddEdgesViaPoints :675-718)
   // association entries are POSITIONS in the static list (sc.static_idx / the LDS obstacle cache)
-  const int cnt = t.assoc_cnt[i];
+  const int cnt = first ? t.assoc_cnt[i] : 0;
+  EVP_DECL
   if (i >= 1) {
     if (sc.fast_points) {
       if (!c.legacy_obstacle_association) {
@@ -212,26 +274,21 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
             TEB_EDGE(M_POSE0, CAT_OBST, edge_obstacle_fast<J_>(c, ox, oy, orad, W, t.w_obst, t.inflated, ACC_));
         }
       }
+      EVP(MODE == 0 ? 0 : 3);
       if (c.include_dynamic_obstacles && c.weight_obstacle != 0) {
         const double ti = l.tdyn[i];
-        int k = 0;
-        if constexpr (MODE != 2) {
-          for (; k + 4 <= sc.n_dyn; k += 4) {   // 4 obstacles in flight; rows are still accumulated in list order
-            double dist[4], gr[4][2];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int p = sc.n_static + k + u;
-              // pos_ + t*centroid_velocity_ (obstacles.h:382-385)
-              dist[u] = pointlike_distance<JAC>(c, w.x0, w.y0, l.obx[p] + ti * l.obvx[p], l.oby[p] + ti * l.obvy[p], l.obr[p], gr[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) dynamic_obstacle_rows<JAC>(c, dist[u], gr[u], A);
+        // far-field culling (dyn_near_mask above): the mask of the first 64 obstacles of the slice was computed by the caller before the
+        // accumulator went live; further blocks (more than 64 dynamic obstacles per slice) are computed here
+        for (int kb = d_lo; kb < d_hi; kb += 64) {
+          const int ke = kb + 64 < d_hi ? kb + 64 : d_hi;
+          unsigned long long near = (kb == d_lo) ? near_first : dyn_near_mask<MODE>(c, sc, l, i, kb, ke);
+          while (near) {
+            const int k = kb + __ffsll((long long)near) - 1;
+            near &= near - 1;
+            const int p = sc.n_static + k;
+            const double ox = l.obx[p] + ti * l.obvx[p], oy = l.oby[p] + ti * l.obvy[p], orad = l.obr[p];
+            TEB_EDGE(M_POSE0, CAT_OBST, edge_dynamic_obstacle_fast<J_>(c, ox, oy, orad, W, ACC_));
           }
-        }
-        for (; k < sc.n_dyn; ++k) {
-          const int p = sc.n_static + k;
-          const double ox = l.obx[p] + ti * l.obvx[p], oy = l.oby[p] + ti * l.obvy[p], orad = l.obr[p];
-          TEB_EDGE(M_POSE0, CAT_OBST, edge_dynamic_obstacle_fast<J_>(c, ox, oy, orad, W, ACC_));
         }
       }
     } else {
@@ -244,13 +301,13 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
       }
       if (c.include_dynamic_obstacles && c.weight_obstacle != 0) {
         const double ti = l.tdyn[i];
-        for (int k = 0; k < sc.n_dyn; ++k) {
+        for (int k = d_lo; k < d_hi; ++k) {
           const int oi = sc.dyn_idx[k];
           TEB_EDGE(M_POSE0, CAT_OBST, edge_dynamic_obstacle<J_>(c, sc, oi, W, ti, ACC_));
         }
       }
     }
-    if (t.via_en && c.weight_viapoint != 0) {
+    if (first && t.via_en && c.weight_viapoint != 0) {
       for (int v = 0; v < sc.nvia; ++v)
         if (t.via_pose[v] == i) {
           const double vx = sc.viax[v], vy = sc.viay[v];
@@ -258,6 +315,8 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
         }
     }
   }
+  EVP(MODE == 0 ? 1 : 4);
+  if (!first) return;   // the other slices only share the dynamic-obstacle edges
   // ---- AddEdgesVelocity :720-769
   if (c.max_vel_y == 0) {
     if (!(c.weight_max_vel_x == 0 && c.weight_max_vel_theta == 0)) TEB_EDGE(M_SEG, CAT_OTHER, edge_velocity<J_>(c, W, ACC_));
@@ -308,6 +367,7 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
       });
     }
   }
+  EVP(MODE == 0 ? 2 : 5);
 }
 #undef TEB_EDGE
 
@@ -374,15 +434,27 @@ __device__ inline void linearize(const teb_amd_config_t& c, const SceneDev& sc, 
   __syncthreads();
   Accum A;
   A.clear_chi();
-  for (int k0 = 0; k0 < n - 1; k0 += kThreads) {
-    const int i = k0 + tid;
+  for (int k0 = 0; k0 < n - 1; ) {
+    const int G = lanes_per_pose(n - 1 - k0);
+    const int i = k0 + tid / G, sl = tid % G;
     const bool active = i <= n - 2;
+    constexpr int EM = JMODE == TEB_AMD_JACOBIAN_G2O_NUMERIC ? 2 : 1;
+    const unsigned long long near = active ? dyn_near_first<EM>(c, sc, l, i, sl, G) : 0ull;   // before the accumulator is live
     A.clear();
-    if (active) eval_index<JMODE == TEB_AMD_JACOBIAN_G2O_NUMERIC ? 2 : 1>(c, sc, t, l, i, A);
+    if (active) eval_index<EM>(c, sc, t, l, i, A, near, sl, G);
+    if (G > 1) {   // the slices of a pose hold partial sums of its dynamic-obstacle rows: pose block (x, y, theta) of H and g
+      for (int off = 1; off < G; off <<= 1) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) A.H[q] += __shfl_xor(A.H[q], off, 64);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) A.g[q] += __shfl_xor(A.g[q], off, 64);
+      }
+    }
     for (int ph = 0; ph < 3; ++ph) {
-      if (active && (i % 3) == ph) scatter<SOLVER>(A, l, i, n);
+      if (active && sl == 0 && (i % 3) == ph) scatter<SOLVER>(A, l, i, n);
       __syncthreads();
     }
+    k0 += kThreads / G;
   }
   // fixed variables (pose 0, pose n-1, the non-existing dt_{n-1}) become identity rows
   if (tid < 3) { *diag_ptr<SOLVER>(l, tid) = 1.0; l.bv[tid] = 0; }
@@ -401,7 +473,15 @@ __device__ inline void evaluate(const teb_amd_config_t& c, const SceneDev& sc, c
   __syncthreads();
   Accum A;   // only chi[] is live when JAC == false
   A.clear_chi();
-  for (int i = threadIdx.x; i <= t.n - 2; i += kThreads) eval_index<0>(c, sc, t, l, i, A);
+  for (int k0 = 0; k0 < t.n - 1; ) {
+    const int G = lanes_per_pose(t.n - 1 - k0);
+    const int i = k0 + (int)threadIdx.x / G;
+    if (i <= t.n - 2) {
+      const unsigned long long near = dyn_near_first<0>(c, sc, l, i, (int)threadIdx.x % G, G);
+      eval_index<0>(c, sc, t, l, i, A, near, (int)threadIdx.x % G, G);
+    }
+    k0 += kThreads / G;
+  }
   cats[0] = A.chi[0]; cats[1] = A.chi[1]; cats[2] = A.chi[2]; cats[3] = A.chi[3];
   block_sum<4>(cats, l.red);
 }
@@ -1418,60 +1498,144 @@ __device__ inline int autoresize(const teb_amd_config_t& c, const Lds& l, int n,
 }
 
 // ---- obstacle association, AddEdgesObstacles (src/optimal_planner.cpp:444-548) -------------------------------
+// One pose per lane scans the static list; a pass with at most kThreads / 2 poses (short bands, the second pass of bands longer than
+// kThreads poses) gives G = 2, 4 or 8 adjacent lanes to a pose, each scanning a contiguous chunk of the list. The chunks are in list
+// order, so concatenating their forced inclusions and taking the first minimum over the chunks reproduces the sequential result bit
+// for bit: forced entries of a slice wait in registers (up to kSliceForced) for their offset (prefix sum over the slices); a pose
+// that overflows them is redone by its first lane the sequential way.
+constexpr int kSliceForced = 6;
+struct AssocScan {
+  double left_min, right_min;
+  int left, right, cnt;
+};
+// scans static-list positions [k_lo, k_hi) for pose i; forced inclusions go to `emit(position)` in list order
+template <typename Emit>
+__device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const SceneDev& sc, const Lds& l, int i, int k_lo, int k_hi, AssocScan& r,
+                                           Emit emit) {
+  const double x = l.sx[i], y = l.sy[i];
+  const double ox_ = l.cs[i], oy_ = l.sn[i];   // orientationUnitVec
+  const double force = c.min_obstacle_dist * c.obstacle_association_force_inclusion_factor;
+  const double cutoff = c.min_obstacle_dist * c.obstacle_association_cutoff_factor;
+  auto visit = [&](int k, double dist, double ccx, double ccy) {
+    if (dist < force) { emit(k); ++r.cnt; return; }
+    if (dist > cutoff) return;
+    // cross2d(pose_orient, centroid - position) > 0 -> left (misc.h:119-123)
+    double vx_ = ccx - x, vy_ = ccy - y;
+    if (ox_ * vy_ - vx_ * oy_ > 0) { if (dist < r.left_min) { r.left_min = dist; r.left = k; } }
+    else { if (dist < r.right_min) { r.right_min = dist; r.right = k; } }
+  };
+  int k0 = k_lo;
+  if (sc.fast_points) {
+    // Far-field culling, exact: an obstacle beyond max(cutoff, force) (+ a relative guard band of 1e-12 against the rounding of the
+    // distance) from the pose is neither included nor a left / right candidate. Pass 1 (uniform over the wave): squared distances, one
+    // bit per obstacle; pass 2: each lane visits the set bits of its own mask in list order - the decisions of the sequential scan,
+    // without the square roots of the ~90 % of the obstacles that are out of reach.
+    const double far_d = fmax(cutoff, force) + (c.footprint_type == TEB_AMD_FOOTPRINT_CIRCULAR ? c.footprint_radius : 0.0);
+    for (; k0 < k_hi; k0 += 64) {
+      const int ke = k0 + 64 < k_hi ? k0 + 64 : k_hi;
+      unsigned long long near = 0;
+#pragma unroll 4
+      for (int k = k0; k < ke; ++k) {
+        const double ddx = x - l.obx[k], ddy = y - l.oby[k];
+        const double d2 = ddx * ddx + ddy * ddy;
+        const double thr = (far_d + l.obr[k]) * (1.0 + 1e-12);
+        if (!(d2 > thr * thr) || thr <= 0) near |= 1ull << (k - k0);   // non-finite distances count as near
+      }
+      while (near) {
+        const int k = k0 + __ffsll((long long)near) - 1;
+        near &= near - 1;
+        const double ccx = l.obx[k], ccy = l.oby[k];
+        const double dist = pointlike_distance<false>(c, x, y, ccx, ccy, l.obr[k], nullptr);
+        visit(k, dist, ccx, ccy);
+      }
+    }
+    k0 = k_hi;
+  }
+  for (int k = k0; k < k_hi; ++k) {
+    double dist, ccx, ccy;
+    if (sc.fast_points) {
+      ccx = l.obx[k]; ccy = l.oby[k];
+      dist = pointlike_distance<false>(c, x, y, ccx, ccy, l.obr[k], nullptr);
+    } else {
+      const int oi = sc.static_idx[k];
+      dist = footprint_distance(c, sc, oi, x, y, ox_, oy_, false, 0.0, nullptr);
+      ccx = sc.cx[oi]; ccy = sc.cy[oi];
+    }
+    visit(k, dist, ccx, ccy);
+  }
+}
+
 __device__ inline void associate(const teb_amd_config_t& c, const SceneDev& sc, const Lds& l, int n, int* assoc_cnt,
                                  int* assoc, int cap, int stride, int* overflow) {
   const int first_vertex = c.weight_velocity_obstacle_ratio == 0 ? 1 : 0;
-  for (int i = threadIdx.x; i < n; i += kThreads) {
-    int cnt = 0;
-    if (i >= first_vertex && i < n - 1) {
-      const double x = l.sx[i], y = l.sy[i];
-      const double ox_ = l.cs[i], oy_ = l.sn[i];   // orientationUnitVec
-      double left_min = 1.7976931348623157e308, right_min = 1.7976931348623157e308;
-      int left = -1, right = -1;
-      const double force = c.min_obstacle_dist * c.obstacle_association_force_inclusion_factor;
-      const double cutoff = c.min_obstacle_dist * c.obstacle_association_cutoff_factor;
-      int k0 = 0;
-      auto visit = [&](int k, double dist, double ccx, double ccy) {
-        if (dist < force) {
-          if (cnt < cap) assoc[(size_t)cnt * stride + i] = k; else *overflow = 1;
-          ++cnt;
-          return;
-        }
-        if (dist > cutoff) return;
-        // cross2d(pose_orient, centroid - position) > 0 -> left (misc.h:119-123)
-        double vx_ = ccx - x, vy_ = ccy - y;
-        if (ox_ * vy_ - vx_ * oy_ > 0) { if (dist < left_min) { left_min = dist; left = k; } }
-        else { if (dist < right_min) { right_min = dist; right = k; } }
-      };
-      if (sc.fast_points) {
-        for (; k0 + 4 <= sc.n_static; k0 += 4) {   // 4 distances in flight, decisions in list order
-          double dist[4], ccx[4], ccy[4];
+  const double kMax = 1.7976931348623157e308;
+  const int tid = threadIdx.x;
+  for (int p0 = 0; p0 < n; ) {
+    const int G = lanes_per_pose(n - p0);
+    const int i = p0 + tid / G, sl = tid % G;
+    const bool has_pose = i < n;
+    const bool scans = has_pose && i >= first_vertex && i < n - 1;
+    // the sequential scan of the whole list by one lane, writing straight into the list (also the fallback of the sliced scan)
+    auto sequential = [&]() {
+      AssocScan r = {kMax, kMax, -1, -1, 0};
+      assoc_scan(c, sc, l, i, 0, sc.n_static, r, [&](int k) { if (r.cnt < cap) assoc[(size_t)r.cnt * stride + i] = k; else *overflow = 1; });
+      int cnt = r.cnt;
+      if (r.left >= 0) { if (cnt < cap) assoc[(size_t)cnt * stride + i] = r.left; else *overflow = 1; ++cnt; }
+      if (r.right >= 0) { if (cnt < cap) assoc[(size_t)cnt * stride + i] = r.right; else *overflow = 1; ++cnt; }
+      assoc_cnt[i] = cnt > cap ? cap : cnt;
+    };
+    if (G == 1) {
+      if (scans) sequential();
+      else if (has_pose) assoc_cnt[i] = 0;
+    } else {
+      const int chunk = ((sc.n_static + G - 1) / G + 3) & ~3;
+      const int k_lo = sl * chunk < sc.n_static ? sl * chunk : sc.n_static;
+      const int k_hi = k_lo + chunk < sc.n_static ? k_lo + chunk : sc.n_static;
+      AssocScan r = {kMax, kMax, -1, -1, 0};
+      int forced[kSliceForced];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            ccx[u] = l.obx[k0 + u]; ccy[u] = l.oby[k0 + u];
-            dist[u] = pointlike_distance<false>(c, x, y, ccx[u], ccy[u], l.obr[k0 + u], nullptr);
-          }
+      for (int q = 0; q < kSliceForced; ++q) forced[q] = 0;
+      if (scans) {
+        assoc_scan(c, sc, l, i, k_lo, k_hi, r, [&](int k) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) visit(k0 + u, dist[u], ccx[u], ccy[u]);
-        }
+          for (int q = 0; q < kSliceForced; ++q) if (r.cnt == q) forced[q] = k;   // register file: no dynamic indexing
+        });
       }
-      for (int k = k0; k < sc.n_static; ++k) {
-        double dist, ccx, ccy;
-        if (sc.fast_points) {
-          ccx = l.obx[k]; ccy = l.oby[k];
-          dist = pointlike_distance<false>(c, x, y, ccx, ccy, l.obr[k], nullptr);
+      // over the G slices of the pose (adjacent lanes): offset of this slice's forced entries, total, first minima, "registers overflowed"
+      int before = 0, total = r.cnt, spilled = r.cnt > kSliceForced;
+      for (int off = 1; off < G; off <<= 1) {
+        const int up = __shfl_up(total, off, 64);
+        if (sl >= off) total += up;   // inclusive scan over sl
+      }
+      before = total - r.cnt;
+      total = __shfl(total, (tid & 63) | (G - 1), 64);   // the last slice holds the sum
+      for (int off = 1; off < G; off <<= 1) {
+        spilled |= __shfl_xor(spilled, off, 64);
+        const double lm = __shfl_xor(r.left_min, off, 64), rm = __shfl_xor(r.right_min, off, 64);
+        const int li = __shfl_xor(r.left, off, 64), ri = __shfl_xor(r.right, off, 64);
+        // strict '<' of the sequential scan keeps the FIRST minimum: on equal distances the lower list position wins
+        if (li >= 0 && (r.left < 0 || lm < r.left_min || (lm == r.left_min && li < r.left))) { r.left_min = lm; r.left = li; }
+        if (ri >= 0 && (r.right < 0 || rm < r.right_min || (rm == r.right_min && ri < r.right))) { r.right_min = rm; r.right = ri; }
+      }
+      if (scans) {
+        const int full = total + (r.left >= 0) + (r.right >= 0);
+        if (spilled || full > cap) {
+          if (sl == 0) sequential();
         } else {
-          const int oi = sc.static_idx[k];
-          dist = footprint_distance(c, sc, oi, x, y, ox_, oy_, false, 0.0, nullptr);
-          ccx = sc.cx[oi]; ccy = sc.cy[oi];
+#pragma unroll
+          for (int q = 0; q < kSliceForced; ++q) if (q < r.cnt) assoc[(size_t)(before + q) * stride + i] = forced[q];
+          if (sl == 0) {
+            int cnt = total;
+            if (r.left >= 0) { assoc[(size_t)cnt * stride + i] = r.left; ++cnt; }
+            if (r.right >= 0) { assoc[(size_t)cnt * stride + i] = r.right; ++cnt; }
+            assoc_cnt[i] = cnt;
+          }
         }
-        visit(k, dist, ccx, ccy);
+      } else if (has_pose && sl == 0) {
+        assoc_cnt[i] = 0;
       }
-      if (left >= 0) { if (cnt < cap) assoc[(size_t)cnt * stride + i] = left; else *overflow = 1; ++cnt; }
-      if (right >= 0) { if (cnt < cap) assoc[(size_t)cnt * stride + i] = right; else *overflow = 1; ++cnt; }
-      if (cnt > cap) cnt = cap;
     }
-    assoc_cnt[i] = cnt;
+    p0 += kThreads / G;
   }
 }
 
