@@ -435,6 +435,27 @@ int  teb_amd_get_full_trajectory(teb_amd_handle_t* h, int32_t b, double* out, in
 int  teb_amd_has_diverged(teb_amd_handle_t* h, int32_t b, int32_t* diverged);
 
 /*
+ * f4 (arithmetic part) — TebOptimalPlanner::isTrajectoryFeasible (src/optimal_planner.cpp:1250-1308; declared optimal_planner.h:500,
+ * called by the ROS adapter at src/teb_local_planner_ros.cpp:396) on the device-resident bands. The costmap is the uint8 grid of
+ * costmap_2d::Costmap2D (cells[my * size_x + mx]; 254 lethal, 253 inscribed, 255 no information; world (wx, wy) -> cell
+ * ((int)((wx - origin_x) / resolution), (int)((wy - origin_y) / resolution))), uploaded once per tick; the footprint test is
+ * base_local_planner::CostmapModel::footprintCost (outline rasterised with Bresenham; < 3 vertices: the centre cell) and, as in the
+ * reference, only its value -1 (lethal) makes a pose infeasible - unknown cells and poses off the map do not.
+ * footprint = footprint_spec [n_footprint <= 64] in the robot frame; inscribed_radius > 0 = robot_inscribed_radius_ (the adapter gets it
+ * from costmap_2d::calculateMinAndMaxDistances); min_resolution_collision_check_angular = cfg.trajectory.<same>; look_ahead_idx =
+ * cfg.trajectory.feasibility_check_no_poses (< 0 or >= n: the whole band); feasibility_check_lookahead_distance <= 0: off.
+ * b >= 0: that band, outputs of 1 entry; b = -1: every band of the batch, outputs [B] (HomotopyClassPlanner checks its best band only,
+ * src/homotopy_class_planner.cpp:727-737 - pass its index). first_infeasible (may be NULL): number of footprint tests that pass, in the
+ * reference's order, before the colliding one; -1 if feasible. TEB_AMD_ERR_CAPACITY when the radii ask for more than 2^22 samples.
+ */
+int  teb_amd_set_costmap(teb_amd_handle_t* h, const uint8_t* cells, int32_t size_x, int32_t size_y, double resolution,
+                         double origin_x, double origin_y);
+int  teb_amd_is_trajectory_feasible(teb_amd_handle_t* h, int32_t b, int32_t n_footprint, const double* footprint_x,
+                                    const double* footprint_y, double inscribed_radius, double min_resolution_collision_check_angular,
+                                    int32_t look_ahead_idx, double feasibility_check_lookahead_distance, int32_t* feasible,
+                                    int32_t* first_infeasible);
+
+/*
  * f3 (arithmetic core) — equivalence classes of the device-resident bands, as HomotopyClassPlanner::calculateEquivalenceClass
  * (homotopy_class_planner.hpp:46-62) computes them for every candidate in renewAndAnalyzeOldTebs: HSignature3d
  * (h_signature.h:281-347; one value per obstacle) when cfg.include_dynamic_obstacles, else HSignature (h_signature.h:96-188; one

@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libteb_amd.so")
 SOURCES = ["teb_amd.hip"]
-HEADERS = ["teb_device.hpp", "teb_comm.hpp", "teb_geometry.hpp", "teb_edges.hpp", "teb_kernel.hpp", "teb_strip.hpp", "teb_hsig.hpp", "teb_graph.hpp",
+HEADERS = ["teb_device.hpp", "teb_comm.hpp", "teb_feasibility.hpp", "teb_geometry.hpp", "teb_edges.hpp", "teb_kernel.hpp", "teb_strip.hpp", "teb_hsig.hpp", "teb_graph.hpp",
            os.path.join("..", "..", "include", "teb_amd.h"), os.path.join("..", "..", "include", "teb_amd_debug.h")]
 
 # -ffp-contract=off: the parity contract is against a plain IEEE mul/add restatement of the reference;

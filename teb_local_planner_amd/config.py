@@ -53,7 +53,7 @@ class TebConfig:
             # C-ABI entry points, not fields of teb_amd_config_t
             global_plan_overwrite_orientation=True, allow_init_with_backwards_motion=False, force_reinit_new_goal_dist=1.0,
             force_reinit_new_goal_angular=0.5 * 3.141592653589793, control_look_ahead_poses=1,
-            prevent_look_ahead_poses_near_goal=0)
+            prevent_look_ahead_poses_near_goal=0, feasibility_check_no_poses=5, feasibility_check_lookahead_distance=-1.0, min_resolution_collision_check_angular=3.141592653589793)
         self.robot = SimpleNamespace(
             max_vel_x=0.4, max_vel_x_backwards=0.2, max_vel_y=0.0, max_vel_trans=0.0, max_vel_theta=0.3,
             acc_lim_x=0.5, acc_lim_y=0.5, acc_lim_theta=0.5, min_turning_radius=0.0)

@@ -19,6 +19,7 @@
 #include "teb_hsig.hpp"
 #include "teb_graph.hpp"
 #include "teb_comm.hpp"
+#include "teb_feasibility.hpp"
 
 using namespace tebamd;
 
@@ -194,6 +195,12 @@ struct teb_amd_handle {
   int best_class_mode = 0;          // 0 = none yet, 2 / 3 = HSignature / HSignature3d
   std::vector<double> initial_class;   // initial_plan_eq_class_: signature of the band made from the last initial plan
   int initial_class_mode = 0;
+  // costmap (f4)
+  DevBuf<unsigned char> cm_cells;
+  DevBuf<double> cm_fp;
+  DevBuf<int> cm_out;
+  int cm_sx = 0, cm_sy = 0;
+  double cm_res = 0, cm_ox = 0, cm_oy = 0;
   std::mt19937 rnd_generator;   // ProbRoadmapGraph::rnd_generator_ (graph_search.h:211): default-seeded 32-bit Mersenne twister
 };
 
@@ -534,6 +541,7 @@ void teb_amd_destroy(teb_amd_handle_t* h) {
   for (auto* q : gi) q->free();
   h->ob_n.free();
   h->g_adj.free();
+  h->cm_cells.free(); h->cm_fp.free(); h->cm_out.free();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -1117,6 +1125,53 @@ int teb_amd_has_diverged(teb_amd_handle_t* h, int32_t b, int32_t* diverged) {
   HIPCHK(hipStreamSynchronize(h->stream));
   if (iters <= 0) return TEB_AMD_OK;                                      // no statistics yet, :1031-1033
   *diverged = chi2 > h->cfg.divergence_detection_max_chi_squared;
+  return TEB_AMD_OK;
+}
+
+// ---- f4: feasibility of the resident bands against a costmap grid (kernel in teb_feasibility.hpp) --------------------------------------
+int teb_amd_set_costmap(teb_amd_handle_t* h, const uint8_t* cells, int32_t size_x, int32_t size_y, double resolution, double origin_x,
+                        double origin_y) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!cells || size_x <= 0 || size_y <= 0 || !(resolution > 0)) return fail(TEB_AMD_ERR_INVALID_ARG, "teb_amd_set_costmap: bad grid");
+  const size_t bytes = (size_t)size_x * size_y;
+  if (h->cm_cells.n < bytes) { h->cm_cells.free(); HIPCHK(h->cm_cells.alloc(bytes)); }
+  HIPCHK(hipMemcpyAsync(h->cm_cells.p, cells, bytes, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));   // the caller's buffer may go away
+  h->cm_sx = size_x; h->cm_sy = size_y; h->cm_res = resolution; h->cm_ox = origin_x; h->cm_oy = origin_y;
+  return TEB_AMD_OK;
+}
+
+int teb_amd_is_trajectory_feasible(teb_amd_handle_t* h, int32_t b, int32_t nf, const double* fx, const double* fy, double inscribed_radius,
+                                   double min_res_angular, int32_t look_ahead_idx, double lookahead_distance, int32_t* feasible,
+                                   int32_t* first_infeasible) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (h->cm_sx <= 0) return fail(TEB_AMD_ERR_INVALID_ARG, "teb_amd_is_trajectory_feasible: no costmap (teb_amd_set_costmap)");
+  if (!feasible || nf < 1 || nf > kMaxFeasFootprint || !fx || !fy) return fail(TEB_AMD_ERR_INVALID_ARG, "bad footprint / output");
+  if (!(inscribed_radius > 0) || !(min_res_angular > 0)) return fail(TEB_AMD_ERR_INVALID_ARG, "inscribed_radius and the angular resolution must be > 0");
+  if (h->B <= 0 || b >= h->B || b < -1) return fail(TEB_AMD_ERR_INVALID_ARG, "TEB index out of range");
+  if (h->stride > 1024) return fail(TEB_AMD_ERR_CAPACITY, "feasibility check supports bands up to 1024 poses");
+  const int first = b < 0 ? 0 : b, count = b < 0 ? h->B : 1;
+  if (h->cm_fp.n < 2 * (size_t)kMaxFeasFootprint) { h->cm_fp.free(); HIPCHK(h->cm_fp.alloc(2 * (size_t)kMaxFeasFootprint)); }
+  if (h->cm_out.n < 2 * (size_t)h->max_tebs + 1) { h->cm_out.free(); HIPCHK(h->cm_out.alloc(2 * (size_t)h->max_tebs + 1)); }
+  HIPCHK(hipMemcpyAsync(h->cm_fp.p, fx, nf * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->cm_fp.p + kMaxFeasFootprint, fy, nf * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  int* ovf = h->cm_out.p + 2 * (size_t)h->max_tebs;
+  HIPCHK(hipMemsetAsync(ovf, 0, sizeof(int), h->stream));
+  GridDev g{h->cm_cells.p, h->cm_sx, h->cm_sy, h->cm_res, h->cm_ox, h->cm_oy};
+  hipLaunchKernelGGL(feasibility_kernel, dim3(count), dim3(kFeasThreads), 0, h->stream, h->n.p, h->x.p, h->y.p, h->th.p, h->stride, first, g, nf,
+                     h->cm_fp.p, h->cm_fp.p + kMaxFeasFootprint, inscribed_radius, min_res_angular, look_ahead_idx, lookahead_distance,
+                     1 << 22, h->cm_out.p, h->cm_out.p + h->max_tebs, ovf);
+  HIPCHK(hipGetLastError());
+  std::vector<int> fe(count), fi(count);
+  int o = 0;
+  HIPCHK(hipMemcpyAsync(fe.data(), h->cm_out.p, count * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(fi.data(), h->cm_out.p + h->max_tebs, count * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(&o, ovf, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (o) return fail(TEB_AMD_ERR_CAPACITY, "feasibility check: more than 2^22 interpolated samples requested (inscribed radius / angular resolution too small)");
+  for (int k = 0; k < count; ++k) { feasible[k] = fe[k]; if (first_infeasible) first_infeasible[k] = fi[k]; }
   return TEB_AMD_OK;
 }
 

@@ -250,6 +250,27 @@ bool TebAmdBatch::check(int rc, const char* what)
   return false;
 }
 
+bool TebAmdBatch::setCostmap(const unsigned char* cells, unsigned int size_x, unsigned int size_y, double resolution, double origin_x,
+                             double origin_y)
+{
+  if (!h_) return false;
+  return check(teb_amd_set_costmap(h_, cells, (int32_t)size_x, (int32_t)size_y, resolution, origin_x, origin_y), "teb_amd_set_costmap");
+}
+
+bool TebAmdBatch::isTrajectoryFeasible(int index, const std::vector<geometry_msgs::Point>& footprint_spec, double inscribed_radius,
+                                       double min_resolution_collision_check_angular, int look_ahead_idx,
+                                       double feasibility_check_lookahead_distance)
+{
+  if (!h_) return false;
+  std::vector<double> fx, fy;
+  for (const geometry_msgs::Point& p : footprint_spec) { fx.push_back(p.x); fy.push_back(p.y); }
+  int32_t feasible = 0;
+  if (!check(teb_amd_is_trajectory_feasible(h_, index, (int32_t)fx.size(), fx.data(), fy.data(), inscribed_radius,
+                                            min_resolution_collision_check_angular, look_ahead_idx, feasibility_check_lookahead_distance,
+                                            &feasible, NULL), "teb_amd_is_trajectory_feasible")) return false;
+  return feasible != 0;
+}
+
 float TebAmdBatch::lastKernelMs() const
 {
   float ms = 0;

@@ -145,6 +145,18 @@ public:
   //! TebOptimalPlanner::getVelocityCommand (src/optimal_planner.cpp:1135-1168) of candidate `index`, from the device-resident band.
   bool getVelocityCommand(const TebConfig& cfg, int index, double& vx, double& vy, double& omega, int look_ahead_poses);
 
+  /**
+   * TebOptimalPlanner::isTrajectoryFeasible (src/optimal_planner.cpp:1250-1308) of candidate `index` on the device, from the resident
+   * band. The reference takes a base_local_planner::CostmapModel*; the adapter owns the costmap behind it (costmap_ros->getCostmap()):
+   * hand its grid to setCostmap() once per tick - Costmap2D::getCharMap(), getSizeInCellsX/Y(), getResolution(), getOriginX/Y() - then
+   * call this with footprint_spec_, robot_inscribed_radius_ and cfg.trajectory.{min_resolution_collision_check_angular,
+   * feasibility_check_no_poses, feasibility_check_lookahead_distance} as src/teb_local_planner_ros.cpp:396 does. Returns false on a
+   * library error as well (lastError()).
+   */
+  bool setCostmap(const unsigned char* cells, unsigned int size_x, unsigned int size_y, double resolution, double origin_x, double origin_y);
+  bool isTrajectoryFeasible(int index, const std::vector<geometry_msgs::Point>& footprint_spec, double inscribed_radius,
+                            double min_resolution_collision_check_angular, int look_ahead_idx, double feasibility_check_lookahead_distance);
+
   const std::string& lastError() const { return error_; }
   float lastKernelMs() const;
 

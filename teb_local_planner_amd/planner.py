@@ -93,6 +93,8 @@ def lib():
         L.teb_amd_get_band_flags.argtypes = [vp, _abi.p_i32, _abi.p_i32, _abi.p_i32]
         L.teb_amd_hcp_params_default.argtypes = [C.POINTER(_abi.HcpParams)]
         L.teb_amd_hcp_params_default.restype = None
+        L.teb_amd_set_costmap.argtypes = [vp, C.c_void_p, i32, i32, d, d, d]
+        L.teb_amd_is_trajectory_feasible.argtypes = [vp, i32, i32, _abi.p_f64, _abi.p_f64, d, d, i32, d, _abi.p_i32, _abi.p_i32]
         # multi-GPU exchange
         L.teb_amd_comm_unique_id.argtypes = [C.c_char_p]
         L.teb_amd_comm_create.argtypes = [C.c_char_p, i32, i32, i32, C.POINTER(vp)]
@@ -299,6 +301,26 @@ class TebBatchSolver:
         d = C.c_int32(0)
         _chk(lib().teb_amd_has_diverged(self._h, b, C.byref(d)), "teb_amd_has_diverged")
         return bool(d.value)
+
+    # -- feasibility of the resident bands against a costmap grid (arithmetic part) -----------
+    def set_costmap(self, cells, resolution, origin_x, origin_y):
+        cells = np.ascontiguousarray(cells, dtype=np.uint8)
+        _chk(lib().teb_amd_set_costmap(self._h, cells.ctypes.data_as(C.c_void_p), cells.shape[1], cells.shape[0], float(resolution),
+                                       float(origin_x), float(origin_y)), "teb_amd_set_costmap")
+
+    def is_trajectory_feasible(self, b, footprint, inscribed_radius, min_resolution_collision_check_angular=3.141592653589793,
+                               look_ahead_idx=-1, feasibility_check_lookahead_distance=-1.0):
+        """isTrajectoryFeasible of band b (-1: every band): (feasible, first_infeasible) - bools / ints, arrays for b = -1."""
+        cnt = self.count if b < 0 else 1
+        fx = _abi.f64([p[0] for p in footprint]); fy = _abi.f64([p[1] for p in footprint])
+        ok = np.zeros(cnt, np.int32); first = np.zeros(cnt, np.int32)
+        _chk(lib().teb_amd_is_trajectory_feasible(self._h, int(b), len(footprint), _abi._ptr(fx, C.c_double), _abi._ptr(fy, C.c_double),
+                                                  float(inscribed_radius), float(min_resolution_collision_check_angular), int(look_ahead_idx),
+                                                  float(feasibility_check_lookahead_distance), _abi._ptr(ok, C.c_int32), _abi._ptr(first, C.c_int32)),
+             "teb_amd_is_trajectory_feasible")
+        if b < 0:
+            return ok.astype(bool), first
+        return bool(ok[0]), int(first[0])
 
     # -- equivalence classes of the resident bands (SURVEY 8f row f3, arithmetic core) ----------------------
     def h_signatures(self, prescaler=1.0, values=True):
@@ -577,6 +599,17 @@ class TebOptimalPlanner:
     def hasDiverged(self):
         return self._ensure_solver().has_diverged(0)
 
+    def isTrajectoryFeasible(self, costmap, footprint_spec, inscribed_radius, circumscribed_radius=0.0, look_ahead_idx=-1,
+                             feasibility_check_lookahead_distance=-1.0):
+        """isTrajectoryFeasible (optimal_planner.h:500, src/optimal_planner.cpp:1250-1308) of the resident band. costmap: an object with
+        cells [size_y, size_x] uint8, resolution, origin_x, origin_y (the grid of costmap_2d::Costmap2D) standing in for the
+        base_local_planner::CostmapModel* of the reference; footprint_spec: [(x, y), ...]. circumscribed_radius is accepted and unused,
+        as in CostmapModel::footprintCost."""
+        s = self._ensure_solver()
+        s.set_costmap(costmap.cells, costmap.resolution, costmap.origin_x, costmap.origin_y)
+        return s.is_trajectory_feasible(0, footprint_spec, inscribed_radius, self.cfg_.trajectory.min_resolution_collision_check_angular,
+                                        look_ahead_idx, feasibility_check_lookahead_distance)[0]
+
 
 class HomotopyClassPlanner:
     """Batch view: owns the candidates resident on one GPU (reference homotopy_class_planner.h). Either constructed around a host
@@ -668,6 +701,38 @@ class HomotopyClassPlanner:
                                              t.prevent_look_ahead_poses_near_goal)
         return ok, float(v[0]), float(v[1]), float(v[2])
 
+    def isTrajectoryFeasible(self, costmap, footprint_spec, inscribed_radius, circumscribed_radius=0.0, look_ahead_idx=-1,
+                             feasibility_check_lookahead_distance=-1.0):
+        """HomotopyClassPlanner::isTrajectoryFeasible (src/homotopy_class_planner.cpp:686-709): the best band is checked; an infeasible
+        one is removed and the next best tried, unless it was already the best band of the previous tick (then False: "not failing could
+        result in oscillations between trajectories")."""
+        s = self.solver
+        if s.count == 0:
+            return False
+        s.set_costmap(costmap.cells, costmap.resolution, costmap.origin_x, costmap.origin_y)
+        feasible = False
+        while not feasible and s.count > 0:
+            if self.best_teb_ < 0:                       # findBestTeb (:711-723): re-select when the best band is gone
+                self.selectBestTeb()
+            best = self.best_teb_
+            if best < 0:
+                return False
+            feasible = s.is_trajectory_feasible(best, footprint_spec, inscribed_radius, self.cfg_.trajectory.min_resolution_collision_check_angular,
+                                                look_ahead_idx, feasibility_check_lookahead_distance)[0]
+            if not feasible:
+                same_as_before = getattr(self, "_last_best_teb", -1) == best
+                keep = np.ones(s.count, np.int32)
+                keep[best] = 0
+                s.compact_bands(keep, -1)                # removeTeb (:725-744)
+                lb = getattr(self, "_last_best_teb", -1)
+                self._last_best_teb = -1 if lb == best else (lb - 1 if lb > best else lb)
+                if 0 <= self.initial_plan_teb_:
+                    self.initial_plan_teb_ = -1 if self.initial_plan_teb_ == best else self.initial_plan_teb_ - (self.initial_plan_teb_ > best)
+                self.best_teb_ = -1
+                if same_as_before:
+                    return False
+        return feasible
+
     def bands(self, stride=None):
         """Host copy of the resident bands: list of (x, y, theta, dt)."""
         s = self.solver
@@ -687,6 +752,7 @@ class HomotopyClassPlanner:
         only allowed when more than that period has passed since the last switch); None = time.monotonic()."""
         import time
         last = self.best_teb_
+        self._last_best_teb = last                       # last_best_teb_ (:566)
         best, _ = self.solver.select_best(self.best_teb_, self.initial_plan_teb_)
         if last >= 0 and best != last:
             now = time.monotonic() if now is None else now
