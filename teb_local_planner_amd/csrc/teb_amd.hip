@@ -152,11 +152,11 @@ struct teb_amd_handle {
   int snap_nmax = -1;      // nmax_known at the time of teb_amd_snapshot_state
   int nmax_known = -1;     // upper bound of the resident pose counts as far as the host knows it, -1 = unknown (device-side producers ran)
   // host copy of the last obstacle table: teb_amd_set_config re-derives the static / dynamic lists from it
-  struct HostObst { std::vector<int> type, dyn, voff; std::vector<double> ax, ay, bx, by, rad, vx, vy, cx, cy, pvx, pvy; } hob;
+  struct HostObst { std::vector<int> type, dyn, voff; std::vector<double> ax, ay, bx, by, rad, vx, vy, cx, cy, brad, pvx, pvy; } hob;
   std::vector<int> host_static;
   // scene
   DevBuf<int> o_type, o_dyn, o_voff, o_static, o_dynidx;
-  DevBuf<double> o_ax, o_ay, o_bx, o_by, o_rad, o_vx, o_vy, o_cx, o_cy, o_pvx, o_pvy, viax, viay;
+  DevBuf<double> o_ax, o_ay, o_bx, o_by, o_rad, o_vx, o_vy, o_cx, o_cy, o_brad, o_pvx, o_pvy, viax, viay;
   // batch
   DevBuf<int> n, has_vs, has_vg, rotdir, via_en, status, optimized, iters, trials, assoc_cnt, assoc, assoc_ovf, via_pose, legacy_idx;
   DevBuf<double> x, y, th, dt, vs, vg, chi2, cost, lambda, Hbackup, Hband, ob_x, ob_y, ob_th, ob_dt;   // ob_*: strips before an optimistic launch
@@ -217,7 +217,7 @@ SceneDev scene_of(teb_amd_handle* h) {
   s.M = h->M;
   s.fast_points = h->fast_points;
   s.type = h->o_type.p; s.ax = h->o_ax.p; s.ay = h->o_ay.p; s.bx = h->o_bx.p; s.by = h->o_by.p;
-  s.rad = h->o_rad.p; s.vx = h->o_vx.p; s.vy = h->o_vy.p; s.cx = h->o_cx.p; s.cy = h->o_cy.p;
+  s.rad = h->o_rad.p; s.vx = h->o_vx.p; s.vy = h->o_vy.p; s.cx = h->o_cx.p; s.cy = h->o_cy.p; s.brad = h->o_brad.p;
   s.dyn = h->o_dyn.p; s.voff = h->o_voff.p; s.pvx = h->o_pvx.p; s.pvy = h->o_pvy.p;
   s.n_static = h->n_static; s.static_idx = h->o_static.p; s.n_dyn = h->n_dyn; s.dyn_idx = h->o_dynidx.p;
   s.nvia = h->nvia; s.viax = h->viax.p; s.viay = h->viay.p;
@@ -486,7 +486,7 @@ int teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max
   auto A = [&](hipError_t e) { if (e != hipSuccess) ok = false; };
   A(h->o_type.alloc(Mo)); A(h->o_dyn.alloc(Mo)); A(h->o_voff.alloc(Mo + 1)); A(h->o_static.alloc(Mo)); A(h->o_dynidx.alloc(Mo));
   A(h->o_ax.alloc(Mo)); A(h->o_ay.alloc(Mo)); A(h->o_bx.alloc(Mo)); A(h->o_by.alloc(Mo)); A(h->o_rad.alloc(Mo));
-  A(h->o_vx.alloc(Mo)); A(h->o_vy.alloc(Mo)); A(h->o_cx.alloc(Mo)); A(h->o_cy.alloc(Mo));
+  A(h->o_vx.alloc(Mo)); A(h->o_vy.alloc(Mo)); A(h->o_cx.alloc(Mo)); A(h->o_cy.alloc(Mo)); A(h->o_brad.alloc(Mo));
   A(h->o_pvx.alloc(max_obstacle_vertices)); A(h->o_pvy.alloc(max_obstacle_vertices));
   A(h->viax.alloc(max_via_points)); A(h->viay.alloc(max_via_points));
   A(h->n.alloc(max_tebs)); A(h->has_vs.alloc(max_tebs)); A(h->has_vg.alloc(max_tebs)); A(h->rotdir.alloc(max_tebs));
@@ -529,7 +529,7 @@ void teb_amd_destroy(teb_amd_handle_t* h) {
                        &h->via_en, &h->status, &h->optimized, &h->iters, &h->trials, &h->assoc_cnt, &h->assoc, &h->assoc_ovf, &h->via_pose, &h->legacy_idx,
                        &h->snap_n, &h->sel_idx, &h->err_flag, &h->hs_pex};
   for (auto* q : ib) q->free();
-  DevBuf<double>* db[] = {&h->o_ax, &h->o_ay, &h->o_bx, &h->o_by, &h->o_rad, &h->o_vx, &h->o_vy, &h->o_cx, &h->o_cy, &h->o_pvx,
+  DevBuf<double>* db[] = {&h->o_ax, &h->o_ay, &h->o_bx, &h->o_by, &h->o_rad, &h->o_vx, &h->o_vy, &h->o_cx, &h->o_cy, &h->o_brad, &h->o_pvx,
                           &h->o_pvy, &h->viax, &h->viay, &h->x, &h->y, &h->th, &h->dt, &h->vs, &h->vg, &h->chi2, &h->cost,
                           &h->lambda, &h->Hbackup, &h->Hband, &h->ob_x, &h->ob_y, &h->ob_th, &h->ob_dt, &h->snap_x, &h->snap_y, &h->snap_th, &h->snap_dt, &h->dbg_H,
                           &h->dbg_b, &h->dbg_chi2, &h->sel_cost, &h->stage_x, &h->stage_y, &h->stage_yaw, &h->out_cmd, &h->out_prof, &h->out_traj, &h->hsig, &h->hs_pre, &h->hs_pim};
@@ -612,7 +612,7 @@ int teb_amd_set_obstacles(teb_amd_handle_t* h, const teb_amd_obstacles_t* o) {
   if (M > 0 && (!o->type || !o->ax || !o->ay)) return fail(TEB_AMD_ERR_INVALID_ARG, "obstacle arrays missing");
   teb_amd_handle::HostObst t;
   t.type.resize(M); t.dyn.resize(M); t.voff.assign(M + 1, 0);
-  t.ax.resize(M); t.ay.resize(M); t.bx.resize(M); t.by.resize(M); t.rad.resize(M); t.vx.resize(M); t.vy.resize(M); t.cx.resize(M); t.cy.resize(M);
+  t.ax.resize(M); t.ay.resize(M); t.bx.resize(M); t.by.resize(M); t.rad.resize(M); t.vx.resize(M); t.vy.resize(M); t.cx.resize(M); t.cy.resize(M); t.brad.assign(M, 0.0);
   for (int i = 0; i < M; ++i) {
     t.type[i] = o->type[i];
     t.ax[i] = o->ax[i]; t.ay[i] = o->ay[i];
@@ -622,14 +622,19 @@ int teb_amd_set_obstacles(teb_amd_handle_t* h, const teb_amd_obstacles_t* o) {
     t.dyn[i] = o->dynamic ? (o->dynamic[i] != 0) : 0;
     t.voff[i] = (int)t.pvx.size();
     switch (t.type[i]) {
-      case TEB_AMD_OBST_POINT: case TEB_AMD_OBST_CIRCULAR: t.cx[i] = t.ax[i]; t.cy[i] = t.ay[i]; break;
-      case TEB_AMD_OBST_LINE: case TEB_AMD_OBST_PILL: t.cx[i] = 0.5 * (t.ax[i] + t.bx[i]); t.cy[i] = 0.5 * (t.ay[i] + t.by[i]); break;
+      case TEB_AMD_OBST_POINT: case TEB_AMD_OBST_CIRCULAR: t.cx[i] = t.ax[i]; t.cy[i] = t.ay[i]; t.brad[i] = std::fabs(t.rad[i]); break;
+      case TEB_AMD_OBST_LINE: case TEB_AMD_OBST_PILL:
+        t.cx[i] = 0.5 * (t.ax[i] + t.bx[i]); t.cy[i] = 0.5 * (t.ay[i] + t.by[i]);
+        t.brad[i] = 0.5 * std::hypot(t.bx[i] - t.ax[i], t.by[i] - t.ay[i]) + std::fabs(t.rad[i]);
+        break;
       case TEB_AMD_OBST_POLYGON: {
         if (!o->vert_offset || !o->vert_x || !o->vert_y) return fail(TEB_AMD_ERR_INVALID_ARG, "polygon obstacle without vertex arrays");
         int k0 = o->vert_offset[i], k1 = o->vert_offset[i + 1];
         if (k1 <= k0) return fail(TEB_AMD_ERR_INVALID_ARG, "polygon obstacle without vertices");
         for (int k = k0; k < k1; ++k) { t.pvx.push_back(o->vert_x[k]); t.pvy.push_back(o->vert_y[k]); }
         polygon_centroid(o->vert_x + k0, o->vert_y + k0, k1 - k0, t.cx[i], t.cy[i]);
+        for (int k = k0; k < k1; ++k) t.brad[i] = std::max(t.brad[i], std::hypot(o->vert_x[k] - t.cx[i], o->vert_y[k] - t.cy[i]));
+        if (!(t.brad[i] == t.brad[i])) t.brad[i] = std::numeric_limits<double>::infinity();   // NaN centroid: never culled
         break;
       }
       default: return fail(TEB_AMD_ERR_INVALID_ARG, "unknown obstacle type");
@@ -641,7 +646,7 @@ int teb_amd_set_obstacles(teb_amd_handle_t* h, const teb_amd_obstacles_t* o) {
   auto up_d = [&](DevBuf<double>& d, const std::vector<double>& v) { return v.empty() ? hipSuccess : hipMemcpyAsync(d.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, h->stream); };
   HIPCHK(up_i(h->o_type, t.type)); HIPCHK(up_i(h->o_dyn, t.dyn)); HIPCHK(up_i(h->o_voff, t.voff));
   HIPCHK(up_d(h->o_ax, t.ax)); HIPCHK(up_d(h->o_ay, t.ay)); HIPCHK(up_d(h->o_bx, t.bx)); HIPCHK(up_d(h->o_by, t.by)); HIPCHK(up_d(h->o_rad, t.rad));
-  HIPCHK(up_d(h->o_vx, t.vx)); HIPCHK(up_d(h->o_vy, t.vy)); HIPCHK(up_d(h->o_cx, t.cx)); HIPCHK(up_d(h->o_cy, t.cy));
+  HIPCHK(up_d(h->o_vx, t.vx)); HIPCHK(up_d(h->o_vy, t.vy)); HIPCHK(up_d(h->o_cx, t.cx)); HIPCHK(up_d(h->o_cy, t.cy)); HIPCHK(up_d(h->o_brad, t.brad));
   HIPCHK(up_d(h->o_pvx, t.pvx)); HIPCHK(up_d(h->o_pvy, t.pvy));
   HIPCHK(hipStreamSynchronize(h->stream));   // the uploads read `t`
   h->M = M;

@@ -45,6 +45,7 @@ struct SceneDev {
                            //    obstacle cache fits the LDS -> specialised distance path on LDS-resident data
   const int* type;
   const double *ax, *ay, *bx, *by, *rad, *vx, *vy, *cx, *cy;
+  const double* brad;      // radius of a circle about the centroid (cx, cy) that contains the obstacle (far-field culling)
   const int* dyn;
   const int* voff;
   const double *pvx, *pvy;

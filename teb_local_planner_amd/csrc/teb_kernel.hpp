@@ -53,7 +53,7 @@ struct Lds {
 
 __host__ __device__ inline int nb_for(int S) { return (4 * S + 7) / 8; }
 __host__ __device__ inline size_t hmat_doubles(int S, int solver) {  // (LDS-resident part)
-  if (solver == SOLVER_BANDG) return (size_t)5 * S + 256;   // only the scratch of autoResize (edit script + new poses + split stack)
+  if (solver == SOLVER_BANDG) return (size_t)6 * S + 256;   // only the scratch of autoResize (edit script + new poses + split stack + runs)
   if (solver == SOLVER_CR) return (size_t)nb_for(S) * (2 * kBlk + 8);
   const size_t band = (size_t)4 * S * kBand, compact = (size_t)((nb_for(S) + 1) / 2) * (2 * kBlk + 8);   // hybrid solve: even block rows in LDS
   return band > compact ? band : compact;
@@ -185,8 +185,8 @@ struct TebCtx {
     }                                                                                                                 \
   } while (0)
 
-// Lanes per pose. A pass over the poses has kThreads lanes; when it holds at most kThreads / 2 poses (short bands, and the second pass
-// of a band with more than kThreads poses, which would otherwise cost a full pass for a handful of poses) G = 2, 4 or 8 adjacent lanes
+// Lanes per pose. A pass over the poses has kThreads lanes; when a LEFTOVER pass (the second pass of a band with more than kThreads
+// poses, which would otherwise cost a full pass for a handful of poses) holds at most kThreads / 2 poses, G = 2, 4 or 8 adjacent lanes
 // share a pose: slice sl of nsl takes a contiguous chunk of the dynamic-obstacle list (the bulk of the per-pose work), slice 0 also
 // everything else of the pose. Partial sums are combined with lane shuffles (fixed tree: deterministic).
 __device__ __forceinline__ int lanes_per_pose(int poses_left) {
@@ -254,18 +254,18 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
 
   // ---- unary edges of pose i (AddEdgesObstacles :444-548, AddEdgesDynamicObstacles :646-673, AddEdgesViaPoints :675-718)
   // association entries are POSITIONS in the static list (sc.static_idx / the LDS obstacle cache)
-  const int cnt = first ? t.assoc_cnt[i] : 0;
+  const int cnt = t.assoc_cnt[i];   // the static edges of the pose are dealt round-robin to its slices (k = sl, sl + nsl, ..)
   EVP_DECL
   if (i >= 1) {
     if (sc.fast_points) {
       if (!c.legacy_obstacle_association) {
-        for (int k = 0; k < cnt; ++k) {
+        for (int k = sl; k < cnt; k += nsl) {
           const int p = t.assoc[(size_t)k * t.stride + i];
           const double ox = l.obx[p], oy = l.oby[p], orad = l.obr[p];
           TEB_EDGE(M_POSE0, CAT_OBST, edge_obstacle_fast<J_>(c, ox, oy, orad, W, t.w_obst, t.inflated, ACC_));
         }
       } else {   // legacy lists carry the triple edge at the closest pose as one flagged entry
-        for (int k = 0; k < cnt; ++k) {
+        for (int k = sl; k < cnt; k += nsl) {
           const int ent = t.assoc[(size_t)k * t.stride + i];
           const int p = ent & kAssocMask;
           const double ox = l.obx[p], oy = l.oby[p], orad = l.obr[p];
@@ -292,7 +292,7 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
         }
       }
     } else {
-      for (int k = 0; k < cnt; ++k) {
+      for (int k = sl; k < cnt; k += nsl) {
         const int ent = t.assoc[(size_t)k * t.stride + i];
         const int oi = sc.static_idx[ent & kAssocMask];
 #pragma unroll 1
@@ -435,7 +435,7 @@ __device__ inline void linearize(const teb_amd_config_t& c, const SceneDev& sc, 
   Accum A;
   A.clear_chi();
   for (int k0 = 0; k0 < n - 1; ) {
-    const int G = lanes_per_pose(n - 1 - k0);
+    const int G = k0 > 0 ? lanes_per_pose(n - 1 - k0) : 1;   // slices only for a leftover pass: bands up to kThreads poses keep their summation order
     const int i = k0 + tid / G, sl = tid % G;
     const bool active = i <= n - 2;
     constexpr int EM = JMODE == TEB_AMD_JACOBIAN_G2O_NUMERIC ? 2 : 1;
@@ -474,7 +474,7 @@ __device__ inline void evaluate(const teb_amd_config_t& c, const SceneDev& sc, c
   Accum A;   // only chi[] is live when JAC == false
   A.clear_chi();
   for (int k0 = 0; k0 < t.n - 1; ) {
-    const int G = lanes_per_pose(t.n - 1 - k0);
+    const int G = k0 > 0 ? lanes_per_pose(t.n - 1 - k0) : 1;
     const int i = k0 + (int)threadIdx.x / G;
     if (i <= t.n - 2) {
       const unsigned long long near = dyn_near_first<0>(c, sc, l, i, (int)threadIdx.x % G, G);
@@ -1311,8 +1311,10 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, dou
 // Pose descriptors: d < kNewPose = input pose d, else new pose d - kNewPose. New-pose record: parent A | parent B << 11 | depth << 22.
 constexpr int kNewPose = 1024;
 constexpr int kSplitStack = 64;
-// scratch (doubles from off_scratch): odt[S] | nx[S] ny[S] nth[S] | ints: out_desc[S] rec[S] | stack dt[64] | ints: stack desc[64]
-__host__ __device__ inline size_t autoresize_scratch_doubles(int S) { return (size_t)5 * S + kSplitStack + kSplitStack / 2 + 8; }
+// scratch (doubles from off_scratch): odt[S] | nx[S] ny[S] nth[S] | ints: out_desc[S] rec[S] | stack dt[64] | ints: stack desc[64] |
+//                                      u64: active masks[16] | ints: runs[S]
+__host__ __device__ inline size_t autoresize_scratch_doubles(int S) { return (size_t)5 * S + kSplitStack + kSplitStack / 2 + 16 + (S + 1) / 2 + 8; }
+constexpr int kActiveMasks = 16;   // 64 intervals each
 
 // wave-uniform copy of a value: arguments of an out-of-line device function arrive in VGPRs and count as divergent, which would turn
 // every `if` of the rule machine into exec-mask bookkeeping (measured: ~860 cycles per rule evaluation); from SGPRs the loop is
@@ -1321,8 +1323,14 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 __device__ __forceinline__ double uni(double v) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
-// results: out[0] = n_out, out[1] = modified, out[2] = overflow, out[3] = #new poses, out[4] = deepest split tree (ints at off_out, in
-// units of ints from the LDS base)
+// results: out[0] = n_out, out[1] = modified, out[2] = overflow, out[3] = #new poses, out[4] = deepest split tree, out[5] = #runs,
+// out[6] = index of the emitted interval that receives the merged last interval (-1: none); its amount is odt_tail (ints at off_out,
+// in units of ints from the LDS base).
+// Stretches of intervals inside the dead band [dt_ref - hyst, dt_ref + hyst] that the machine reaches with nothing pending (no excess
+// pushed onto them, no split halves waiting) pass through unchanged: the caller marks the intervals OUTSIDE the band in bit masks
+// (one ballot per wave), the machine jumps from one marked interval to the next and leaves a run record (first output index, first
+// input index, length) for the lanes to expand afterwards. The number of sequential steps is the number of marked intervals plus the
+// lengths of the excess / split chains they start, typically a tenth of the band.
 __device__ __noinline__ void autoresize_script_lane0(double dt_ref_, double hyst_, int max_samples_, int min_samples_, int off_state_,
                                                        int off_scratch_, int n_in_, int stride_, int off_out_) {
   // all operands are addressed from the dynamic LDS base inside this function, so that the sequential loop is compiled to
@@ -1339,20 +1347,47 @@ __device__ __noinline__ void autoresize_script_lane0(double dt_ref_, double hyst
   int* rec = out_desc + stride;
   double* stk_dt = odt + 5 * stride;
   int* stk_desc = reinterpret_cast<int*>(stk_dt + kSplitStack);
+  const unsigned long long* masks = reinterpret_cast<const unsigned long long*>(stk_dt + kSplitStack + kSplitStack / 2);
+  int* runs = reinterpret_cast<int*>(stk_dt + kSplitStack + kSplitStack / 2 + kActiveMasks);
   const int Tin = n_in - 1;
   int T = Tin;           // sizeTimeDiffs()
   int j = 1;             // next unread input interval
   int sp = 0;            // stack size
   int k = 0;             // emitted intervals
   int nn = 0, md = 0;    // new poses, deepest split tree
+  int nruns = 0, tail_k = -1;
   bool modified = false;
   int cdesc = 0, cdepth = 0;
   double cdt = in_dt[0];
+  bool fresh = true;     // cur is the untouched input interval cdesc (nothing was added to it)
   // the next unread input interval is kept in a register one step ahead, so that its LDS latency overlaps the rule evaluation
   double pdt = (j < Tin) ? in_dt[j] : 0.0;
+  bool ptouched = false; // an excess was pushed onto the prefetched interval
   bool alive = Tin >= 1;
   int top_desc = 0, top_depth = 0; double top_dt = 0;   // register copy of the stack top
   while (alive) {
+    if (fresh && sp == 0) {
+      // run of unmarked intervals starting at cur = input interval cdesc: up to the next marked one (or the end of the band)
+      const int j0 = cdesc;
+      int a = Tin;
+      for (int cidx = j0 >> 6; cidx < kActiveMasks && (cidx << 6) < Tin; ++cidx) {
+        unsigned long long m = masks[cidx];
+        if (cidx == (j0 >> 6)) m &= ~0ull << (j0 & 63);
+        if (m) { a = (cidx << 6) + __ffsll((long long)m) - 1; break; }
+      }
+      if (a > Tin) a = Tin;
+      const int len = a - j0;
+      if (len >= 2) {
+        if (k + len > stride - 1) { ovf = 1; break; }
+        runs[nruns++] = k | (j0 << 10) | (len << 20);
+        k += len;
+        j = a + 1;
+        if (a < Tin) {
+          cdesc = a; cdepth = 0; cdt = in_dt[a]; fresh = true;
+          pdt = (j < Tin) ? in_dt[j] : 0.0; ptouched = false;
+        } else { alive = false; break; }
+      }
+    }
     const bool has_next = (sp > 0) || (j < Tin);
     if (cdt > dt_ref + hyst && T < max_samples) {
       if (cdt > 2 * dt_ref) {
@@ -1368,16 +1403,16 @@ __device__ __noinline__ void autoresize_script_lane0(double dt_ref_, double hyst
         if (sp > 0) { stk_dt[sp - 1] = top_dt; stk_desc[sp - 1] = top_desc | (top_depth << 16); }   // spill the old top
         top_desc = kNewPose + nn; top_depth = depth; top_dt = newtime;
         ++nn; ++sp;
-        cdt = newtime;
+        cdt = newtime; fresh = false;
         ++T;
         modified = true;
         continue;   // i-- : re-check the left half
       } else {
         if (has_next) {
           if (sp > 0) top_dt += cdt - dt_ref;
-          else pdt += cdt - dt_ref;
+          else { pdt += cdt - dt_ref; ptouched = true; }
         }
-        cdt = dt_ref;
+        cdt = dt_ref; fresh = false;
       }
     } else if (cdt < dt_ref - hyst && T > min_samples) {
       if (has_next) {
@@ -1388,13 +1423,17 @@ __device__ __noinline__ void autoresize_script_lane0(double dt_ref_, double hyst
         } else {
           cdt = pdt + cdt; ++j;
           if (j < Tin) pdt = in_dt[j];
+          ptouched = false;
         }
+        fresh = false;
         --T;
         modified = true;
         continue;
       } else if (k > 0) {
-        // last interval: TimeDiff(i-1) += TimeDiff(i); deleteTimeDiff(i); deletePose(i)
-        odt[k - 1] += cdt;
+        // last interval: TimeDiff(i-1) += TimeDiff(i); deleteTimeDiff(i); deletePose(i). The interval before may still sit in a run
+        // record: the amount is applied after the runs have been expanded.
+        tail_k = k - 1;
+        odt[stride - 1] = cdt;   // (slot never used by an emitted interval: k <= stride - 1 intervals)
         --T;
         modified = true;
         alive = false;
@@ -1406,15 +1445,16 @@ __device__ __noinline__ void autoresize_script_lane0(double dt_ref_, double hyst
     out_desc[k] = cdesc; odt[k] = cdt;
     ++k;
     if (sp > 0) {
-      cdesc = top_desc; cdepth = top_depth; cdt = top_dt; --sp;
+      cdesc = top_desc; cdepth = top_depth; cdt = top_dt; --sp; fresh = false;
       if (sp > 0) { top_dt = stk_dt[sp - 1]; const int e = stk_desc[sp - 1]; top_desc = e & 0xffff; top_depth = e >> 16; }
     } else if (j < Tin) {
-      cdesc = j; cdepth = 0; cdt = pdt; ++j;
+      cdesc = j; cdepth = 0; cdt = pdt; fresh = !ptouched; ++j;
       if (j < Tin) pdt = in_dt[j];
+      ptouched = false;
     } else alive = false;
   }
-  out_desc[k] = n_in - 1;   // the goal pose
-  res[0] = k + 1; res[1] = modified ? 1 : 0; res[2] = ovf; res[3] = nn; res[4] = md;
+  res[0] = k + 1; res[1] = modified ? 1 : 0; res[2] = ovf; res[3] = nn; res[4] = md; res[5] = nruns; res[6] = tail_k;
+  if (!ovf) out_desc[k] = n_in - 1;   // the goal pose
 }
 
 __device__ inline int autoresize(const teb_amd_config_t& c, const Lds& l, int n, int off_state, int off_scratch, int stride,
@@ -1425,12 +1465,22 @@ __device__ inline int autoresize(const teb_amd_config_t& c, const Lds& l, int n,
   const int* out_desc = reinterpret_cast<const int*>(odt + 4 * stride);
   const int* rec = out_desc + stride;
   for (int rep = 0; rep < 100; ++rep) {
-    // parallel pre-check: a sweep is a no-op iff no interval satisfies either trigger condition
+    // parallel pre-check: a sweep is a no-op iff no interval satisfies either trigger condition; the same pass marks the intervals
+    // outside the dead band for the rule machine (one ballot per wave and 64 intervals)
     const int T = n - 1;
     int trig = 0;
-    for (int i = tid; i < T; i += kThreads) {
-      double d = l.sdt[i];
-      if ((d > c.dt_ref + c.dt_hysteresis && T < c.max_samples) || (d < c.dt_ref - c.dt_hysteresis && T > c.min_samples)) trig = 1;
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(odt + 5 * stride + kSplitStack + kSplitStack / 2);
+    for (int i0 = 0; i0 < kActiveMasks * 64; i0 += kThreads) {
+      const int i = i0 + tid;
+      bool mark = true;   // beyond the band: marked, so that no run crosses the end
+      if (i < T) {
+        const double d = l.sdt[i];
+        const bool hi = d > c.dt_ref + c.dt_hysteresis, lo = d < c.dt_ref - c.dt_hysteresis;
+        mark = hi || lo;
+        if ((hi && T < c.max_samples) || (lo && T > c.min_samples)) trig = 1;
+      }
+      const unsigned long long bal = __ballot(mark);
+      if ((tid & 63) == 0 && (i >> 6) < kActiveMasks) masks[i >> 6] = bal;
     }
     trig = __syncthreads_or(trig);
     if (!trig) break;
@@ -1450,8 +1500,20 @@ __device__ inline int autoresize(const teb_amd_config_t& c, const Lds& l, int n,
       for (int i = tid - 64; i < n; i += kThreads - 64) { const double th = l.sth[i]; l.cs[i] = cos(th); l.sn[i] = sin(th); }
     }
     __syncthreads();
-    const int n_out = l.ired[16], mod = l.ired[17], ovf = l.ired[18], n_new = l.ired[19], md = l.ired[20];
+    const int n_out = l.ired[16], mod = l.ired[17], ovf = l.ired[18], n_new = l.ired[19], md = l.ired[20], nruns = l.ired[21], tail_k = l.ired[22];
     if (ovf) { *overflow_flag = 1; return n; }
+    // expand the run records: output intervals [k0, k0 + len) = input intervals [j0, j0 + len), unchanged
+    {
+      int* out_desc_w = reinterpret_cast<int*>(odt + 4 * stride);
+      const int* runs = reinterpret_cast<const int*>(odt + 5 * stride + kSplitStack + kSplitStack / 2 + kActiveMasks);
+      for (int q = tid; q < nruns; q += kThreads) {
+        const int r = runs[q], k0 = r & 1023, j0 = (r >> 10) & 1023, len = r >> 20;
+        for (int t2 = 0; t2 < len; ++t2) { out_desc_w[k0 + t2] = j0 + t2; odt[k0 + t2] = l.sdt[j0 + t2]; }
+      }
+      __syncthreads();
+      if (tid == 0 && tail_k >= 0) odt[tail_k] += odt[stride - 1];   // the merged last interval (src/timed_elastic_band.cpp:274-279)
+      __syncthreads();
+    }
     // new poses, level by level: PoseSE2::average (pose_se2.h:266-269) with g2o::average_angle
     for (int d = 1; d <= md; ++d) {
       for (int q = tid; q < n_new; q += kThreads) {
@@ -1551,17 +1613,36 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
     }
     k0 = k_hi;
   }
-  for (int k = k0; k < k_hi; ++k) {
-    double dist, ccx, ccy;
-    if (sc.fast_points) {
-      ccx = l.obx[k]; ccy = l.oby[k];
-      dist = pointlike_distance<false>(c, x, y, ccx, ccy, l.obr[k], nullptr);
-    } else {
-      const int oi = sc.static_idx[k];
-      dist = footprint_distance(c, sc, oi, x, y, ox_, oy_, false, 0.0, nullptr);
-      ccx = sc.cx[oi]; ccy = sc.cy[oi];
+  if (!sc.fast_points) {
+    // Generic shapes: the same two passes with bounding circles. The robot lies within frad of the pose, the obstacle within brad of its
+    // centroid, so their distance is at least |centroid - pose| - brad - frad; beyond max(cutoff, force) (+ guard band) the obstacle
+    // cannot matter and its exact distance (segment / polygon loops, the expensive part: 75 % of BASELINE C5 before) is never computed.
+    double frad = 0;
+    if (c.footprint_type == TEB_AMD_FOOTPRINT_CIRCULAR) frad = c.footprint_radius;
+    else if (c.footprint_type == TEB_AMD_FOOTPRINT_TWO_CIRCLES)
+      frad = fmax(fabs(c.footprint_front_offset) + c.footprint_front_radius, fabs(c.footprint_rear_offset) + c.footprint_rear_radius);
+    else if (c.footprint_type == TEB_AMD_FOOTPRINT_LINE || c.footprint_type == TEB_AMD_FOOTPRINT_POLYGON)
+      for (int v = 0; v < c.footprint_n_vertices; ++v) frad = fmax(frad, sqrt(c.footprint_vx[v] * c.footprint_vx[v] + c.footprint_vy[v] * c.footprint_vy[v]));
+    const double far_d = fmax(cutoff, force) + frad;
+    for (; k0 < k_hi; k0 += 64) {
+      const int ke = k0 + 64 < k_hi ? k0 + 64 : k_hi;
+      unsigned long long near = 0;
+#pragma unroll 4
+      for (int k = k0; k < ke; ++k) {
+        const int oi = sc.static_idx[k];
+        const double ddx = x - sc.cx[oi], ddy = y - sc.cy[oi];
+        const double d2 = ddx * ddx + ddy * ddy;
+        const double thr = (far_d + sc.brad[oi]) * (1.0 + 1e-9);
+        if (!(d2 > thr * thr) || thr <= 0) near |= 1ull << (k - k0);   // NaN / infinite bounds count as near
+      }
+      while (near) {
+        const int k = k0 + __ffsll((long long)near) - 1;
+        near &= near - 1;
+        const int oi = sc.static_idx[k];
+        const double dist = footprint_distance(c, sc, oi, x, y, ox_, oy_, false, 0.0, nullptr);
+        visit(k, dist, sc.cx[oi], sc.cy[oi]);
+      }
     }
-    visit(k, dist, ccx, ccy);
   }
 }
 
@@ -1571,7 +1652,7 @@ __device__ inline void associate(const teb_amd_config_t& c, const SceneDev& sc, 
   const double kMax = 1.7976931348623157e308;
   const int tid = threadIdx.x;
   for (int p0 = 0; p0 < n; ) {
-    const int G = lanes_per_pose(n - p0);
+    const int G = p0 > 0 ? lanes_per_pose(n - p0) : 1;
     const int i = p0 + tid / G, sl = tid % G;
     const bool has_pose = i < n;
     const bool scans = has_pose && i >= first_vertex && i < n - 1;

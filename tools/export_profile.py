@@ -62,6 +62,49 @@ def main():
                                   "'%%teb_optimize%%' and grid_size_x=%d group by counter_name" % grid):
             lines.append("%-24s %.6g" % (cn, avg))
             summary[cn] = avg
+    db = os.path.join(SRC, "pmc_sq2", "sq2_results.db")
+    if os.path.exists(db):
+        for cn, cnt, avg in q(db, "select counter_name, count(*), avg(value) from counters_collection where kernel_name like "
+                                  "'%%teb_optimize%%' and grid_size_x=%d group by counter_name" % grid):
+            lines.append("%-24s %.6g" % (cn, avg))
+            summary[cn] = avg
+    if "SQ_WAVE_CYCLES" in summary:
+        wc = summary["SQ_WAVE_CYCLES"]
+        att = {k: summary[k] / wc for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_LDS") if k in summary}
+        summary["wave_cycle_shares"] = att
+        lines.append("")
+        lines.append("# shares of SQ_WAVE_CYCLES (WAIT_ANY = parked at s_waitcnt / s_barrier, WAIT_INST_ANY = issue stalls, ACTIVE_INST_ANY = issuing)")
+        lines.append("  ".join("%s %.1f %%" % (k, 100 * v) for k, v in att.items()))
+    # matrix-core counters of the -DTEB_AMD_MFMA_SCHUR build (profiled with TEB_AMD_LIB=tools/libteb_amd_mfma.so)
+    db = os.path.join(SRC, "pmc_mfma", "mfma_results.db")
+    mt = os.path.join(SRC, "mfma_trace", "mtrace_results.db")
+    if os.path.exists(db) and os.path.exists(mt):
+        mf = {cn: avg for cn, cnt, avg in q(db, "select counter_name, count(*), avg(value) from counters_collection where kernel_name like "
+                                                "'%%teb_optimize%%' and grid_size_x=%d group by counter_name" % grid)}
+        r = q(mt, "select avg(duration) from kernels where name like '%%teb_optimize%%' and grid_x=%d" % grid)
+        mfma_ms = r[0][0] / 1e6
+        lines.append("")
+        lines.append("# -DTEB_AMD_MFMA_SCHUR build (Schur update of the cyclic reduction on v_mfma_f64_16x16x4_f64), same command: mean per full launch")
+        for k, v in sorted(mf.items()):
+            lines.append("%-28s %.6g" % (k, v))
+        lines.append("kernel avg %.3f ms (vector build: %.3f ms)" % (mfma_ms, summary["avg_ms"]))
+        n_mfma = mf.get("SQ_INSTS_MFMA", 0.0)
+        flop = n_mfma * 2048.0                         # 16 x 16 x 4 x 2 per instruction
+        busy = mf.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+        summary["mfma"] = {"build": "-DTEB_AMD_MFMA_SCHUR (off by default: measured slower)", "instruction": "v_mfma_f64_16x16x4_f64",
+                           "kernel_ms": mfma_ms, "kernel_ms_vector_build": summary["avg_ms"],
+                           "insts_mfma_per_launch": n_mfma, "mops_f64_per_launch": mf.get("SQ_INSTS_VALU_MFMA_MOPS_F64"),
+                           "mfma_busy_cycles_per_launch": busy, "flop_per_launch": flop,
+                           "achieved": flop / (mfma_ms * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                           "frac": flop / (mfma_ms * 1e-3) / 1e12 / 78.6,
+                           "busy_share_of_cu_time": busy / (4.0 * 256 * mfma_ms * 1e-3 * 2.4e9) if busy else None,
+                           "note": "fp64 matrix rate on gfx950 = fp64 vector rate (64 cycles per 16x16x4 issue, measured: tools/mfma_probe.py); "
+                                   "the update is 2 issues per elimination with 75 % useful MACs; the matrix build is slower end to end, so "
+                                   "the product keeps the vector code"}
+        lines.append("mfma: %.3g FLOP per launch on the matrix cores = %.3f TFLOP/s = %.2f %% of 78.6" % (flop, summary["mfma"]["achieved"], 100 * summary["mfma"]["frac"]))
+        pr = os.path.join(SRC, "mfma_probe.txt")
+        if os.path.exists(pr):
+            lines.append(open(pr).read().strip())
     db = os.path.join(SRC, "pmc_f64", "f64_results.db")
     if os.path.exists(db):
         lines.append("")

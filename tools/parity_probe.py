@@ -1,4 +1,5 @@
-"""Distribution of device-vs-oracle differences (same closed-form Jacobian mode) on the measured configurations, next to two
+"""Distribution of device-vs-oracle differences (same closed-form Jacobian mode) on the measured configurations (c4on c4 c2 c3) and on
+the randomized scenes ("random"), next to two
 yardsticks of how well conditioned a band is: (a) the oracle's analytic vs numeric mode (tests/sensitivity.py), (b) the oracle against
 itself when the inputs move by 1e-13 relative."""
 import os, sys, time
@@ -34,7 +35,41 @@ def run(name, cfg, obst, via, batch):
     bad = np.where(err > 1e-7)[0]
     for b in bad[:12]:
         print("   band %3d err %.2e self_err %.2e tol(a) %s n %d/%d trials %d/%d" % (b, err[b], self_err[b], tols[b], out.n[b], ref.n[b], res.lm_trials[b], rres.lm_trials[b]))
+def run_random():
+    """The 80 randomized scenes of tests/random_cases.py: every option of the path toggled at random."""
+    from random_cases import random_case
+    rows = []
+    for seed in range(80):
+        cfg, obst, via, batch = random_case(seed)
+        s = planner.make_solver(cfg, obst, via, batch)
+        s.optimize(cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations, True, cfg.hcp.selection_obst_cost_scale, cfg.hcp.selection_viapoint_cost_scale, cfg.hcp.selection_alternative_time_cost)
+        res = s.results(); out = s.download(batch.copy()); s.close()
+        ref, rres = oracle_py.optimize_batch(cfg, obst, via, batch)
+        tols = sensitivity.band_tolerances(oracle_py, cfg, obst, via, batch)
+        pert = batch.copy(); rng = np.random.default_rng(seed)
+        pert.x *= 1 + 1e-13 * rng.standard_normal(pert.x.shape); pert.y *= 1 + 1e-13 * rng.standard_normal(pert.y.shape)
+        pref, pres = oracle_py.optimize_batch(cfg, obst, via, pert)
+        for b in range(batch.count):
+            same = out.n[b] == ref.n[b] and res.lm_iterations[b] == rres.lm_iterations[b] and res.lm_trials[b] == rres.lm_trials[b] and res.status[b] == rres.status[b]
+            err = max(np.abs(u - v).max() for u, v in zip(out.get_teb(b), ref.get_teb(b))) if out.n[b] == ref.n[b] else np.inf
+            serr = max(np.abs(u - v).max() for u, v in zip(pref.get_teb(b), ref.get_teb(b))) if pref.n[b] == ref.n[b] else np.inf
+            sc = pres.lm_trials[b] == rres.lm_trials[b] and pres.lm_iterations[b] == rres.lm_iterations[b]
+            rows.append((seed, b, same, err, serr, sc, tols[b], int(res.status[b])))
+    err = np.array([r[3] for r in rows]); serr = np.array([r[4] for r in rows]); same = np.array([r[2] for r in rows]); sc = np.array([r[5] for r in rows])
+    well = np.array([r[6] is not None and r[6] <= 2e-5 for r in rows])
+    print("bands", len(rows), "counts identical", same.sum(), "well (a)", well.sum())
+    for lo, hi in ((0, 1e-12), (1e-12, 1e-10), (1e-10, 1e-8), (1e-8, 1e-7), (1e-7, 1e-5), (1e-5, 1e-2), (1e-2, np.inf)):
+        sel = (err >= lo) & (err < hi)
+        print("  err in [%g, %g): %3d (well (a) %3d; self-err < 1e-9: %3d; self-err < 1e-7: %3d)" % (lo, hi, sel.sum(), (sel & well).sum(), (sel & (serr < 1e-9)).sum(), (sel & (serr < 1e-7)).sum()))
+    print("  self-reproducible (serr < 1e-9 and same counts):", ((serr < 1e-9) & sc).sum(), " of those with device err <= 1e-7:", ((serr < 1e-9) & sc & (err <= 1e-7)).sum())
+    for r in rows:
+        if r[3] > 1e-7: print("   seed %d band %d same %s err %.2e self %.2e tol(a) %s status %d" % (r[0], r[1], r[2], r[3], r[4], r[6], r[7]))
+
+
 for which in sys.argv[1:] or ["c4on", "c4", "c2", "c3"]:
+    if which == "random":
+        run_random()
+        continue
     if which == "c4on": a = scenes.scene_c4(B=256, n=200, seed=1004, stride=288)
     elif which == "c4":
         a = scenes.scene_c4(B=256, n=200, seed=1004, stride=208); a[0].trajectory.teb_autosize = False
