@@ -435,7 +435,7 @@ __device__ inline void linearize(const teb_amd_config_t& c, const SceneDev& sc, 
   Accum A;
   A.clear_chi();
   for (int k0 = 0; k0 < n - 1; ) {
-    const int G = k0 > 0 ? lanes_per_pose(n - 1 - k0) : 1;   // slices only for a leftover pass: bands up to kThreads poses keep their summation order
+    const int G = (k0 > 0 || kThreads > 256) ? lanes_per_pose(n - 1 - k0) : 1;   // slices only for a leftover pass: bands up to kThreads poses keep their summation order
     const int i = k0 + tid / G, sl = tid % G;
     const bool active = i <= n - 2;
     constexpr int EM = JMODE == TEB_AMD_JACOBIAN_G2O_NUMERIC ? 2 : 1;
@@ -474,7 +474,7 @@ __device__ inline void evaluate(const teb_amd_config_t& c, const SceneDev& sc, c
   Accum A;   // only chi[] is live when JAC == false
   A.clear_chi();
   for (int k0 = 0; k0 < t.n - 1; ) {
-    const int G = k0 > 0 ? lanes_per_pose(t.n - 1 - k0) : 1;
+    const int G = (k0 > 0 || kThreads > 256) ? lanes_per_pose(t.n - 1 - k0) : 1;
     const int i = k0 + (int)threadIdx.x / G;
     if (i <= t.n - 2) {
       const unsigned long long near = dyn_near_first<0>(c, sc, l, i, (int)threadIdx.x % G, G);
@@ -1652,7 +1652,7 @@ __device__ inline void associate(const teb_amd_config_t& c, const SceneDev& sc, 
   const double kMax = 1.7976931348623157e308;
   const int tid = threadIdx.x;
   for (int p0 = 0; p0 < n; ) {
-    const int G = p0 > 0 ? lanes_per_pose(n - p0) : 1;
+    const int G = (p0 > 0 || kThreads > 256) ? lanes_per_pose(n - p0) : 1;
     const int i = p0 + tid / G, sl = tid % G;
     const bool has_pose = i < n;
     const bool scans = has_pose && i >= first_vertex && i < n - 1;
