@@ -1947,7 +1947,7 @@ int teb_amd_debug_profile(teb_amd_handle_t* h, double* cycles8) {
   HIPCHK(hipMemcpy(cycles8, h->dbg_H.p, 8 * sizeof(double), hipMemcpyDeviceToHost));
   long long crp[8];
   HIPCHK(hipMemcpyFromSymbol(crp, HIP_SYMBOL(tebamd::g_cr_prof), sizeof crp));
-  fprintf(stderr, "[cr_solve cycles, workgroup 0, cumulative] prologue %lld compute %lld barrier0 %lld writes+2 barriers %lld top %lld backsub %lld\n",
+  fprintf(stderr, "[cr_solve cycles, workgroup 0, cumulative; hybrid solve: init compact | level 0 | compact forward | top + backward | odd rows] %lld %lld %lld %lld %lld %lld\n",
           crp[0], crp[1], crp[2], crp[3], crp[4], crp[5]);
   long long evp[8];
   HIPCHK(hipMemcpyFromSymbol(evp, HIP_SYMBOL(tebamd::g_ev_prof), sizeof evp));

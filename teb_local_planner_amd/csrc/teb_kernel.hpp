@@ -558,6 +558,12 @@ __device__ __forceinline__ double fast_rcp(double d) {
 // is compiled with -ffp-contract=off. The reference has no bit-level contract for the solve either (CSparse eliminates in AMD
 // order); measured effect: 5 - 8 % on the C4 step, parity tests unchanged (poses <= 1e-8, identical LM trial counts).
 #define TEB_SOLVER_FMA _Pragma("clang fp contract(fast)")
+// scheduling fences inside the Schur-product loops of the cyclic reduction (they bound the number of LDS operands in flight)
+#ifdef TEB_AMD_NO_CR_FENCE
+#define TEB_CR_SCHED_BARRIER
+#else
+#define TEB_CR_SCHED_BARRIER __builtin_amdgcn_sched_barrier(0);
+#endif
 struct Ldl8 {   // in-place LDL^T of one 8x8 SPD block: a[r(r+1)/2 + c] holds l_rc (r > c) and 1/d_r on the diagonal
   double a[36];
   __device__ __forceinline__ static constexpr int idx(int r, int c) { return r * (r + 1) / 2 + c; }   // r >= c
@@ -668,7 +674,7 @@ __device__ __forceinline__ bool cr_forward(double* __restrict__ D, double* __res
 #pragma unroll
           for (int aa = 0; aa < 8; ++aa) o1[aa] += Li[k * 8 + aa] * wL[k];
           s1 += Li[k * 8 + c] * wf[k];
-          __builtin_amdgcn_sched_barrier(0);
+          TEB_CR_SCHED_BARRIER
         }
         if (hasU) {
 #pragma unroll
@@ -679,7 +685,7 @@ __device__ __forceinline__ bool cr_forward(double* __restrict__ D, double* __res
               o2[aa] -= lp * wL[k];
               o3[aa] += lp * wU[k];
             }
-            __builtin_amdgcn_sched_barrier(0);
+            TEB_CR_SCHED_BARRIER
           }
 #pragma unroll
           for (int k = 0; k < 8; ++k) s2 += Lp[c * 8 + k] * wf[k];
@@ -1038,7 +1044,7 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, const SceneDev&
 #pragma unroll
           for (int aa = 0; aa < 8; ++aa) o1[aa] += Li[k * 8 + aa] * wL[k];   // (L_i^T W_L)[aa][c]
           s1 += Li[k * 8 + c] * wf[k];                                         // (L_i^T P f_i)[c]
-          __builtin_amdgcn_sched_barrier(0);
+          TEB_CR_SCHED_BARRIER
         }
         if (hasU) {
 #pragma unroll
@@ -1049,7 +1055,7 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, const SceneDev&
               o2[aa] -= lp * wL[k];                                            // -(L_{i+s} W_L)[aa][c]
               o3[aa] += lp * wU[k];                                            //  (L_{i+s} W_U)[aa][c]
             }
-            __builtin_amdgcn_sched_barrier(0);
+            TEB_CR_SCHED_BARRIER
           }
 #pragma unroll
           for (int k = 0; k < 8; ++k) s2 += Lp[c * 8 + k] * wf[k];            // (L_{i+s} P f_i)[c]
@@ -1170,6 +1176,7 @@ constexpr int kHybridRounds = 3;   // level-0 rounds of 32 eliminations: block r
 __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, double lambda, double* gbuf) {
   TEB_SOLVER_FMA
   extern __shared__ __attribute__((aligned(16))) double lds_base[];
+  CRP_DECL
   const Lds l = carve(lds_base, plan);
   const int tid = threadIdx.x;
   const int Nt = 4 * n, Nb = (Nt + 7) >> 3, Nc = (Nb + 1) >> 1, E = Nb >> 1;
@@ -1178,13 +1185,24 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, dou
   double* __restrict__ Dc = lds_base + plan.off_H;
   double* __restrict__ Lc = Dc + Nc * kBlk;
   double* __restrict__ fc = Lc + Nc * kBlk;
-  // compact system = the even block rows (+ lambda); their couplings are filled in by the eliminations
-  for (int q = tid; q < Nc * 64; q += kThreads) {
-    const int j = q >> 6, w = q & 63;
-    double v = Dg[(size_t)(2 * j) * kBlk + w];
-    if ((w >> 3) == (w & 7)) v += lambda;
-    Dc[j * kBlk + w] = v;
-    Lc[j * kBlk + w] = 0.0;
+  // compact system = the even block rows (+ lambda); their couplings are written by the eliminations (row 0 has none and is never
+  // read). The loads of a batch are issued together: one L2 round trip per batch instead of one per element.
+  constexpr int kInitBatch = 8;
+  for (int q0 = tid; q0 < Nc * 64; q0 += kThreads * kInitBatch) {
+    double v[kInitBatch];
+#pragma unroll
+    for (int u = 0; u < kInitBatch; ++u) {
+      const int q = q0 + u * kThreads;
+      v[u] = q < Nc * 64 ? Dg[(size_t)(2 * (q >> 6)) * kBlk + (q & 63)] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < kInitBatch; ++u) {
+      const int q = q0 + u * kThreads;
+      if (q < Nc * 64) {
+        const int w = q & 63;
+        Dc[(q >> 6) * kBlk + w] = ((w >> 3) == (w & 7)) ? v[u] + lambda : v[u];
+      }
+    }
   }
   for (int q = tid; q < Nc * 8; q += kThreads) {
     const int src = 16 * (q >> 3) + (q & 7);
@@ -1192,6 +1210,7 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, dou
   }
   if (tid == 0) l.ired[0] = 1;
   __syncthreads();
+  CRP(0);
   // level 0: 8 lanes per elimination of an odd row i = 2 e + 1 (lane c owns column c of L_i, of U_i = L_{i+1}^T and, redundantly, f_i).
   // The records W_L = P L_i, W_U = P U_i, P f_i of the eliminated rows stay in the registers of the lanes that computed them (column c
   // each) until the back substitution at the end: nothing but the read-only blocks crosses the LDS boundary during a solve.
@@ -1265,14 +1284,17 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, dou
     for (int k = 0; k < 8; ++k) { kL[rr][k] = act ? wL[k] : 0.0; kU[rr][k] = act ? wU[k] : 0.0; }
     kf[rr] = act ? wf[c] : 0.0;
   }
+  CRP(1);
   // levels >= 1 on the compact system in LDS
   ok = TEB_CR_FORWARD(Dc, Lc, fc, Nc, 1, Nc) && ok;
+  CRP(2);
   ok = cr_top(Dc, fc) && ok;
   if (!ok) l.ired[0] = 0;
   __syncthreads();
   int stop = 1;
   while (stop * 2 < Nc) stop *= 2;
   if (Nc > 1) cr_backward(Dc, Lc, fc, Nc, stop, 1);
+  CRP(3);
   // x of the even rows, then the odd rows from the records in registers: x_i = P f_i - W_L x_{i-1} - W_U x_{i+1}; lane c holds column c of
   // W_L and W_U, so the 8 lanes of a group add up their column contributions (butterfly over c), then lane r keeps component r
   for (int q = tid; q < Nc * 8; q += kThreads) {
@@ -1297,7 +1319,7 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, dou
     }
     if (act && 8 * i + c < Nt) l.dxv[8 * i + c] = kf[rr] - mine;
   }
-  __syncthreads();
+  __syncthreads();  CRP(4);
 }
 
 // ---- TimedElasticBand::autoResize (src/timed_elastic_band.cpp:227-286) -------------------------------------
@@ -1356,6 +1378,7 @@ __device__ __noinline__ void autoresize_script_lane0(double dt_ref_, double hyst
   int k = 0;             // emitted intervals
   int nn = 0, md = 0;    // new poses, deepest split tree
   int nruns = 0, tail_k = -1;
+  int mchunk = -1; unsigned long long mcur = 0;   // register copy of the marks of the current chunk
   bool modified = false;
   int cdesc = 0, cdepth = 0;
   double cdt = in_dt[0];
@@ -1367,15 +1390,22 @@ __device__ __noinline__ void autoresize_script_lane0(double dt_ref_, double hyst
   int top_desc = 0, top_depth = 0; double top_dt = 0;   // register copy of the stack top
   while (alive) {
     if (fresh && sp == 0) {
-      // run of unmarked intervals starting at cur = input interval cdesc: up to the next marked one (or the end of the band)
+      // run of unmarked intervals starting at cur = input interval cdesc: up to the next marked one (or the end of the band). The mask of
+      // the current 64-interval chunk is kept in registers: a marked interval (the common case where every step counts) costs no LDS read.
       const int j0 = cdesc;
-      int a = Tin;
-      for (int cidx = j0 >> 6; cidx < kActiveMasks && (cidx << 6) < Tin; ++cidx) {
-        unsigned long long m = masks[cidx];
-        if (cidx == (j0 >> 6)) m &= ~0ull << (j0 & 63);
-        if (m) { a = (cidx << 6) + __ffsll((long long)m) - 1; break; }
+      if ((j0 >> 6) != mchunk) { mchunk = j0 >> 6; mcur = mchunk < kActiveMasks ? masks[mchunk] : ~0ull; }
+      int a = j0;
+      if (!((mcur >> (j0 & 63)) & 1ull)) {
+        a = Tin;
+        unsigned long long m = mcur & (~0ull << (j0 & 63));
+        for (int cidx = mchunk; ; ) {
+          if (m) { a = (cidx << 6) + __ffsll((long long)m) - 1; break; }
+          ++cidx;
+          if (cidx >= kActiveMasks || (cidx << 6) >= Tin) break;
+          m = masks[cidx];
+        }
+        if (a > Tin) a = Tin;
       }
-      if (a > Tin) a = Tin;
       const int len = a - j0;
       if (len >= 2) {
         if (k + len > stride - 1) { ovf = 1; break; }
