@@ -157,18 +157,39 @@ def main():
 
     # the path's only exchange. Primary: inside libteb_amd.so (RCCL communicator of its own). The torch.distributed all-gather of
     # parallel.select_best_distributed is kept as a cross-check during warm-up and as the fallback should RCCL refuse a second communicator.
-    comm, exchange = None, "none (single GPU)"
+    comm, exchange, comm_stuck = None, "none (single GPU)", False
     if distributed:
+        # ncclCommInitRank is itself a collective: should one rank fail, the others would wait in it for ever. It therefore runs in a
+        # helper thread with a deadline; afterwards all ranks agree (over torch's process group) on the route they take.
+        import threading
+        box = {}
+        uid = [parallel.RcclComm.unique_id() if rank == 0 else None]
         try:
-            comm = parallel.RcclComm.from_torch(local_rank)
-            exchange = "libteb_amd.so: ncclAllGather of 16 B per rank on a communicator of its own (teb_amd_select_best_distributed)"
+            dist.broadcast_object_list(uid, src=0)
         except Exception as e:   # noqa: BLE001
-            exchange = "torch.distributed all_gather (C-ABI communicator unavailable: %s)" % str(e)[:120]
+            uid = [None]
+            box["err"] = "id broadcast failed: %s" % str(e)[:100]
+
+        def _create():
+            try:
+                torch.cuda.set_device(local_rank)
+                box["comm"] = parallel.RcclComm(uid[0], rank, world, local_rank)
+            except Exception as e:   # noqa: BLE001
+                box["err"] = str(e)[:120]
+        if uid[0] is not None:
+            th = threading.Thread(target=_create, daemon=True)
+            th.start()
+            th.join(timeout=float(os.environ.get("TEB_AMD_COMM_TIMEOUT_S", "90")))
+            comm_stuck = th.is_alive()
+        comm = box.get("comm") if not comm_stuck else None
+        if comm is not None:
+            exchange = "libteb_amd.so: ncclAllGather of 16 B per rank on a communicator of its own (teb_amd_select_best_distributed)"
+        else:
+            exchange = "torch.distributed all_gather (C-ABI communicator unavailable: %s)" % (box.get("err") or "creation timed out")
         flag = torch.tensor([1.0 if comm is not None else 0.0], device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # all ranks take the same route
         if float(flag[0]) == 0.0 and comm is not None:
-            comm.close()
-            comm = None
+            comm = None                                   # (not closed: destroying a communicator a peer never joined may block)
             exchange = "torch.distributed all_gather (a peer could not create the C-ABI communicator)"
 
     winner_poses = [0]
@@ -544,6 +565,9 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if comm_stuck:          # a helper thread is still inside ncclCommInitRank: leave without waiting for it
+        sys.stdout.flush()
+        os._exit(0)
     return out
 
 
