@@ -193,20 +193,24 @@ def main():
             exchange = "torch.distributed all_gather (a peer could not create the C-ABI communicator)"
 
     winner_poses = [0]
+    route = {"comm": comm, "note": None}
 
     def step(check=False):
         s.restore()
         hp.optimizeAllTEBs(inner, outer)
         if not distributed:
             return s.select_best(-1, -1)[0]              # K9 on the resident costs; synchronises the stream (16-byte D2H)
-        if comm is not None:
-            best, cost, owner = s.select_best_distributed(comm, offset)
-            if check:
+        if route["comm"] is not None:
+            best, cost, owner = s.select_best_distributed(route["comm"], offset)
+            if check:                                    # warm-up only: the torch.distributed all-gather must give the same answer
                 lb, lc = s.select_best(-1, -1)
                 tc, tb = parallel.select_best_distributed(lc, offset + lb, device="cuda")
-                assert tb == best and tc == cost, ("C-ABI exchange disagrees with torch.distributed", best, cost, tb, tc)
+                if not (tb == best and tc == cost):      # identical inputs on every rank -> every rank takes the same decision
+                    route["comm"] = None
+                    route["note"] = "torch.distributed all_gather (the C-ABI exchange disagreed at warm-up: %r vs %r)" % ((best, cost), (tb, tc))
+                    return tb
             if args.scaling == "strong":                 # the rank that talks to the robot needs the winner's strip
-                x, _, _, _ = s.broadcast_band(comm, owner, best - offset if owner == rank else 0, STRIDE)
+                x, _, _, _ = s.broadcast_band(route["comm"], owner, best - offset if owner == rank else 0, STRIDE)
                 winner_poses[0] = len(x)
             return best
         lb, lc = s.select_best(-1, -1)
@@ -299,7 +303,7 @@ def main():
                        "poses_after": [int(n_after.min()), int(n_after.max())],
                        "pose_capacity": STRIDE, "tebs_ok": tebs_ok, "obstacles": M, "units_per_step_per_gpu": units_step,
                        "lm_trials_per_step_per_gpu": int(res.lm_trials.sum()), "jacobian_mode": "analytic (closed form)",
-                       "exchange": exchange, "source_hash": src_hash},
+                       "exchange": route["note"] or exchange, "source_hash": src_hash},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,

@@ -62,7 +62,7 @@ __host__ __device__ inline size_t hmat_doubles(int S, int solver) {  // (LDS-res
 // works on (the hybrid solve only reads them)
 __host__ __device__ inline size_t hbm_scratch_doubles(int S, int solver) {
   const size_t nb = (size_t)nb_for(S);
-  const size_t blocks = nb * (2 * kBlk + 8);
+  const size_t blocks = nb * (2 * kBlk + 8);   // (>= the band copy of the hybrid solve: nb * 88)
   const size_t own = hmat_doubles(S, solver);
   return own > blocks ? own : blocks;
 }
@@ -1146,27 +1146,15 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, const SceneDev&
 //   back substitution of the odd rows from those records.
 // Same arithmetic as cr_solve_t (an exact re-indexing: compact row j' = row 2 j'); no backup / restore of H, no obstacle-cache reload.
 // gbuf: D [Nb * kBlk] | L [Nb * kBlk]
-template <bool HB_GLOBAL>
-__device__ __forceinline__ void cr_expand_blocks(const Lds& l, int n, double* __restrict__ gbuf) {
+// the band as it stands in LDS -> the band's HBM scratch, rows [0, 8 Nb): a coalesced copy (101 KB at 287 poses; 32 bands per XCD stay
+// inside the 4 MB L2); the padding rows of an odd pose count become identity rows
+__device__ __forceinline__ void cr_copy_band(const Lds& l, int n, double* __restrict__ gband) {
   const int tid = threadIdx.x;
   const int Nt = 4 * n, Nb = (Nt + 7) >> 3;
-  double* __restrict__ D = gbuf;
-  double* __restrict__ L = gbuf + (size_t)Nb * kBlk;
   const double* Hb = l.Hb;
-  for (int q = tid; q < Nb * 128; q += kThreads) {
-    const int j = q >> 7, w = q & 127, a = (w & 63) >> 3, bcol = w & 7;
-    const int r = 8 * j + a;
-    double v = 0;
-    if (w < 64) {            // D_j[a][bcol]
-      const int cc = 8 * j + bcol;
-      if (r < Nt && cc < Nt) v = (cc <= r) ? Hb[r * kBand + (r - cc)] : Hb[cc * kBand + (cc - r)];
-      else if (r == cc) v = 1.0;
-      D[j * kBlk + a * 8 + bcol] = v;
-    } else {                 // L_j[a][bcol] = H[8j+a][8(j-1)+bcol]
-      const int d = 8 + a - bcol;
-      if (j >= 1 && r < Nt && d < kBand) v = Hb[r * kBand + d];
-      L[j * kBlk + a * 8 + bcol] = v;
-    }
+  for (int q = tid; q < Nb * 8 * kBand; q += kThreads) {
+    const int r = q / kBand;
+    gband[q] = r < Nt ? Hb[q] : ((q - r * kBand) == 0 ? 1.0 : 0.0);
   }
   __threadfence_block();
   __syncthreads();
@@ -1180,8 +1168,10 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, dou
   const Lds l = carve(lds_base, plan);
   const int tid = threadIdx.x;
   const int Nt = 4 * n, Nb = (Nt + 7) >> 3, Nc = (Nb + 1) >> 1, E = Nb >> 1;
-  const double* __restrict__ Dg = gbuf;
-  const double* __restrict__ Lg = gbuf + (size_t)Nb * kBlk;
+  // Hg: the band copy, entry (r, c), c <= r <= c + 10, at Hg[r * 11 + (r - c)]. In terms of 8x8 blocks:
+  //   D_j[a][b] (b <= a)        = Hg[(8 j + a) * 11 + (a - b)]
+  //   L_j[a][b] = H(8j+a, 8(j-1)+b) = Hg[(8 j + a) * 11 + (8 + a - b)]   for b >= a - 2, structurally zero otherwise (49 of 64 entries)
+  const double* __restrict__ Hg = gbuf;
   double* __restrict__ Dc = lds_base + plan.off_H;
   double* __restrict__ Lc = Dc + Nc * kBlk;
   double* __restrict__ fc = Lc + Nc * kBlk;
@@ -1193,7 +1183,9 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, dou
 #pragma unroll
     for (int u = 0; u < kInitBatch; ++u) {
       const int q = q0 + u * kThreads;
-      v[u] = q < Nc * 64 ? Dg[(size_t)(2 * (q >> 6)) * kBlk + (q & 63)] : 0.0;
+      const int j = q >> 6, a8 = (q >> 3) & 7, b8 = q & 7;
+      const int hi = a8 > b8 ? a8 : b8, lo = a8 > b8 ? b8 : a8;
+      v[u] = q < Nc * 64 ? Hg[(size_t)(16 * j + hi) * kBand + (hi - lo)] : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < kInitBatch; ++u) {
@@ -1213,7 +1205,7 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, dou
   CRP(0);
   // level 0: 8 lanes per elimination of an odd row i = 2 e + 1 (lane c owns column c of L_i, of U_i = L_{i+1}^T and, redundantly, f_i).
   // The records W_L = P L_i, W_U = P U_i, P f_i of the eliminated rows stay in the registers of the lanes that computed them (column c
-  // each) until the back substitution at the end: nothing but the read-only blocks crosses the LDS boundary during a solve.
+  // each) until the back substitution at the end: nothing but the read-only band copy crosses the LDS boundary during a solve.
   const int grp = tid >> 3, c = tid & 7;
   bool ok = true;
   double kL[kHybridRounds][8], kU[kHybridRounds][8], kf[kHybridRounds];
@@ -1227,17 +1219,20 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, dou
     double s1 = 0, s2 = 0;
     if (rr * (kThreads / 8) < E) {   // (uniform) this round has eliminations at all
       if (act) {
-        const double* Di = Dg + (size_t)i * kBlk;
-        const double* Li = Lg + (size_t)i * kBlk;
-        const double* Lp = Lg + (size_t)(i + 1) * kBlk;   // U_i^T, valid iff hasU
+        const double* Hi = Hg + (size_t)(8 * i) * kBand;         // band rows of block row i
+        const double* Hp = Hg + (size_t)(8 * (i + 1)) * kBand;   // ... of block row i + 1 (valid iff hasU)
         Ldl8 F;
-        F.load(Di);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+          for (int cc = 0; cc <= r; ++cc) F.a[Ldl8::idx(r, cc)] = Hi[r * kBand + (r - cc)];
 #pragma unroll
         for (int k = 0; k < 8; ++k) F.a[Ldl8::idx(k, k)] += lambda;
+        double cl[8], cu[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          wL[k] = Li[k * 8 + c];
-          wU[k] = hasU ? Lp[c * 8 + k] : 0.0;
+          cl[k] = wL[k] = (c >= k - 2) ? Hi[k * kBand + (8 + k - c)] : 0.0;                 // L_i[k][c]
+          cu[k] = wU[k] = (hasU && k >= c - 2) ? Hp[c * kBand + (8 + c - k)] : 0.0;         // U_i[k][c] = L_{i+1}[c][k]
           wf[k] = (8 * i + k < Nt) ? l.bv[8 * i + k] : 0.0;
         }
         ok = F.factor() && ok;
@@ -1247,21 +1242,24 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, dou
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
 #pragma unroll
-          for (int aa = 0; aa < 8; ++aa) o1[aa] += Li[k * 8 + aa] * wL[k];
-          s1 += Li[k * 8 + c] * wf[k];
+          for (int aa = 0; aa < 8; ++aa)
+            if (aa >= k - 2) o1[aa] += Hi[k * kBand + (8 + k - aa)] * wL[k];              // (L_i^T W_L)[aa][c]
+          s1 += cl[k] * wf[k];                                                             // (L_i^T P f_i)[c]
         }
         if (hasU) {
 #pragma unroll
           for (int aa = 0; aa < 8; ++aa) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-              const double lp = Lp[aa * 8 + k];
-              o2[aa] -= lp * wL[k];
-              o3[aa] += lp * wU[k];
+              if (k >= aa - 2) {
+                const double lp = Hp[aa * kBand + (8 + aa - k)];                          // L_{i+1}[aa][k]
+                o2[aa] -= lp * wL[k];
+                o3[aa] += lp * wU[k];
+              }
             }
           }
 #pragma unroll
-          for (int k = 0; k < 8; ++k) s2 += Lp[c * 8 + k] * wf[k];
+          for (int k = 0; k < 8; ++k) s2 += cu[k] * wf[k];                                  // (L_{i+1} P f_i)[c]
         }
         // fold into the compact rows e (= row i - 1) and e + 1 (= row i + 1); two phases: neighbouring eliminations share a row
 #pragma unroll
@@ -1982,7 +1980,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       const bool keep_copy = !(SOLVER != SOLVER_CR && !args.band_ldlt);   // the HBM-block reductions never touch the band
       if (keep_copy)
         for (int q = tid; q < hsz; q += kThreads) Hbk[q] = *hmat_ptr<SOLVER>(l, q, Nt);   // saved for rejected trials
-      if (SOLVER == SOLVER_BAND && !args.band_ldlt) cr_expand_blocks<false>(l, n, Hbk);   // hybrid solve: blocks to HBM once per iteration
+      if (SOLVER == SOLVER_BAND && !args.band_ldlt) cr_copy_band(l, n, Hbk);   // hybrid solve: the band to HBM once per iteration
       PROF_END(3);
       double rho = 0;
       int qmax = 0;
