@@ -1945,8 +1945,9 @@ int teb_amd_debug_profile(teb_amd_handle_t* h, double* cycles8) {
 #ifdef TEB_PROFILE
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipMemcpy(cycles8, h->dbg_H.p, 8 * sizeof(double), hipMemcpyDeviceToHost));
-  long long crp[8];
+  long long crp[16];
   HIPCHK(hipMemcpyFromSymbol(crp, HIP_SYMBOL(tebamd::g_cr_prof), sizeof crp));
+  fprintf(stderr, "[cr_forward rounds, workgroup 0 thread 0, cumulative: load+factor | loads+solve3 | Schur products | writes 1 | barrier 1 | writes 2 + barrier 2] %lld %lld %lld %lld %lld %lld\n", crp[8], crp[9], crp[10], crp[11], crp[12], crp[13]);
   fprintf(stderr, "[cr_solve cycles, workgroup 0, cumulative; hybrid solve: init compact | level 0 | compact forward | top + backward | odd rows] %lld %lld %lld %lld %lld %lld\n",
           crp[0], crp[1], crp[2], crp[3], crp[4], crp[5]);
   long long evp[8];

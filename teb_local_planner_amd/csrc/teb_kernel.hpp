@@ -559,6 +559,9 @@ __device__ __forceinline__ double fast_rcp(double d) {
 // order); measured effect: 5 - 8 % on the C4 step, parity tests unchanged (poses <= 1e-8, identical LM trial counts).
 #define TEB_SOLVER_FMA _Pragma("clang fp contract(fast)")
 // scheduling fences inside the Schur-product loops of the cyclic reduction (they bound the number of LDS operands in flight)
+#ifndef TEB_CR_FENCE_EVERY
+#define TEB_CR_FENCE_EVERY 4   // rows of a Schur product between two fences
+#endif
 #ifdef TEB_AMD_NO_CR_FENCE
 #define TEB_CR_SCHED_BARRIER
 #else
@@ -628,12 +631,16 @@ struct Ldl8 {   // in-place LDL^T of one 8x8 SPD block: a[r(r+1)/2 + c] holds l_
 };
 
 #ifdef TEB_PROFILE
-__device__ long long g_cr_prof[8];
+__device__ long long g_cr_prof[16];
 #define CRP_DECL long long crp_t0 = clock64(), crp_t1;
 #define CRP(k) do { crp_t1 = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) g_cr_prof[k] += crp_t1 - crp_t0; crp_t0 = crp_t1; } while (0)
+#define CRR_DECL long long crr_t0 = clock64(), crr_t1;
+#define CRR(k) do { crr_t1 = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) g_cr_prof[8 + k] += crr_t1 - crr_t0; crr_t0 = crr_t1; } while (0)
 #else
 #define CRP_DECL
 #define CRP(k)
+#define CRR_DECL
+#define CRR(k)
 #endif
 // ---- pieces of the block cyclic reduction, usable on blocks in either memory (used by the HBM variant, which runs the finer
 //      levels on HBM-resident blocks and the coarser ones on a compact copy in LDS). Same arithmetic as cr_solve_t<false>.
@@ -653,6 +660,7 @@ __device__ __forceinline__ bool cr_forward(double* __restrict__ D, double* __res
       const bool hasU = act && (i + s < Nb);
       double wL[8], wU[8], wf[8], o1[8], o2[8], o3[8];
       double s1 = 0, s2 = 0;
+      CRR_DECL
       if (act) {
         const double* Di = D + i * kBlk;
         const double* Li = L + i * kBlk;
@@ -660,6 +668,7 @@ __device__ __forceinline__ bool cr_forward(double* __restrict__ D, double* __res
         Ldl8 F;
         F.load(Di);
         ok = F.factor() && ok;
+        CRR(0);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           wL[k] = Li[k * 8 + c];
@@ -667,6 +676,7 @@ __device__ __forceinline__ bool cr_forward(double* __restrict__ D, double* __res
           wf[k] = f[i * 8 + k];
         }
         F.solve3(wL, wU, wf);
+        CRR(1);
 #pragma unroll
         for (int aa = 0; aa < 8; ++aa) { o1[aa] = 0; o2[aa] = 0; o3[aa] = 0; }
 #pragma unroll
@@ -674,7 +684,7 @@ __device__ __forceinline__ bool cr_forward(double* __restrict__ D, double* __res
 #pragma unroll
           for (int aa = 0; aa < 8; ++aa) o1[aa] += Li[k * 8 + aa] * wL[k];
           s1 += Li[k * 8 + c] * wf[k];
-          TEB_CR_SCHED_BARRIER
+          if ((k % TEB_CR_FENCE_EVERY) == TEB_CR_FENCE_EVERY - 1) { TEB_CR_SCHED_BARRIER }
         }
         if (hasU) {
 #pragma unroll
@@ -685,12 +695,13 @@ __device__ __forceinline__ bool cr_forward(double* __restrict__ D, double* __res
               o2[aa] -= lp * wL[k];
               o3[aa] += lp * wU[k];
             }
-            TEB_CR_SCHED_BARRIER
+            if ((aa % TEB_CR_FENCE_EVERY) == TEB_CR_FENCE_EVERY - 1) { TEB_CR_SCHED_BARRIER }
           }
 #pragma unroll
           for (int k = 0; k < 8; ++k) s2 += Lp[c * 8 + k] * wf[k];
         }
       }
+      CRR(2);
       // No barrier before the writes: within a level the eliminated rows i = s (2 e + 1) and the blocks read for them (D_i, L_i,
       // L_{i+s}, f_i) belong to exactly one 8-lane group, and the survivors' D / f are only written (never read) in this level.
       if (act) {
@@ -709,7 +720,9 @@ __device__ __forceinline__ bool cr_forward(double* __restrict__ D, double* __res
         f[(i - s) * 8 + c] -= s1;
         f[i * 8 + c] = wf[c];
       }
+      CRR(3);
       __syncthreads();
+      CRR(4);
       if (hasU) {
         double* Dp = D + (i + s) * kBlk;
 #pragma unroll
@@ -717,6 +730,7 @@ __device__ __forceinline__ bool cr_forward(double* __restrict__ D, double* __res
         f[(i + s) * 8 + c] -= s2;
       }
       __syncthreads();
+      CRR(5);
     }
   }
   return ok;
@@ -1008,89 +1022,8 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, const SceneDev&
     CRP(5);
     return;
   }
-#ifdef TEB_AMD_MFMA_SCHUR
-  bool ok = cr_forward_mfma(D, L, f, Nb, 1, Nb);
-#else
-  // 8 lanes per elimination: lane c owns column c of L_i, of U_i and (redundantly) f_i; 32 eliminations per round
-  const int grp = tid >> 3, c = tid & 7;
-  bool ok = true;
-  for (int s = 1; s < Nb; s <<= 1) {
-    const int E = (Nb - 1 - s) / (2 * s) + 1;
-    for (int e0 = 0; e0 < E; e0 += kThreads / 8) {
-      const int e = e0 + grp;
-      const bool act = e < E;
-      const int i = s * (2 * e + 1);
-      const bool hasU = act && (i + s < Nb);
-      double wL[8], wU[8], wf[8], o1[8], o2[8], o3[8];
-      double s1 = 0, s2 = 0;
-      if (act) {
-        const double* Di = D + i * kBlk;
-        const double* Li = L + i * kBlk;
-        const double* Lp = L + (i + s) * kBlk;   // U_i^T, valid iff hasU
-        Ldl8 F;
-        F.load(Di);
-        ok = F.factor() && ok;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          wL[k] = Li[k * 8 + c];                    // column c of L_i
-          wU[k] = hasU ? Lp[c * 8 + k] : 0.0;       // column c of U_i = row c of L_{i+s}
-          wf[k] = f[i * 8 + k];
-        }
-        F.solve3(wL, wU, wf);                       // three independent chains, interleaved
-#pragma unroll
-        for (int aa = 0; aa < 8; ++aa) { o1[aa] = 0; o2[aa] = 0; o3[aa] = 0; }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-#pragma unroll
-          for (int aa = 0; aa < 8; ++aa) o1[aa] += Li[k * 8 + aa] * wL[k];   // (L_i^T W_L)[aa][c]
-          s1 += Li[k * 8 + c] * wf[k];                                         // (L_i^T P f_i)[c]
-          TEB_CR_SCHED_BARRIER
-        }
-        if (hasU) {
-#pragma unroll
-          for (int aa = 0; aa < 8; ++aa) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              const double lp = Lp[aa * 8 + k];
-              o2[aa] -= lp * wL[k];                                            // -(L_{i+s} W_L)[aa][c]
-              o3[aa] += lp * wU[k];                                            //  (L_{i+s} W_U)[aa][c]
-            }
-            TEB_CR_SCHED_BARRIER
-          }
-#pragma unroll
-          for (int k = 0; k < 8; ++k) s2 += Lp[c * 8 + k] * wf[k];            // (L_{i+s} P f_i)[c]
-        }
-      }
-      CRP(1);
-      CRP(2);   // (no barrier here: see cr_forward)
-      if (act) {
-        double* Dm = D + (i - s) * kBlk;
-        double* Di = D + i * kBlk;
-        double* Li = L + i * kBlk;
-#pragma unroll
-        for (int aa = 0; aa < 8; ++aa) Dm[aa * 8 + c] -= o1[aa];
-        if (hasU) {
-          double* Lp = L + (i + s) * kBlk;
-#pragma unroll
-          for (int aa = 0; aa < 8; ++aa) Lp[aa * 8 + c] = o2[aa];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { Di[k * 8 + c] = wL[k]; Li[k * 8 + c] = wU[k]; }   // W_L, W_U
-        f[(i - s) * 8 + c] -= s1;
-        f[i * 8 + c] = wf[c];                                                            // P f_i
-      }
-      __syncthreads();
-      if (hasU) {
-        double* Dp = D + (i + s) * kBlk;
-#pragma unroll
-        for (int aa = 0; aa < 8; ++aa) Dp[aa * 8 + c] -= o3[aa];
-        f[(i + s) * 8 + c] -= s2;
-      }
-      __syncthreads();
-      CRP(3);
-    }
-  }
-#endif
+  // forward reduction in place (8 lanes per elimination, 32 eliminations per round; TEB_CR_FORWARD = cr_forward, or the matrix-core variant)
+  bool ok = TEB_CR_FORWARD(D, L, f, Nb, 1, Nb);
   // the last surviving block row: x_0 = D_0^{-1} f_0
   if (tid < 8) {
     double v[8];
