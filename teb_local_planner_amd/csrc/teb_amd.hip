@@ -1945,9 +1945,12 @@ int teb_amd_debug_profile(teb_amd_handle_t* h, double* cycles8) {
 #ifdef TEB_PROFILE
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipMemcpy(cycles8, h->dbg_H.p, 8 * sizeof(double), hipMemcpyDeviceToHost));
-  long long crp[16];
+  long long crp[8], crw[32];
   HIPCHK(hipMemcpyFromSymbol(crp, HIP_SYMBOL(tebamd::g_cr_prof), sizeof crp));
-  fprintf(stderr, "[cr_forward rounds, workgroup 0 thread 0, cumulative: load+factor | loads+solve3 | Schur products | writes 1 | barrier 1 | writes 2 + barrier 2] %lld %lld %lld %lld %lld %lld\n", crp[8], crp[9], crp[10], crp[11], crp[12], crp[13]);
+  HIPCHK(hipMemcpyFromSymbol(crw, HIP_SYMBOL(tebamd::g_crw_prof), sizeof crw));
+  for (int w = 0; w < 4; ++w)
+    fprintf(stderr, "[cr_forward rounds of %2d-lane groups, workgroup 0 thread 0, cumulative: load+factor | loads+solve3 | Schur products | writes 1 | barrier 1 | writes 2 + barrier 2 | rounds] %lld %lld %lld %lld %lld %lld | %lld\n",
+            8 << w, crw[w * 8 + 0], crw[w * 8 + 1], crw[w * 8 + 2], crw[w * 8 + 3], crw[w * 8 + 4], crw[w * 8 + 5], crw[w * 8 + 6]);
   fprintf(stderr, "[cr_solve cycles, workgroup 0, cumulative; hybrid solve: init compact | level 0 | compact forward | top + backward | odd rows] %lld %lld %lld %lld %lld %lld\n",
           crp[0], crp[1], crp[2], crp[3], crp[4], crp[5]);
   long long evp[8];

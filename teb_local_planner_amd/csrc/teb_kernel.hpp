@@ -631,106 +631,134 @@ struct Ldl8 {   // in-place LDL^T of one 8x8 SPD block: a[r(r+1)/2 + c] holds l_
 };
 
 #ifdef TEB_PROFILE
-__device__ long long g_cr_prof[16];
+__device__ long long g_cr_prof[8];
+__device__ long long g_crw_prof[32];   // per group width (8, 16, 32, 64 lanes): 6 sections of a round + the number of rounds
 #define CRP_DECL long long crp_t0 = clock64(), crp_t1;
 #define CRP(k) do { crp_t1 = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) g_cr_prof[k] += crp_t1 - crp_t0; crp_t0 = crp_t1; } while (0)
 #define CRR_DECL long long crr_t0 = clock64(), crr_t1;
-#define CRR(k) do { crr_t1 = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) g_cr_prof[8 + k] += crr_t1 - crr_t0; crr_t0 = crr_t1; } while (0)
+#define CRR(k) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); crr_t1 = clock64(); __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && threadIdx.x == 0) { g_crw_prof[kW * 8 + k] += crr_t1 - crr_t0; if (k == 5) g_crw_prof[kW * 8 + 6] += 1; } crr_t0 = crr_t1; } while (0)
 #else
 #define CRP_DECL
 #define CRP(k)
 #define CRR_DECL
 #define CRR(k)
 #endif
-// ---- pieces of the block cyclic reduction, usable on blocks in either memory (used by the HBM variant, which runs the finer
-//      levels on HBM-resident blocks and the coarser ones on a compact copy in LDS). Same arithmetic as cr_solve_t<false>.
-// rows live at D + i * kBlk, L + i * kBlk (coupling of row i with the previous surviving row), f + i * 8; levels s_lo, 2 s_lo, .. < s_hi
+// ---- pieces of the block cyclic reduction, usable on blocks in either memory (all three layouts run their LDS-resident levels
+//      through them; the HBM layout runs its finer levels on HBM-resident blocks and the coarser ones on a compact copy in LDS).
+// One round of a level: the eliminations e0 .. of the rows i = s (2 e + 1), 8 M lanes each. Lane (q, c) of a group, q < M, owns column c
+// of the three Schur products and, of that column, the rows q R .. q R + R - 1 (R = 8 / M); the factorisation of D_i and the three
+// triangular solves are repeated by the M lanes that share a column (they cost latency, not throughput, at the levels where M > 1: there
+// the machine is mostly idle). Every output element is summed in the same order for every M, so the result does not depend on M.
+template <int M>
+__device__ __forceinline__ bool cr_forward_round(double* __restrict__ D, double* __restrict__ L, double* __restrict__ f, int Nb, int s,
+                                                 int e0, int E) {
+  TEB_SOLVER_FMA
+  constexpr int R = 8 / M;
+  constexpr int kW = M == 1 ? 0 : M == 2 ? 1 : M == 4 ? 2 : 3;   // (profiling build) row of the per-width counters
+  (void)kW;
+  const int tid = threadIdx.x;
+  const int grp = tid / (8 * M), c = tid & 7, q = (tid >> 3) & (M - 1), a0 = q * R;
+  const int e = e0 + grp;
+  const bool act = e < E;
+  const int i = s * (2 * e + 1);
+  const bool hasU = act && (i + s < Nb);
+  bool ok = true;
+  double wL[8], wU[8], wf[8], o1[R], o2[R], o3[R];
+  double s1 = 0, s2 = 0;
+  CRR_DECL
+  if (act) {
+    const double* Di = D + i * kBlk;
+    const double* Li = L + i * kBlk;
+    const double* Lp = L + (i + s) * kBlk;   // U_i^T, valid iff hasU
+    Ldl8 F;
+    F.load(Di);
+    ok = F.factor();
+    CRR(0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      wL[k] = Li[k * 8 + c];
+      wU[k] = hasU ? Lp[c * 8 + k] : 0.0;
+      wf[k] = f[i * 8 + k];
+    }
+    F.solve3(wL, wU, wf);
+    CRR(1);
+#pragma unroll
+    for (int t = 0; t < R; ++t) { o1[t] = 0; o2[t] = 0; o3[t] = 0; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+      for (int t = 0; t < R; ++t) o1[t] += Li[k * 8 + a0 + t] * wL[k];
+      s1 += Li[k * 8 + c] * wf[k];
+      if ((k % TEB_CR_FENCE_EVERY) == TEB_CR_FENCE_EVERY - 1) { TEB_CR_SCHED_BARRIER }
+    }
+    if (hasU) {
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const double lp = Lp[(a0 + t) * 8 + k];
+          o2[t] -= lp * wL[k];
+          o3[t] += lp * wU[k];
+        }
+        if ((t % TEB_CR_FENCE_EVERY) == TEB_CR_FENCE_EVERY - 1) { TEB_CR_SCHED_BARRIER }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s2 += Lp[c * 8 + k] * wf[k];
+    }
+  }
+  CRR(2);
+  // No barrier before the writes: within a level the eliminated rows i = s (2 e + 1) and the blocks read for them (D_i, L_i,
+  // L_{i+s}, f_i) belong to exactly one group, a group never straddles two waves (8 M <= 64), and the survivors' D / f are only written
+  // (never read) in this level.
+  if (act) {
+    double* Dm = D + (i - s) * kBlk;
+    double* Di = D + i * kBlk;
+    double* Li = L + i * kBlk;
+#pragma unroll
+    for (int t = 0; t < R; ++t) Dm[(a0 + t) * 8 + c] -= o1[t];
+    if (hasU) {
+      double* Lp = L + (i + s) * kBlk;
+#pragma unroll
+      for (int t = 0; t < R; ++t) Lp[(a0 + t) * 8 + c] = o2[t];
+    }
+    if (q == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { Di[k * 8 + c] = wL[k]; Li[k * 8 + c] = wU[k]; }
+      f[(i - s) * 8 + c] -= s1;
+      f[i * 8 + c] = wf[c];
+    }
+  }
+  CRR(3);
+  __syncthreads();
+  CRR(4);
+  if (hasU) {
+    double* Dp = D + (i + s) * kBlk;
+#pragma unroll
+    for (int t = 0; t < R; ++t) Dp[(a0 + t) * 8 + c] -= o3[t];
+    if (q == 0) f[(i + s) * 8 + c] -= s2;
+  }
+  __syncthreads();
+  CRR(5);
+  return ok;
+}
+// rows live at D + i * kBlk, L + i * kBlk (coupling of row i with the previous surviving row), f + i * 8; levels s_lo, 2 s_lo, .. < s_hi.
+// The group width of a round follows the number of eliminations left in the level: 8 lanes while there are more than 8 of them, then
+// 32 / 64 lanes (the coarse levels are latency chains of mostly idle lanes; the wider groups shorten the Schur products 4 / 8 x). Measured
+// alone on a CU (tools/micro/cr_round_bench.hip): 5.1 k cycles per round with 8-lane groups, 3.9 k with 32, 3.3 k with 64; 16-lane groups
+// gain too little to pay for their code (-DTEB_CR_NARROW_ONLY: 8-lane groups everywhere).
 __device__ __forceinline__ bool cr_forward(double* __restrict__ D, double* __restrict__ L, double* __restrict__ f, int Nb, int s_lo,
                                            int s_hi) {
-  TEB_SOLVER_FMA
-  const int tid = threadIdx.x;
-  const int grp = tid >> 3, c = tid & 7;
   bool ok = true;
   for (int s = s_lo; s < s_hi; s <<= 1) {
     const int E = (Nb - 1 - s) / (2 * s) + 1;
     for (int e0 = 0; e0 < E; e0 += kThreads / 8) {
-      const int e = e0 + grp;
-      const bool act = e < E;
-      const int i = s * (2 * e + 1);
-      const bool hasU = act && (i + s < Nb);
-      double wL[8], wU[8], wf[8], o1[8], o2[8], o3[8];
-      double s1 = 0, s2 = 0;
-      CRR_DECL
-      if (act) {
-        const double* Di = D + i * kBlk;
-        const double* Li = L + i * kBlk;
-        const double* Lp = L + (i + s) * kBlk;   // U_i^T, valid iff hasU
-        Ldl8 F;
-        F.load(Di);
-        ok = F.factor() && ok;
-        CRR(0);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          wL[k] = Li[k * 8 + c];
-          wU[k] = hasU ? Lp[c * 8 + k] : 0.0;
-          wf[k] = f[i * 8 + k];
-        }
-        F.solve3(wL, wU, wf);
-        CRR(1);
-#pragma unroll
-        for (int aa = 0; aa < 8; ++aa) { o1[aa] = 0; o2[aa] = 0; o3[aa] = 0; }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-#pragma unroll
-          for (int aa = 0; aa < 8; ++aa) o1[aa] += Li[k * 8 + aa] * wL[k];
-          s1 += Li[k * 8 + c] * wf[k];
-          if ((k % TEB_CR_FENCE_EVERY) == TEB_CR_FENCE_EVERY - 1) { TEB_CR_SCHED_BARRIER }
-        }
-        if (hasU) {
-#pragma unroll
-          for (int aa = 0; aa < 8; ++aa) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              const double lp = Lp[aa * 8 + k];
-              o2[aa] -= lp * wL[k];
-              o3[aa] += lp * wU[k];
-            }
-            if ((aa % TEB_CR_FENCE_EVERY) == TEB_CR_FENCE_EVERY - 1) { TEB_CR_SCHED_BARRIER }
-          }
-#pragma unroll
-          for (int k = 0; k < 8; ++k) s2 += Lp[c * 8 + k] * wf[k];
-        }
-      }
-      CRR(2);
-      // No barrier before the writes: within a level the eliminated rows i = s (2 e + 1) and the blocks read for them (D_i, L_i,
-      // L_{i+s}, f_i) belong to exactly one 8-lane group, and the survivors' D / f are only written (never read) in this level.
-      if (act) {
-        double* Dm = D + (i - s) * kBlk;
-        double* Di = D + i * kBlk;
-        double* Li = L + i * kBlk;
-#pragma unroll
-        for (int aa = 0; aa < 8; ++aa) Dm[aa * 8 + c] -= o1[aa];
-        if (hasU) {
-          double* Lp = L + (i + s) * kBlk;
-#pragma unroll
-          for (int aa = 0; aa < 8; ++aa) Lp[aa * 8 + c] = o2[aa];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { Di[k * 8 + c] = wL[k]; Li[k * 8 + c] = wU[k]; }
-        f[(i - s) * 8 + c] -= s1;
-        f[i * 8 + c] = wf[c];
-      }
-      CRR(3);
-      __syncthreads();
-      CRR(4);
-      if (hasU) {
-        double* Dp = D + (i + s) * kBlk;
-#pragma unroll
-        for (int aa = 0; aa < 8; ++aa) Dp[aa * 8 + c] -= o3[aa];
-        f[(i + s) * 8 + c] -= s2;
-      }
-      __syncthreads();
-      CRR(5);
+      const int left = E - e0;
+#ifndef TEB_CR_NARROW_ONLY
+      if (left <= kThreads / 64) ok = cr_forward_round<8>(D, L, f, Nb, s, e0, E) && ok;
+      else if (left <= kThreads / 32) ok = cr_forward_round<4>(D, L, f, Nb, s, e0, E) && ok;
+      else
+#endif
+        ok = cr_forward_round<1>(D, L, f, Nb, s, e0, E) && ok;
     }
   }
   return ok;
