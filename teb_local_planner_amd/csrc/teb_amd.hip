@@ -1953,6 +1953,14 @@ int teb_amd_debug_profile(teb_amd_handle_t* h, double* cycles8) {
             8 << w, crw[w * 8 + 0], crw[w * 8 + 1], crw[w * 8 + 2], crw[w * 8 + 3], crw[w * 8 + 4], crw[w * 8 + 5], crw[w * 8 + 6]);
   fprintf(stderr, "[cr_solve cycles, workgroup 0, cumulative; hybrid solve: init compact | level 0 | compact forward | top + backward | odd rows] %lld %lld %lld %lld %lld %lld\n",
           crp[0], crp[1], crp[2], crp[3], crp[4], crp[5]);
+  unsigned long long nq[2];
+  HIPCHK(hipMemcpyFromSymbol(&nq[0], HIP_SYMBOL(tebamd::g_near_recomputed), sizeof nq[0]));
+  HIPCHK(hipMemcpyFromSymbol(&nq[1], HIP_SYMBOL(tebamd::g_near_queries), sizeof nq[1]));
+  fprintf(stderr, "[near masks of the dynamic-obstacle edges, all workgroups, cumulative] recomputed by %llu of %llu lane passes\n", nq[0], nq[1]);
+  long long lnp[16];
+  HIPCHK(hipMemcpyFromSymbol(lnp, HIP_SYMBOL(tebamd::g_lin_prof), sizeof lnp));
+  fprintf(stderr, "[linearize cycles, thread 0 of workgroup 0, cumulative] zero H, b %lld | trig + barrier %lld | near masks %lld | edges %lld | slice reduction %lld | scatter (3 phases) %lld | tail + chi2 sum %lld\n",
+          lnp[0], lnp[1], lnp[2], lnp[3], lnp[4], lnp[5], lnp[6]);
   long long evp[8];
   HIPCHK(hipMemcpyFromSymbol(evp, HIP_SYMBOL(tebamd::g_ev_prof), sizeof evp));
   fprintf(stderr, "[eval_index cycles, thread 0 of workgroup 0, cumulative] evaluate: static %lld dynamic %lld chain %lld | linearise: static %lld dynamic %lld chain %lld\n",

@@ -27,12 +27,18 @@ namespace tebamd {
 #endif
 
 #ifdef TEB_PROFILE
-__device__ long long g_ev_prof[8];   // thread 0 of workgroup 0: evaluate {static, dynamic, chain}, linearise {static, dynamic, chain}, trig, scatter
+__device__ long long g_ev_prof[8];   // thread 1 (pose 1) of workgroup 0: evaluate {static, dynamic, chain}, linearise {static, dynamic, chain}, trig, scatter
 #define EVP_DECL long long evp_t0 = clock64(), evp_t1;
-#define EVP(k) do { evp_t1 = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) g_ev_prof[k] += evp_t1 - evp_t0; evp_t0 = evp_t1; } while (0)
+#define EVP(k) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); evp_t1 = clock64(); __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && threadIdx.x == 1) g_ev_prof[k] += evp_t1 - evp_t0; evp_t0 = evp_t1; } while (0)
+__device__ unsigned long long g_near_recomputed, g_near_queries;   // lanes that recomputed their near mask / that asked for it
+__device__ long long g_lin_prof[16];  // thread 0 of workgroup 0: sections of linearize()
+#define LNP_DECL long long lnp_t0 = clock64(), lnp_t1;
+#define LNP(k) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); lnp_t1 = clock64(); __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && threadIdx.x == 0) g_lin_prof[k] += lnp_t1 - lnp_t0; lnp_t0 = lnp_t1; } while (0)
 #else
 #define EVP_DECL
 #define EVP(k)
+#define LNP_DECL
+#define LNP(k)
 #endif
 // Storage formats of the normal matrix (selected per handle by the pose capacity S and the obstacle cache):
 //   SOLVER_BAND : Hb[4S][11] lower band in LDS (S <= 343); solved by cyclic reduction on HBM-resident 8x8 blocks expanded from it
@@ -203,10 +209,14 @@ __device__ __forceinline__ int lanes_per_pose(int poses_left) {
 // accumulator of the pose is live, so that its unrolled chains do not compete with it for registers. Pass 2 (eval_index): each lane
 // walks the set bits of its own mask in list order and evaluates only those edges (fp64 sqrt, divisions, penalties: > 100 operations
 // each) - same operations, same order, same bits as the full loop, which spent > 95 % of its time adding zeros.
+__device__ __forceinline__ double dyn_far_distance(const teb_amd_config_t& c) {
+  return fmax(c.min_obstacle_dist + c.penalty_epsilon, c.dynamic_obstacle_inflation_dist) +
+         (c.footprint_type == TEB_AMD_FOOTPRINT_CIRCULAR ? c.footprint_radius : 0.0);
+}
 template <int MODE>
-__device__ __forceinline__ unsigned long long dyn_near_mask(const teb_amd_config_t& c, const SceneDev& sc, const Lds& l, int i, int kb, int ke) {
-  const double far_d = fmax(c.min_obstacle_dist + c.penalty_epsilon, c.dynamic_obstacle_inflation_dist) +
-                       (c.footprint_type == TEB_AMD_FOOTPRINT_CIRCULAR ? c.footprint_radius : 0.0);
+__device__ __forceinline__ unsigned long long dyn_near_mask(const teb_amd_config_t& c, const SceneDev& sc, const Lds& l, int i, int kb, int ke,
+                                                            double margin = 0.0) {
+  const double far_d = dyn_far_distance(c) + margin;
   const double x = l.sx[i], y = l.sy[i], ti = l.tdyn[i];
   unsigned long long near = 0;
 #pragma unroll 4   // independent chains: at one wave per SIMD only instruction-level parallelism hides the fp64 latency
@@ -226,13 +236,47 @@ __device__ __forceinline__ void dyn_chunk(const SceneDev& sc, int sl, int nsl, i
   d_lo = sl * dchunk < sc.n_dyn ? sl * dchunk : sc.n_dyn;
   d_hi = d_lo + dchunk < sc.n_dyn ? d_lo + dchunk : sc.n_dyn;
 }
-// mask of the first 64 obstacles of the slice for pose i (0 when the pose has no dynamic-obstacle edges or the scene is not point-like)
+// The masks are reused across the linearisations and error evaluations of one outer iteration. The time stamps of the dynamic edges
+// are frozen when the graph is built (src/optimal_planner.cpp:662-670), so the obstacle positions a pose sees do not change during
+// optimize(); only the pose moves. A mask taken at the reference position r with the threshold widened by m holds every obstacle
+// that is near at any position p with |p - r| <= m (triangle inequality), and a superset is all pass 2 needs: the edges it
+// evaluates beyond the true threshold contribute exact zeros, like in the full loop. So each lane keeps (mask, r) per pose it serves
+// (kMaxPoseIter of them, in registers) and recomputes only when its pose has left the disc - or when the graph was rebuilt (r = NaN).
+// m = TEB_NEAR_MARGIN_FACTOR x the culling distance: the wider the disc the rarer the recomputation and the more zero edges in pass 2
+// (headline kernel 4.21 ms without the cache; 4.04 / 3.99 / 3.96 / 3.99 ms at factor 0.5 / 1 / 2 / 3).
+#ifndef TEB_NEAR_MARGIN_FACTOR
+#define TEB_NEAR_MARGIN_FACTOR 1.5
+#endif
+struct NearCache {
+  unsigned long long m0, m1;
+  double rx0, ry0, rx1, ry1;
+  __device__ __forceinline__ void invalidate() { rx0 = ry0 = rx1 = ry1 = __builtin_nan(""); m0 = m1 = 0; }
+};
 template <int MODE>
-__device__ __forceinline__ unsigned long long dyn_near_first(const teb_amd_config_t& c, const SceneDev& sc, const Lds& l, int i, int sl, int nsl) {
+__device__ __forceinline__ unsigned long long dyn_near_cached(const teb_amd_config_t& c, const SceneDev& sc, const Lds& l, int i, int sl, int nsl,
+                                                              NearCache& nc, int pass) {
   if (!(sc.fast_points && i >= 1 && c.include_dynamic_obstacles && c.weight_obstacle != 0)) return 0;
-  int d_lo, d_hi;
-  dyn_chunk(sc, sl, nsl, d_lo, d_hi);
-  return dyn_near_mask<MODE>(c, sc, l, i, d_lo, d_lo + 64 < d_hi ? d_lo + 64 : d_hi);
+  const double m = TEB_NEAR_MARGIN_FACTOR * dyn_far_distance(c);
+  const double x = l.sx[i], y = l.sy[i];
+  const double rx = pass == 0 ? nc.rx0 : nc.rx1, ry = pass == 0 ? nc.ry0 : nc.ry1;
+  unsigned long long mask = pass == 0 ? nc.m0 : nc.m1;
+  const double ddx = x - rx, ddy = y - ry;
+  const double lim = m * (1.0 - 1e-9);
+  // left the disc, or no mask yet (NaN reference). When one lane of the wave has to recompute, the whole wave walks the loop anyway: every
+  // lane then refreshes its mask at its current position (a fresh disc costs the others nothing and postpones their next recomputation)
+  if (__any(!(ddx * ddx + ddy * ddy <= lim * lim))) {
+    int d_lo, d_hi;
+    dyn_chunk(sc, sl, nsl, d_lo, d_hi);
+    mask = dyn_near_mask<MODE>(c, sc, l, i, d_lo, d_lo + 64 < d_hi ? d_lo + 64 : d_hi, m);
+    if (pass == 0) { nc.m0 = mask; nc.rx0 = x; nc.ry0 = y; } else { nc.m1 = mask; nc.rx1 = x; nc.ry1 = y; }
+#ifdef TEB_PROFILE
+    atomicAdd(&g_near_recomputed, 1ull);
+#endif
+  }
+#ifdef TEB_PROFILE
+  atomicAdd(&g_near_queries, 1ull);
+#endif
+  return mask;
 }
 
 template <int MODE>
@@ -277,8 +321,8 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
       EVP(MODE == 0 ? 0 : 3);
       if (c.include_dynamic_obstacles && c.weight_obstacle != 0) {
         const double ti = l.tdyn[i];
-        // far-field culling (dyn_near_mask above): the mask of the first 64 obstacles of the slice was computed by the caller before the
-        // accumulator went live; further blocks (more than 64 dynamic obstacles per slice) are computed here
+        // far-field culling (dyn_near_mask above): the mask of the first 64 obstacles of the slice comes from the caller (dyn_near_cached,
+        // before the accumulator went live; a superset of the near obstacles); further blocks (more than 64 dynamic obstacles per slice) are computed here
         for (int kb = d_lo; kb < d_hi; kb += 64) {
           const int ke = kb + 64 < d_hi ? kb + 64 : d_hi;
           unsigned long long near = (kb == d_lo) ? near_first : dyn_near_mask<MODE>(c, sc, l, i, kb, ke);
@@ -371,13 +415,17 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
 }
 #undef TEB_EDGE
 
-// scatter the thread-local window into the LDS normal matrix; rows/cols of fixed variables are dropped
-template <int SOLVER>
+// scatter the thread-local window into the LDS normal matrix; rows/cols of fixed variables are dropped. Step K (0, 1, 2) adds the rows of
+// pose i + K (window rows 4K .. 4K+3): in one step every lane writes the rows of a different pose, so the three steps (a barrier between
+// them) are free of conflicts with ALL lanes busy in each, and every entry receives its up to three contributions in the fixed order
+// lane p, p-1, p-2 - deterministic, no atomics. In the block layout only the lower triangle of a diagonal block is kept (the
+// factorisation reads nothing else).
+template <int SOLVER, int K>
 __device__ __forceinline__ void scatter(const Accum& A, const Lds& l, int i, int n) {
   const int base = 4 * i;
   const int last_pose = 4 * (n - 1);
 #pragma unroll
-  for (int a = 0; a < 11; ++a) {
+  for (int a = 4 * K; a < (4 * K + 4 < 11 ? 4 * K + 4 : 11); ++a) {
     int ra = base + a;
     bool fa = (ra < 3) || (ra >= last_pose);
     if (fa) continue;
@@ -392,12 +440,8 @@ __device__ __forceinline__ void scatter(const Accum& A, const Lds& l, int i, int
         l.Hb[ra * kBand + (a - b)] += v;
       } else {
         const int jr = ra >> 3, jc = rb >> 3;   // window spans at most two consecutive block rows
-        if (jr == jc) {
-          l.Db[jr * kBlk + (ra & 7) * 8 + (rb & 7)] += v;
-          if (a != b) l.Db[jr * kBlk + (rb & 7) * 8 + (ra & 7)] += v;
-        } else {
-          l.Lb[jr * kBlk + (ra & 7) * 8 + (rb & 7)] += v;
-        }
+        if (jr == jc) l.Db[jr * kBlk + (ra & 7) * 8 + (rb & 7)] += v;
+        else l.Lb[jr * kBlk + (ra & 7) * 8 + (rb & 7)] += v;
       }
     }
   }
@@ -424,24 +468,29 @@ __device__ __forceinline__ void refresh_trig(const Lds& l, int n) {
 
 // buildSystem: H = sum J^T Omega J, b = -sum J^T Omega e, and chi^2 per category at the current state.
 template <int SOLVER, int JMODE>
-__device__ inline void linearize(const teb_amd_config_t& c, const SceneDev& sc, const TebCtx& t, const Lds& l,
+__device__ inline void linearize(const teb_amd_config_t& c, const SceneDev& sc, const TebCtx& t, const Lds& l, NearCache& nc,
                                  double* cats /*4, out on all threads*/) {
   const int n = t.n, Nt = 4 * n, tid = threadIdx.x;
   const int hsz = (SOLVER != SOLVER_CR) ? Nt * kBand : ((Nt + 7) >> 3) * 2 * kBlk;
+  LNP_DECL
   for (int q = tid; q < hsz; q += kThreads) *hmat_ptr<SOLVER>(l, q, Nt) = 0;
   for (int q = tid; q < Nt + 8; q += kThreads) l.bv[q] = 0;
+  LNP(0);
   refresh_trig(l, n);
   __syncthreads();
+  LNP(1);
   Accum A;
   A.clear_chi();
-  for (int k0 = 0; k0 < n - 1; ) {
+  for (int k0 = 0, pass = 0; k0 < n - 1; ++pass) {
     const int G = (k0 > 0 || kThreads > 256) ? lanes_per_pose(n - 1 - k0) : 1;   // slices only for a leftover pass: bands up to kThreads poses keep their summation order
     const int i = k0 + tid / G, sl = tid % G;
     const bool active = i <= n - 2;
     constexpr int EM = JMODE == TEB_AMD_JACOBIAN_G2O_NUMERIC ? 2 : 1;
-    const unsigned long long near = active ? dyn_near_first<EM>(c, sc, l, i, sl, G) : 0ull;   // before the accumulator is live
+    const unsigned long long near = active ? dyn_near_cached<EM>(c, sc, l, i, sl, G, nc, pass) : 0ull;   // before the accumulator is live
+    LNP(2);
     A.clear();
     if (active) eval_index<EM>(c, sc, t, l, i, A, near, sl, G);
+    LNP(3);
     if (G > 1) {   // the slices of a pose hold partial sums of its dynamic-obstacle rows: pose block (x, y, theta) of H and g
       for (int off = 1; off < G; off <<= 1) {
 #pragma unroll
@@ -450,10 +499,14 @@ __device__ inline void linearize(const teb_amd_config_t& c, const SceneDev& sc, 
         for (int q = 0; q < 3; ++q) A.g[q] += __shfl_xor(A.g[q], off, 64);
       }
     }
-    for (int ph = 0; ph < 3; ++ph) {
-      if (active && sl == 0 && (i % 3) == ph) scatter<SOLVER>(A, l, i, n);
-      __syncthreads();
-    }
+    LNP(4);
+    if (active && sl == 0) scatter<SOLVER, 0>(A, l, i, n);
+    __syncthreads();
+    if (active && sl == 0) scatter<SOLVER, 1>(A, l, i, n);
+    __syncthreads();
+    if (active && sl == 0) scatter<SOLVER, 2>(A, l, i, n);
+    __syncthreads();
+    LNP(5);
     k0 += kThreads / G;
   }
   // fixed variables (pose 0, pose n-1, the non-existing dt_{n-1}) become identity rows
@@ -464,20 +517,21 @@ __device__ inline void linearize(const teb_amd_config_t& c, const SceneDev& sc, 
   }
   cats[0] = A.chi[0]; cats[1] = A.chi[1]; cats[2] = A.chi[2]; cats[3] = A.chi[3];
   block_sum<4>(cats, l.red);
+  LNP(6);
 }
 
 // computeActiveErrors + activeRobustChi2 at the current state
-__device__ inline void evaluate(const teb_amd_config_t& c, const SceneDev& sc, const TebCtx& t, const Lds& l,
+__device__ inline void evaluate(const teb_amd_config_t& c, const SceneDev& sc, const TebCtx& t, const Lds& l, NearCache& nc,
                                 double* cats) {
   refresh_trig(l, t.n);
   __syncthreads();
   Accum A;   // only chi[] is live when JAC == false
   A.clear_chi();
-  for (int k0 = 0; k0 < t.n - 1; ) {
+  for (int k0 = 0, pass = 0; k0 < t.n - 1; ++pass) {
     const int G = (k0 > 0 || kThreads > 256) ? lanes_per_pose(t.n - 1 - k0) : 1;
     const int i = k0 + (int)threadIdx.x / G;
     if (i <= t.n - 2) {
-      const unsigned long long near = dyn_near_first<0>(c, sc, l, i, (int)threadIdx.x % G, G);
+      const unsigned long long near = dyn_near_cached<0>(c, sc, l, i, (int)threadIdx.x % G, G, nc, pass);
       eval_index<0>(c, sc, t, l, i, A, near, (int)threadIdx.x % G, G);
     }
     k0 += kThreads / G;
@@ -1829,6 +1883,8 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   double chi2_final = 0, lambda = 0, cost = __longlong_as_double(0x7ff8000000000000LL);
   double last_cats[4] = {0, 0, 0, 0};
   double weight_multiplier = args.debug_linearize ? args.debug_weight_multiplier : 1.0;
+  NearCache near_cache;   // near masks of the dynamic-obstacle edges, per lane (dyn_near_cached)
+  near_cache.invalidate();
   const bool fast_mode = !c.include_dynamic_obstacles;
   bool done = false;
   PROF_DECL
@@ -1899,6 +1955,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     __syncthreads();
     PROF_END(1);
 
+    near_cache.invalidate();   // the graph was rebuilt: new pose numbering, new time stamps
     // ---- optimize(): Levenberg-Marquardt
     if (args.inner <= 0 && !args.debug_linearize) { status = TEB_AMD_TEB_FAILED; break; }   // optimize(0) returns 0
     double ni = 2;
@@ -1906,7 +1963,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     for (int it = 0; it < args.inner && lm_ok; ++it) {
       double cats[4];
       PROF_START();
-      linearize<SOLVER, JMODE>(c, sc, t, l, cats);
+      linearize<SOLVER, JMODE>(c, sc, t, l, near_cache, cats);
       PROF_END(2);
       double currentChi = ((cats[0] + cats[1]) + cats[2]) + cats[3];
       if (args.debug_linearize) {
@@ -1989,7 +2046,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
         }
         __syncthreads();
         double tc[5];
-        evaluate(c, sc, t, l, tc);
+        evaluate(c, sc, t, l, near_cache, tc);
         last_cats[0] = tc[0]; last_cats[1] = tc[1]; last_cats[2] = tc[2]; last_cats[3] = tc[3];
         double tempChi = ((tc[0] + tc[1]) + tc[2]) + tc[3];
         double scv[1] = {sc_part};
@@ -2030,7 +2087,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       if (qmax == 10 || rho == 0 || !isfinite(lambda)) lm_ok = false;   // Terminate
       if (c.divergence_detection_enable) {   // setComputeBatchStatistics -> computeActiveErrors after each solve
         double fc[4];
-        evaluate(c, sc, t, l, fc);
+        evaluate(c, sc, t, l, near_cache, fc);
         last_cats[0] = fc[0]; last_cats[1] = fc[1]; last_cats[2] = fc[2]; last_cats[3] = fc[3];
         chi2_final = ((fc[0] + fc[1]) + fc[2]) + fc[3];
       }
