@@ -647,11 +647,10 @@ __device__ __forceinline__ double pointlike_distance(const teb_amd_config_t& c, 
   return dist;
 }
 
+// residual rows of EdgeObstacle / EdgeInflatedObstacle given the distance and its gradient (split from the distance so that the
+// sqrt / divide chains of several obstacles can be in flight at once)
 template <bool JAC, class ACC>
-__device__ __forceinline__ void edge_obstacle_fast(const teb_amd_config_t& c, double ox, double oy, double orad, const Win& w,
-                                                   double w_obst, bool inflated, ACC& A) {
-  double gr[2];
-  double dist = pointlike_distance<JAC>(c, w.x0, w.y0, ox, oy, orad, gr);
+__device__ __forceinline__ void obstacle_rows(const teb_amd_config_t& c, double dist, const double* gr, double w_obst, bool inflated, ACC& A) {
   double d0;
   double e0 = pen_below(dist, c.min_obstacle_dist, c.penalty_epsilon, d0);
   if (c.obstacle_cost_exponent != 1.0 && c.min_obstacle_dist > 0.0) {
@@ -671,6 +670,13 @@ __device__ __forceinline__ void edge_obstacle_fast(const teb_amd_config_t& c, do
     if (JAC) { r[0] = d1 * gr[0]; r[1] = d1 * gr[1]; }
     A.template row<0x003, JAC>(CAT_OBST, e1, c.weight_inflation, r);
   }
+}
+template <bool JAC, class ACC>
+__device__ __forceinline__ void edge_obstacle_fast(const teb_amd_config_t& c, double ox, double oy, double orad, const Win& w,
+                                                   double w_obst, bool inflated, ACC& A) {
+  double gr[2];
+  double dist = pointlike_distance<JAC>(c, w.x0, w.y0, ox, oy, orad, gr);
+  obstacle_rows<JAC>(c, dist, gr, w_obst, inflated, A);
 }
 
 // residual rows of EdgeDynamicObstacle given the distance and its gradient (split from the distance so that

@@ -303,10 +303,42 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
   if (i >= 1) {
     if (sc.fast_points) {
       if (!c.legacy_obstacle_association) {
-        for (int k = sl; k < cnt; k += nsl) {
-          const int p = t.assoc[(size_t)k * t.stride + i];
-          const double ox = l.obx[p], oy = l.oby[p], orad = l.obr[p];
-          TEB_EDGE(M_POSE0, CAT_OBST, edge_obstacle_fast<J_>(c, ox, oy, orad, W, t.w_obst, t.inflated, ACC_));
+        // The association lists live in HBM (pose-major, coalesced over the lanes); a lane walks its list in order and at one wave per
+        // SIMD every dependent load is a full round trip (L2 for the entry, LDS for the obstacle, then the sqrt chain: ~ 1.1 k cycles per
+        // edge, measured). Four entries are fetched together and their distances computed side by side (independent chains); the
+        // residual rows then follow in list order - same operations per edge, same order of accumulation.
+        constexpr int kStaticBatch = 4;
+        for (int k0 = sl; k0 < cnt; k0 += kStaticBatch * nsl) {
+          int pp[kStaticBatch];
+          bool valid[kStaticBatch];
+#pragma unroll
+          for (int u = 0; u < kStaticBatch; ++u) {
+            const int kq = k0 + u * nsl;
+            valid[u] = kq < cnt;
+            pp[u] = valid[u] ? t.assoc[(size_t)kq * t.stride + i] : 0;
+          }
+          if constexpr (MODE == 2) {
+#pragma unroll
+            for (int u = 0; u < kStaticBatch; ++u)
+              if (valid[u]) {
+                const double ox = l.obx[pp[u]], oy = l.oby[pp[u]], orad = l.obr[pp[u]];
+                TEB_EDGE(M_POSE0, CAT_OBST, edge_obstacle_fast<J_>(c, ox, oy, orad, W, t.w_obst, t.inflated, ACC_));
+              }
+          } else {
+            double dist[kStaticBatch], g0[kStaticBatch], g1[kStaticBatch];
+#pragma unroll
+            for (int u = 0; u < kStaticBatch; ++u) {
+              double gr[2];
+              dist[u] = pointlike_distance<JAC>(c, w.x0, w.y0, l.obx[pp[u]], l.oby[pp[u]], l.obr[pp[u]], gr);
+              g0[u] = JAC ? gr[0] : 0.0; g1[u] = JAC ? gr[1] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < kStaticBatch; ++u)
+              if (valid[u]) {
+                const double gr[2] = {g0[u], g1[u]};
+                obstacle_rows<JAC>(c, dist[u], gr, t.w_obst, t.inflated, A);
+              }
+          }
         }
       } else {   // legacy lists carry the triple edge at the closest pose as one flagged entry
         for (int k = sl; k < cnt; k += nsl) {
