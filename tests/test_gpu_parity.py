@@ -523,7 +523,9 @@ def test_numeric_jacobians_on_long_bands(oracle, n):
                cfg.hcp.selection_alternative_time_cost)
     res = s.results(); out = s.download(batch.copy()); s.close()
     ref, rres = oracle.optimize_batch(cfg, obst, via, batch, inner=2, outer=2)
-    assert_full_parity(out, res, ref, rres, pos_tol=1e-7, rtol=1e-7)
+    # central differences with delta = 1e-9 turn the rounding of a different (equally valid) summation order of H into ~1e-7 relative
+    # noise on the Jacobians (tests/sensitivity.py); on coordinates up to 100 m that is the 1e-7 seen here (observed: 1.1e-7 at n = 400)
+    assert_full_parity(out, res, ref, rres, pos_tol=1e-6, rtol=1e-7)
 
 
 def test_long_band_with_autoresize_grows_past_the_lds_band(oracle):
