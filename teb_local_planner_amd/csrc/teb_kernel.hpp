@@ -500,7 +500,7 @@ __device__ __forceinline__ double* diag_ptr(const Lds& l, int r) {
 
 // per-pose cos/sin cache: every cost term that needs the heading reads these instead of re-evaluating libm
 __device__ __forceinline__ void refresh_trig(const Lds& l, int n) {
-  for (int i = threadIdx.x; i < n; i += kThreads) { const double th = l.sth[i]; l.cs[i] = cos(th); l.sn[i] = sin(th); }
+  for (int i = threadIdx.x; i < n; i += kThreads) { double sv, cv; sincos(l.sth[i], &sv, &cv); l.cs[i] = cv; l.sn[i] = sv; }   // one argument reduction for both
 }
 
 // buildSystem: H = sum J^T Omega J, b = -sum J^T Omega e, and chi^2 per category at the current state.
@@ -1577,7 +1577,7 @@ __device__ inline int autoresize(const teb_amd_config_t& c, const Lds& l, int n,
     } else if (tid >= 64) {
       // meanwhile the other waves refresh cos / sin of the poses as they are now (the cache may date from a rejected LM trial);
       // wave 0 is excluded so that lane 0 is not held up by its own wave
-      for (int i = tid - 64; i < n; i += kThreads - 64) { const double th = l.sth[i]; l.cs[i] = cos(th); l.sn[i] = sin(th); }
+      for (int i = tid - 64; i < n; i += kThreads - 64) { double sv, cv; sincos(l.sth[i], &sv, &cv); l.cs[i] = cv; l.sn[i] = sv; }
     }
     __syncthreads();
     const int n_out = l.ired[16], mod = l.ired[17], ovf = l.ired[18], n_new = l.ired[19], md = l.ired[20], nruns = l.ired[21], tail_k = l.ired[22];
