@@ -1961,6 +1961,8 @@ int teb_amd_debug_profile(teb_amd_handle_t* h, double* cycles8) {
   HIPCHK(hipMemcpyFromSymbol(lnp, HIP_SYMBOL(tebamd::g_lin_prof), sizeof lnp));
   fprintf(stderr, "[linearize cycles, thread 0 of workgroup 0, cumulative] zero H, b %lld | trig + barrier %lld | near masks %lld | edges %lld | slice reduction %lld | scatter (3 phases) %lld | tail + chi2 sum %lld\n",
           lnp[0], lnp[1], lnp[2], lnp[3], lnp[4], lnp[5], lnp[6]);
+  fprintf(stderr, "[graph side data cycles, thread 0 of workgroup 0, cumulative] trig %lld | association %lld | time stamps (one lane) %lld | via-points + barrier %lld\n",
+          lnp[8], lnp[9], lnp[10], lnp[11]);
   long long evp[8];
   HIPCHK(hipMemcpyFromSymbol(evp, HIP_SYMBOL(tebamd::g_ev_prof), sizeof evp));
   fprintf(stderr, "[eval_index cycles, thread 0 of workgroup 0, cumulative] evaluate: static %lld dynamic %lld chain %lld | linearise: static %lld dynamic %lld chain %lld\n",

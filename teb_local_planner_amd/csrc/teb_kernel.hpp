@@ -1947,8 +1947,10 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     // ---- buildGraph side data: association (K2), dynamic-obstacle time stamps, via-point attachment
     t.w_obst = c.weight_obstacle * weight_multiplier;
     PROF_START();
+    LNP_DECL
     refresh_trig(l, n);
     __syncthreads();
+    LNP(8);
     const bool obst_edges = !(c.weight_obstacle == 0 || weight_multiplier == 0);
     if (obst_edges) {
       int ovf = 0;
@@ -1960,10 +1962,12 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     } else {
       for (int i = tid; i < n; i += kThreads) assoc_cnt[i] = 0;
     }
+    LNP(9);
     if (tid == 0) {   // :662-670, sequential left-to-right sum like the reference
       double time = l.sdt[0];
       for (int i = 1; i < n - 1; ++i) { l.tdyn[i] = time; time += l.sdt[i]; }
     }
+    LNP(10);
     if (t.via_en && c.weight_viapoint != 0 && sc.nvia > 0 && n >= 3) {   // :675-718
       int start_pose_idx = 0;
       for (int v = 0; v < sc.nvia; ++v) {
@@ -1990,6 +1994,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     }
     __threadfence_block();
     __syncthreads();
+    LNP(11);
     PROF_END(1);
 
     near_cache.invalidate();   // the graph was rebuilt: new pose numbering, new time stamps
