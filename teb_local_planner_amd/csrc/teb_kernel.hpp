@@ -1965,7 +1965,15 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     LNP(9);
     if (tid == 0) {   // :662-670, sequential left-to-right sum like the reference
       double time = l.sdt[0];
-      for (int i = 1; i < n - 1; ++i) { l.tdyn[i] = time; time += l.sdt[i]; }
+      int i = 1;
+      for (; i + 8 <= n - 1; i += 8) {   // the loads of 8 intervals in flight at once; the additions keep their order
+        double d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) d[u] = l.sdt[i + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { l.tdyn[i + u] = time; time += d[u]; }
+      }
+      for (; i < n - 1; ++i) { l.tdyn[i] = time; time += l.sdt[i]; }
     }
     LNP(10);
     if (t.via_en && c.weight_viapoint != 0 && sc.nvia > 0 && n >= 3) {   // :675-718
