@@ -1953,6 +1953,9 @@ int teb_amd_debug_profile(teb_amd_handle_t* h, double* cycles8) {
             8 << w, crw[w * 8 + 0], crw[w * 8 + 1], crw[w * 8 + 2], crw[w * 8 + 3], crw[w * 8 + 4], crw[w * 8 + 5], crw[w * 8 + 6]);
   fprintf(stderr, "[cr_solve cycles, workgroup 0, cumulative; hybrid solve: init compact | level 0 | compact forward | top + backward | odd rows] %lld %lld %lld %lld %lld %lld\n",
           crp[0], crp[1], crp[2], crp[3], crp[4], crp[5]);
+  unsigned long long ars[4];
+  HIPCHK(hipMemcpyFromSymbol(ars, HIP_SYMBOL(tebamd::g_ar_steps), sizeof ars));
+  fprintf(stderr, "[autoResize rule machine, workgroup 0, cumulative] %llu calls, %llu steps, %llu cycles\n", ars[2], ars[1], ars[3]);
   unsigned long long nq[2];
   HIPCHK(hipMemcpyFromSymbol(&nq[0], HIP_SYMBOL(tebamd::g_near_recomputed), sizeof nq[0]));
   HIPCHK(hipMemcpyFromSymbol(&nq[1], HIP_SYMBOL(tebamd::g_near_queries), sizeof nq[1]));

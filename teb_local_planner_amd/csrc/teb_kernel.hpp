@@ -30,6 +30,7 @@ namespace tebamd {
 __device__ long long g_ev_prof[8];   // thread 1 (pose 1) of workgroup 0: evaluate {static, dynamic, chain}, linearise {static, dynamic, chain}, trig, scatter
 #define EVP_DECL long long evp_t0 = clock64(), evp_t1;
 #define EVP(k) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); evp_t1 = clock64(); __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && threadIdx.x == 1) g_ev_prof[k] += evp_t1 - evp_t0; evp_t0 = evp_t1; } while (0)
+__device__ unsigned long long g_ar_steps[4];   // autoResize machine, workgroup 0: -, steps, calls, cycles
 __device__ unsigned long long g_near_recomputed, g_near_queries;   // lanes that recomputed their near mask / that asked for it
 __device__ long long g_lin_prof[16];  // thread 0 of workgroup 0: sections of linearize()
 #define LNP_DECL long long lnp_t0 = clock64(), lnp_t1;
@@ -1421,6 +1422,10 @@ __device__ __noinline__ void autoresize_script_lane0(double dt_ref_, double hyst
   int* stk_desc = reinterpret_cast<int*>(stk_dt + kSplitStack);
   const unsigned long long* masks = reinterpret_cast<const unsigned long long*>(stk_dt + kSplitStack + kSplitStack / 2);
   int* runs = reinterpret_cast<int*>(stk_dt + kSplitStack + kSplitStack / 2 + kActiveMasks);
+#ifdef TEB_PROFILE
+  if (blockIdx.x == 0) g_ar_steps[2] += 1;
+  const long long ar_t0 = clock64();
+#endif
   const int Tin = n_in - 1;
   int T = Tin;           // sizeTimeDiffs()
   int j = 1;             // next unread input interval
@@ -1439,6 +1444,9 @@ __device__ __noinline__ void autoresize_script_lane0(double dt_ref_, double hyst
   bool alive = Tin >= 1;
   int top_desc = 0, top_depth = 0; double top_dt = 0;   // register copy of the stack top
   while (alive) {
+#ifdef TEB_PROFILE
+    if (blockIdx.x == 0) g_ar_steps[1] += 1;
+#endif
     if (fresh && sp == 0) {
       // run of unmarked intervals starting at cur = input interval cdesc: up to the next marked one (or the end of the band). The mask of
       // the current 64-interval chunk is kept in registers: a marked interval (the common case where every step counts) costs no LDS read.
@@ -1533,6 +1541,9 @@ __device__ __noinline__ void autoresize_script_lane0(double dt_ref_, double hyst
       ptouched = false;
     } else alive = false;
   }
+#ifdef TEB_PROFILE
+  if (blockIdx.x == 0) g_ar_steps[3] += clock64() - ar_t0;
+#endif
   res[0] = k + 1; res[1] = modified ? 1 : 0; res[2] = ovf; res[3] = nn; res[4] = md; res[5] = nruns; res[6] = tail_k;
   if (!ovf) out_desc[k] = n_in - 1;   // the goal pose
 }
