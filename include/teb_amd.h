@@ -244,7 +244,9 @@ typedef struct teb_amd_options {
   int32_t band_ldlt;              /* 1: TEB_AMD_LAYOUT_BAND_LDS solves with the sequential banded LDL^T (cross-check, slow)     */
   int32_t generic_distance_path;  /* 1: never use the point-like LDS obstacle cache                                             */
   int32_t hsig3d_kernel;          /* TEB_AMD_HSIG3D_*: pin one of the two HSignature3d kernels                                  */
-  int32_t reserved[10];           /* must be 0                                                                                  */
+  int32_t no_near_cache;          /* 1: the near masks of the dynamic-obstacle edges are recomputed at every pass instead of    */
+                                  /*    cached across one optimize() (cross-check: the results must not change by one bit)      */
+  int32_t reserved[9];            /* must be 0                                                                                  */
 } teb_amd_options_t;
 void teb_amd_options_default(teb_amd_options_t* opt);
 

@@ -97,9 +97,10 @@ HSIG3D_AUTO, HSIG3D_WIDE, HSIG3D_SMALL = 0, 1, 2
 class Options(C.Structure):
     """teb_amd_options_t (include/teb_amd.h): behaviour switches of a handle, fixed at create."""
     _fields_ = [("struct_size", c_i32), ("layout", c_i32), ("fixed_layout", c_i32), ("band_ldlt", c_i32),
-                ("generic_distance_path", c_i32), ("hsig3d_kernel", c_i32), ("reserved", c_i32 * 10)]
+                ("generic_distance_path", c_i32), ("hsig3d_kernel", c_i32), ("no_near_cache", c_i32), ("reserved", c_i32 * 9)]
 
-    def __init__(self, layout=LAYOUT_AUTO, fixed_layout=False, band_ldlt=False, generic_distance_path=False, hsig3d_kernel=HSIG3D_AUTO):
+    def __init__(self, layout=LAYOUT_AUTO, fixed_layout=False, band_ldlt=False, generic_distance_path=False, hsig3d_kernel=HSIG3D_AUTO,
+                 no_near_cache=False):
         super().__init__()
         self.struct_size = C.sizeof(Options)
         self.layout = {"auto": LAYOUT_AUTO, "cr": LAYOUT_BLOCKS_LDS, "band": LAYOUT_BAND_LDS, "bandg": LAYOUT_BAND_HBM}.get(layout, layout)
@@ -107,6 +108,7 @@ class Options(C.Structure):
         self.band_ldlt = int(band_ldlt)
         self.generic_distance_path = int(generic_distance_path)
         self.hsig3d_kernel = {"auto": HSIG3D_AUTO, "wide": HSIG3D_WIDE, "small": HSIG3D_SMALL}.get(hsig3d_kernel, hsig3d_kernel)
+        self.no_near_cache = int(no_near_cache)
 
 
 class Results(C.Structure):

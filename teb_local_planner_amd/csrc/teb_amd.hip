@@ -746,7 +746,7 @@ int teb_amd_optimize_batch(teb_amd_handle_t* h, int32_t inner, int32_t outer, in
   if (inner < 0 || outer < 0) return fail(TEB_AMD_ERR_INVALID_ARG, "negative iteration count");
   OptArgs a;
   std::memset(&a, 0, sizeof a);
-  a.inner = inner; a.outer = outer; a.compute_cost = compute_cost; a.band_ldlt = h->solver == SOLVER_BANDG ? 0 : h->band_ldlt; a.Hband = h->Hband.p; a.hband_stride = h->hband_stride;
+  a.inner = inner; a.outer = outer; a.compute_cost = compute_cost; a.no_near_cache = h->opt.no_near_cache != 0; a.band_ldlt = h->solver == SOLVER_BANDG ? 0 : h->band_ldlt; a.Hband = h->Hband.p; a.hband_stride = h->hband_stride;
   a.obst_scale = obst_cost_scale; a.via_scale = viapoint_cost_scale; a.alt_time = alternative_time_cost;
 #ifdef TEB_PROFILE
   a.dbg_H = h->dbg_H.p;
@@ -1848,7 +1848,7 @@ int teb_amd_debug_linearize(teb_amd_handle_t* h, int32_t b, double weight_multip
   // run the kernel in debug mode on TEB b only: temporarily view the batch as starting at b
   OptArgs a;
   std::memset(&a, 0, sizeof a);
-  a.inner = 1; a.outer = 1; a.debug_linearize = 1; a.debug_weight_multiplier = weight_multiplier; a.band_ldlt = h->solver == SOLVER_BANDG ? 0 : h->band_ldlt; a.Hband = h->Hband.p; a.hband_stride = h->hband_stride;
+  a.inner = 1; a.outer = 1; a.no_near_cache = h->opt.no_near_cache != 0; a.debug_linearize = 1; a.debug_weight_multiplier = weight_multiplier; a.band_ldlt = h->solver == SOLVER_BANDG ? 0 : h->band_ldlt; a.Hband = h->Hband.p; a.hband_stride = h->hband_stride;
   a.dbg_H = h->dbg_H.p; a.dbg_b = h->dbg_b.p; a.dbg_chi2 = h->dbg_chi2.p;
   SceneDev sc = scene_of(h);
   BatchDev bt = batch_of(h);

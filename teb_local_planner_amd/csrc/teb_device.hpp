@@ -97,6 +97,7 @@ struct OptArgs {
   double* Hband;         // SOLVER_BANDG: per-band normal matrix in band form in HBM, hband_stride doubles each
   size_t hband_stride;
   int band_ldlt;         // SOLVER_BAND only: 1 = sequential banded LDL^T in LDS (v1), 0 = cyclic reduction on HBM-resident blocks
+  int no_near_cache;     // teb_amd_options_t::no_near_cache
   int debug_linearize;   // test hook: stop after the first linearisation and dump H, b, chi2 categories
   double debug_weight_multiplier;
   double* dbg_H;         // [4*stride*kBand] of TEB 0

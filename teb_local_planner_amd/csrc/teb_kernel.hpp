@@ -251,13 +251,14 @@ __device__ __forceinline__ void dyn_chunk(const SceneDev& sc, int sl, int nsl, i
 struct NearCache {
   unsigned long long m0, m1;
   double rx0, ry0, rx1, ry1;
+  bool off;   // teb_amd_options_t::no_near_cache: exact mask (no margin) at every pass
   __device__ __forceinline__ void invalidate() { rx0 = ry0 = rx1 = ry1 = __builtin_nan(""); m0 = m1 = 0; }
 };
 template <int MODE>
 __device__ __forceinline__ unsigned long long dyn_near_cached(const teb_amd_config_t& c, const SceneDev& sc, const Lds& l, int i, int sl, int nsl,
                                                               NearCache& nc, int pass) {
   if (!(sc.fast_points && i >= 1 && c.include_dynamic_obstacles && c.weight_obstacle != 0)) return 0;
-  const double m = TEB_NEAR_MARGIN_FACTOR * dyn_far_distance(c);
+  const double m = nc.off ? 0.0 : TEB_NEAR_MARGIN_FACTOR * dyn_far_distance(c);
   const double x = l.sx[i], y = l.sy[i];
   const double rx = pass == 0 ? nc.rx0 : nc.rx1, ry = pass == 0 ? nc.ry0 : nc.ry1;
   unsigned long long mask = pass == 0 ? nc.m0 : nc.m1;
@@ -265,7 +266,7 @@ __device__ __forceinline__ unsigned long long dyn_near_cached(const teb_amd_conf
   const double lim = fmax(m * (1.0 - 1e-6) - 2e-6, 0.0);   // (the numeric mode evaluates residuals 1e-9 away from the pose and culls 1e-6 wider)
   // left the disc, or no mask yet (NaN reference). When one lane of the wave has to recompute, the whole wave walks the loop anyway: every
   // lane then refreshes its mask at its current position (a fresh disc costs the others nothing and postpones their next recomputation)
-  if (__any(!(ddx * ddx + ddy * ddy <= lim * lim))) {
+  if (nc.off || __any(!(ddx * ddx + ddy * ddy <= lim * lim))) {
     int d_lo, d_hi;
     dyn_chunk(sc, sl, nsl, d_lo, d_hi);
     mask = dyn_near_mask<MODE>(c, sc, l, i, d_lo, d_lo + 64 < d_hi ? d_lo + 64 : d_hi, m);
@@ -1933,6 +1934,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   double weight_multiplier = args.debug_linearize ? args.debug_weight_multiplier : 1.0;
   NearCache near_cache;   // near masks of the dynamic-obstacle edges, per lane (dyn_near_cached)
   near_cache.invalidate();
+  near_cache.off = args.no_near_cache != 0;
   const bool fast_mode = !c.include_dynamic_obstacles;
   bool done = false;
   PROF_DECL

@@ -659,3 +659,25 @@ def test_skip_rules_have_a_floor():
     for name, (checked, seen) in _SKIP_STATS.items():
         if seen:
             assert checked >= 0.9 * seen, (name, checked, seen)
+
+
+@pytest.mark.parametrize("jmode", ["analytic", "numeric"])
+def test_cached_near_masks_do_not_change_one_bit(jmode):
+    """The near masks of the dynamic-obstacle edges are cached per lane across one optimize() (a superset taken at a reference position,
+    exact test on the candidates); teb_amd_options_t::no_near_cache recomputes the exact mask at every pass. Both must give the same
+    bits: bands, costs, chi2, iteration and trial counts - on a scene whose poses move by more than the margin of the cache (the
+    recomputation path) and with fast and slow moving obstacles, in both Jacobian modes."""
+    cfg, obst, via, batch = scenes.scene_c4(B=24, n=120, M_static=60, M_dyn=64, seed=77, stride=160, length=12.0)
+    cfg.jacobian_mode = _abi.JACOBIAN_G2O_NUMERIC if jmode == "numeric" else _abi.JACOBIAN_ANALYTIC
+    outs = []
+    for off in (False, True):
+        out, res, best = run_gpu(cfg, obst, via, batch, options=_abi.Options(no_near_cache=off))
+        outs.append((out, res, best))
+    (a, ra, ba), (b, rb, bb) = outs
+    assert ba == bb
+    np.testing.assert_array_equal(a.n, b.n)
+    for k in ("status", "lm_iterations", "lm_trials"):
+        np.testing.assert_array_equal(getattr(ra, k), getattr(rb, k))
+    for u, v in ((a.x, b.x), (a.y, b.y), (a.theta, b.theta), (a.dt, b.dt), (ra.cost, rb.cost), (ra.chi2, rb.chi2)):
+        assert np.array_equal(u, v, equal_nan=True)
+    assert ra.lm_iterations.sum() >= batch.count and (ra.lm_trials >= ra.lm_iterations).all()   # the batch did iterate
