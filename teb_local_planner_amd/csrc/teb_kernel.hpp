@@ -109,9 +109,34 @@ __device__ __forceinline__ Lds carve(double* base, const LdsPlan& p, double* gH 
 }
 
 // ---- deterministic block reductions (fixed tree: lanes via shuffles, then the waves in order) ---------
+// v[l] += v[l + off], off = 32, 16, .., 1: lane 0 ends with the sum over the wave (the tree of __shfl_down, without its six LDS-crossbar
+// round trips: the two wide steps are lane swaps of gfx950, the four narrow ones DPP row shifts on the two halves of the double)
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
+#ifdef TEB_AMD_SHFL_REDUCE
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+#else
+  {
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+    v += __hiloint2double(hi[1], lo[1]);    // lanes 0..31: v[l + 32]
+  }
+  {
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+    v += __hiloint2double(hi[1], lo[1]);    // rows 0 and 2: v[l + 16]
+  }
+  v += dpp_move<0x108>(v);   // row_shl:8
+  v += dpp_move<0x104>(v);   // row_shl:4
+  v += dpp_move<0x102>(v);   // row_shl:2
+  v += dpp_move<0x101>(v);   // row_shl:1
+#endif
   return v;
 }
 template <int K>
@@ -559,9 +584,10 @@ __device__ inline void linearize(const teb_amd_config_t& c, const SceneDev& sc, 
   LNP(6);
 }
 
-// computeActiveErrors + activeRobustChi2 at the current state
+// computeActiveErrors + activeRobustChi2 at the current state. cats[4] rides along: a fifth per-lane value summed over the workgroup by the
+// same reduction (the computeScale term of the LM step; one reduction and one pair of barriers less per trial)
 __device__ inline void evaluate(const teb_amd_config_t& c, const SceneDev& sc, const TebCtx& t, const Lds& l, NearCache& nc,
-                                double* cats) {
+                                double* cats /*5*/) {
   refresh_trig(l, t.n);
   __syncthreads();
   Accum A;   // only chi[] is live when JAC == false
@@ -576,7 +602,7 @@ __device__ inline void evaluate(const teb_amd_config_t& c, const SceneDev& sc, c
     k0 += kThreads / G;
   }
   cats[0] = A.chi[0]; cats[1] = A.chi[1]; cats[2] = A.chi[2]; cats[3] = A.chi[3];
-  block_sum<4>(cats, l.red);
+  block_sum<5>(cats, l.red);
 }
 
 // ---- damped solve (K6 v1): in-LDS banded LDL^T by wave 0, right-looking, 65 work items per pivot ------------
@@ -2109,11 +2135,11 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
         }
         __syncthreads();
         double tc[5];
+        tc[4] = sc_part;
         evaluate(c, sc, t, l, near_cache, tc);
         last_cats[0] = tc[0]; last_cats[1] = tc[1]; last_cats[2] = tc[2]; last_cats[3] = tc[3];
         double tempChi = ((tc[0] + tc[1]) + tc[2]) + tc[3];
-        double scv[1] = {sc_part};
-        block_sum<1>(scv, l.red);
+        double scv[1] = {tc[4]};
         PROF_END(5);
         PROF_START();
         if (!ok2) tempChi = 1.7976931348623157e308;
@@ -2149,7 +2175,8 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       chi2_final = currentChi;
       if (qmax == 10 || rho == 0 || !isfinite(lambda)) lm_ok = false;   // Terminate
       if (c.divergence_detection_enable) {   // setComputeBatchStatistics -> computeActiveErrors after each solve
-        double fc[4];
+        double fc[5];
+        fc[4] = 0;
         evaluate(c, sc, t, l, near_cache, fc);
         last_cats[0] = fc[0]; last_cats[1] = fc[1]; last_cats[2] = fc[2]; last_cats[3] = fc[3];
         chi2_final = ((fc[0] + fc[1]) + fc[2]) + fc[3];
