@@ -1390,9 +1390,11 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, dou
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       double t = kL[rr][r] * xm + kU[rr][r] * xp;
-      t += __shfl_xor(t, 1, 64);
-      t += __shfl_xor(t, 2, 64);
-      t += __shfl_xor(t, 4, 64);
+      // butterfly over the 8 lanes of the group with DPP moves (no LDS crossbar): lane ^ 1, lane ^ 2 are quad permutations; after them the
+      // four lanes of a quad hold the same value, so the mirror within the half row (lane -> 7 - lane) delivers the other quad's sum
+      t += dpp_move<0xB1>(t);    // quad_perm:[1,0,3,2]
+      t += dpp_move<0x4E>(t);    // quad_perm:[2,3,0,1]
+      t += dpp_move<0x141>(t);   // row_half_mirror
       mine = (c == r) ? t : mine;
     }
     if (act && 8 * i + c < Nt) l.dxv[8 * i + c] = kf[rr] - mine;
