@@ -1317,6 +1317,10 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, dou
         }
         ok = F.factor() && ok;
         F.solve3(wL, wU, wf);
+        double dm[8];   // the entries of compact row e this lane updates, fetched before the products (nobody else writes them in this phase)
+#pragma unroll
+        for (int aa = 0; aa < 8; ++aa) dm[aa] = Dc[e * kBlk + aa * 8 + c];
+        const double fm = fc[e * 8 + c];
 #pragma unroll
         for (int aa = 0; aa < 8; ++aa) { o1[aa] = 0; o2[aa] = 0; o3[aa] = 0; }
 #pragma unroll
@@ -1343,8 +1347,8 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, dou
         }
         // fold into the compact rows e (= row i - 1) and e + 1 (= row i + 1); two phases: neighbouring eliminations share a row
 #pragma unroll
-        for (int aa = 0; aa < 8; ++aa) Dc[e * kBlk + aa * 8 + c] -= o1[aa];
-        fc[e * 8 + c] -= s1;
+        for (int aa = 0; aa < 8; ++aa) Dc[e * kBlk + aa * 8 + c] = dm[aa] - o1[aa];
+        fc[e * 8 + c] = fm - s1;
         if (hasU) {
 #pragma unroll
           for (int aa = 0; aa < 8; ++aa) Lc[(e + 1) * kBlk + aa * 8 + c] = o2[aa];
