@@ -1,6 +1,6 @@
 """bitwise fingerprint of the optimised headline bands of a build (TEB_AMD_LIB=...)"""
-import sys, hashlib, numpy as np
-sys.path.insert(0, "/root/repo")
+import os, sys, hashlib, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from teb_local_planner_amd import planner, scenes
 for name, mk in (("c4on", lambda: scenes.scene_c4(stride=288)), ("c2", lambda: scenes.scene_c2(stride=208))):
     cfg, obst, via, batch = mk()
