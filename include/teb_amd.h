@@ -234,7 +234,7 @@ void teb_amd_config_default(teb_amd_config_t* cfg);   /* TebConfig::TebConfig(),
  */
 enum { TEB_AMD_LAYOUT_AUTO = 0,        /* by capacity and obstacle count, and per launch by the current pose counts (see create) */
        TEB_AMD_LAYOUT_BLOCKS_LDS = 1,  /* normal matrix as 8x8 blocks in LDS, cyclic reduction in place (<= 238 poses)           */
-       TEB_AMD_LAYOUT_BAND_LDS = 2,    /* band in LDS, cyclic reduction on HBM-resident blocks (<= 343 poses)                   */
+       TEB_AMD_LAYOUT_BAND_LDS = 2,    /* band in LDS, cyclic reduction: level 0 from a band copy in HBM (<= 343 poses)         */
        TEB_AMD_LAYOUT_BAND_HBM = 3 };  /* band in HBM as well (<= 512 poses)                                                    */
 enum { TEB_AMD_HSIG3D_AUTO = 0, TEB_AMD_HSIG3D_WIDE = 1, TEB_AMD_HSIG3D_SMALL = 2 };
 typedef struct teb_amd_options {

@@ -144,7 +144,7 @@ struct teb_amd_handle {
   size_t lds_bytes = 0;
   int solver = 0, solver_created = 0;   // solver_created: the choice of teb_amd_create; teb_amd_set_obstacles may move a band to HBM
   size_t hmat_stride = 0;
-  int band_ldlt = 0;   // SOLVER_BAND: 1 = sequential banded LDL^T (TEB_AMD_BAND_SOLVE=ldlt), 0 = cyclic reduction on HBM blocks
+  int band_ldlt = 0;   // SOLVER_BAND: 1 = sequential banded LDL^T (teb_amd_options_t::band_ldlt), 0 = hybrid cyclic reduction
   size_t lds_limit = 0;
   LdsPlan plan;
   int fast_points = 0;
@@ -432,8 +432,8 @@ int teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max
   HIPCHK(hipSetDevice(device));
   // Normal matrix as 8x8 blocks in LDS (SOLVER_CR: cyclic reduction in place, fastest) when that fits TOGETHER with the LDS cache
   // of a full obstacle table of max_obstacles point-like entries; otherwise as a band in LDS (SOLVER_BAND: 44 instead of 70
-  // doubles per pose) with the cyclic reduction on HBM-resident blocks - ~15 % slower per step, but it keeps the obstacle cache
-  // and holds bands up to 343 poses.
+  // doubles per pose) with the hybrid cyclic reduction (level 0 from a band-form copy in HBM) - within 2 % of the block layout
+  // per step, keeps the obstacle cache and holds bands up to 343 poses.
   int solver = SOLVER_CR;
   // the kernel also owns a little static LDS (__syncthreads_or scratch): keep 1 KiB of head-room
   const size_t lds_limit = (size_t)prop.sharedMemPerBlock - 1024;

@@ -96,7 +96,7 @@ struct OptArgs {
   int alt_time;
   double* Hband;         // SOLVER_BANDG: per-band normal matrix in band form in HBM, hband_stride doubles each
   size_t hband_stride;
-  int band_ldlt;         // SOLVER_BAND only: 1 = sequential banded LDL^T in LDS (v1), 0 = cyclic reduction on HBM-resident blocks
+  int band_ldlt;         // SOLVER_BAND only: 1 = sequential banded LDL^T in LDS (v1), 0 = hybrid cyclic reduction (cr_solve_hybrid)
   int no_near_cache;     // teb_amd_options_t::no_near_cache
   int debug_linearize;   // test hook: stop after the first linearisation and dump H, b, chi2 categories
   double debug_weight_multiplier;

@@ -42,8 +42,9 @@ __device__ long long g_lin_prof[16];  // thread 0 of workgroup 0: sections of li
 #define LNP(k)
 #endif
 // Storage formats of the normal matrix (selected per handle by the pose capacity S and the obstacle cache):
-//   SOLVER_BAND : Hb[4S][11] lower band in LDS (S <= 343); solved by cyclic reduction on HBM-resident 8x8 blocks expanded from it
-//                 (or, TEB_AMD_BAND_SOLVE=ldlt, by the sequential in-LDS LDL^T of wave 0)
+//   SOLVER_BAND : Hb[4S][11] lower band in LDS (S <= 343); solved by the hybrid cyclic reduction (cr_solve_hybrid: level 0 from a
+//                 band-form copy in HBM into a compact even-row system in LDS) or, teb_amd_options_t::band_ldlt, by the sequential
+//                 in-LDS LDL^T of wave 0
 //   SOLVER_BANDG: the same band in a per-band HBM buffer (S <= 512, or when the obstacle cache would not fit beside the LDS band)
 //   SOLVER_CR   : block-tridiagonal in 8x8 blocks (two 4-scalar pose groups per block row): D_j (full, symmetric)
 //                 and L_j (coupling to block row j-1), solved by block cyclic reduction with all 256 threads
@@ -1060,19 +1061,19 @@ __device__ __forceinline__ void cr_backward(const double* __restrict__ D, const 
   }
 }
 
-// Out of line by default: measured on MI355X (C4 step, 3 runs each) 4.72 ms vs 4.82 ms inlined. The price of the call is the
-// callee-saved VGPR block it spills and reloads (~1.9 GB of scratch traffic per launch, absorbed by L2 / MALL and off the critical
-// path); -DTEB_AMD_INLINE_SOLVE builds the inlined variant (HBM traffic 3.5 -> 1.6 GB per launch, 2 % slower).
+// Out of line by default: measured on MI355X (headline step, round 2) 3.72 ms vs 4.39 ms inlined. The price of the call is the
+// callee-saved register block it spills and reloads (~ 980 B per lane and call: 5 of the 7.8 GB of fabric traffic per launch);
+// -DTEB_AMD_INLINE_SOLVE builds the inlined variant (4.1 GB per launch, 18 % slower: it spills inside the loops instead).
 #ifdef TEB_AMD_INLINE_SOLVE
 #define TEB_SOLVE_LINKAGE __forceinline__
 #else
 #define TEB_SOLVE_LINKAGE __noinline__
 #endif
 // GLOBAL == false: the blocks are the LDS-resident normal matrix (SOLVER_CR), which the solve destroys.
-// GLOBAL == true : the normal matrix stays in LDS in band form (SOLVER_BAND, bands too long for the block layout); its 8x8
-//                  blocks (+ lambda) are expanded into a per-band HBM buffer (L2-resident: ~70 doubles per pose) and the same
-//                  reduction runs there - log2(n/2) levels of round trips to L2 instead of 4n sequential pivots, and no
-//                  backup / restore of H since the band is never touched.
+// GLOBAL == true : the normal matrix is a band in HBM (SOLVER_BANDG, bands too long for any LDS layout); its 8x8 blocks (+ lambda)
+//                  are expanded into a per-band HBM buffer (L2-resident: ~70 doubles per pose) and the same reduction runs there -
+//                  fine levels as round trips to L2, coarse levels on a compact copy in LDS; no backup / restore of H since the
+//                  band is never touched.
 template <bool GLOBAL, bool HB_GLOBAL>
 __device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, const SceneDev& sc, int n, double lambda, double* gbuf, double* gH) {
   TEB_SOLVER_FMA
@@ -1217,15 +1218,16 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, const SceneDev&
 }
 
 // ---- damped solve (K6 v4, "hybrid"): for bands whose block layout does not fit the LDS (SOLVER_BAND) ------------------------------------
-// The normal matrix is linearised into the LDS band. ONCE per LM iteration its 8x8 blocks are expanded into the band's HBM scratch
-// (read-only from then on, lambda-free); the band region of the LDS is dead until the next linearisation. Every damped trial then runs
-//   level 0: the odd block rows are eliminated straight from the HBM blocks (+ lambda on the fly; loads only, no read-modify-write on
-//            HBM) INTO a compact system of the even rows built in the former band region of the LDS (35 S <= 44 S doubles),
-//            their (W_L, W_U, P f) records stay in registers;
+// The normal matrix is linearised into the LDS band. ONCE per LM iteration the band is copied as it is into the band's HBM scratch
+// (cr_copy_band: coalesced, read-only from then on, lambda-free, L2-resident); the band region of the LDS is dead until the next
+// linearisation. Every damped trial then runs
+//   level 0: the odd block rows are eliminated straight from that copy (only the structurally non-zero entries are gathered, + lambda
+//            on the fly; loads only, no read-modify-write on HBM) INTO a compact system of the even rows built in the former band
+//            region of the LDS (35 S <= 44 S doubles), their (W_L, W_U, P f) records stay in registers;
 //   levels >= 1, top solve, back substitution of the even rows: the in-LDS block cyclic reduction (cr_forward / cr_top / cr_backward);
 //   back substitution of the odd rows from those records.
 // Same arithmetic as cr_solve_t (an exact re-indexing: compact row j' = row 2 j'); no backup / restore of H, no obstacle-cache reload.
-// gbuf: D [Nb * kBlk] | L [Nb * kBlk]
+// gbuf: the band copy, [8 Nb][kBand]
 // the band as it stands in LDS -> the band's HBM scratch, rows [0, 8 Nb): a coalesced copy (101 KB at 287 poses; 32 bands per XCD stay
 // inside the 4 MB L2); the padding rows of an odd pose count become identity rows
 __device__ __forceinline__ void cr_copy_band(const Lds& l, int n, double* __restrict__ gband) {
