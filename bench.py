@@ -41,13 +41,19 @@ def alg_bytes_per_unit(n, M, e_assoc, inner):
     return 64 * n + r_obst + 4 * e_assoc + 32 + (32 * n + r_obst + 4 * e_assoc) / inner
 
 
-def kernel_source_hash():
-    """sha256 over the device sources: ties a committed rocprof summary to the binary it was taken from."""
+def kernel_source_hash(root=None):
+    """sha256 over the device sources with comments and white space stripped (a comment edit does not make a new binary): ties a
+    committed rocprof summary to the binary it was taken from."""
+    import re
     h = hashlib.sha256()
-    d = os.path.join(ROOT, "teb_local_planner_amd", "csrc")
+    d = os.path.join(root or ROOT, "teb_local_planner_amd", "csrc")
     for f in sorted(os.listdir(d)):
         if f.endswith((".hip", ".hpp")):
-            h.update(open(os.path.join(d, f), "rb").read())
+            src = open(os.path.join(d, f), "r", errors="replace").read()
+            src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)      # block comments
+            src = re.sub(r"//[^\n]*", "", src)                   # line comments (no string literal of the sources holds "//")
+            h.update(f.encode())
+            h.update("".join(src.split()).encode())
     return h.hexdigest()[:16]
 
 
