@@ -109,6 +109,13 @@ struct Accum {
   // one residual row: e, information w, gradient row r (only columns with bit set in MASK can be non-zero)
   template <unsigned MASK, bool JAC>
   __device__ __forceinline__ void row(int cat, double e, double w, const double* r) {
+    // The accumulation (and only it) may fuse a*b+c into v_fma_f64: the residual e and the Jacobian row r - everything that decides on
+    // which side of a penalty kink a value falls - are computed by the caller under -ffp-contract=off; what is summed here has no
+    // bit-level counterpart in the reference (g2o adds the edges in another order). -DTEB_AMD_NO_ROW_FMA: separate mul / add
+    // (C4 with 200 fixed poses + 5 %, C2 / C3 + 3 %, headline + 2 %).
+#ifndef TEB_AMD_NO_ROW_FMA
+    _Pragma("clang fp contract(fast)")
+#endif
     chi[cat] += e * (w * e);
     if (JAC) {
 #pragma unroll
