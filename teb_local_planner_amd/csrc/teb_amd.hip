@@ -280,6 +280,27 @@ int max_capacity_of(teb_amd_handle* h, int solver, int upto) {
   return (size_t)make_lds_plan(S, solver, ob).total_bytes <= h->lds_limit ? S : 0;
 }
 
+// the four strips and the pose counts in ONE launch (five copy commands cost more in launch gaps than in bytes: 2.4 MB at the headline)
+__global__ void __launch_bounds__(256) copy_state_kernel(double* __restrict__ x, double* __restrict__ y, double* __restrict__ th,
+                                                         double* __restrict__ dt, int* __restrict__ n, const double* __restrict__ sx,
+                                                         const double* __restrict__ sy, const double* __restrict__ sth,
+                                                         const double* __restrict__ sdt, const int* __restrict__ sn, size_t count, int B) {
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += step) {
+    x[i] = sx[i]; y[i] = sy[i]; th[i] = sth[i]; dt[i] = sdt[i];
+    if (i < (size_t)B) n[i] = sn[i];
+  }
+}
+struct Strips { double *x, *y, *th, *dt; int* n; };
+static int copy_strips(teb_amd_handle_t* h, const Strips& dst, const Strips& src, int bands) {
+  const size_t count = (size_t)bands * h->stride;   // >= bands
+  const int grid = (int)std::min<size_t>(2048, (count + 255) / 256);
+  hipLaunchKernelGGL(copy_state_kernel, dim3(grid), dim3(256), 0, h->stream, dst.x, dst.y, dst.th, dst.dt, dst.n, src.x, src.y, src.th,
+                     src.dt, src.n, count, bands);
+  HIPCHK(hipGetLastError());
+  return TEB_AMD_OK;
+}
+
 int launch(teb_amd_handle* h, const OptArgs& args) {
   if (h->B <= 0) return fail(TEB_AMD_ERR_INVALID_ARG, "no TEBs uploaded");
   SceneDev sc = scene_of(h);
@@ -314,15 +335,9 @@ int launch(teb_amd_handle* h, const OptArgs& args) {
       HIPCHK(h->ob_x.alloc(BS)); HIPCHK(h->ob_y.alloc(BS)); HIPCHK(h->ob_th.alloc(BS)); HIPCHK(h->ob_dt.alloc(BS)); HIPCHK(h->ob_n.alloc(h->max_tebs));
       h->opt_backup_ready = true;
     }
-    const size_t bytes = (size_t)h->B * h->stride * sizeof(double);
-    HIPCHK(hipMemcpyAsync(h->ob_x.p, h->x.p, bytes, hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->ob_y.p, h->y.p, bytes, hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->ob_th.p, h->th.p, bytes, hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->ob_dt.p, h->dt.p, bytes, hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->ob_n.p, h->n.p, h->B * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+    if (int crc = copy_strips(h, Strips{h->ob_x.p, h->ob_y.p, h->ob_th.p, h->ob_dt.p, h->ob_n.p}, Strips{h->x.p, h->y.p, h->th.p, h->dt.p, h->n.p}, h->B)) return crc;
   }
-  HIPCHK(hipMemsetAsync(h->assoc_ovf.p, 0, sizeof(int) * h->max_tebs, h->stream));
-  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  HIPCHK(hipEventRecord(h->ev0, h->stream));   // (the kernel clears its bands' overflow flags itself)
   launch_opt(h, h->B, sc, bt, args, eff_solver, eff_plan);
   if (optimistic) {
     HIPCHK(hipGetLastError());
@@ -336,13 +351,7 @@ int launch(teb_amd_handle* h, const OptArgs& args) {
     h->nmax_known = 0;
     for (int v : nn) h->nmax_known = std::max(h->nmax_known, v);
     if (outgrown) {
-      const size_t bytes = (size_t)h->B * h->stride * sizeof(double);
-      HIPCHK(hipMemcpyAsync(h->x.p, h->ob_x.p, bytes, hipMemcpyDeviceToDevice, h->stream));
-      HIPCHK(hipMemcpyAsync(h->y.p, h->ob_y.p, bytes, hipMemcpyDeviceToDevice, h->stream));
-      HIPCHK(hipMemcpyAsync(h->th.p, h->ob_th.p, bytes, hipMemcpyDeviceToDevice, h->stream));
-      HIPCHK(hipMemcpyAsync(h->dt.p, h->ob_dt.p, bytes, hipMemcpyDeviceToDevice, h->stream));
-      HIPCHK(hipMemcpyAsync(h->n.p, h->ob_n.p, h->B * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
-      HIPCHK(hipMemsetAsync(h->assoc_ovf.p, 0, sizeof(int) * h->max_tebs, h->stream));
+      if (int crc = copy_strips(h, Strips{h->x.p, h->y.p, h->th.p, h->dt.p, h->n.p}, Strips{h->ob_x.p, h->ob_y.p, h->ob_th.p, h->ob_dt.p, h->ob_n.p}, h->B)) return crc;
       launch_opt(h, h->B, sc, bt, args);   // ev0 stays where it was: the reported time includes the discarded first launch
       h->nmax_known = -1;
     }
@@ -1792,12 +1801,7 @@ int teb_amd_device_state(teb_amd_handle_t* h, void** x, void** y, void** theta, 
 int teb_amd_snapshot_state(teb_amd_handle_t* h) {
   int rc = check_handle(h);
   if (rc) return rc;
-  const size_t BS = (size_t)h->max_tebs * h->stride * sizeof(double);
-  HIPCHK(hipMemcpyAsync(h->snap_x.p, h->x.p, BS, hipMemcpyDeviceToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->snap_y.p, h->y.p, BS, hipMemcpyDeviceToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->snap_th.p, h->th.p, BS, hipMemcpyDeviceToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->snap_dt.p, h->dt.p, BS, hipMemcpyDeviceToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->snap_n.p, h->n.p, h->max_tebs * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+  if ((rc = copy_strips(h, Strips{h->snap_x.p, h->snap_y.p, h->snap_th.p, h->snap_dt.p, h->snap_n.p}, Strips{h->x.p, h->y.p, h->th.p, h->dt.p, h->n.p}, h->max_tebs))) return rc;
   h->snap_nmax = h->nmax_known;
   return TEB_AMD_OK;
 }
@@ -1805,12 +1809,7 @@ int teb_amd_snapshot_state(teb_amd_handle_t* h) {
 int teb_amd_restore_state(teb_amd_handle_t* h) {
   int rc = check_handle(h);
   if (rc) return rc;
-  const size_t BS = (size_t)h->max_tebs * h->stride * sizeof(double);
-  HIPCHK(hipMemcpyAsync(h->x.p, h->snap_x.p, BS, hipMemcpyDeviceToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->y.p, h->snap_y.p, BS, hipMemcpyDeviceToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->th.p, h->snap_th.p, BS, hipMemcpyDeviceToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->dt.p, h->snap_dt.p, BS, hipMemcpyDeviceToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->n.p, h->snap_n.p, h->max_tebs * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+  if ((rc = copy_strips(h, Strips{h->x.p, h->y.p, h->th.p, h->dt.p, h->n.p}, Strips{h->snap_x.p, h->snap_y.p, h->snap_th.p, h->snap_dt.p, h->snap_n.p}, h->max_tebs))) return rc;
   h->consumers_valid = false; h->nmax_known = h->snap_nmax;
   h->hsig_mode = 0;   // the bands change: signatures of an earlier teb_amd_compute_h_signatures call are stale
   return TEB_AMD_OK;

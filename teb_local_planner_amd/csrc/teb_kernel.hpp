@@ -1968,6 +1968,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     l.sx[i] = bt.x[so + i]; l.sy[i] = bt.y[so + i]; l.sth[i] = bt.th[so + i];
     l.sdt[i] = (i < n - 1) ? bt.dt[so + i] : 0.0;
   }
+  if (tid == 0) bt.assoc_overflow[b] = 0;   // this band's flags (only this workgroup touches them): no memset command per launch
   __syncthreads();
 
   TebCtx t;
