@@ -1952,6 +1952,9 @@ int teb_amd_debug_profile(teb_amd_handle_t* h, double* cycles8) {
             8 << w, crw[w * 8 + 0], crw[w * 8 + 1], crw[w * 8 + 2], crw[w * 8 + 3], crw[w * 8 + 4], crw[w * 8 + 5], crw[w * 8 + 6]);
   fprintf(stderr, "[cr_solve cycles, workgroup 0, cumulative; hybrid solve: init compact | level 0 | compact forward | top + backward | odd rows] %lld %lld %lld %lld %lld %lld\n",
           crp[0], crp[1], crp[2], crp[3], crp[4], crp[5]);
+  unsigned long long ast[4];
+  HIPCHK(hipMemcpyFromSymbol(ast, HIP_SYMBOL(tebamd::g_assoc_stats), sizeof ast));
+  fprintf(stderr, "[association of generic shapes, all workgroups, cumulative] %llu candidates after the far-field cull, %llu exact distances\n", ast[0], ast[1]);
   unsigned long long ars[4];
   HIPCHK(hipMemcpyFromSymbol(ars, HIP_SYMBOL(tebamd::g_ar_steps), sizeof ars));
   fprintf(stderr, "[autoResize rule machine, workgroup 0, cumulative] %llu calls, %llu steps, %llu cycles\n", ars[2], ars[1], ars[3]);

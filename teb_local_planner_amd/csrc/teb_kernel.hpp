@@ -30,6 +30,7 @@ namespace tebamd {
 __device__ long long g_ev_prof[8];   // thread 1 (pose 1) of workgroup 0: evaluate {static, dynamic, chain}, linearise {static, dynamic, chain}, trig, scatter
 #define EVP_DECL long long evp_t0 = clock64(), evp_t1;
 #define EVP(k) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); evp_t1 = clock64(); __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && threadIdx.x == 1) g_ev_prof[k] += evp_t1 - evp_t0; evp_t0 = evp_t1; } while (0)
+__device__ unsigned long long g_assoc_stats[4];   // generic association: candidates after the far-field cull, exact distances computed
 __device__ unsigned long long g_ar_steps[4];   // autoResize machine, workgroup 0: -, steps, calls, cycles
 __device__ unsigned long long g_near_recomputed, g_near_queries;   // lanes that recomputed their near mask / that asked for it
 __device__ long long g_lin_prof[16];  // thread 0 of workgroup 0: sections of linearize()
@@ -204,12 +205,31 @@ struct TebCtx {
   int has_vs, has_vg, rotdir, via_en;
   double vs[3], vg[3];
   double w_obst;       // weight_obstacle * weight_multiplier
+  double frad;         // the robot lies within frad of its pose (footprint_bound_radius)
   bool inflated;
   const int* assoc_cnt;   // + b*stride
   const int* assoc;       // + b*cap*stride
   const int* via_pose;    // + b*via_cap
   int stride;
 };
+
+// radius of a circle about the pose that contains the robot, whatever its heading (bounding-circle culling of the generic shapes)
+__device__ __forceinline__ double footprint_bound_radius(const teb_amd_config_t& c) {
+  double frad = 0;
+  if (c.footprint_type == TEB_AMD_FOOTPRINT_CIRCULAR) frad = c.footprint_radius;
+  else if (c.footprint_type == TEB_AMD_FOOTPRINT_TWO_CIRCLES)
+    frad = fmax(fabs(c.footprint_front_offset) + c.footprint_front_radius, fabs(c.footprint_rear_offset) + c.footprint_rear_radius);
+  else if (c.footprint_type == TEB_AMD_FOOTPRINT_LINE || c.footprint_type == TEB_AMD_FOOTPRINT_POLYGON)
+    for (int v = 0; v < c.footprint_n_vertices; ++v) frad = fmax(frad, sqrt(c.footprint_vx[v] * c.footprint_vx[v] + c.footprint_vy[v] * c.footprint_vy[v]));
+  return frad;
+}
+// lower bound of calculateDistance(pose, obstacle) from the two bounding circles, shrunk by a guard band against its own rounding
+// (NaN / infinite bounds compare false everywhere: such an obstacle is never culled)
+__device__ __forceinline__ double distance_lower_bound(const SceneDev& sc, int oi, double x, double y, double frad) {
+  const double bx = sc.cx[oi] - x, by = sc.cy[oi] - y;
+  const double lbd = sqrt(bx * bx + by * by) - sc.brad[oi] - frad;
+  return lbd - 1e-9 * (fabs(lbd) + sc.brad[oi] + frad + 1.0);
+}
 
 // All cost terms whose first vertex is pose i / timediff i (0 <= i <= n-2). JAC=true also accumulates
 // J^T Omega J and J^T Omega e into the thread-local window accumulator.
@@ -409,12 +429,27 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
         }
       }
     } else {
-      for (int k = sl; k < cnt; k += nsl) {
-        const int ent = t.assoc[(size_t)k * t.stride + i];
-        const int oi = sc.static_idx[ent & kAssocMask];
+      // An obstacle whose bounding circle stays clear of the robot's by more than every penalty bound has residuals and Jacobians that
+      // are exactly zero (penalties.h:75-87): its exact distance - polygon against polygon - is not computed (the nearest left / right
+      // obstacle of a pose is usually such a one)
+      // Pass 1 marks the entries that are not clear (cheap, every lane busy); pass 2 walks each lane's marks in list order: the exact
+      // distances are paid per marked entry, not per list position at which some lane of the wave happens to hold a marked one.
+      const double clear_d = fmax(c.min_obstacle_dist + c.penalty_epsilon, t.inflated ? c.inflation_dist : 0.0) + (MODE == 2 ? 1e-6 : 0.0);
+      for (int kb = sl; kb < cnt; kb += 64 * nsl) {
+        unsigned long long todo = 0;
+        for (int q = 0, k = kb; q < 64 && k < cnt; ++q, k += nsl) {
+          const int oi = sc.static_idx[t.assoc[(size_t)k * t.stride + i] & kAssocMask];
+          if (!(distance_lower_bound(sc, oi, w.x0, w.y0, t.frad) >= clear_d)) todo |= 1ull << q;
+        }
+        while (todo) {
+          const int k = kb + (__ffsll((long long)todo) - 1) * nsl;
+          todo &= todo - 1;
+          const int ent = t.assoc[(size_t)k * t.stride + i];
+          const int oi = sc.static_idx[ent & kAssocMask];
 #pragma unroll 1
-        for (int rep = (ent & kAssocTriple) ? 3 : 1; rep > 0; --rep)
-          TEB_EDGE(M_POSE0, CAT_OBST, edge_obstacle<J_>(c, sc, oi, W, t.w_obst, t.inflated, ACC_));
+          for (int rep = (ent & kAssocTriple) ? 3 : 1; rep > 0; --rep)
+            TEB_EDGE(M_POSE0, CAT_OBST, edge_obstacle<J_>(c, sc, oi, W, t.w_obst, t.inflated, ACC_));
+        }
       }
       if (c.include_dynamic_obstacles && c.weight_obstacle != 0) {
         const double ti = l.tdyn[i];
@@ -1764,12 +1799,7 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
     // Generic shapes: the same two passes with bounding circles. The robot lies within frad of the pose, the obstacle within brad of its
     // centroid, so their distance is at least |centroid - pose| - brad - frad; beyond max(cutoff, force) (+ guard band) the obstacle
     // cannot matter and its exact distance (segment / polygon loops, the expensive part: 75 % of BASELINE C5 before) is never computed.
-    double frad = 0;
-    if (c.footprint_type == TEB_AMD_FOOTPRINT_CIRCULAR) frad = c.footprint_radius;
-    else if (c.footprint_type == TEB_AMD_FOOTPRINT_TWO_CIRCLES)
-      frad = fmax(fabs(c.footprint_front_offset) + c.footprint_front_radius, fabs(c.footprint_rear_offset) + c.footprint_rear_radius);
-    else if (c.footprint_type == TEB_AMD_FOOTPRINT_LINE || c.footprint_type == TEB_AMD_FOOTPRINT_POLYGON)
-      for (int v = 0; v < c.footprint_n_vertices; ++v) frad = fmax(frad, sqrt(c.footprint_vx[v] * c.footprint_vx[v] + c.footprint_vy[v] * c.footprint_vy[v]));
+    const double frad = footprint_bound_radius(c);
     const double far_d = fmax(cutoff, force) + frad;
     for (; k0 < k_hi; k0 += 64) {
       const int ke = k0 + 64 < k_hi ? k0 + 64 : k_hi;
@@ -1786,6 +1816,18 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
         const int k = k0 + __ffsll((long long)near) - 1;
         near &= near - 1;
         const int oi = sc.static_idx[k];
+        // The same bound decides most candidates without their exact distance: one that is certainly not force-included (bound >= force)
+        // and certainly not closer than the nearest obstacle found so far on its side (bound >= that minimum; the scan keeps the FIRST
+        // minimum, so an equal distance would not replace it either) leaves the scan's state untouched.
+        const double lb = distance_lower_bound(sc, oi, x, y, frad);
+        const bool on_left = ox_ * (sc.cy[oi] - y) - (sc.cx[oi] - x) * oy_ > 0;
+#ifdef TEB_PROFILE
+        atomicAdd(&g_assoc_stats[0], 1ull);
+#endif
+        if (lb >= force && lb >= (on_left ? r.left_min : r.right_min)) continue;
+#ifdef TEB_PROFILE
+        atomicAdd(&g_assoc_stats[1], 1ull);
+#endif
         const double dist = footprint_distance(c, sc, oi, x, y, ox_, oy_, false, 0.0, nullptr);
         visit(k, dist, sc.cx[oi], sc.cy[oi]);
       }
@@ -1977,6 +2019,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
 #pragma unroll
   for (int q = 0; q < 3; ++q) { t.vs[q] = bt.vs[3 * b + q]; t.vg[q] = bt.vg[3 * b + q]; }
   t.inflated = c.inflation_dist > c.min_obstacle_dist;
+  t.frad = footprint_bound_radius(c);
   int* assoc_cnt = bt.assoc_cnt + so;
   int* assoc = bt.assoc + (size_t)b * bt.assoc_cap * S;
   int* via_pose = bt.via_pose + (size_t)b * bt.via_cap;
