@@ -205,7 +205,6 @@ struct TebCtx {
   int has_vs, has_vg, rotdir, via_en;
   double vs[3], vg[3];
   double w_obst;       // weight_obstacle * weight_multiplier
-  double frad;         // the robot lies within frad of its pose (footprint_bound_radius)
   bool inflated;
   const int* assoc_cnt;   // + b*stride
   const int* assoc;       // + b*cap*stride
@@ -429,27 +428,12 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
         }
       }
     } else {
-      // An obstacle whose bounding circle stays clear of the robot's by more than every penalty bound has residuals and Jacobians that
-      // are exactly zero (penalties.h:75-87): its exact distance - polygon against polygon - is not computed (the nearest left / right
-      // obstacle of a pose is usually such a one)
-      // Pass 1 marks the entries that are not clear (cheap, every lane busy); pass 2 walks each lane's marks in list order: the exact
-      // distances are paid per marked entry, not per list position at which some lane of the wave happens to hold a marked one.
-      const double clear_d = fmax(c.min_obstacle_dist + c.penalty_epsilon, t.inflated ? c.inflation_dist : 0.0) + (MODE == 2 ? 1e-6 : 0.0);
-      for (int kb = sl; kb < cnt; kb += 64 * nsl) {
-        unsigned long long todo = 0;
-        for (int q = 0, k = kb; q < 64 && k < cnt; ++q, k += nsl) {
-          const int oi = sc.static_idx[t.assoc[(size_t)k * t.stride + i] & kAssocMask];
-          if (!(distance_lower_bound(sc, oi, w.x0, w.y0, t.frad) >= clear_d)) todo |= 1ull << q;
-        }
-        while (todo) {
-          const int k = kb + (__ffsll((long long)todo) - 1) * nsl;
-          todo &= todo - 1;
-          const int ent = t.assoc[(size_t)k * t.stride + i];
-          const int oi = sc.static_idx[ent & kAssocMask];
+      for (int k = sl; k < cnt; k += nsl) {
+        const int ent = t.assoc[(size_t)k * t.stride + i];
+        const int oi = sc.static_idx[ent & kAssocMask];
 #pragma unroll 1
-          for (int rep = (ent & kAssocTriple) ? 3 : 1; rep > 0; --rep)
-            TEB_EDGE(M_POSE0, CAT_OBST, edge_obstacle<J_>(c, sc, oi, W, t.w_obst, t.inflated, ACC_));
-        }
+        for (int rep = (ent & kAssocTriple) ? 3 : 1; rep > 0; --rep)
+          TEB_EDGE(M_POSE0, CAT_OBST, edge_obstacle<J_>(c, sc, oi, W, t.w_obst, t.inflated, ACC_));
       }
       if (c.include_dynamic_obstacles && c.weight_obstacle != 0) {
         const double ti = l.tdyn[i];
@@ -2019,7 +2003,6 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
 #pragma unroll
   for (int q = 0; q < 3; ++q) { t.vs[q] = bt.vs[3 * b + q]; t.vg[q] = bt.vg[3 * b + q]; }
   t.inflated = c.inflation_dist > c.min_obstacle_dist;
-  t.frad = footprint_bound_radius(c);
   int* assoc_cnt = bt.assoc_cnt + so;
   int* assoc = bt.assoc + (size_t)b * bt.assoc_cap * S;
   int* via_pose = bt.via_pose + (size_t)b * bt.via_cap;
