@@ -1800,9 +1800,12 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
         const int k = k0 + __ffsll((long long)near) - 1;
         near &= near - 1;
         const int oi = sc.static_idx[k];
+#ifdef TEB_AMD_GENERIC_ASSOC_PRUNE
         // The same bound decides most candidates without their exact distance: one that is certainly not force-included (bound >= force)
         // and certainly not closer than the nearest obstacle found so far on its side (bound >= that minimum; the scan keeps the FIRST
-        // minimum, so an equal distance would not replace it either) leaves the scan's state untouched.
+        // minimum, so an equal distance would not replace it either) leaves the scan's state untouched. Bit-identical, C5 14.1 -> 12.9 ms
+        // (25 -> 10 exact distances per pose), but OFF by default: with these lines in the kernel the point-like configurations run
+        // 1.5 % slower (the branch is never taken there: code layout / register allocation; same-box A/B of full builds, three times).
         const double lb = distance_lower_bound(sc, oi, x, y, frad);
         const bool on_left = ox_ * (sc.cy[oi] - y) - (sc.cx[oi] - x) * oy_ > 0;
 #ifdef TEB_PROFILE
@@ -1811,6 +1814,7 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
         if (lb >= force && lb >= (on_left ? r.left_min : r.right_min)) continue;
 #ifdef TEB_PROFILE
         atomicAdd(&g_assoc_stats[1], 1ull);
+#endif
 #endif
         const double dist = footprint_distance(c, sc, oi, x, y, ox_, oy_, false, 0.0, nullptr);
         visit(k, dist, sc.cx[oi], sc.cy[oi]);
