@@ -292,6 +292,18 @@ int  teb_amd_synchronize(teb_amd_handle_t* h);
 int  teb_amd_get_results(teb_amd_handle_t* h, teb_amd_results_t* out);   /* synchronises, copies D2H */
 
 /*
+ * Per-iteration log of the Levenberg-Marquardt loop, opt-in - the data of the line g2o prints per iteration when the reference sets
+ * SparseOptimizer::setVerbose(cfg_->optim.optimization_verbose) (src/optimal_planner.cpp:384): "iteration= i chi2= .. lambda= ..
+ * levenbergIter= ..". Row r (4 doubles) of band b describes LM iteration r of the last teb_amd_optimize_batch, counted over all outer
+ * iterations: { chi^2 after the iteration (of the accepted state), lambda after it, damping trials the iteration took, pose count of
+ * the band in that outer iteration }. At most TEB_AMD_ITERATION_LOG_ROWS rows per band are kept. Off by default (one extra store per
+ * iteration and band when on). teb_amd_get_iteration_log synchronises; *n_rows = min(lm_iterations[b], capacity_rows, ROWS).
+ */
+#define TEB_AMD_ITERATION_LOG_ROWS 256
+int  teb_amd_set_iteration_log(teb_amd_handle_t* h, int32_t enable);
+int  teb_amd_get_iteration_log(teb_amd_handle_t* h, int32_t b, double* rows, int32_t capacity_rows, int32_t* n_rows);
+
+/*
  * selectBestTeb (src/homotopy_class_planner.cpp:564-667) on the device-resident costs:
  * cost[last_best] *= selection_cost_hysteresis, cost[initial_plan] *= selection_prefer_initial_plan
  * (indices < 0 = none), strict '<' so the lowest index wins ties; TEBs whose status != OK still take

@@ -46,6 +46,16 @@ int teb_amd_debug_stream(teb_amd_handle_t* h, int64_t n_doubles, int32_t repeats
  * TEB_AMD_ERR_UNSUPPORTED): C [16x16] = A [16x8, row-major] * B [8x16]; *cycles_per_mfma = clock ticks per issue on one wave. */
 int teb_amd_debug_mfma_selftest(teb_amd_handle_t* h, const double* A, const double* B, double* C, int32_t reps, double* cycles_per_mfma);
 
+/* The host-side reduction of teb_amd_select_best_distributed on its own (no GPU, no communicator): `records` = world x (cost, global
+ * index as double; index < 0 = that rank holds no candidate), as the all-gather delivers them. Lowest cost wins, ties go to the lowest
+ * global index (strict '<' of selectBestTeb, src/homotopy_class_planner.cpp:610). best_global = -1 when no rank has a candidate. */
+int teb_amd_debug_world_argmin(const double* records, int32_t world, int32_t* best_global, double* best_cost, int32_t* owner_rank);
+
+/* Overwrites the resident pose count of band b WITHOUT any check and without telling the host side (its cached upper bound of the
+ * counts stays as it was): reproduces a careless write through teb_amd_device_state's `n` pointer. The optimise kernel must refuse such
+ * a band (status FAILED, flag bit 1) instead of running off its LDS strips. */
+int teb_amd_debug_poke_pose_count(teb_amd_handle_t* h, int32_t b, int32_t n);
+
 /* per-TEB flags of the last launch: bit0 association list overflow, bit1 autoResize capacity overflow */
 int teb_amd_debug_assoc_overflow(teb_amd_handle_t* h, int32_t* flags);
 

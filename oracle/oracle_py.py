@@ -78,8 +78,9 @@ def _check(rc, what):
 
 
 def optimize_batch(cfg, obst, via, batch, inner=None, outer=None, compute_cost=True, obst_cost_scale=None,
-                   viapoint_cost_scale=None, alternative_time_cost=None, cost_mode=COST_REFERENCE, threads=1):
-    """Runs B x optimizeTEB on a COPY of batch; returns (new_batch, ResultsHost)."""
+                   viapoint_cost_scale=None, alternative_time_cost=None, cost_mode=COST_REFERENCE, threads=1, trace=False):
+    """Runs B x optimizeTEB on a COPY of batch; returns (new_batch, ResultsHost), with trace=True also the per-band LM traces
+    (list of [iterations, 4] arrays: chi2, lambda, damping trials, pose count per LM iteration)."""
     c = cfg.to_c()
     out = batch.copy()
     res = _abi.ResultsHost(batch.count)
@@ -91,11 +92,21 @@ def optimize_batch(cfg, obst, via, batch, inner=None, outer=None, compute_cost=T
     atc = cfg.hcp.selection_alternative_time_cost if alternative_time_cost is None else alternative_time_cost
     bs = out.c_struct()
     rs = res.c_struct()
-    rc = lib().teb_oracle_optimize_batch(
-        C.byref(c), C.byref(obst.freeze()), len(via), _abi._ptr(vx, C.c_double), _abi._ptr(vy, C.c_double),
-        C.byref(bs), inner, outer, int(compute_cost), float(osc), float(vsc), int(atc), cost_mode, threads,
-        C.byref(rs))
+    cap = max(1, int(inner) * int(outer))
+    if trace:
+        tbuf = np.zeros((batch.count, cap, 4)); trows = np.zeros(batch.count, np.int32)
+        lib().teb_oracle_set_trace(_abi._ptr(tbuf, C.c_double), cap, _abi._ptr(trows, C.c_int32))
+    try:
+        rc = lib().teb_oracle_optimize_batch(
+            C.byref(c), C.byref(obst.freeze()), len(via), _abi._ptr(vx, C.c_double), _abi._ptr(vy, C.c_double),
+            C.byref(bs), inner, outer, int(compute_cost), float(osc), float(vsc), int(atc), cost_mode, threads,
+            C.byref(rs))
+    finally:
+        if trace:
+            lib().teb_oracle_set_trace(None, 0, None)
     _check(rc, "teb_oracle_optimize_batch")
+    if trace:
+        return out, res, [tbuf[b, :trows[b]].copy() for b in range(batch.count)]
     return out, res
 
 

@@ -243,8 +243,9 @@ def h_signatures(cfg, obst, batch, mode, prescaler=1.0, threshold=0.1):
     return dict(sig=sig, equal=eq, valid=valid, reasonable=reas)
 
 
-def optimize_batch(cfg, obst, via, batch, inner=None, outer=None, compute_cost=True, threads=1):
-    """B x the reference's TebOptimalPlanner::optimizeTEB (thread per band, capped): (new_batch, ok [B], cost [B], lm_iterations [B])."""
+def optimize_batch(cfg, obst, via, batch, inner=None, outer=None, compute_cost=True, threads=1, trace=False):
+    """B x the reference's TebOptimalPlanner::optimizeTEB (thread per band, capped): (new_batch, ok [B], cost [B], lm_iterations [B]);
+    with trace=True also the per-band LM traces of the stand-in optimiser (list of [iterations, 4]: chi2, lambda, trials, pose count)."""
     c = cfg.to_c()
     out = batch.copy()
     bs = out.c_struct()
@@ -254,11 +255,21 @@ def optimize_batch(cfg, obst, via, batch, inner=None, outer=None, compute_cost=T
     B = batch.count
     ok = np.zeros(B, np.int32); cost = np.zeros(B); it = np.zeros(B, np.int32)
     I = lambda a: _abi._ptr(a, C.c_int32)
-    rc = lib().ref_optimize_batch(C.byref(c), C.byref(obst.freeze()), len(via), _P(vx), _P(vy), C.byref(bs), int(inner), int(outer),
-                                  int(compute_cost), C.c_double(cfg.hcp.selection_obst_cost_scale),
-                                  C.c_double(cfg.hcp.selection_viapoint_cost_scale), int(cfg.hcp.selection_alternative_time_cost),
-                                  int(threads), I(ok), _P(cost), I(it))
+    cap = max(1, int(inner) * int(outer))
+    if trace:
+        tbuf = np.zeros((B, cap, 4)); trows = np.zeros(B, np.int32)
+        lib().ref_set_trace(_P(tbuf), cap, I(trows))
+    try:
+        rc = lib().ref_optimize_batch(C.byref(c), C.byref(obst.freeze()), len(via), _P(vx), _P(vy), C.byref(bs), int(inner), int(outer),
+                                      int(compute_cost), C.c_double(cfg.hcp.selection_obst_cost_scale),
+                                      C.c_double(cfg.hcp.selection_viapoint_cost_scale), int(cfg.hcp.selection_alternative_time_cost),
+                                      int(threads), I(ok), _P(cost), I(it))
+    finally:
+        if trace:
+            lib().ref_set_trace(None, 0, None)
     assert rc == 0, rc
+    if trace:
+        return out, ok, cost, it, [tbuf[b, :trows[b]].copy() for b in range(B)]
     return out, ok, cost, it
 
 

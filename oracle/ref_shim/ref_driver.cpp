@@ -411,6 +411,15 @@ int ref_h_signatures(const teb_amd_config_t* acfg, const teb_amd_obstacles_t* o,
   return 0;
 }
 
+// trace of the LM loop (the stand-in's, shim_g2o.h) of the following ref_optimize_batch calls: buf [B][cap_rows][4], rows [B]; NULL = off
+static double* g_trace_buf = nullptr;
+static int g_trace_cap = 0;
+static int32_t* g_trace_rows = nullptr;
+int ref_set_trace(double* buf, int cap_rows, int32_t* rows) {
+  g_trace_buf = buf; g_trace_cap = cap_rows; g_trace_rows = rows;
+  return 0;
+}
+
 // B x TebOptimalPlanner::optimizeTEB of the reference, one std::thread per band capped at `threads` - the reference's own
 // optimizeAllTEBs uses one boost::thread per candidate (src/homotopy_class_planner.cpp:476-483). Used as the CPU baseline of bench.py.
 int ref_optimize_batch(const teb_amd_config_t* acfg, const teb_amd_obstacles_t* o, int n_via, const double* via_x, const double* via_y,
@@ -436,7 +445,10 @@ int ref_optimize_batch(const teb_amd_config_t* acfg, const teb_amd_obstacles_t* 
                    bt->vel_start ? bt->vel_start + 3 * b : nullptr, bt->has_vel_goal ? bt->has_vel_goal[b] : 1,
                    bt->vel_goal ? bt->vel_goal + 3 * b : nullptr, bt->prefer_rotdir ? bt->prefer_rotdir[b] : TEB_AMD_ROT_NONE);
       g2o::SparseOptimizer::iterationCounter() = 0;
+      g2o::SparseOptimizer::LmTrace& tr = g2o::SparseOptimizer::lmTrace();
+      if (g_trace_buf && g_trace_rows) { tr.buf = g_trace_buf + (size_t)b * g_trace_cap * 4; tr.cap = g_trace_cap; tr.rows = g_trace_rows + b; g_trace_rows[b] = 0; }
       const bool ok = pl.optimizeTEB(inner, outer, compute_cost != 0, osc, vsc, atc != 0);
+      tr = g2o::SparseOptimizer::LmTrace();
       if (ok_out) ok_out[b] = ok;
       if (cost_out) cost_out[b] = pl.getCurrentCost();
       if (lm_iterations) lm_iterations[b] = (int32_t)g2o::SparseOptimizer::iterationCounter();

@@ -307,6 +307,10 @@ class SparseOptimizer : public OptimizableGraph {
   double activeChi2() const { double c = 0; for (OptimizableGraph::Edge* e : _active) c += e->chi2(); return c; }
 
   static long& iterationCounter() { static thread_local long c = 0; return c; }   // LM iterations run by this thread (bench accounting)
+  // opt-in trace of the LM loop run by this thread (ref_set_trace in ref_driver.cpp): one row per LM iteration = {chi2 after it, lambda
+  // after it, damping trials, pose count (from the system size N = 4 n - 7)} - what g2o prints per iteration in verbose mode
+  struct LmTrace { double* buf = nullptr; int cap = 0; int32_t* rows = nullptr; };
+  static LmTrace& lmTrace() { static thread_local LmTrace t; return t; }
   int optimize(int iterations) {
     if (_index.empty()) return -1;
     _batch.clear();
@@ -392,6 +396,12 @@ class SparseOptimizer : public OptimizableGraph {
       }
       qmax++;
     } while (rho < 0 && qmax < 10);
+    LmTrace& tr = lmTrace();
+    if (tr.buf && tr.rows && *tr.rows < tr.cap) {
+      double* row = tr.buf + (size_t)(*tr.rows) * 4;
+      row[0] = currentChi; row[1] = _lambda; row[2] = (double)qmax; row[3] = (double)((N + 7) / 4);
+      ++*tr.rows;
+    }
     if (qmax == 10 || rho == 0 || !std::isfinite(_lambda)) return false;
     return true;
   }

@@ -1,0 +1,87 @@
+"""Device result against the REFERENCE'S OWN CODE (oracle/_ref/libteb_ref.so = src/optimal_planner.cpp compiled in place) on the
+same bands — TEST INFRASTRUCTURE: used by tests/ and by bench.py's parity_check, never by the product.
+
+Yardstick: SURVEY.md section 8(c), tolerance T3 "vs the faithful oracle": after the full optimizeTEB poses / time differences
+<= 1e-3 (m, rad, s) and chi^2 <= 1e-3 relative - the noise floor of the reference's delta = 1e-9 central differences; any band
+beyond it is reported with the LM iteration at which the two runs part (first iteration whose accept/reject sequence - the
+number of damping trials - or pose count differs, else the first whose chi^2 differs by more than 1e-6 relative).
+
+LM traces: rows {chi2 after the iteration, lambda after it, damping trials, pose count}, one per LM iteration; the device's come
+from teb_amd_get_iteration_log, the reference's from the stand-in optimiser of oracle/ref_shim/shim_g2o.h (ref_set_trace), the
+oracle's from teb_oracle_set_trace."""
+import numpy as np
+
+T3_STATE = 1e-3   # m / rad / s
+T3_CHI2_REL = 1e-3
+
+
+def first_divergence(tr_a, tr_b, chi2_rel=1e-6):
+    """Where two LM traces part: ("accept/reject", k) = first LM iteration whose trial count or pose count differs (or where
+    one run stopped), ("chi2", k) = same decisions throughout, first iteration whose chi^2 differs by more than chi2_rel,
+    None = they do not part at that resolution."""
+    m = min(len(tr_a), len(tr_b))
+    for k in range(m):
+        if tr_a[k][2] != tr_b[k][2] or tr_a[k][3] != tr_b[k][3]:
+            return ("accept/reject", k)
+    if len(tr_a) != len(tr_b):
+        return ("accept/reject", m)
+    for k in range(m):
+        d = abs(tr_a[k][0] - tr_b[k][0])
+        if d > chi2_rel * max(abs(tr_b[k][0]), 1e-300):
+            return ("chi2", k)
+    return None
+
+
+def state_error(a, b):
+    """max |difference| over x, y, theta, dt of two bands given as (x, y, theta, dt) tuples of equal length."""
+    return max(float(np.abs(u - v).max()) if len(u) else 0.0 for u, v in zip(a, b))
+
+
+def compare_with_reference_code(out, res, traces, ref_out, ref_ok, ref_cost, ref_traces, ok_status=0, bands=None):
+    """out / res / traces: device batch, results and per-band LM traces; ref_*: the same from oracle.ref_py.optimize_batch(trace=True).
+    Returns a JSON-able dict:
+      bands, pose_counts_equal, success_equal, lm_sequences_equal (iteration count and every trial count identical),
+      state_err {p50, p99, max} and chi2_rel {p50, p99, max} over the bands whose pose count agrees, cost_rel max,
+      bands_outside_T3 (count), outside (list of {band, state_err, chi2_rel, first_divergence}),
+      pose_count_mismatch (list of {band, n_device, n_reference, first_divergence})."""
+    bands = list(range(out.count)) if bands is None else list(bands)
+    st, ch, co = [], [], []
+    rep = {"bands": len(bands), "pose_counts_equal": 0, "success_equal": 0, "lm_sequences_equal": 0, "bands_outside_T3": 0,
+           "outside": [], "pose_count_mismatch": []}
+    for b in bands:
+        rep["success_equal"] += int((int(res.status[b]) == ok_status) == bool(ref_ok[b]))
+        div = first_divergence(traces[b], ref_traces[b])
+        rep["lm_sequences_equal"] += int(div is None or div[0] != "accept/reject")
+        if int(out.n[b]) != int(ref_out.n[b]):
+            rep["pose_count_mismatch"].append({"band": int(b), "n_device": int(out.n[b]), "n_reference": int(ref_out.n[b]),
+                                               "first_divergence": list(div) if div else None})
+            continue
+        rep["pose_counts_equal"] += 1
+        d = state_error(out.get_teb(b), ref_out.get_teb(b))
+        rchi = float(ref_traces[b][-1][0]) if len(ref_traces[b]) else 0.0
+        c = abs(float(res.chi2[b]) - rchi) / abs(rchi) if rchi != 0 else abs(float(res.chi2[b]))
+        st.append(d); ch.append(c)
+        if np.isfinite(ref_cost[b]) and ref_cost[b] != 0:
+            co.append(abs(float(res.cost[b]) - float(ref_cost[b])) / abs(float(ref_cost[b])))
+        if not (d <= T3_STATE and c <= T3_CHI2_REL):
+            rep["bands_outside_T3"] += 1
+            rep["outside"].append({"band": int(b), "state_err": d, "chi2_rel": c, "first_divergence": list(div) if div else None})
+    q = lambda v: {"p50": float(np.median(v)), "p99": float(np.percentile(v, 99)), "max": float(np.max(v))} if len(v) else None
+    rep["state_err"] = q(st); rep["chi2_rel"] = q(ch); rep["cost_rel_max"] = float(np.max(co)) if co else None
+    return rep
+
+
+def run_device_traced(planner, cfg, obst, via, batch, options=None):
+    """optimizeAllTEBs with the reference's cost scaling on the device, iteration log on: (out, res, traces, kernel_ms)."""
+    s = planner.make_solver(cfg, obst, via, batch, options=options)
+    s.set_iteration_log(True)
+    s.optimize(cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations, True, cfg.hcp.selection_obst_cost_scale,
+               cfg.hcp.selection_viapoint_cost_scale, cfg.hcp.selection_alternative_time_cost)
+    res = s.results()
+    out = s.download(batch.copy())
+    traces = [s.iteration_log(b) for b in range(batch.count)]
+    ms = s.last_kernel_ms()
+    flags = s.debug_overflow_flags()
+    s.close()
+    assert not flags.any(), flags
+    return out, res, traces, ms

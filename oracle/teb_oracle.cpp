@@ -1562,7 +1562,14 @@ void apply_update(Graph& g, const std::vector<double>& x) {  // SparseOptimizer:
 }
 
 struct LMState { double lambda = 0, ni = 2; };
-struct OptStats { int iterations = 0, trials = 0; double chi2 = 0; double lambda = 0; bool nonfinite = false; };
+struct OptStats {
+  int iterations = 0, trials = 0; double chi2 = 0; double lambda = 0; bool nonfinite = false;
+  // opt-in trace (teb_oracle_set_trace): one row per LM iteration = {chi2 after it, lambda after it, damping trials, pose count} - the
+  // data of g2o's verbose line (src/optimal_planner.cpp:384), used by the tests to say WHERE two implementations part
+  double* trace = nullptr; int trace_cap = 0; int32_t* trace_rows = nullptr;
+};
+struct TraceCfg { double* buf = nullptr; int cap = 0; int32_t* rows = nullptr; };
+TraceCfg g_trace;
 
 // OptimizationAlgorithmLevenberg::solve; returns true for OK, false for Terminate
 bool lm_solve(Graph& g, System& sys, LMState& lm, int iteration, int jac_mode, OptStats& st, double* cats_last) {
@@ -1610,6 +1617,11 @@ bool lm_solve(Graph& g, System& sys, LMState& lm, int iteration, int jac_mode, O
   } while (rho < 0 && qmax < 10);
   st.chi2 = currentChi;
   st.lambda = lm.lambda;
+  if (st.trace && st.trace_rows && *st.trace_rows < st.trace_cap) {
+    double* row = st.trace + (size_t)(*st.trace_rows) * 4;
+    row[0] = currentChi; row[1] = lm.lambda; row[2] = (double)qmax; row[3] = (double)g.n;
+    ++*st.trace_rows;
+  }
   if (qmax == 10 || rho == 0 || !std::isfinite(lm.lambda)) return false;
   return true;
 }
@@ -1643,8 +1655,9 @@ struct TebResult { int status = TEB_AMD_TEB_OK; int iterations = 0; int trials =
 
 // TebOptimalPlanner::optimizeTEB, src/optimal_planner.cpp:182-231
 bool optimize_teb(const Scene& s, Teb& t, int inner, int outer, bool compute_cost, double obst_cost_scale,
-                  double viapoint_cost_scale, bool alternative_time_cost, int cost_mode, TebResult& res) {
+                  double viapoint_cost_scale, bool alternative_time_cost, int cost_mode, TebResult& res, int band = -1) {
   const teb_amd_config_t& c = s.cfg;
+  if (band >= 0 && g_trace.rows) g_trace.rows[band] = 0;
   if (!c.optimization_activate) return false;
   double weight_multiplier = 1.0;
   bool fast_mode = !c.include_dynamic_obstacles;
@@ -1653,6 +1666,9 @@ bool optimize_teb(const Scene& s, Teb& t, int inner, int outer, bool compute_cos
   g.teb = &t;
   System sys;
   OptStats st;
+  if (band >= 0 && g_trace.buf && g_trace.rows) {
+    st.trace = g_trace.buf + (size_t)band * g_trace.cap * 4; st.trace_cap = g_trace.cap; st.trace_rows = g_trace.rows + band;
+  }
   for (int i = 0; i < outer; ++i) {
     if (c.teb_autosize) auto_resize(t, c.dt_ref, c.dt_hysteresis, c.min_samples, c.max_samples, fast_mode);
     build_graph(g, weight_multiplier);
@@ -1747,7 +1763,7 @@ int teb_oracle_optimize_batch(const teb_amd_config_t* cfg, const teb_amd_obstacl
     teb_from_batch(batch, b, t);
     TebResult& r = results[b];
     bool ok = optimize_teb(s, t, inner, outer, compute_cost != 0, obst_cost_scale, viapoint_cost_scale,
-                           alternative_time_cost != 0, cost_mode, r);
+                           alternative_time_cost != 0, cost_mode, r, b);
     r.status = ok ? TEB_AMD_TEB_OK : TEB_AMD_TEB_FAILED;
     if (!state_finite(t)) r.status = TEB_AMD_TEB_NONFINITE;
     rcs[b] = teb_to_batch(t, batch, b);
@@ -1779,6 +1795,13 @@ int teb_oracle_optimize_batch(const teb_amd_config_t* cfg, const teb_amd_obstacl
       if (out->lambda) out->lambda[b] = results[b].lambda;
     }
   }
+  return TEB_AMD_OK;
+}
+
+// trace of the following teb_oracle_optimize_batch calls: buf [B][cap_rows][4], rows [B]; buf = NULL switches it off. Not thread-safe
+// against concurrent optimize_batch calls (one process-wide setting; the bands of one call write disjoint slices).
+int teb_oracle_set_trace(double* buf, int32_t cap_rows, int32_t* rows) {
+  g_trace.buf = buf; g_trace.cap = cap_rows; g_trace.rows = rows;
   return TEB_AMD_OK;
 }
 

@@ -36,6 +36,10 @@ int teb_oracle_optimize_batch(const teb_amd_config_t* cfg, const teb_amd_obstacl
                               double viapoint_cost_scale, int32_t alternative_time_cost,
                               int32_t cost_mode, int32_t threads, teb_amd_results_t* out);
 
+/* Opt-in trace of the LM loop of the following teb_oracle_optimize_batch calls: trace [B][cap_rows][4] = per LM iteration
+ * {chi2 after it, lambda after it, damping trials, pose count}, rows [B] = rows written. trace = NULL: off. */
+int teb_oracle_set_trace(double* trace, int32_t cap_rows, int32_t* rows);
+
 /* selectBestTeb (src/homotopy_class_planner.cpp:564-667) on a cost array. */
 int teb_oracle_select_best(const teb_amd_config_t* cfg, int32_t count, const double* cost,
                            int32_t last_best, int32_t initial_plan, int32_t* best, double* best_cost);

@@ -1,40 +1,117 @@
-"""Builds libteb_amd.so (hipcc, gfx950 only) in-tree so it travels with the repo snapshot to the GPU box."""
+"""Builds libteb_amd.so (hipcc, gfx950 only) in-tree so it travels with the repo snapshot to the GPU box.
+
+The host side (csrc/teb_amd.hip: C-ABI, small kernels) and every instantiation of the optimise kernel (csrc/teb_opt_inst.hip with
+-DTEB_INST_SOLVER / _JMODE / _SCENE: 3 layouts x 2 Jacobian modes x 2 scene kinds) are separate translation units compiled in
+parallel into build/<variant>/*.o and linked into one shared library. Variants:
+    product : libteb_amd.so
+    mfma    : libteb_amd_mfma.so  (-DTEB_AMD_MFMA_SCHUR -DTEB_AMD_ANALYTIC_ONLY: the Schur update of the cyclic reduction on
+              v_mfma_f64_16x16x4_f64 - SURVEY section 8 row g; exercised by tests/test_gpu_mfma_build.py)"""
+import concurrent.futures
+import hashlib
 import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libteb_amd.so")
-SOURCES = ["teb_amd.hip"]
-HEADERS = ["teb_device.hpp", "teb_comm.hpp", "teb_feasibility.hpp", "teb_geometry.hpp", "teb_edges.hpp", "teb_kernel.hpp", "teb_strip.hpp", "teb_hsig.hpp", "teb_graph.hpp",
+LIB_MFMA = os.path.join(HERE, "libteb_amd_mfma.so")
+HEADERS = ["teb_device.hpp", "teb_comm.hpp", "teb_feasibility.hpp", "teb_geometry.hpp", "teb_edges.hpp", "teb_kernel.hpp", "teb_strip.hpp",
+           "teb_hsig.hpp", "teb_graph.hpp", "teb_opt_launch.hpp", "teb_multicu.hpp",
            os.path.join("..", "..", "include", "teb_amd.h"), os.path.join("..", "..", "include", "teb_amd_debug.h")]
 
 # -ffp-contract=off: the parity contract is against a plain IEEE mul/add restatement of the reference;
 # letting the compiler fuse a*b+c would change which side of a penalty kink borderline residuals fall on.
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-ldl"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+
+VARIANTS = {
+    "product": dict(lib=LIB, defines=[], jmodes=(0, 1)),
+    "mfma": dict(lib=LIB_MFMA, defines=["-DTEB_AMD_MFMA_SCHUR", "-DTEB_AMD_ANALYTIC_ONLY"], jmodes=(0,)),
+    # closed-form Jacobians only: the quick build the tools/ A/B experiments use (build(variant="analytic", extra_defines=[..], out=..))
+    "analytic": dict(lib=os.path.join(HERE, "..", "tools", "libteb_amd_ar.so"), defines=["-DTEB_AMD_ANALYTIC_ONLY"], jmodes=(0,)),
+}
+PRODUCT_VARIANTS = ("product", "mfma")
 
 
-def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    for f in SOURCES + HEADERS:
+def _units(variant):
+    """(object name, source, extra defines) of every translation unit of the variant."""
+    v = VARIANTS[variant]
+    units = [("teb_amd.o", "teb_amd.hip", [])]
+    for jm in v["jmodes"]:
+        for sv in (0, 1, 2):
+            for sk in (0, 1):
+                units.append(("opt_%d_%d_%d.o" % (sv, jm, sk), "teb_opt_inst.hip",
+                              ["-DTEB_INST_SOLVER=%d" % sv, "-DTEB_INST_JMODE=%d" % jm, "-DTEB_INST_SCENE=%d" % sk]))
+    return units
+
+
+# what a kernel instantiation is made of (the host translation unit depends on everything)
+KERNEL_DEPS = ["teb_opt_inst.hip", "teb_device.hpp", "teb_geometry.hpp", "teb_edges.hpp", "teb_kernel.hpp", "teb_opt_launch.hpp", "teb_multicu.hpp",
+               os.path.join("..", "..", "include", "teb_amd.h")]
+
+
+def _newest_source(files=None):
+    t = 0.0
+    for f in (files or ["teb_amd.hip", "teb_opt_inst.hip"] + HEADERS):
         p = os.path.join(CSRC, f)
-        if os.path.exists(p) and os.path.getmtime(p) > t:
-            return True
-    return False
+        if os.path.exists(p):
+            t = max(t, os.path.getmtime(p))
+    return max(t, os.path.getmtime(os.path.abspath(__file__)))
 
 
-def build(force=False, verbose=False):
-    """Compile the HIP extension if sources are newer than the .so. Returns the library path."""
-    if force or _stale():
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+def _stale(path):
+    return not os.path.exists(path) or os.path.getmtime(path) < _newest_source()
+
+
+def source_hash():
+    """sha256 over the device + host sources of the library (what a committed profile is tied to)."""
+    h = hashlib.sha256()
+    for f in sorted(["teb_amd.hip", "teb_opt_inst.hip"] + HEADERS):
+        p = os.path.join(CSRC, f)
+        if os.path.exists(p):
+            h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build(force=False, verbose=False, variant="product", jobs=None, extra_defines=(), out=None):
+    """Compile the variant if its sources are newer than the library. Returns the library path."""
+    v = VARIANTS[variant]
+    lib = os.path.abspath(out or v["lib"])
+    if not (force or _stale(lib)):
+        return lib
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    tag = variant if not extra_defines else variant + "_" + hashlib.sha256(" ".join(extra_defines).encode()).hexdigest()[:8]
+    bdir = os.path.join(HERE, "build", tag)
+    os.makedirs(bdir, exist_ok=True)
+    jobs = jobs or int(os.environ.get("TEB_AMD_BUILD_JOBS", "0")) or min(os.cpu_count() or 1, 8)
+    newest_all, newest_kernel = _newest_source(), _newest_source(KERNEL_DEPS)
+
+    def compile_unit(u):
+        obj, src, defs = u
+        o = os.path.join(bdir, obj)
+        newest = newest_kernel if src == "teb_opt_inst.hip" else newest_all
+        if not force and os.path.exists(o) and os.path.getmtime(o) >= newest:
+            return o
+        cmd = [hipcc] + HIPCC_FLAGS + v["defines"] + list(extra_defines) + defs + ["-c", os.path.join(CSRC, src), "-o", o]
         if verbose:
-            print(" ".join(cmd))
+            print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=CSRC)
-    return LIB
+        return o
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(compile_unit, _units(variant)))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", lib]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=CSRC)
+    return lib
+
+
+def build_all(force=False, verbose=False):
+    return [build(force=force, verbose=verbose, variant=k) for k in PRODUCT_VARIANTS]
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    names = [a for a in sys.argv[1:] if a in VARIANTS] or list(PRODUCT_VARIANTS)
+    for k in names:
+        print(build(force="--force" in sys.argv, verbose=True, variant=k))

@@ -15,6 +15,7 @@
 #include "../../include/teb_amd.h"
 #include "../../include/teb_amd_debug.h"
 #include "teb_kernel.hpp"
+#include "teb_opt_launch.hpp"
 #include "teb_strip.hpp"
 #include "teb_hsig.hpp"
 #include "teb_graph.hpp"
@@ -22,6 +23,12 @@
 #include "teb_feasibility.hpp"
 
 using namespace tebamd;
+
+// the instantiations of teb_optimize_kernel live in translation units of their own (teb_opt_launch.hpp)
+TEB_OPT_FOR_ALL(TEB_OPT_DECLARE)
+#ifdef TEB_AMD_SINGLE_TU
+TEB_OPT_FOR_ALL(TEB_OPT_DEFINE)
+#endif
 
 namespace {
 
@@ -150,6 +157,7 @@ struct teb_amd_handle {
   int fast_points = 0;
   teb_amd_options_t opt;   // behaviour switches fixed at create (ABI 2; never the process environment)
   int snap_nmax = -1;      // nmax_known at the time of teb_amd_snapshot_state
+  int snap_B = -1;         // B at that time (the bound covers those bands only)
   int nmax_known = -1;     // upper bound of the resident pose counts as far as the host knows it, -1 = unknown (device-side producers ran)
   // host copy of the last obstacle table: teb_amd_set_config re-derives the static / dynamic lists from it
   struct HostObst { std::vector<int> type, dyn, voff; std::vector<double> ax, ay, bx, by, rad, vx, vy, cx, cy, brad, pvx, pvy; } hob;
@@ -161,6 +169,8 @@ struct teb_amd_handle {
   DevBuf<int> n, has_vs, has_vg, rotdir, via_en, status, optimized, iters, trials, assoc_cnt, assoc, assoc_ovf, via_pose, legacy_idx;
   DevBuf<double> x, y, th, dt, vs, vg, chi2, cost, lambda, Hbackup, Hband, ob_x, ob_y, ob_th, ob_dt;   // ob_*: strips before an optimistic launch
   DevBuf<int> ob_n;
+  DevBuf<double> iter_log;   // teb_amd_set_iteration_log: [max_tebs][TEB_AMD_ITERATION_LOG_ROWS][4]
+  bool iter_log_on = false;
   bool opt_backup_ready = false;
   size_t hband_stride = 0;
   // snapshot
@@ -252,24 +262,21 @@ int validate_config(const teb_amd_config_t* c) {
   return TEB_AMD_OK;
 }
 
-typedef void (*opt_kernel_t)(const teb_amd_config_t, const SceneDev, const BatchDev, const OptArgs, const LdsPlan);
-opt_kernel_t opt_kernel(int solver, int jmode) {
-#ifndef TEB_AMD_ANALYTIC_ONLY   // tools/ builds (-DTEB_AMD_ANALYTIC_ONLY) skip the numeric instantiations: 35 s instead of 3 min
-  if (jmode == TEB_AMD_JACOBIAN_G2O_NUMERIC)
-    return solver == SOLVER_CR ? teb_optimize_kernel<SOLVER_CR, TEB_AMD_JACOBIAN_G2O_NUMERIC>
-           : solver == SOLVER_BAND ? teb_optimize_kernel<SOLVER_BAND, TEB_AMD_JACOBIAN_G2O_NUMERIC>
-                                   : teb_optimize_kernel<SOLVER_BANDG, TEB_AMD_JACOBIAN_G2O_NUMERIC>;
-#endif
-  return solver == SOLVER_CR ? teb_optimize_kernel<SOLVER_CR, TEB_AMD_JACOBIAN_ANALYTIC>
-         : solver == SOLVER_BAND ? teb_optimize_kernel<SOLVER_BAND, TEB_AMD_JACOBIAN_ANALYTIC>
-                                 : teb_optimize_kernel<SOLVER_BANDG, TEB_AMD_JACOBIAN_ANALYTIC>;
+const void* opt_kernel(int solver, int jmode, int scene) {
+#define TEB_OPT_PICK(S, J, P) if (solver == S && jmode == J && scene == P) return TEB_OPT_KERNEL_FN(S, J, P)();
+  TEB_OPT_FOR_ALL(TEB_OPT_PICK)
+#undef TEB_OPT_PICK
+  return nullptr;   // (a -DTEB_AMD_ANALYTIC_ONLY build asked for the numeric mode)
 }
-void launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const BatchDev& bt, const OptArgs& a, int solver, const LdsPlan& plan) {
-  hipLaunchKernelGGL(opt_kernel(solver, h->cfg.jacobian_mode), dim3(grid), dim3(kThreads), plan.total_bytes, h->stream,
-                     h->cfg, sc, bt, a, plan);
+hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const BatchDev& bt, const OptArgs& a, int solver, const LdsPlan& plan) {
+  const void* k = opt_kernel(solver, h->cfg.jacobian_mode, sc.fast_points ? SCENE_POINTS : SCENE_GENERIC);
+  if (!k) return hipErrorInvalidDeviceFunction;
+  void* params[] = {const_cast<teb_amd_config_t*>(&h->cfg), const_cast<SceneDev*>(&sc), const_cast<BatchDev*>(&bt), const_cast<OptArgs*>(&a),
+                    const_cast<LdsPlan*>(&plan)};
+  return hipLaunchKernel(k, dim3(grid), dim3(kThreads), params, plan.total_bytes, h->stream);
 }
-void launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const BatchDev& bt, const OptArgs& a) {
-  launch_opt(h, grid, sc, bt, a, h->solver, h->plan);
+hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const BatchDev& bt, const OptArgs& a) {
+  return launch_opt(h, grid, sc, bt, a, h->solver, h->plan);
 }
 
 // largest pose capacity whose LDS plan (with the obstacle cache of this scene, if it is in use) fits
@@ -338,7 +345,7 @@ int launch(teb_amd_handle* h, const OptArgs& args) {
     if (int crc = copy_strips(h, Strips{h->ob_x.p, h->ob_y.p, h->ob_th.p, h->ob_dt.p, h->ob_n.p}, Strips{h->x.p, h->y.p, h->th.p, h->dt.p, h->n.p}, h->B)) return crc;
   }
   HIPCHK(hipEventRecord(h->ev0, h->stream));   // (the kernel clears its bands' overflow flags itself)
-  launch_opt(h, h->B, sc, bt, args, eff_solver, eff_plan);
+  HIPCHK(launch_opt(h, h->B, sc, bt, args, eff_solver, eff_plan));
   if (optimistic) {
     HIPCHK(hipGetLastError());
     // this mode is synchronous: the overflow flags decide whether the launch has to be repeated (documented in teb_amd.h)
@@ -352,7 +359,7 @@ int launch(teb_amd_handle* h, const OptArgs& args) {
     for (int v : nn) h->nmax_known = std::max(h->nmax_known, v);
     if (outgrown) {
       if (int crc = copy_strips(h, Strips{h->x.p, h->y.p, h->th.p, h->dt.p, h->n.p}, Strips{h->ob_x.p, h->ob_y.p, h->ob_th.p, h->ob_dt.p, h->ob_n.p}, h->B)) return crc;
-      launch_opt(h, h->B, sc, bt, args);   // ev0 stays where it was: the reported time includes the discarded first launch
+      HIPCHK(launch_opt(h, h->B, sc, bt, args));   // ev0 stays where it was: the reported time includes the discarded first launch
       h->nmax_known = -1;
     }
   } else if (h->cfg.teb_autosize && !args.debug_linearize) {
@@ -518,8 +525,10 @@ int teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max
   if (ok && hipEventCreate(&h->ev1) != hipSuccess) ok = false;
   for (int sv : {SOLVER_BAND, SOLVER_CR, SOLVER_BANDG})   // every layout may be launched (teb_amd_set_obstacles / per-launch choice)
     for (int jm : {TEB_AMD_JACOBIAN_ANALYTIC, TEB_AMD_JACOBIAN_G2O_NUMERIC})
-      if (ok && hipFuncSetAttribute(reinterpret_cast<const void*>(opt_kernel(sv, jm)),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit) != hipSuccess) ok = false;
+      for (int sk : {SCENE_POINTS, SCENE_GENERIC}) {
+        const void* k = opt_kernel(sv, jm, sk);
+        if (ok && k && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit) != hipSuccess) ok = false;
+      }
   if (ok && hipMemset(h->cost.p, 0, sizeof(double) * max_tebs) != hipSuccess) ok = false;
   if (ok && hipMemset(h->chi2.p, 0, sizeof(double) * max_tebs) != hipSuccess) ok = false;
   if (ok && hipMemset(h->iters.p, 0, sizeof(int) * max_tebs) != hipSuccess) ok = false;   // hasDiverged: "no statistics yet"
@@ -549,6 +558,7 @@ void teb_amd_destroy(teb_amd_handle_t* h) {
   DevBuf<int>* gi[] = {&h->cand_n, &h->cand_off, &h->cand_map, &h->tmp_n, &h->tmp_i};
   for (auto* q : gi) q->free();
   h->ob_n.free();
+  h->iter_log.free();
   h->g_adj.free();
   h->cm_cells.free(); h->cm_fp.free(); h->cm_out.free();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -607,8 +617,17 @@ int teb_amd_set_config(teb_amd_handle_t* h, const teb_amd_config_t* cfg) {
   if (rc) return rc;   // the handle keeps its previous configuration
   const bool lists_changed = (cfg->include_dynamic_obstacles != h->cfg.include_dynamic_obstacles) ||
                              (cfg->footprint_type != h->cfg.footprint_type);
+  const teb_amd_config_t previous = h->cfg;
   h->cfg = *cfg;
-  if (lists_changed && h->M > 0) return commit_obstacles(h);
+  if (lists_changed && h->M > 0) {
+    rc = commit_obstacles(h);   // derives the static / dynamic lists, the distance path and the LDS plan from h->cfg
+    if (rc) {                   // "keeps its previous configuration" (teb_amd.h): put it back together with what is derived from it
+      const std::string why = g_last_error;
+      h->cfg = previous;
+      (void)commit_obstacles(h);
+      return fail(rc, why);
+    }
+  }
   return TEB_AMD_OK;
 }
 
@@ -757,10 +776,43 @@ int teb_amd_optimize_batch(teb_amd_handle_t* h, int32_t inner, int32_t outer, in
   std::memset(&a, 0, sizeof a);
   a.inner = inner; a.outer = outer; a.compute_cost = compute_cost; a.no_near_cache = h->opt.no_near_cache != 0; a.band_ldlt = h->solver == SOLVER_BANDG ? 0 : h->band_ldlt; a.Hband = h->Hband.p; a.hband_stride = h->hband_stride;
   a.obst_scale = obst_cost_scale; a.via_scale = viapoint_cost_scale; a.alt_time = alternative_time_cost;
+  if (h->iter_log_on) { a.iter_log = h->iter_log.p; a.iter_log_cap = TEB_AMD_ITERATION_LOG_ROWS; }
 #ifdef TEB_PROFILE
   a.dbg_H = h->dbg_H.p;
 #endif
   return launch(h, a);
+}
+
+// g2o's per-iteration console line ("iteration= i chi2= .. lambda= .. levenbergIter= ..", printed when optimization_verbose sets
+// SparseOptimizer::setVerbose, src/optimal_planner.cpp:384) as data: one row per LM iteration of the last teb_amd_optimize_batch.
+int teb_amd_set_iteration_log(teb_amd_handle_t* h, int32_t enable) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (enable && !h->iter_log.p) {
+    const size_t count = (size_t)h->max_tebs * TEB_AMD_ITERATION_LOG_ROWS * 4;
+    HIPCHK(h->iter_log.alloc(count));
+    HIPCHK(hipMemsetAsync(h->iter_log.p, 0, count * sizeof(double), h->stream));
+  }
+  h->iter_log_on = enable != 0;
+  return TEB_AMD_OK;
+}
+
+int teb_amd_get_iteration_log(teb_amd_handle_t* h, int32_t b, double* rows, int32_t capacity_rows, int32_t* n_rows) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!h->iter_log_on || !h->iter_log.p) return fail(TEB_AMD_ERR_INVALID_ARG, "the iteration log is off (teb_amd_set_iteration_log)");
+  if (b < 0 || b >= h->B || !rows || !n_rows || capacity_rows < 0) return fail(TEB_AMD_ERR_INVALID_ARG, "teb_amd_get_iteration_log: bad arguments");
+  int iters = 0;
+  HIPCHK(hipMemcpyAsync(&iters, h->iters.p + b, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  int nr = std::min(std::min(iters, (int)TEB_AMD_ITERATION_LOG_ROWS), (int)capacity_rows);
+  if (nr < 0) nr = 0;
+  if (nr > 0) {
+    HIPCHK(hipMemcpyAsync(rows, h->iter_log.p + (size_t)b * TEB_AMD_ITERATION_LOG_ROWS * 4, (size_t)nr * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  *n_rows = nr;
+  return TEB_AMD_OK;
 }
 
 int teb_amd_synchronize(teb_amd_handle_t* h) {
@@ -807,15 +859,15 @@ int teb_amd_select_best(teb_amd_handle_t* h, int32_t last_best, int32_t initial_
 // ---- multi-GPU: the selection exchange (teb_comm.hpp) --------------------------------------------------------------------------------
 #define NCCLCHK(expr)                                                                                                     \
   do {                                                                                                                    \
-    ncclResult_t _r = (expr);                                                                                             \
-    if (_r != ncclSuccess) return fail(TEB_AMD_ERR_HIP, std::string(#expr) + " -> " + rccl().GetErrorString(_r));         \
+    int _r = (expr);                                                                                                      \
+    if (_r != kRcclSuccess) return fail(TEB_AMD_ERR_HIP, std::string(#expr) + " -> " + rccl().GetErrorString(_r));        \
   } while (0)
 
 int teb_amd_comm_unique_id(char id[TEB_AMD_COMM_ID_BYTES]) {
-  static_assert(sizeof(ncclUniqueId) == TEB_AMD_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+  static_assert(sizeof(rccl_unique_id_t) == TEB_AMD_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
   if (!id) return fail(TEB_AMD_ERR_INVALID_ARG, "null id buffer");
   if (!rccl().load()) return fail(TEB_AMD_ERR_UNSUPPORTED, rccl().error);
-  ncclUniqueId u;
+  rccl_unique_id_t u;
   NCCLCHK(rccl().GetUniqueId(&u));
   std::memcpy(id, &u, sizeof(u));
   return TEB_AMD_OK;
@@ -830,10 +882,10 @@ int teb_amd_comm_create(const char id[TEB_AMD_COMM_ID_BYTES], int32_t rank, int3
   HIPCHK(hipSetDevice(device));
   teb_amd_comm* c = new teb_amd_comm();
   c->rank = rank; c->world = world; c->device = device;
-  ncclUniqueId u;
+  rccl_unique_id_t u;
   std::memcpy(&u, id, sizeof(u));
-  ncclResult_t r = rccl().CommInitRank(&c->comm, world, u, rank);
-  if (r != ncclSuccess) { delete c; return fail(TEB_AMD_ERR_HIP, std::string("ncclCommInitRank -> ") + rccl().GetErrorString(r)); }
+  int r = rccl().CommInitRank(&c->comm, world, u, rank);
+  if (r != kRcclSuccess) { delete c; return fail(TEB_AMD_ERR_HIP, std::string("ncclCommInitRank -> ") + rccl().GetErrorString(r)); }
   if (hipMalloc(reinterpret_cast<void**>(&c->rec), 2 * sizeof(double)) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&c->all), 2 * (size_t)world * sizeof(double)) != hipSuccess) {
     teb_amd_comm_destroy(c);
@@ -868,46 +920,72 @@ int teb_amd_select_best_distributed(teb_amd_handle_t* h, teb_amd_comm_t* c, int3
                        h->cfg.selection_cost_hysteresis, h->cfg.selection_prefer_initial_plan, h->sel_cost.p, h->sel_idx.p);
   }
   hipLaunchKernelGGL(pack_record_kernel, dim3(1), dim3(64), 0, h->stream, h->sel_cost.p, h->sel_idx.p, global_offset, have, c->rec);
-  HIPCHK(hipGetLastError());
-  NCCLCHK(rccl().AllGather(c->rec, c->all, 2, ncclDouble, c->comm, h->stream));
+  // a launch error on THIS rank must not keep it out of the collective (the peers would wait for ever): an unusable record is sent instead
+  const bool local_ok = hipGetLastError() == hipSuccess;
+  if (!local_ok) {
+    const double none[2] = {1.7976931348623157e308, -1.0};
+    (void)hipMemcpyAsync(c->rec, none, sizeof(none), hipMemcpyHostToDevice, h->stream);
+  }
+  NCCLCHK(rccl().AllGather(c->rec, c->all, 2, kRcclFloat64, c->comm, h->stream));
   std::vector<double> all(2 * (size_t)c->world);
   HIPCHK(hipMemcpyAsync(all.data(), c->all, all.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  double bc = 1.7976931348623157e308; int bi = -1, owner = -1;
-  for (int r = 0; r < c->world; ++r) {
-    const double cst = all[2 * r]; const int idx = (int)all[2 * r + 1];
-    if (idx < 0) continue;
-    if (bi < 0 || cst < bc || (cst == bc && idx < bi)) { bc = cst; bi = idx; owner = r; }
-  }
+  if (!local_ok) return fail(TEB_AMD_ERR_HIP, "teb_amd_select_best_distributed: local selection kernels failed to launch");
+  double bc; int bi, owner;
+  world_argmin(all.data(), c->world, &bi, &bc, &owner);
   *best_global = bi;
   if (best_cost) *best_cost = bc;
   if (owner_rank) *owner_rank = owner;
   return TEB_AMD_OK;
 }
 
+// A collective: no rank may leave before the peers are released. Everything that can go wrong on ONE rank (an index out of range on the
+// owner, an allocation failure, capacities that differ between the ranks) is therefore found out by all ranks together - an all-gather of
+// (status, capacity) per rank - BEFORE the broadcast, and every rank returns the same verdict. Only a rank without a communicator cannot
+// take part at all (TEB_AMD_ERR_INVALID_ARG there; its peers then wait in the all-gather like in any collective a rank never enters).
 int teb_amd_broadcast_band(teb_amd_handle_t* h, teb_amd_comm_t* c, int32_t owner_rank, int32_t local_index, int32_t capacity, int32_t* n,
                            double* x, double* y, double* theta, double* dt) {
-  int rc = check_handle(h);
-  if (rc) return rc;
-  if (!c || !c->comm || !n || !x || !y || !theta || !dt || capacity < 2) return fail(TEB_AMD_ERR_INVALID_ARG, "teb_amd_broadcast_band: bad arguments");
-  if (owner_rank < 0 || owner_rank >= c->world) return fail(TEB_AMD_ERR_INVALID_ARG, "owner_rank out of range");
-  if (c->rank == owner_rank && (local_index < 0 || local_index >= h->B)) return fail(TEB_AMD_ERR_INVALID_ARG, "local_index out of range on the owner");
-  const size_t count = 1 + 4 * (size_t)capacity;
-  if (c->msg_cap < count) {
+  if (!c || !c->comm) return fail(TEB_AMD_ERR_INVALID_ARG, "teb_amd_broadcast_band: null communicator");
+  int local = TEB_AMD_OK;
+  std::string why;
+  if (check_handle(h)) { local = TEB_AMD_ERR_INVALID_ARG; why = "bad handle"; }
+  else if (!n || !x || !y || !theta || !dt || capacity < 2) { local = TEB_AMD_ERR_INVALID_ARG; why = "null output / capacity < 2"; }
+  else if (owner_rank < 0 || owner_rank >= c->world) { local = TEB_AMD_ERR_INVALID_ARG; why = "owner_rank out of range"; }
+  else if (c->rank == owner_rank && (local_index < 0 || local_index >= h->B)) { local = TEB_AMD_ERR_INVALID_ARG; why = "local_index out of range on the owner"; }
+  (void)hipSetDevice(c->device);
+  hipStream_t stream = h ? h->stream : nullptr;   // (a rank with a bad handle still takes part, on the null stream)
+  const size_t count = capacity >= 2 ? 1 + 4 * (size_t)capacity : 0;
+  if (local == TEB_AMD_OK && c->msg_cap < count) {
     if (c->msg) (void)hipFree(c->msg);
     c->msg = nullptr; c->msg_cap = 0;
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->msg), count * sizeof(double)));
-    c->msg_cap = count;
+    if (hipMalloc(reinterpret_cast<void**>(&c->msg), count * sizeof(double)) != hipSuccess) { local = TEB_AMD_ERR_HIP; why = "message buffer allocation failed"; }
+    else c->msg_cap = count;
   }
-  if (c->rank == owner_rank) {
-    hipLaunchKernelGGL(pack_band_kernel, dim3((capacity + 255) / 256), dim3(256), 0, h->stream, h->n.p, h->x.p, h->y.p, h->th.p, h->dt.p,
+  // round 1: (status, capacity) of every rank
+  const double mine[2] = {(double)local, (double)capacity};
+  std::vector<double> all(2 * (size_t)c->world);
+  if (hipMemcpyAsync(c->rec, mine, sizeof(mine), hipMemcpyHostToDevice, stream) != hipSuccess) return fail(TEB_AMD_ERR_HIP, "teb_amd_broadcast_band: staging copy failed");
+  NCCLCHK(rccl().AllGather(c->rec, c->all, 2, kRcclFloat64, c->comm, stream));
+  HIPCHK(hipMemcpyAsync(all.data(), c->all, all.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  for (int r = 0; r < c->world; ++r) {
+    if ((int)all[2 * r] != TEB_AMD_OK)
+      return fail(r == c->rank ? local : TEB_AMD_ERR_INVALID_ARG,
+                  r == c->rank ? "teb_amd_broadcast_band: " + why : "teb_amd_broadcast_band: rank " + std::to_string(r) + " reported an error; no band was sent");
+    if ((int)all[2 * r + 1] != capacity)
+      return fail(TEB_AMD_ERR_INVALID_ARG, "teb_amd_broadcast_band: `capacity` differs between the ranks (rank " + std::to_string(r) + " passed " +
+                                               std::to_string((int)all[2 * r + 1]) + ", this rank " + std::to_string(capacity) + ")");
+  }
+  // round 2: the strip itself
+  if (c->rank == owner_rank)
+    hipLaunchKernelGGL(pack_band_kernel, dim3((capacity + 255) / 256), dim3(256), 0, stream, h->n.p, h->x.p, h->y.p, h->th.p, h->dt.p,
                        local_index, h->stride, capacity, c->msg);
-    HIPCHK(hipGetLastError());
-  }
-  NCCLCHK(rccl().Broadcast(c->msg, c->msg, count, ncclDouble, owner_rank, c->comm, h->stream));
+  const bool packed = hipGetLastError() == hipSuccess;   // (a failed pack still enters the broadcast; what arrives is then rejected below)
+  NCCLCHK(rccl().Broadcast(c->msg, c->msg, count, kRcclFloat64, owner_rank, c->comm, stream));
   std::vector<double> host(count);
-  HIPCHK(hipMemcpyAsync(host.data(), c->msg, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpyAsync(host.data(), c->msg, count * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  if (!packed) return fail(TEB_AMD_ERR_HIP, "teb_amd_broadcast_band: packing the band failed on the owner");
   const int nb = (int)host[0];
   *n = nb;
   if (nb > capacity) return fail(TEB_AMD_ERR_CAPACITY, "the winner has more poses than `capacity`");
@@ -915,6 +993,16 @@ int teb_amd_broadcast_band(teb_amd_handle_t* h, teb_amd_comm_t* c, int32_t owner
   std::memcpy(y, host.data() + 1 + capacity, capacity * sizeof(double));
   std::memcpy(theta, host.data() + 1 + 2 * (size_t)capacity, capacity * sizeof(double));
   std::memcpy(dt, host.data() + 1 + 3 * (size_t)capacity, capacity * sizeof(double));
+  return TEB_AMD_OK;
+}
+
+int teb_amd_debug_world_argmin(const double* records, int32_t world, int32_t* best_global, double* best_cost, int32_t* owner_rank) {
+  if (!records || world < 1 || !best_global) return fail(TEB_AMD_ERR_INVALID_ARG, "teb_amd_debug_world_argmin: bad arguments");
+  int bi, owner; double bc;
+  world_argmin(records, world, &bi, &bc, &owner);
+  *best_global = bi;
+  if (best_cost) *best_cost = bc;
+  if (owner_rank) *owner_rank = owner;
   return TEB_AMD_OK;
 }
 
@@ -1795,6 +1883,9 @@ int teb_amd_device_state(teb_amd_handle_t* h, void** x, void** y, void** theta, 
   if (rc) return rc;
   if (x) *x = h->x.p; if (y) *y = h->y.p; if (theta) *theta = h->th.p; if (dt) *dt = h->dt.p; if (n) *n = h->n.p;
   if (stride) *stride = h->stride;
+  h->nmax_known = -1;        // the caller may write pose counts through `n`: the host's upper bound is void from here on (the kernel guards
+  h->consumers_valid = false;   // itself against counts beyond its LDS strips as well)
+  h->hsig_mode = 0;
   return TEB_AMD_OK;
 }
 
@@ -1803,6 +1894,7 @@ int teb_amd_snapshot_state(teb_amd_handle_t* h) {
   if (rc) return rc;
   if ((rc = copy_strips(h, Strips{h->snap_x.p, h->snap_y.p, h->snap_th.p, h->snap_dt.p, h->snap_n.p}, Strips{h->x.p, h->y.p, h->th.p, h->dt.p, h->n.p}, h->max_tebs))) return rc;
   h->snap_nmax = h->nmax_known;
+  h->snap_B = h->B;
   return TEB_AMD_OK;
 }
 
@@ -1810,7 +1902,9 @@ int teb_amd_restore_state(teb_amd_handle_t* h) {
   int rc = check_handle(h);
   if (rc) return rc;
   if ((rc = copy_strips(h, Strips{h->x.p, h->y.p, h->th.p, h->dt.p, h->n.p}, Strips{h->snap_x.p, h->snap_y.p, h->snap_th.p, h->snap_dt.p, h->snap_n.p}, h->max_tebs))) return rc;
-  h->consumers_valid = false; h->nmax_known = h->snap_nmax;
+  // snap_nmax bounded the first snap_B bands only; the copy brings back the counts of ALL max_tebs slots, so with another batch size the
+  // bound says nothing about the bands beyond the old B
+  h->consumers_valid = false; h->nmax_known = (h->B == h->snap_B) ? h->snap_nmax : -1;
   h->hsig_mode = 0;   // the bands change: signatures of an earlier teb_amd_compute_h_signatures call are stale
   return TEB_AMD_OK;
 }
@@ -1866,7 +1960,7 @@ int teb_amd_debug_linearize(teb_amd_handle_t* h, int32_t b, double weight_multip
   HIPCHK(hipMemcpy(&sv_d[0], h->chi2.p + b, sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(&sv_d[1], h->cost.p + b, sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(&sv_d[2], h->lambda.p + b, sizeof(double), hipMemcpyDeviceToHost));
-  launch_opt(h, 1, sc, bt, a);
+  HIPCHK(launch_opt(h, 1, sc, bt, a));
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipMemcpy(h->status.p + b, &sv_i[0], sizeof(int), hipMemcpyHostToDevice));
@@ -2033,6 +2127,17 @@ int teb_amd_debug_stream(teb_amd_handle_t* h, int64_t n_doubles, int32_t repeats
   }
   HIPCHK(hipStreamSynchronize(h->stream));
   a.free(); b.free();
+  return TEB_AMD_OK;
+}
+
+// test hook: overwrites the resident pose count of band b behind the host's back (no range check, the host's cached upper bound of the
+// counts is NOT invalidated) - what a careless writer through teb_amd_device_state's `n` pointer could do. The kernel has to survive it.
+int teb_amd_debug_poke_pose_count(teb_amd_handle_t* h, int32_t b, int32_t n) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (b < 0 || b >= h->max_tebs) return fail(TEB_AMD_ERR_INVALID_ARG, "band index out of range");
+  HIPCHK(hipMemcpyAsync(h->n.p + b, &n, sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
   return TEB_AMD_OK;
 }
 

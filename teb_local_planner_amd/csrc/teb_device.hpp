@@ -98,6 +98,8 @@ struct OptArgs {
   size_t hband_stride;
   int band_ldlt;         // SOLVER_BAND only: 1 = sequential banded LDL^T in LDS (v1), 0 = hybrid cyclic reduction (cr_solve_hybrid)
   int no_near_cache;     // teb_amd_options_t::no_near_cache
+  double* iter_log;      // opt-in (teb_amd_set_iteration_log): [B][iter_log_cap][4] = per LM iteration chi2, lambda, trials, pose count -
+  int iter_log_cap;      //   what g2o prints per iteration with setVerbose(optimization_verbose) (src/optimal_planner.cpp:384); else nullptr
   int debug_linearize;   // test hook: stop after the first linearisation and dump H, b, chi2 categories
   double debug_weight_multiplier;
   double* dbg_H;         // [4*stride*kBand] of TEB 0

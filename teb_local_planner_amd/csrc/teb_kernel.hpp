@@ -307,10 +307,10 @@ struct NearCache {
   bool off;   // teb_amd_options_t::no_near_cache: exact mask (no margin) at every pass
   __device__ __forceinline__ void invalidate() { rx0 = ry0 = rx1 = ry1 = __builtin_nan(""); m0 = m1 = 0; }
 };
-template <int MODE>
+template <int MODE, bool FAST>
 __device__ __forceinline__ unsigned long long dyn_near_cached(const teb_amd_config_t& c, const SceneDev& sc, const Lds& l, int i, int sl, int nsl,
                                                               NearCache& nc, int pass) {
-  if (!(sc.fast_points && i >= 1 && c.include_dynamic_obstacles && c.weight_obstacle != 0)) return 0;
+  if (!(FAST && i >= 1 && c.include_dynamic_obstacles && c.weight_obstacle != 0)) return 0;
   const double m = nc.off ? 0.0 : TEB_NEAR_MARGIN_FACTOR * dyn_far_distance(c);
   const double x = l.sx[i], y = l.sy[i];
   const double rx = pass == 0 ? nc.rx0 : nc.rx1, ry = pass == 0 ? nc.ry0 : nc.ry1;
@@ -334,7 +334,7 @@ __device__ __forceinline__ unsigned long long dyn_near_cached(const teb_amd_conf
   return mask;
 }
 
-template <int MODE>
+template <int MODE, bool FAST>
 __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const SceneDev& sc, const TebCtx& t,
                                            const Lds& l, int i, Accum& A, unsigned long long near_first, int sl = 0, int nsl = 1) {
   constexpr bool JAC = (MODE == 1);
@@ -356,7 +356,7 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
   const int cnt = t.assoc_cnt[i];   // the static edges of the pose are dealt round-robin to its slices (k = sl, sl + nsl, ..)
   EVP_DECL
   if (i >= 1) {
-    if (sc.fast_points) {
+    if constexpr (FAST) {
       if (!c.legacy_obstacle_association) {
         // The association lists live in HBM (pose-major, coalesced over the lanes); a lane walks its list in order and at one wave per
         // SIMD every dependent load is a full round trip (L2 for the entry, LDS for the obstacle, then the sqrt chain: ~ 1.1 k cycles per
@@ -497,7 +497,7 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
       TEB_EDGE(M_SEG, CAT_OTHER, {
         double gr[3] = {0, 0, 0};
         double dobs;
-        if (sc.fast_points) dobs = pointlike_distance<J_>(c, W.x0, W.y0, l.obx[p], l.oby[p], l.obr[p], gr);
+        if constexpr (FAST) dobs = pointlike_distance<J_>(c, W.x0, W.y0, l.obx[p], l.oby[p], l.obr[p], gr);
         else dobs = footprint_distance(c, sc, sc.static_idx[p], W.x0, W.y0, W.c0, W.s0, false, 0.0, J_ ? gr : nullptr);
         edge_velocity_obstacle_ratio<J_>(c, dobs, gr, W, ACC_);
       });
@@ -559,7 +559,7 @@ __device__ __forceinline__ void refresh_trig(const Lds& l, int n) {
 }
 
 // buildSystem: H = sum J^T Omega J, b = -sum J^T Omega e, and chi^2 per category at the current state.
-template <int SOLVER, int JMODE>
+template <int SOLVER, int JMODE, bool FAST>
 __device__ inline void linearize(const teb_amd_config_t& c, const SceneDev& sc, const TebCtx& t, const Lds& l, NearCache& nc,
                                  double* cats /*4, out on all threads*/) {
   const int n = t.n, Nt = 4 * n, tid = threadIdx.x;
@@ -578,10 +578,10 @@ __device__ inline void linearize(const teb_amd_config_t& c, const SceneDev& sc, 
     const int i = k0 + tid / G, sl = tid % G;
     const bool active = i <= n - 2;
     constexpr int EM = JMODE == TEB_AMD_JACOBIAN_G2O_NUMERIC ? 2 : 1;
-    const unsigned long long near = active ? dyn_near_cached<EM>(c, sc, l, i, sl, G, nc, pass) : 0ull;   // before the accumulator is live
+    const unsigned long long near = active ? dyn_near_cached<EM, FAST>(c, sc, l, i, sl, G, nc, pass) : 0ull;   // before the accumulator is live
     LNP(2);
     A.clear();
-    if (active) eval_index<EM>(c, sc, t, l, i, A, near, sl, G);
+    if (active) eval_index<EM, FAST>(c, sc, t, l, i, A, near, sl, G);
     LNP(3);
     if (G > 1) {   // the slices of a pose hold partial sums of its dynamic-obstacle rows: pose block (x, y, theta) of H and g
       for (int off = 1; off < G; off <<= 1) {
@@ -614,6 +614,7 @@ __device__ inline void linearize(const teb_amd_config_t& c, const SceneDev& sc, 
 
 // computeActiveErrors + activeRobustChi2 at the current state. cats[4] rides along: a fifth per-lane value summed over the workgroup by the
 // same reduction (the computeScale term of the LM step; one reduction and one pair of barriers less per trial)
+template <bool FAST>
 __device__ inline void evaluate(const teb_amd_config_t& c, const SceneDev& sc, const TebCtx& t, const Lds& l, NearCache& nc,
                                 double* cats /*5*/) {
   refresh_trig(l, t.n);
@@ -624,8 +625,8 @@ __device__ inline void evaluate(const teb_amd_config_t& c, const SceneDev& sc, c
     const int G = (k0 > 0 || kThreads > 256) ? lanes_per_pose(t.n - 1 - k0) : 1;
     const int i = k0 + (int)threadIdx.x / G;
     if (i <= t.n - 2) {
-      const unsigned long long near = dyn_near_cached<0>(c, sc, l, i, (int)threadIdx.x % G, G, nc, pass);
-      eval_index<0>(c, sc, t, l, i, A, near, (int)threadIdx.x % G, G);
+      const unsigned long long near = dyn_near_cached<0, FAST>(c, sc, l, i, (int)threadIdx.x % G, G, nc, pass);
+      eval_index<0, FAST>(c, sc, t, l, i, A, near, (int)threadIdx.x % G, G);
     }
     k0 += kThreads / G;
   }
@@ -1737,7 +1738,7 @@ struct AssocScan {
   int left, right, cnt;
 };
 // scans static-list positions [k_lo, k_hi) for pose i; forced inclusions go to `emit(position)` in list order
-template <typename Emit>
+template <bool FAST, typename Emit>
 __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const SceneDev& sc, const Lds& l, int i, int k_lo, int k_hi, AssocScan& r,
                                            Emit emit) {
   const double x = l.sx[i], y = l.sy[i];
@@ -1753,7 +1754,7 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
     else { if (dist < r.right_min) { r.right_min = dist; r.right = k; } }
   };
   int k0 = k_lo;
-  if (sc.fast_points) {
+  if constexpr (FAST) {
     // Far-field culling, exact: an obstacle beyond max(cutoff, force) (+ a relative guard band of 1e-12 against the rounding of the
     // distance) from the pose is neither included nor a left / right candidate. Pass 1 (uniform over the wave): squared distances, one
     // bit per obstacle; pass 2: each lane visits the set bits of its own mask in list order - the decisions of the sequential scan,
@@ -1779,7 +1780,7 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
     }
     k0 = k_hi;
   }
-  if (!sc.fast_points) {
+  if constexpr (!FAST) {
     // Generic shapes: the same two passes with bounding circles. The robot lies within frad of the pose, the obstacle within brad of its
     // centroid, so their distance is at least |centroid - pose| - brad - frad; beyond max(cutoff, force) (+ guard band) the obstacle
     // cannot matter and its exact distance (segment / polygon loops, the expensive part: 75 % of BASELINE C5 before) is never computed.
@@ -1800,12 +1801,12 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
         const int k = k0 + __ffsll((long long)near) - 1;
         near &= near - 1;
         const int oi = sc.static_idx[k];
-#ifdef TEB_AMD_GENERIC_ASSOC_PRUNE
+#ifndef TEB_AMD_NO_GENERIC_ASSOC_PRUNE
         // The same bound decides most candidates without their exact distance: one that is certainly not force-included (bound >= force)
         // and certainly not closer than the nearest obstacle found so far on its side (bound >= that minimum; the scan keeps the FIRST
         // minimum, so an equal distance would not replace it either) leaves the scan's state untouched. Bit-identical, C5 14.1 -> 12.9 ms
-        // (25 -> 10 exact distances per pose), but OFF by default: with these lines in the kernel the point-like configurations run
-        // 1.5 % slower (the branch is never taken there: code layout / register allocation; same-box A/B of full builds, three times).
+        // (25 -> 10 exact distances per pose). Round 2 kept it out of the one kernel that served both scene kinds (its mere presence
+        // cost the point-like configurations 1.5 % through code placement); the generic scenes now have their own instantiation.
         const double lb = distance_lower_bound(sc, oi, x, y, frad);
         const bool on_left = ox_ * (sc.cy[oi] - y) - (sc.cx[oi] - x) * oy_ > 0;
 #ifdef TEB_PROFILE
@@ -1823,6 +1824,7 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
   }
 }
 
+template <bool FAST>
 __device__ inline void associate(const teb_amd_config_t& c, const SceneDev& sc, const Lds& l, int n, int* assoc_cnt,
                                  int* assoc, int cap, int stride, int* overflow) {
   const int first_vertex = c.weight_velocity_obstacle_ratio == 0 ? 1 : 0;
@@ -1836,7 +1838,7 @@ __device__ inline void associate(const teb_amd_config_t& c, const SceneDev& sc, 
     // the sequential scan of the whole list by one lane, writing straight into the list (also the fallback of the sliced scan)
     auto sequential = [&]() {
       AssocScan r = {kMax, kMax, -1, -1, 0};
-      assoc_scan(c, sc, l, i, 0, sc.n_static, r, [&](int k) { if (r.cnt < cap) assoc[(size_t)r.cnt * stride + i] = k; else *overflow = 1; });
+      assoc_scan<FAST>(c, sc, l, i, 0, sc.n_static, r, [&](int k) { if (r.cnt < cap) assoc[(size_t)r.cnt * stride + i] = k; else *overflow = 1; });
       int cnt = r.cnt;
       if (r.left >= 0) { if (cnt < cap) assoc[(size_t)cnt * stride + i] = r.left; else *overflow = 1; ++cnt; }
       if (r.right >= 0) { if (cnt < cap) assoc[(size_t)cnt * stride + i] = r.right; else *overflow = 1; ++cnt; }
@@ -1854,7 +1856,7 @@ __device__ inline void associate(const teb_amd_config_t& c, const SceneDev& sc, 
 #pragma unroll
       for (int q = 0; q < kSliceForced; ++q) forced[q] = 0;
       if (scans) {
-        assoc_scan(c, sc, l, i, k_lo, k_hi, r, [&](int k) {
+        assoc_scan<FAST>(c, sc, l, i, k_lo, k_hi, r, [&](int k) {
 #pragma unroll
           for (int q = 0; q < kSliceForced; ++q) if (r.cnt == q) forced[q] = k;   // register file: no dynamic indexing
         });
@@ -1975,14 +1977,19 @@ __device__ inline void associate_legacy(const teb_amd_config_t& c, const SceneDe
 }
 
 // =================================================================================================================
-template <int SOLVER, int JMODE>
+// SCENE: SCENE_POINTS = every obstacle and the footprint are point-like and the obstacle table is cached in LDS (SceneDev::fast_points),
+// SCENE_GENERIC = any shapes (segment / polygon distance loops, bounding-circle culling). One instantiation each, so that neither pays
+// for the other's code (placement, registers).
+enum { SCENE_POINTS = 0, SCENE_GENERIC = 1 };
+template <int SOLVER, int JMODE, int SCENE>
 __global__ void __launch_bounds__(kThreads)
 teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev bt, const OptArgs args,
                     const LdsPlan plan) {
   extern __shared__ __attribute__((aligned(16))) double lds_base[];
   const int b = blockIdx.x, tid = threadIdx.x, S = bt.stride;
   const Lds l = carve(lds_base, plan, SOLVER == SOLVER_BANDG ? args.Hband + (size_t)b * args.hband_stride : nullptr, SOLVER == SOLVER_BANDG);
-  if (sc.fast_points) {   // stage the point-like obstacle table once: static list first, then the dynamic list
+  constexpr bool FAST = SCENE == SCENE_POINTS;
+  if constexpr (FAST) {   // stage the point-like obstacle table once: static list first, then the dynamic list
     const int tot = sc.n_static + sc.n_dyn;
     for (int k = tid; k < tot; k += kThreads) {
       const int oi = (k < sc.n_static) ? sc.static_idx[k] : sc.dyn_idx[k - sc.n_static];
@@ -1992,6 +1999,17 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   }
   int n = bt.n[b];
   const size_t so = (size_t)b * S;
+  // Memory safety does not rest on the host's idea of the pose counts: a band longer than the LDS strips of THIS launch (an optimistic
+  // layout chosen from a stale upper bound, counts written through teb_amd_device_state) is flagged like a band that outgrew the layout
+  // during autoResize (the host repeats the launch in the handle's own layout) and leaves without touching the LDS.
+  if (n > plan.S || n > S || n < 0) {
+    if (tid == 0) {
+      bt.assoc_overflow[b] = 2;
+      bt.status[b] = TEB_AMD_TEB_FAILED; bt.iters[b] = 0; bt.trials[b] = 0;
+      bt.chi2[b] = 0; bt.cost[b] = __longlong_as_double(0x7ff8000000000000LL); bt.lambda[b] = 0;
+    }
+    return;
+  }
 
   // ---- K0: strip load, coalesced 8 B / lane
   for (int i = tid; i < n; i += kThreads) {
@@ -2056,7 +2074,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       if (c.legacy_obstacle_association)
         associate_legacy(c, sc, l, n, assoc_cnt, assoc, bt.assoc_cap, S, &ovf, bt.legacy_idx + (size_t)b * bt.assoc_cap);
       else
-        associate(c, sc, l, n, assoc_cnt, assoc, bt.assoc_cap, S, &ovf);
+        associate<FAST>(c, sc, l, n, assoc_cnt, assoc, bt.assoc_cap, S, &ovf);
       if (ovf && tid < kThreads) bt.assoc_overflow[b] |= 1;
     } else {
       for (int i = tid; i < n; i += kThreads) assoc_cnt[i] = 0;
@@ -2112,7 +2130,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     for (int it = 0; it < args.inner && lm_ok; ++it) {
       double cats[4];
       PROF_START();
-      linearize<SOLVER, JMODE>(c, sc, t, l, near_cache, cats);
+      linearize<SOLVER, JMODE, FAST>(c, sc, t, l, near_cache, cats);
       PROF_END(2);
       double currentChi = ((cats[0] + cats[1]) + cats[2]) + cats[3];
       if (args.debug_linearize) {
@@ -2196,7 +2214,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
         __syncthreads();
         double tc[5];
         tc[4] = sc_part;
-        evaluate(c, sc, t, l, near_cache, tc);
+        evaluate<FAST>(c, sc, t, l, near_cache, tc);
         last_cats[0] = tc[0]; last_cats[1] = tc[1]; last_cats[2] = tc[2]; last_cats[3] = tc[3];
         double tempChi = ((tc[0] + tc[1]) + tc[2]) + tc[3];
         double scv[1] = {tc[4]};
@@ -2231,13 +2249,19 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
         PROF_END(6);
         qmax++;
       } while (rho < 0 && qmax < 10);
+#ifndef TEB_AMD_NO_ITER_LOG   // (A/B switch: what the opt-in log costs the launches that leave it off)
+      if (args.iter_log && tid == 0 && iters < args.iter_log_cap) {   // "iteration= i chi2= .. lambda= .. levenbergIter= .." of g2o's verbose mode
+        double* row = args.iter_log + ((size_t)b * args.iter_log_cap + iters) * 4;
+        row[0] = currentChi; row[1] = lambda; row[2] = (double)qmax; row[3] = (double)n;
+      }
+#endif
       ++iters;
       chi2_final = currentChi;
       if (qmax == 10 || rho == 0 || !isfinite(lambda)) lm_ok = false;   // Terminate
       if (c.divergence_detection_enable) {   // setComputeBatchStatistics -> computeActiveErrors after each solve
         double fc[5];
         fc[4] = 0;
-        evaluate(c, sc, t, l, near_cache, fc);
+        evaluate<FAST>(c, sc, t, l, near_cache, fc);
         last_cats[0] = fc[0]; last_cats[1] = fc[1]; last_cats[2] = fc[2]; last_cats[3] = fc[3];
         chi2_final = ((fc[0] + fc[1]) + fc[2]) + fc[3];
       }

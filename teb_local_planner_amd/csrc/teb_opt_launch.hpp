@@ -1,0 +1,22 @@
+// teb_opt_launch.hpp — how the host side of libteb_amd.so reaches the instantiations of teb_optimize_kernel.
+//
+// Every (solver layout, Jacobian mode, scene kind) instantiation is ~ 0.5 MB of code and 20 - 50 s of compile time; each one is built
+// in a translation unit of its own (teb_opt_inst.hip with -DTEB_INST_SOLVER / _JMODE / _SCENE), in parallel, and hands the host side
+// the address of its kernel through one hidden function. -DTEB_AMD_SINGLE_TU (the tools/ builds with profiling counters, which read
+// __device__ symbols of the kernel's translation unit) defines them all inside teb_amd.hip instead.
+#pragma once
+
+#define TEB_OPT_CAT_(a, b, c, d) a##_##b##_##c##_##d
+#define TEB_OPT_CAT(a, b, c, d) TEB_OPT_CAT_(a, b, c, d)
+#define TEB_OPT_KERNEL_FN(S, J, P) TEB_OPT_CAT(teb_opt_kernel, S, J, P)
+#define TEB_OPT_DECLARE(S, J, P) __attribute__((visibility("hidden"))) const void* TEB_OPT_KERNEL_FN(S, J, P)();
+#define TEB_OPT_DEFINE(S, J, P)                                                                                      \
+  __attribute__((visibility("hidden"))) const void* TEB_OPT_KERNEL_FN(S, J, P)() {                                   \
+    return reinterpret_cast<const void*>(&tebamd::teb_optimize_kernel<S, J, P>);                                     \
+  }
+// solver: 0 SOLVER_BAND, 1 SOLVER_CR, 2 SOLVER_BANDG; jmode: 0 analytic, 1 g2o numeric; scene: 0 SCENE_POINTS, 1 SCENE_GENERIC
+#ifdef TEB_AMD_ANALYTIC_ONLY
+#define TEB_OPT_FOR_ALL(X) X(0, 0, 0) X(1, 0, 0) X(2, 0, 0) X(0, 0, 1) X(1, 0, 1) X(2, 0, 1)
+#else
+#define TEB_OPT_FOR_ALL(X) X(0, 0, 0) X(1, 0, 0) X(2, 0, 0) X(0, 0, 1) X(1, 0, 1) X(2, 0, 1) X(0, 1, 0) X(1, 1, 0) X(2, 1, 0) X(0, 1, 1) X(1, 1, 1) X(2, 1, 1)
+#endif

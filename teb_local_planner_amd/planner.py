@@ -54,6 +54,10 @@ def lib():
         L.teb_amd_synchronize.argtypes = [vp]
         L.teb_amd_get_results.argtypes = [vp, C.POINTER(_abi.Results)]
         L.teb_amd_select_best.argtypes = [vp, C.c_int32, C.c_int32, _abi.p_i32, _abi.p_f64]
+        if hasattr(L, "teb_amd_set_iteration_log"):   # (absent from the older builds tools/ compares against through TEB_AMD_LIB)
+            L.teb_amd_set_iteration_log.argtypes = [vp, C.c_int32]
+            L.teb_amd_get_iteration_log.argtypes = [vp, C.c_int32, _abi.p_f64, C.c_int32, _abi.p_i32]
+            L.teb_amd_debug_world_argmin.argtypes = [_abi.p_f64, C.c_int32, _abi.p_i32, _abi.p_f64, _abi.p_i32]
         L.teb_amd_device_state.argtypes = [vp] + [C.POINTER(vp)] * 5 + [_abi.p_i32]
         L.teb_amd_snapshot_state.argtypes = [vp]
         L.teb_amd_restore_state.argtypes = [vp]
@@ -184,6 +188,18 @@ class TebBatchSolver:
         rs = res.c_struct()
         _chk(lib().teb_amd_get_results(self._h, C.byref(rs)), "teb_amd_get_results")
         return res
+
+    def set_iteration_log(self, enable=True):
+        """Opt-in per-iteration log of the LM loop (g2o's verbose line as data, src/optimal_planner.cpp:384)."""
+        _chk(lib().teb_amd_set_iteration_log(self._h, int(bool(enable))), "teb_amd_set_iteration_log")
+
+    def iteration_log(self, b, capacity_rows=256):
+        """[iterations, 4] of band b after the last optimize(): chi2 after the iteration, lambda after it, damping trials, pose count."""
+        rows = np.zeros((int(capacity_rows), 4))
+        n = C.c_int32(0)
+        _chk(lib().teb_amd_get_iteration_log(self._h, int(b), _abi._ptr(rows, C.c_double), int(capacity_rows), C.byref(n)),
+             "teb_amd_get_iteration_log")
+        return rows[:n.value].copy()
 
     def select_best(self, last_best=-1, initial_plan=-1):
         best = C.c_int32(-1)

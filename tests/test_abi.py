@@ -68,3 +68,26 @@ def test_fails_loudly_without_gpu():
     with pytest.raises(planner.TebAmdError) as e:
         planner.make_solver(*scenes.scene_c1())
     assert e.value.code == _abi.ERR_NO_DEVICE
+
+
+def test_world_argmin_of_the_distributed_selection():
+    """Host-side reduction of teb_amd_select_best_distributed over the gathered (cost, global index) records (no GPU, no RCCL):
+    lowest cost wins, ties go to the lowest GLOBAL index whatever rank holds it (strict '<' of selectBestTeb,
+    src/homotopy_class_planner.cpp:610), empty ranks (index -1) and ranks whose best cost is DBL_MAX are handled."""
+    import numpy as np
+    L = planner.lib()
+    DMAX = 1.7976931348623157e308
+
+    def run(recs):
+        a = np.ascontiguousarray(np.array(recs, np.float64).reshape(-1))
+        best = C.c_int32(-7); cost = C.c_double(0); owner = C.c_int32(-7)
+        assert L.teb_amd_debug_world_argmin(_abi._ptr(a, C.c_double), len(recs), C.byref(best), C.byref(cost), C.byref(owner)) == 0
+        return best.value, cost.value, owner.value
+
+    assert run([(3.0, 5), (2.0, 40), (4.0, 70)]) == (40, 2.0, 1)
+    assert run([(2.0, 64), (2.0, 3), (2.0, 130)]) == (3, 2.0, 1)              # tie: lowest global index, owner = the rank that holds it
+    assert run([(DMAX, -1), (5.0, 9)]) == (9, 5.0, 1)                           # rank 0 holds no candidate
+    assert run([(DMAX, -1), (DMAX, -1)])[0] == -1                               # nobody does
+    assert run([(DMAX, 2), (DMAX, -1), (DMAX, 1)]) == (1, DMAX, 2)              # all costs at DBL_MAX: still the lowest index
+    assert run([(1.0, 0)]) == (0, 1.0, 0)
+    assert L.teb_amd_debug_world_argmin(None, 2, None, None, None) != 0
