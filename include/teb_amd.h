@@ -246,7 +246,14 @@ typedef struct teb_amd_options {
   int32_t hsig3d_kernel;          /* TEB_AMD_HSIG3D_*: pin one of the two HSignature3d kernels                                  */
   int32_t no_near_cache;          /* 1: the near masks of the dynamic-obstacle edges are recomputed at every pass instead of    */
                                   /*    cached across one optimize() (cross-check: the results must not change by one bit)      */
-  int32_t reserved[9];            /* must be 0                                                                                  */
+  int32_t multi_cu;               /* small batches of generic-shape scenes on more than one CU (obstacle association and the       */
+                                  /* robot <-> obstacle distances of every (pose, obstacle) pair are computed by helper workgroups */
+                                  /* on the idle CUs, the bands are bit-identical to the single-CU result): 0 = automatic (<= 16   */
+                                  /* bands, closed-form Jacobians, new association, enough obstacles x poses), -1 = never,         */
+                                  /* n > 0 = at most n helper workgroups per band, whatever the size of the scene                  */
+  int32_t multi_cu_timeout_us;    /* how long a band waits for its helper workgroups before it gives the launch up (it is then     */
+                                  /* repeated on one CU per band); 0 = 50 000 (50 ms)                                            */
+  int32_t reserved[7];            /* must be 0                                                                                  */
 } teb_amd_options_t;
 void teb_amd_options_default(teb_amd_options_t* opt);
 
@@ -312,6 +319,10 @@ int  teb_amd_get_iteration_log(teb_amd_handle_t* h, int32_t b, double* rows, int
  */
 int  teb_amd_select_best(teb_amd_handle_t* h, int32_t last_best, int32_t initial_plan,
                          int32_t* best, double* best_cost);
+
+/* How the last teb_amd_optimize_batch ran: helper workgroups per band of the multi-CU mode (0 = one CU per band), and whether the
+ * launch had to be repeated on one CU per band because the helpers did not arrive in time (a device busy with other work). */
+int  teb_amd_last_launch_info(teb_amd_handle_t* h, int32_t* helpers_per_band, int32_t* repeated_single_cu);
 
 /* -- zero-copy access for callers that already live on the GPU (benchmarks, torch interop) ---------- */
 /*

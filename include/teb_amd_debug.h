@@ -56,6 +56,15 @@ int teb_amd_debug_world_argmin(const double* records, int32_t world, int32_t* be
  * a band (status FAILED, flag bit 1) instead of running off its LDS strips. */
 int teb_amd_debug_poke_pose_count(teb_amd_handle_t* h, int32_t b, int32_t n);
 
+/* Development aid of the multi-CU mode: every multi-CU launch leaves host-visible breadcrumbs (one word per workgroup), and a launch that
+ * is still running after `milliseconds` prints them to stderr and ENDS THE PROCESS with exit code 3 (a kernel cannot be cancelled).
+ * 0 = off. */
+int teb_amd_debug_mcu_watchdog(teb_amd_handle_t* h, int32_t milliseconds);
+
+/* Development aid of the multi-CU mode: bit 0 = the association scan stays with the band's own workgroup, bit 1 = the distance records do
+ * (to bisect a difference between the two modes). */
+int teb_amd_debug_mcu_flags(teb_amd_handle_t* h, int32_t flags);
+
 /* per-TEB flags of the last launch: bit0 association list overflow, bit1 autoResize capacity overflow */
 int teb_amd_debug_assoc_overflow(teb_amd_handle_t* h, int32_t* flags);
 

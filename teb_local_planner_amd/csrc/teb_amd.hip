@@ -2,8 +2,10 @@
 // Plain HIP runtime; no torch, no oracle, no CPU fallback: every entry point fails loudly without a gfx950 GPU.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <unistd.h>
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
@@ -153,6 +155,7 @@ struct teb_amd_handle {
   size_t hmat_stride = 0;
   int band_ldlt = 0;   // SOLVER_BAND: 1 = sequential banded LDL^T (teb_amd_options_t::band_ldlt), 0 = hybrid cyclic reduction
   size_t lds_limit = 0;
+  int num_cus = 0;
   LdsPlan plan;
   int fast_points = 0;
   teb_amd_options_t opt;   // behaviour switches fixed at create (ABI 2; never the process environment)
@@ -169,6 +172,15 @@ struct teb_amd_handle {
   DevBuf<int> n, has_vs, has_vg, rotdir, via_en, status, optimized, iters, trials, assoc_cnt, assoc, assoc_ovf, via_pose, legacy_idx;
   DevBuf<double> x, y, th, dt, vs, vg, chi2, cost, lambda, Hbackup, Hband, ob_x, ob_y, ob_th, ob_dt;   // ob_*: strips before an optimistic launch
   DevBuf<int> ob_n;
+  // multi-CU mode (teb_multicu.hpp): control words, published poses, distance records; sized on first use
+  DevBuf<unsigned> mcu_ctl;
+  DevBuf<double> mcu_pub, mcu_items;
+  size_t mcu_items_have = 0;
+  int mcu_last_helpers = 0;   // helper workgroups per band of the last launch (0: single-CU), teb_amd_last_launch_info
+  int mcu_last_repeated = 0;  // that launch timed out waiting for its helpers and was repeated on one CU per band
+  unsigned* mcu_trace = nullptr;   // teb_amd_debug_mcu_watchdog: host-pinned breadcrumbs of the multi-CU launch, one word per workgroup
+  int mcu_watchdog_ms = 0;
+  int mcu_debug_flags = 0;
   DevBuf<double> iter_log;   // teb_amd_set_iteration_log: [max_tebs][TEB_AMD_ITERATION_LOG_ROWS][4]
   bool iter_log_on = false;
   bool opt_backup_ready = false;
@@ -268,15 +280,34 @@ const void* opt_kernel(int solver, int jmode, int scene) {
 #undef TEB_OPT_PICK
   return nullptr;   // (a -DTEB_AMD_ANALYTIC_ONLY build asked for the numeric mode)
 }
-hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const BatchDev& bt, const OptArgs& a, int solver, const LdsPlan& plan) {
+hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const BatchDev& bt, const OptArgs& a, int solver, const LdsPlan& plan,
+                      const McuDev* mcu = nullptr) {
   const void* k = opt_kernel(solver, h->cfg.jacobian_mode, sc.fast_points ? SCENE_POINTS : SCENE_GENERIC);
   if (!k) return hipErrorInvalidDeviceFunction;
+  McuDev none;
+  std::memset(&none, 0, sizeof none);
+  const McuDev* mc = mcu ? mcu : &none;
   void* params[] = {const_cast<teb_amd_config_t*>(&h->cfg), const_cast<SceneDev*>(&sc), const_cast<BatchDev*>(&bt), const_cast<OptArgs*>(&a),
-                    const_cast<LdsPlan*>(&plan)};
-  return hipLaunchKernel(k, dim3(grid), dim3(kThreads), params, plan.total_bytes, h->stream);
+                    const_cast<LdsPlan*>(&plan), const_cast<McuDev*>(mc)};
+  return hipLaunchKernel(k, dim3(grid * (1 + mc->H)), dim3(kThreads), params, plan.total_bytes, h->stream);
 }
 hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const BatchDev& bt, const OptArgs& a) {
   return launch_opt(h, grid, sc, bt, a, h->solver, h->plan);
+}
+
+// Multi-CU mode (teb_multicu.hpp): how many helper workgroups each band of this launch gets, 0 = none. Generic scenes only (the
+// point-like path has no per-pair work worth a hand-off), closed-form Jacobians, new association; one workgroup per CU (the LDS
+// footprint of the layouts) means B (1 + H) <= number of CUs keeps every workgroup resident.
+int mcu_helpers_for(teb_amd_handle* h, const OptArgs& args) {
+  if (h->opt.multi_cu < 0 || h->fast_points || args.debug_linearize || h->cfg.jacobian_mode != TEB_AMD_JACOBIAN_ANALYTIC ||
+      h->cfg.legacy_obstacle_association || h->M <= 0)
+    return 0;
+  const int cus = h->num_cus > 0 ? h->num_cus : 256;
+  int H = cus / h->B - 1;
+  if (H > 63) H = 63;                                     // beyond ~ 4 poses per helper the hand-off costs more than the tile
+  if (h->opt.multi_cu > 0) H = std::min(H, (int)h->opt.multi_cu);
+  else if (h->B > 16 || (size_t)h->M * (size_t)(h->nmax_known > 0 ? h->nmax_known : h->stride) < 4096) return 0;   // auto: small batches with enough (pose, obstacle) work
+  return H >= 2 ? H : 0;
 }
 
 // largest pose capacity whose LDS plan (with the obstacle cache of this scene, if it is in use) fits
@@ -336,7 +367,28 @@ int launch(teb_amd_handle* h, const OptArgs& args) {
     if (s_cr > 0 && need <= s_cr) { eff_solver = SOLVER_CR; eff_plan = make_lds_plan(s_cr, SOLVER_CR, ob); optimistic = true; }
     else if (s_band > 0 && need <= s_band) { eff_solver = SOLVER_BAND; eff_plan = make_lds_plan(s_band, SOLVER_BAND, ob); optimistic = true; }
   }
-  if (optimistic) {   // strips as they are now, for the repeat
+  // multi-CU mode: helper workgroups per band (0 = off); its buffers, and the control words zeroed on the stream before the launch
+  const int H = mcu_helpers_for(h, args);
+  McuDev mcu;
+  std::memset(&mcu, 0, sizeof mcu);
+  if (H > 0) {
+    const size_t need_items = (size_t)h->B * h->M * 4 * h->stride;
+    if (!h->mcu_ctl.p) { HIPCHK(h->mcu_ctl.alloc((size_t)h->max_tebs * kMcuCtlWords)); HIPCHK(h->mcu_pub.alloc((size_t)h->max_tebs * kMcuPubArrays * h->stride)); }
+    if (h->mcu_items_have < need_items) {
+      h->mcu_items.free(); h->mcu_items_have = 0;
+      HIPCHK(h->mcu_items.alloc(need_items));
+      h->mcu_items_have = need_items;
+    }
+    HIPCHK(hipMemsetAsync(h->mcu_ctl.p, 0, (size_t)h->B * kMcuCtlWords * sizeof(unsigned), h->stream));
+    mcu.H = H; mcu.ctl = h->mcu_ctl.p; mcu.pub = h->mcu_pub.p; mcu.items = h->mcu_items.p; mcu.item_cap = h->M;
+    mcu.timeout_ticks = (long long)(h->opt.multi_cu_timeout_us > 0 ? h->opt.multi_cu_timeout_us : 50000) * 100LL;   // 100 MHz real-time counter
+    mcu.trace = h->mcu_trace;
+    mcu.debug_flags = h->mcu_debug_flags;
+    if (h->mcu_trace) std::memset(h->mcu_trace, 0, 1024 * sizeof(unsigned));
+  }
+  h->mcu_last_helpers = H; h->mcu_last_repeated = 0;
+  const bool checked = optimistic || H > 0;   // the launch is followed by a look at the per-band flags (and possibly repeated)
+  if (checked) {   // strips as they are now, for the repeat
     if (!h->opt_backup_ready) {
       const size_t BS = (size_t)h->max_tebs * h->stride;
       HIPCHK(h->ob_x.alloc(BS)); HIPCHK(h->ob_y.alloc(BS)); HIPCHK(h->ob_th.alloc(BS)); HIPCHK(h->ob_dt.alloc(BS)); HIPCHK(h->ob_n.alloc(h->max_tebs));
@@ -345,21 +397,39 @@ int launch(teb_amd_handle* h, const OptArgs& args) {
     if (int crc = copy_strips(h, Strips{h->ob_x.p, h->ob_y.p, h->ob_th.p, h->ob_dt.p, h->ob_n.p}, Strips{h->x.p, h->y.p, h->th.p, h->dt.p, h->n.p}, h->B)) return crc;
   }
   HIPCHK(hipEventRecord(h->ev0, h->stream));   // (the kernel clears its bands' overflow flags itself)
-  HIPCHK(launch_opt(h, h->B, sc, bt, args, eff_solver, eff_plan));
-  if (optimistic) {
+  HIPCHK(launch_opt(h, h->B, sc, bt, args, eff_solver, eff_plan, H > 0 ? &mcu : nullptr));
+  if (H > 0 && h->mcu_trace && h->mcu_watchdog_ms > 0) {
+    // diagnostic: a multi-CU launch that does not finish in time is reported with the breadcrumbs of its workgroups, and the process ends
+    // (a kernel cannot be cancelled; the bounded spins of the kernel make this unreachable unless the protocol itself is broken)
+    const auto t0 = std::chrono::steady_clock::now();
+    while (hipStreamQuery(h->stream) == hipErrorNotReady) {
+      if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > h->mcu_watchdog_ms) {
+        fprintf(stderr, "[teb_amd multi-CU watchdog] launch of %d bands x (1 + %d) workgroups still running after %d ms; breadcrumbs (epoch << 8 | code):\n", h->B, H, h->mcu_watchdog_ms);
+        for (int w = 0; w < h->B * (1 + H) && w < 1024; ++w) fprintf(stderr, " wg%d:%x", w, h->mcu_trace[w]);
+        fprintf(stderr, "\n");
+        fflush(stderr);
+        _exit(3);
+      }
+    }
+  }
+  if (checked) {
     HIPCHK(hipGetLastError());
     // this mode is synchronous: the overflow flags decide whether the launch has to be repeated (documented in teb_amd.h)
     std::vector<int> ovf(h->B), nn(h->B);
     HIPCHK(hipMemcpyAsync(ovf.data(), h->assoc_ovf.p, h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(nn.data(), h->n.p, h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    bool outgrown = false;
-    for (int v : ovf) outgrown = outgrown || (v & 2);
+    bool outgrown = false, helpers_late = false;
+    for (int v : ovf) { outgrown = outgrown || (v & 2); helpers_late = helpers_late || (v & 4); }
     h->nmax_known = 0;
     for (int v : nn) h->nmax_known = std::max(h->nmax_known, v);
-    if (outgrown) {
+    if (outgrown || helpers_late) {
+      // from the saved strips: in the handle's own layout when a band outgrew the optimistic one, and on one CU per band when the
+      // helpers of the multi-CU mode did not show up in time (a busy device: nothing promises their residency)
       if (int crc = copy_strips(h, Strips{h->x.p, h->y.p, h->th.p, h->dt.p, h->n.p}, Strips{h->ob_x.p, h->ob_y.p, h->ob_th.p, h->ob_dt.p, h->ob_n.p}, h->B)) return crc;
-      HIPCHK(launch_opt(h, h->B, sc, bt, args));   // ev0 stays where it was: the reported time includes the discarded first launch
+      if (outgrown || !optimistic) HIPCHK(launch_opt(h, h->B, sc, bt, args));   // ev0 stays where it was: the reported time includes the discarded first launch
+      else HIPCHK(launch_opt(h, h->B, sc, bt, args, eff_solver, eff_plan));
+      h->mcu_last_repeated = helpers_late ? 1 : 0;
       h->nmax_known = -1;
     }
   } else if (h->cfg.teb_autosize && !args.debug_linearize) {
@@ -485,6 +555,7 @@ int teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max
   h->lds_bytes = lds;
   h->solver = solver; h->solver_created = solver;
   h->lds_limit = lds_limit;
+  h->num_cus = prop.multiProcessorCount;
   h->plan = make_lds_plan(max_poses, solver, 0);
   // per-band HBM buffer: the copy of H for rejected trials (SOLVER_CR, banded LDL^T) or the blocks the cyclic reduction of a
   // SOLVER_BAND handle works on (D, L, f: nb * (2 * kBlk + 8) doubles)
@@ -559,6 +630,8 @@ void teb_amd_destroy(teb_amd_handle_t* h) {
   for (auto* q : gi) q->free();
   h->ob_n.free();
   h->iter_log.free();
+  h->mcu_ctl.free(); h->mcu_pub.free(); h->mcu_items.free();
+  if (h->mcu_trace) (void)hipHostFree(h->mcu_trace);
   h->g_adj.free();
   h->cm_cells.free(); h->cm_fp.free(); h->cm_out.free();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1909,6 +1982,14 @@ int teb_amd_restore_state(teb_amd_handle_t* h) {
   return TEB_AMD_OK;
 }
 
+int teb_amd_last_launch_info(teb_amd_handle_t* h, int32_t* helpers_per_band, int32_t* repeated_single_cu) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (helpers_per_band) *helpers_per_band = h->mcu_last_helpers;
+  if (repeated_single_cu) *repeated_single_cu = h->mcu_last_repeated;
+  return TEB_AMD_OK;
+}
+
 int teb_amd_last_kernel_ms(teb_amd_handle_t* h, float* ms) {
   int rc = check_handle(h);
   if (rc) return rc;
@@ -2140,6 +2221,35 @@ int teb_amd_debug_poke_pose_count(teb_amd_handle_t* h, int32_t b, int32_t n) {
   HIPCHK(hipStreamSynchronize(h->stream));
   return TEB_AMD_OK;
 }
+
+// diagnostic of the multi-CU mode: from now on every multi-CU launch leaves host-visible breadcrumbs, and one that is still running after
+// `milliseconds` prints them and ENDS THE PROCESS (exit code 3). Development tool; 0 switches the watchdog off again.
+int teb_amd_debug_mcu_watchdog(teb_amd_handle_t* h, int32_t milliseconds) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (milliseconds > 0 && !h->mcu_trace) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->mcu_trace), 1024 * sizeof(unsigned), hipHostMallocMapped));
+  h->mcu_watchdog_ms = milliseconds;
+  return TEB_AMD_OK;
+}
+
+// diagnostic of the multi-CU mode: 1 = the association stays with the band's own workgroup, 2 = the distances do (bisecting a difference)
+int teb_amd_debug_mcu_flags(teb_amd_handle_t* h, int32_t flags) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  h->mcu_debug_flags = flags;
+  return TEB_AMD_OK;
+}
+
+#ifdef TEB_MCU_VERIFY
+extern "C" int teb_amd_debug_mcu_verify(teb_amd_handle_t* h, double* out16) {
+  (void)h;
+  unsigned long long c[8]; double v[8];
+  HIPCHK(hipMemcpyFromSymbol(c, HIP_SYMBOL(tebamd::g_mcu_verify), sizeof c));
+  HIPCHK(hipMemcpyFromSymbol(v, HIP_SYMBOL(tebamd::g_mcu_verify_val), sizeof v));
+  for (int q = 0; q < 8; ++q) { out16[q] = (double)c[q]; out16[8 + q] = v[q]; }
+  return TEB_AMD_OK;
+}
+#endif
 
 int teb_amd_debug_assoc_overflow(teb_amd_handle_t* h, int32_t* flags) {
   int rc = check_handle(h);

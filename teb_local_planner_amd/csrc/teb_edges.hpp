@@ -109,13 +109,27 @@ struct Accum {
   // one residual row: e, information w, gradient row r (only columns with bit set in MASK can be non-zero)
   template <unsigned MASK, bool JAC>
   __device__ __forceinline__ void row(int cat, double e, double w, const double* r) {
-    // The accumulation (and only it) may fuse a*b+c into v_fma_f64: the residual e and the Jacobian row r - everything that decides on
+    // The accumulation (and only it) uses fused multiply-adds: the residual e and the Jacobian row r - everything that decides on
     // which side of a penalty kink a value falls - are computed by the caller under -ffp-contract=off; what is summed here has no
-    // bit-level counterpart in the reference (g2o adds the edges in another order). -DTEB_AMD_NO_ROW_FMA: separate mul / add
-    // (C4 with 200 fixed poses + 5 %, C2 / C3 + 3 %, headline + 2 %).
+    // bit-level counterpart in the reference (g2o adds the edges in another order). The fusion is spelled out (fma(), not a contraction
+    // pragma that leaves the choice to the optimiser): every instantiation that replays a row - single-CU, multi-CU, any layout - rounds
+    // it the same way. -DTEB_AMD_NO_ROW_FMA: separate mul / add (C4 with 200 fixed poses + 5 %, C2 / C3 + 3 %, headline + 2 %).
 #ifndef TEB_AMD_NO_ROW_FMA
-    _Pragma("clang fp contract(fast)")
-#endif
+    chi[cat] = fma(e, w * e, chi[cat]);
+    if (JAC) {
+#pragma unroll
+      for (int a = 0; a < 11; ++a) {
+        if (!((MASK >> a) & 1u)) continue;
+        const double ra = r[a] * w;
+        g[a] = fma(ra, e, g[a]);
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+          if (!((MASK >> b) & 1u)) continue;
+          H[a * (a + 1) / 2 + b] = fma(ra, r[b], H[a * (a + 1) / 2 + b]);
+        }
+      }
+    }
+#else
     chi[cat] += e * (w * e);
     if (JAC) {
 #pragma unroll
@@ -130,6 +144,7 @@ struct Accum {
         }
       }
     }
+#endif
   }
 };
 
@@ -605,6 +620,43 @@ __device__ __forceinline__ void edge_obstacle(const teb_amd_config_t& c, const S
     if (JAC) { r[0] = d1 * gr[0]; r[1] = d1 * gr[1]; r[2] = d1 * gr[2]; }
     A.template row<M_POSE0, JAC>(CAT_OBST, e1, c.weight_inflation, r);
   }
+}
+
+// residual rows of EdgeObstacle / EdgeInflatedObstacle and of EdgeDynamicObstacle for the generic shapes, given the distance and its
+// gradient (d/dx, d/dy, d/dtheta): exactly what edge_obstacle / edge_dynamic_obstacle do after footprint_distance. The multi-CU mode
+// (teb_multicu.hpp) replays the rows from distances other workgroups computed.
+template <bool JAC, class ACC>
+__device__ __forceinline__ void obstacle_rows_g(const teb_amd_config_t& c, double dist, const double* gr, double w_obst, bool inflated, ACC& A) {
+  double d0;
+  double e0 = pen_below(dist, c.min_obstacle_dist, c.penalty_epsilon, d0);
+  if (c.obstacle_cost_exponent != 1.0 && c.min_obstacle_dist > 0.0) {
+    double lin = e0;
+    e0 = c.min_obstacle_dist * pow(lin / c.min_obstacle_dist, c.obstacle_cost_exponent);
+    if (JAC) {
+      if (lin > 0) d0 *= c.obstacle_cost_exponent * pow(lin / c.min_obstacle_dist, c.obstacle_cost_exponent - 1.0);
+      else d0 = 0;
+    }
+  }
+  double r[11];
+  if (JAC) { r[0] = d0 * gr[0]; r[1] = d0 * gr[1]; r[2] = d0 * gr[2]; }
+  A.template row<M_POSE0, JAC>(CAT_OBST, e0, w_obst, r);
+  if (inflated) {
+    double d1;
+    double e1 = pen_below(dist, c.inflation_dist, 0.0, d1);
+    if (JAC) { r[0] = d1 * gr[0]; r[1] = d1 * gr[1]; r[2] = d1 * gr[2]; }
+    A.template row<M_POSE0, JAC>(CAT_OBST, e1, c.weight_inflation, r);
+  }
+}
+template <bool JAC, class ACC>
+__device__ __forceinline__ void dynamic_obstacle_rows_g(const teb_amd_config_t& c, double dist, const double* gr, ACC& A) {
+  double d0, d1;
+  double e0 = pen_below(dist, c.min_obstacle_dist, c.penalty_epsilon, d0);
+  double e1 = pen_below(dist, c.dynamic_obstacle_inflation_dist, 0.0, d1);
+  double r[11];
+  if (JAC) { r[0] = d0 * gr[0]; r[1] = d0 * gr[1]; r[2] = d0 * gr[2]; }
+  A.template row<M_POSE0, JAC>(CAT_OBST, e0, c.weight_dynamic_obstacle, r);
+  if (JAC) { r[0] = d1 * gr[0]; r[1] = d1 * gr[1]; r[2] = d1 * gr[2]; }
+  A.template row<M_POSE0, JAC>(CAT_OBST, e1, c.weight_dynamic_obstacle_inflation, r);
 }
 
 template <bool JAC, class ACC>

@@ -13,6 +13,7 @@
 //   red                : 64       reduction scratch
 #pragma once
 #include "teb_edges.hpp"
+#include "teb_multicu.hpp"
 
 namespace tebamd {
 
@@ -26,6 +27,10 @@ namespace tebamd {
 #define PROF_END(k)
 #endif
 
+#ifdef TEB_MCU_VERIFY
+__device__ unsigned long long g_mcu_verify[8];   // records checked | evaluate: dist differs, grad differs | linearise: dist differs, only grad differs
+__device__ double g_mcu_verify_val[8];
+#endif
 #ifdef TEB_PROFILE
 __device__ long long g_ev_prof[8];   // thread 1 (pose 1) of workgroup 0: evaluate {static, dynamic, chain}, linearise {static, dynamic, chain}, trig, scatter
 #define EVP_DECL long long evp_t0 = clock64(), evp_t1;
@@ -210,6 +215,7 @@ struct TebCtx {
   const int* assoc;       // + b*cap*stride
   const int* via_pose;    // + b*via_cap
   int stride;
+  McuView mcu;            // multi-CU mode (generic scenes): delivered distance records / lists written by other workgroups
 };
 
 // radius of a circle about the pose that contains the robot, whatever its heading (bounding-circle culling of the generic shapes)
@@ -334,7 +340,10 @@ __device__ __forceinline__ unsigned long long dyn_near_cached(const teb_amd_conf
   return mask;
 }
 
-template <int MODE, bool FAST>
+// PART (multi-CU mode only): 0 = every cost term of the pose, 1 = the static / dynamic obstacle edges alone, 2 = everything else. The four
+// chi^2 categories are separate accumulators, so an error evaluation may run part 2 while the helpers still compute the distances part 1
+// needs; a linearisation (one window accumulator, fixed edge order) always runs part 0.
+template <int MODE, bool FAST, int PART = 0>
 __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const SceneDev& sc, const TebCtx& t,
                                            const Lds& l, int i, Accum& A, unsigned long long near_first, int sl = 0, int nsl = 1) {
   constexpr bool JAC = (MODE == 1);
@@ -353,9 +362,11 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
 
   // ---- unary edges of pose i (AddEdgesObstacles :444-548, AddEdgesDynamicObstacles :646-673, AddEdgesViaPoints :675-718)
   // association entries are POSITIONS in the static list (sc.static_idx / the LDS obstacle cache)
-  const int cnt = t.assoc_cnt[i];   // the static edges of the pose are dealt round-robin to its slices (k = sl, sl + nsl, ..)
+  // the static edges of the pose are dealt round-robin to its slices (k = sl, sl + nsl, ..)
+  const int cnt = FAST ? t.assoc_cnt[i] : ld_list(t.mcu.shared_lists, t.assoc_cnt + i);
   EVP_DECL
   if (i >= 1) {
+   if constexpr (PART != 2) {
     if constexpr (FAST) {
       if (!c.legacy_obstacle_association) {
         // The association lists live in HBM (pose-major, coalesced over the lanes); a lane walks its list in order and at one wave per
@@ -428,21 +439,67 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
         }
       }
     } else {
-      for (int k = sl; k < cnt; k += nsl) {
-        const int ent = t.assoc[(size_t)k * t.stride + i];
-        const int oi = sc.static_idx[ent & kAssocMask];
+      bool replayed = false;
+      if constexpr (MODE != 2) {
+        if (t.mcu.items != nullptr) {
+          // multi-CU mode: record k of the pose = distance and gradient of list entry k, records cnt .. cnt + n_dyn - 1 = the dynamic
+          // obstacles; the rows follow in the order of the loops below, from the numbers those loops would compute
+          replayed = true;
+          const double* it = t.mcu.items + i;
+          for (int k = sl; k < cnt; k += nsl) {
+            const int ent = ld_list(true, &t.assoc[(size_t)k * t.stride + i]);
+            const double dist = ld_agent_f64(it + (size_t)(4 * k) * t.stride);
+            double gr[3] = {0, 0, 0};
+            if (JAC) { gr[0] = ld_agent_f64(it + (size_t)(4 * k + 1) * t.stride); gr[1] = ld_agent_f64(it + (size_t)(4 * k + 2) * t.stride);
+                       gr[2] = ld_agent_f64(it + (size_t)(4 * k + 3) * t.stride); }
+#ifdef TEB_MCU_VERIFY   // (diagnostic build) the record against the same quantity computed here
+            {
+              double g2[3] = {0, 0, 0};
+              const double d2 = footprint_distance(c, sc, sc.static_idx[ent & kAssocMask], w.x0, w.y0, w.c0, w.s0, false, 0.0, JAC ? g2 : nullptr);
+              const int bad = (d2 != dist ? 1 : 0) | (JAC && (g2[0] != gr[0] || g2[1] != gr[1] || g2[2] != gr[2]) ? 2 : 0);
+              atomicAdd(&g_mcu_verify[0], 1ull);
+              if (bad) {
+                if (atomicAdd(&g_mcu_verify[1 + (bad & 1 ? 0 : 1) + (JAC ? 2 : 0)], 1ull) == 0) {
+                  g_mcu_verify_val[0] = dist; g_mcu_verify_val[1] = d2; g_mcu_verify_val[2] = gr[0]; g_mcu_verify_val[3] = g2[0]; g_mcu_verify_val[4] = gr[2]; g_mcu_verify_val[5] = g2[2];
+                  g_mcu_verify_val[6] = (double)i; g_mcu_verify_val[7] = (double)k;
+                }
+              }
+            }
+#endif
 #pragma unroll 1
-        for (int rep = (ent & kAssocTriple) ? 3 : 1; rep > 0; --rep)
-          TEB_EDGE(M_POSE0, CAT_OBST, edge_obstacle<J_>(c, sc, oi, W, t.w_obst, t.inflated, ACC_));
+            for (int rep = (ent & kAssocTriple) ? 3 : 1; rep > 0; --rep) obstacle_rows_g<JAC>(c, dist, gr, t.w_obst, t.inflated, A);
+          }
+          if (c.include_dynamic_obstacles && c.weight_obstacle != 0) {
+            for (int k = d_lo; k < d_hi; ++k) {
+              const int q = cnt + k;
+              const double dist = ld_agent_f64(it + (size_t)(4 * q) * t.stride);
+              double gr[3] = {0, 0, 0};
+              if (JAC) { gr[0] = ld_agent_f64(it + (size_t)(4 * q + 1) * t.stride); gr[1] = ld_agent_f64(it + (size_t)(4 * q + 2) * t.stride);
+                         gr[2] = ld_agent_f64(it + (size_t)(4 * q + 3) * t.stride); }
+              dynamic_obstacle_rows_g<JAC>(c, dist, gr, A);
+            }
+          }
+        }
       }
-      if (c.include_dynamic_obstacles && c.weight_obstacle != 0) {
-        const double ti = l.tdyn[i];
-        for (int k = d_lo; k < d_hi; ++k) {
-          const int oi = sc.dyn_idx[k];
-          TEB_EDGE(M_POSE0, CAT_OBST, edge_dynamic_obstacle<J_>(c, sc, oi, W, ti, ACC_));
+      if (!replayed) {
+        for (int k = sl; k < cnt; k += nsl) {
+          const int ent = ld_list(t.mcu.shared_lists, &t.assoc[(size_t)k * t.stride + i]);
+          const int oi = sc.static_idx[ent & kAssocMask];
+#pragma unroll 1
+          for (int rep = (ent & kAssocTriple) ? 3 : 1; rep > 0; --rep)
+            TEB_EDGE(M_POSE0, CAT_OBST, edge_obstacle<J_>(c, sc, oi, W, t.w_obst, t.inflated, ACC_));
+        }
+        if (c.include_dynamic_obstacles && c.weight_obstacle != 0) {
+          const double ti = l.tdyn[i];
+          for (int k = d_lo; k < d_hi; ++k) {
+            const int oi = sc.dyn_idx[k];
+            TEB_EDGE(M_POSE0, CAT_OBST, edge_dynamic_obstacle<J_>(c, sc, oi, W, ti, ACC_));
+          }
         }
       }
     }
+   }   // PART != 2
+   if constexpr (PART != 1)
     if (first && t.via_en && c.weight_viapoint != 0) {
       for (int v = 0; v < sc.nvia; ++v)
         if (t.via_pose[v] == i) {
@@ -452,6 +509,7 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
     }
   }
   EVP(MODE == 0 ? 1 : 4);
+  if constexpr (PART == 1) return;
   if (!first) return;   // the other slices only share the dynamic-obstacle edges
   // ---- AddEdgesVelocity :720-769
   if (c.max_vel_y == 0) {
@@ -493,14 +551,27 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
   // ---- AddEdgesVelocityObstacleRatio :999-1021
   if (c.weight_velocity_obstacle_ratio > 0 && !c.legacy_obstacle_association) {   // obstacles_per_vertex_ stays empty in legacy mode
     for (int k = 0; k < cnt; ++k) {
-      const int p = t.assoc[(size_t)k * t.stride + i];
-      TEB_EDGE(M_SEG, CAT_OTHER, {
-        double gr[3] = {0, 0, 0};
-        double dobs;
-        if constexpr (FAST) dobs = pointlike_distance<J_>(c, W.x0, W.y0, l.obx[p], l.oby[p], l.obr[p], gr);
-        else dobs = footprint_distance(c, sc, sc.static_idx[p], W.x0, W.y0, W.c0, W.s0, false, 0.0, J_ ? gr : nullptr);
-        edge_velocity_obstacle_ratio<J_>(c, dobs, gr, W, ACC_);
-      });
+      const int p = FAST ? t.assoc[(size_t)k * t.stride + i] : ld_list(t.mcu.shared_lists, &t.assoc[(size_t)k * t.stride + i]);
+      bool replayed = false;
+      if constexpr (!FAST && MODE != 2) {
+        if (t.mcu.items != nullptr) {   // (multi-CU mode) calculateDistance(pose i, obstacle) is record k of the pose
+          replayed = true;
+          const double* it = t.mcu.items + i;
+          const double dobs = ld_agent_f64(it + (size_t)(4 * k) * t.stride);
+          double gr[3] = {0, 0, 0};
+          if (JAC) { gr[0] = ld_agent_f64(it + (size_t)(4 * k + 1) * t.stride); gr[1] = ld_agent_f64(it + (size_t)(4 * k + 2) * t.stride);
+                     gr[2] = ld_agent_f64(it + (size_t)(4 * k + 3) * t.stride); }
+          edge_velocity_obstacle_ratio<JAC>(c, dobs, gr, w, A);
+        }
+      }
+      if (!replayed)
+        TEB_EDGE(M_SEG, CAT_OTHER, {
+          double gr[3] = {0, 0, 0};
+          double dobs;
+          if constexpr (FAST) dobs = pointlike_distance<J_>(c, W.x0, W.y0, l.obx[p], l.oby[p], l.obr[p], gr);
+          else dobs = footprint_distance(c, sc, sc.static_idx[p & kAssocMask], W.x0, W.y0, W.c0, W.s0, false, 0.0, J_ ? gr : nullptr);
+          edge_velocity_obstacle_ratio<J_>(c, dobs, gr, W, ACC_);
+        });
     }
   }
   EVP(MODE == 0 ? 2 : 5);
@@ -614,6 +685,18 @@ __device__ inline void linearize(const teb_amd_config_t& c, const SceneDev& sc, 
 
 // computeActiveErrors + activeRobustChi2 at the current state. cats[4] rides along: a fifth per-lane value summed over the workgroup by the
 // same reduction (the computeScale term of the LM step; one reduction and one pair of barriers less per trial)
+template <bool FAST, int PART>
+__device__ __forceinline__ void evaluate_pass(const teb_amd_config_t& c, const SceneDev& sc, const TebCtx& t, const Lds& l, NearCache& nc, Accum& A) {
+  for (int k0 = 0, pass = 0; k0 < t.n - 1; ++pass) {
+    const int G = (k0 > 0 || kThreads > 256) ? lanes_per_pose(t.n - 1 - k0) : 1;
+    const int i = k0 + (int)threadIdx.x / G;
+    if (i <= t.n - 2) {
+      const unsigned long long near = dyn_near_cached<0, FAST>(c, sc, l, i, (int)threadIdx.x % G, G, nc, pass);
+      eval_index<0, FAST, PART>(c, sc, t, l, i, A, near, (int)threadIdx.x % G, G);
+    }
+    k0 += kThreads / G;
+  }
+}
 template <bool FAST>
 __device__ inline void evaluate(const teb_amd_config_t& c, const SceneDev& sc, const TebCtx& t, const Lds& l, NearCache& nc,
                                 double* cats /*5*/) {
@@ -621,17 +704,31 @@ __device__ inline void evaluate(const teb_amd_config_t& c, const SceneDev& sc, c
   __syncthreads();
   Accum A;   // only chi[] is live when JAC == false
   A.clear_chi();
-  for (int k0 = 0, pass = 0; k0 < t.n - 1; ++pass) {
-    const int G = (k0 > 0 || kThreads > 256) ? lanes_per_pose(t.n - 1 - k0) : 1;
-    const int i = k0 + (int)threadIdx.x / G;
-    if (i <= t.n - 2) {
-      const unsigned long long near = dyn_near_cached<0, FAST>(c, sc, l, i, (int)threadIdx.x % G, G, nc, pass);
-      eval_index<0, FAST>(c, sc, t, l, i, A, near, (int)threadIdx.x % G, G);
-    }
-    k0 += kThreads / G;
+  evaluate_pass<FAST, 0>(c, sc, t, l, nc, A);
+  cats[0] = A.chi[0]; cats[1] = A.chi[1]; cats[2] = A.chi[2]; cats[3] = A.chi[3];
+  block_sum<5>(cats, l.red);
+}
+// The same in the multi-CU mode (generic scenes): the helpers compute the obstacle distances of the new state while this workgroup
+// evaluates every other cost term; the obstacle rows follow from the delivered records. The chi^2 categories are separate sums, each in
+// its single-CU order: same bits. Returns false when the helpers did not deliver (the band is flagged and given up).
+__device__ inline bool evaluate_mcu(const teb_amd_config_t& c, const SceneDev& sc, const TebCtx& t, const Lds& l, NearCache& nc, McuMaster& m, int S,
+                                    double* cats /*5*/) {
+  refresh_trig(l, t.n);
+  __syncthreads();
+  mcu_publish(m, l.sx, l.sy, l.cs, l.sn, l.tdyn, t.n, S);
+  mcu_issue(m, MCU_KIND_DIST, t.n);
+  Accum A;
+  A.clear_chi();
+  const bool overlap = c.weight_velocity_obstacle_ratio == 0;   // (those edges read the records as well)
+  if (overlap) evaluate_pass<false, 2>(c, sc, t, l, nc, A);
+  const bool ok = mcu_wait(m, l.ired + 26);
+  if (ok) {
+    if (overlap) evaluate_pass<false, 1>(c, sc, t, l, nc, A);
+    else evaluate_pass<false, 0>(c, sc, t, l, nc, A);
   }
   cats[0] = A.chi[0]; cats[1] = A.chi[1]; cats[2] = A.chi[2]; cats[3] = A.chi[3];
   block_sum<5>(cats, l.red);
+  return ok;
 }
 
 // ---- damped solve (K6 v1): in-LDS banded LDL^T by wave 0, right-looking, 65 work items per pivot ------------
@@ -1824,29 +1921,31 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
   }
 }
 
-template <bool FAST>
-__device__ inline void associate(const teb_amd_config_t& c, const SceneDev& sc, const Lds& l, int n, int* assoc_cnt,
-                                 int* assoc, int cap, int stride, int* overflow) {
+// Poses [p_begin, p_end) of a band of n poses. SHARED: the lists are read by other workgroups (multi-CU mode: a helper scans its pose
+// tile, always sliced) and are written with agent-scope stores.
+template <bool FAST, bool SHARED>
+__device__ inline void associate_range(const teb_amd_config_t& c, const SceneDev& sc, const Lds& l, int n, int p_begin, int p_end, int* assoc_cnt,
+                                       int* assoc, int cap, int stride, int* overflow) {
   const int first_vertex = c.weight_velocity_obstacle_ratio == 0 ? 1 : 0;
   const double kMax = 1.7976931348623157e308;
   const int tid = threadIdx.x;
-  for (int p0 = 0; p0 < n; ) {
-    const int G = (p0 > 0 || kThreads > 256) ? lanes_per_pose(n - p0) : 1;
+  for (int p0 = p_begin; p0 < p_end; ) {
+    const int G = (SHARED || p0 > 0 || kThreads > 256) ? lanes_per_pose(p_end - p0) : 1;
     const int i = p0 + tid / G, sl = tid % G;
-    const bool has_pose = i < n;
+    const bool has_pose = i < p_end;
     const bool scans = has_pose && i >= first_vertex && i < n - 1;
     // the sequential scan of the whole list by one lane, writing straight into the list (also the fallback of the sliced scan)
     auto sequential = [&]() {
       AssocScan r = {kMax, kMax, -1, -1, 0};
-      assoc_scan<FAST>(c, sc, l, i, 0, sc.n_static, r, [&](int k) { if (r.cnt < cap) assoc[(size_t)r.cnt * stride + i] = k; else *overflow = 1; });
+      assoc_scan<FAST>(c, sc, l, i, 0, sc.n_static, r, [&](int k) { if (r.cnt < cap) st_list<SHARED>(&assoc[(size_t)r.cnt * stride + i], k); else *overflow = 1; });
       int cnt = r.cnt;
-      if (r.left >= 0) { if (cnt < cap) assoc[(size_t)cnt * stride + i] = r.left; else *overflow = 1; ++cnt; }
-      if (r.right >= 0) { if (cnt < cap) assoc[(size_t)cnt * stride + i] = r.right; else *overflow = 1; ++cnt; }
-      assoc_cnt[i] = cnt > cap ? cap : cnt;
+      if (r.left >= 0) { if (cnt < cap) st_list<SHARED>(&assoc[(size_t)cnt * stride + i], r.left); else *overflow = 1; ++cnt; }
+      if (r.right >= 0) { if (cnt < cap) st_list<SHARED>(&assoc[(size_t)cnt * stride + i], r.right); else *overflow = 1; ++cnt; }
+      st_list<SHARED>(&assoc_cnt[i], cnt > cap ? cap : cnt);
     };
     if (G == 1) {
       if (scans) sequential();
-      else if (has_pose) assoc_cnt[i] = 0;
+      else if (has_pose) st_list<SHARED>(&assoc_cnt[i], 0);
     } else {
       const int chunk = ((sc.n_static + G - 1) / G + 3) & ~3;
       const int k_lo = sl * chunk < sc.n_static ? sl * chunk : sc.n_static;
@@ -1883,19 +1982,116 @@ __device__ inline void associate(const teb_amd_config_t& c, const SceneDev& sc, 
           if (sl == 0) sequential();
         } else {
 #pragma unroll
-          for (int q = 0; q < kSliceForced; ++q) if (q < r.cnt) assoc[(size_t)(before + q) * stride + i] = forced[q];
+          for (int q = 0; q < kSliceForced; ++q) if (q < r.cnt) st_list<SHARED>(&assoc[(size_t)(before + q) * stride + i], forced[q]);
           if (sl == 0) {
             int cnt = total;
-            if (r.left >= 0) { assoc[(size_t)cnt * stride + i] = r.left; ++cnt; }
-            if (r.right >= 0) { assoc[(size_t)cnt * stride + i] = r.right; ++cnt; }
-            assoc_cnt[i] = cnt;
+            if (r.left >= 0) { st_list<SHARED>(&assoc[(size_t)cnt * stride + i], r.left); ++cnt; }
+            if (r.right >= 0) { st_list<SHARED>(&assoc[(size_t)cnt * stride + i], r.right); ++cnt; }
+            st_list<SHARED>(&assoc_cnt[i], cnt);
           }
         }
       } else if (has_pose && sl == 0) {
-        assoc_cnt[i] = 0;
+        st_list<SHARED>(&assoc_cnt[i], 0);
       }
     }
     p0 += kThreads / G;
+  }
+}
+template <bool FAST>
+__device__ inline void associate(const teb_amd_config_t& c, const SceneDev& sc, const Lds& l, int n, int* assoc_cnt,
+                                 int* assoc, int cap, int stride, int* overflow) {
+  associate_range<FAST, false>(c, sc, l, n, 0, n, assoc_cnt, assoc, cap, stride, overflow);
+}
+
+// ---- multi-CU mode: the helper workgroups of a band (teb_multicu.hpp) ---------------------------------------------------------------
+// Helper j of H serves the pose tile [j P, (j + 1) P), P = ceil(n / H), of every phase the master issues, until MCU_KIND_EXIT, an abort
+// or the timeout. The published poses are staged into the helper's own LDS strips (same layout as the master's), so the device
+// functions of the single-CU path (association scan, footprint_distance) run here unchanged.
+__device__ inline void mcu_helper(const teb_amd_config_t& c, const SceneDev& sc, const BatchDev& bt, const McuDev& mc, const LdsPlan& plan, int b, int j) {
+  extern __shared__ __attribute__((aligned(16))) double lds_base[];
+  const Lds l = carve(lds_base, plan);
+  const int tid = threadIdx.x, S = bt.stride;
+  unsigned* ctl = mc.ctl + (size_t)b * kMcuCtlWords;
+  const double* pub = mc.pub + (size_t)b * kMcuPubArrays * S;
+  double* items = mc.items + (size_t)b * mc.item_cap * 4 * S;
+  int* assoc_cnt = bt.assoc_cnt + (size_t)b * S;
+  int* assoc = bt.assoc + (size_t)b * bt.assoc_cap * S;
+  int* prefix = reinterpret_cast<int*>(lds_base + plan.off_H);   // [P + 1] record offsets of the tile's poses (the normal-matrix region is free here)
+  unsigned epoch = 0;
+  for (;;) {
+    mcu_trace(mc.trace, epoch, 0x10);
+    // ONE lane polls ONE word (relaxed, agent scope); the others sleep at the barrier
+    if (tid == 0) {
+      unsigned cmd = 0;
+      const long long t0 = realtime_ticks();
+      for (;;) {
+        cmd = ld_agent_u32(ctl + MCU_CMD);
+        if ((cmd >> 8) > epoch) break;
+        // (four times the master's patience: a master may be busy with a solve between two phases)
+        if (ld_agent_u32(ctl + MCU_ABORT) != 0 || realtime_ticks() - t0 > 4 * mc.timeout_ticks + 100000) { cmd = ((epoch + 1) << 8) | MCU_KIND_EXIT; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      l.ired[24] = (int)cmd;
+      l.ired[25] = (int)ld_agent_u32(ctl + MCU_N);
+    }
+    __syncthreads();
+    const unsigned cmd = (unsigned)l.ired[24];
+    const int n = l.ired[25];
+    __syncthreads();
+    epoch = cmd >> 8;
+    const int kind = (int)(cmd & 0xffu);
+    mcu_trace(mc.trace, epoch, 0x20 + (unsigned)kind);
+    if (kind == MCU_KIND_EXIT || n < 2 || n > plan.S) return;
+    const int P = (n + mc.H - 1) / mc.H;
+    const int p_lo = j * P < n ? j * P : n, p_hi = p_lo + P < n ? p_lo + P : n;
+    // stage the poses of the tile (agent-scope loads: the lines were written through by the master)
+    for (int i = p_lo + tid; i < p_hi; i += kThreads) {
+      l.sx[i] = ld_agent_f64(pub + i); l.sy[i] = ld_agent_f64(pub + S + i); l.cs[i] = ld_agent_f64(pub + 2 * S + i); l.sn[i] = ld_agent_f64(pub + 3 * S + i);
+      l.tdyn[i] = ld_agent_f64(pub + 4 * S + i);
+    }
+    __syncthreads();
+    mcu_trace(mc.trace, epoch, 0x30);
+    if (kind == MCU_KIND_ASSOC) {
+      int ovf = 0;
+      if (p_lo < p_hi) associate_range<false, true>(c, sc, l, n, p_lo, p_hi, assoc_cnt, assoc, bt.assoc_cap, S, &ovf);
+      if (ovf) or_agent_i32(bt.assoc_overflow + b, 1);
+    } else {   // MCU_KIND_DIST: one (pose, record) pair per lane
+      const bool dyn_on = c.include_dynamic_obstacles && c.weight_obstacle != 0;
+      const int ndyn = dyn_on ? sc.n_dyn : 0;
+      const int np = p_hi - p_lo;
+      for (int q = tid; q < np; q += kThreads) {
+        int cnt = ld_agent_i32(assoc_cnt + p_lo + q);
+        if (p_lo + q >= n - 1) cnt = 0;                               // the goal pose carries no edge
+        const bool unary = p_lo + q >= 1;                             // pose 0: only the velocity-obstacle-ratio edges read records
+        prefix[q + 1] = cnt + (unary && p_lo + q < n - 1 ? ndyn : 0);
+      }
+      __syncthreads();
+      if (tid == 0) { prefix[0] = 0; for (int q = 0; q < np; ++q) prefix[q + 1] += prefix[q]; }
+      __syncthreads();
+      const int total = np > 0 ? prefix[np] : 0;
+      for (int w = tid; w < total; w += kThreads) {
+        int lo = 0, hi = np - 1;                                      // largest q with prefix[q] <= w
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (prefix[mid] <= w) lo = mid; else hi = mid - 1; }
+        const int i = p_lo + lo, k = w - prefix[lo];
+        int cnt = ld_agent_i32(assoc_cnt + i);
+        double gr[3], dist;
+        if (k < cnt) {
+          const int ent = ld_agent_i32(&assoc[(size_t)k * S + i]);
+          dist = footprint_distance(c, sc, sc.static_idx[ent & kAssocMask], l.sx[i], l.sy[i], l.cs[i], l.sn[i], false, 0.0, gr);
+        } else {
+          dist = footprint_distance(c, sc, sc.dyn_idx[k - cnt], l.sx[i], l.sy[i], l.cs[i], l.sn[i], true, l.tdyn[i], gr);
+        }
+        double* it = items + i;
+        st_agent_f64(it + (size_t)(4 * k) * S, dist); st_agent_f64(it + (size_t)(4 * k + 1) * S, gr[0]);
+        st_agent_f64(it + (size_t)(4 * k + 2) * S, gr[1]); st_agent_f64(it + (size_t)(4 * k + 3) * S, gr[2]);
+      }
+    }
+    // every storing wave drains, the workgroup meets, ONE lane arrives
+    mcu_trace(mc.trace, epoch, 0x40);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) add_agent_u32(ctl + MCU_DONE, 1u);
+    mcu_trace(mc.trace, epoch, 0x50);
   }
 }
 
@@ -1984,11 +2180,24 @@ enum { SCENE_POINTS = 0, SCENE_GENERIC = 1 };
 template <int SOLVER, int JMODE, int SCENE>
 __global__ void __launch_bounds__(kThreads)
 teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev bt, const OptArgs args,
-                    const LdsPlan plan) {
+                    const LdsPlan plan, const McuDev mc) {
   extern __shared__ __attribute__((aligned(16))) double lds_base[];
+  constexpr bool FAST = SCENE == SCENE_POINTS;
+  constexpr bool MCU = !FAST && JMODE == TEB_AMD_JACOBIAN_ANALYTIC;   // the multi-CU mode exists for generic scenes with closed-form Jacobians
+  if constexpr (MCU) {
+    if (mc.H > 0 && (int)blockIdx.x >= bt.B) {   // workgroups B .. B (1 + H) - 1: helpers of band (x - B) / H
+      const int hb = ((int)blockIdx.x - bt.B) / mc.H;
+      mcu_helper(c, sc, bt, mc, plan, hb, ((int)blockIdx.x - bt.B) - hb * mc.H);
+      return;
+    }
+  }
   const int b = blockIdx.x, tid = threadIdx.x, S = bt.stride;
   const Lds l = carve(lds_base, plan, SOLVER == SOLVER_BANDG ? args.Hband + (size_t)b * args.hband_stride : nullptr, SOLVER == SOLVER_BANDG);
-  constexpr bool FAST = SCENE == SCENE_POINTS;
+  McuMaster mm;
+  mm.H = MCU ? mc.H : 0; mm.epoch = 0; mm.failed = false; mm.timeout = mc.timeout_ticks; mm.trace = mc.trace;
+  mm.ctl = mm.H > 0 ? mc.ctl + (size_t)b * kMcuCtlWords : nullptr;
+  mm.pub = mm.H > 0 ? mc.pub + (size_t)b * kMcuPubArrays * S : nullptr;
+  const bool mcu_on = MCU && mm.H > 0 && !args.debug_linearize && !c.legacy_obstacle_association;
   if constexpr (FAST) {   // stage the point-like obstacle table once: static list first, then the dynamic list
     const int tot = sc.n_static + sc.n_dyn;
     for (int k = tid; k < tot; k += kThreads) {
@@ -2008,6 +2217,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       bt.status[b] = TEB_AMD_TEB_FAILED; bt.iters[b] = 0; bt.trials[b] = 0;
       bt.chi2[b] = 0; bt.cost[b] = __longlong_as_double(0x7ff8000000000000LL); bt.lambda[b] = 0;
     }
+    if (MCU && mm.H > 0) mcu_exit(mm);   // the helpers of this band must not wait for a master that has left
     return;
   }
 
@@ -2016,7 +2226,9 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     l.sx[i] = bt.x[so + i]; l.sy[i] = bt.y[so + i]; l.sth[i] = bt.th[so + i];
     l.sdt[i] = (i < n - 1) ? bt.dt[so + i] : 0.0;
   }
-  if (tid == 0) bt.assoc_overflow[b] = 0;   // this band's flags (only this workgroup touches them): no memset command per launch
+  // this band's flags: no memset command per launch. Single-CU launches: only this workgroup touches them. Multi-CU mode: the helpers
+  // may set bits too, so every access is an agent-scope atomic there (a plain store could be written back over a helper's bit later)
+  if (tid == 0) { if (MCU && mm.H > 0) st_agent_i32(bt.assoc_overflow + b, 0); else bt.assoc_overflow[b] = 0; }
   __syncthreads();
 
   TebCtx t;
@@ -2029,6 +2241,8 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   int* assoc = bt.assoc + (size_t)b * bt.assoc_cap * S;
   int* via_pose = bt.via_pose + (size_t)b * bt.via_cap;
   t.assoc_cnt = assoc_cnt; t.assoc = assoc; t.via_pose = via_pose;
+  t.mcu.items = nullptr; t.mcu.shared_lists = false;
+  const double* mcu_items = mcu_on ? mc.items + (size_t)b * mc.item_cap * 4 * S : nullptr;
   double* Hbk = bt.Hbackup + (size_t)b * bt.hmat_stride;
 
   int status = TEB_AMD_TEB_OK, iters = 0, trials = 0;
@@ -2056,7 +2270,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       // edit script + new poses + split stack (autoresize_scratch_doubles: 5 S + 104 doubles) live in the LDS region of the normal matrix, which is rebuilt afterwards
       n = autoresize(c, l, n, plan.off_state, plan.off_H, plan.S, fast_mode, &ovf);   // plan.S: LDS strip spacing = pose capacity of this launch
       PROF_END(0);
-      if (ovf) { status = TEB_AMD_TEB_FAILED; if (tid == 0) bt.assoc_overflow[b] |= 2; break; }
+      if (ovf) { status = TEB_AMD_TEB_FAILED; if (tid == 0) { if (MCU && mm.H > 0) or_agent_i32(bt.assoc_overflow + b, 2); else bt.assoc_overflow[b] |= 2; } break; }
     }
     t.n = n;
     // optimizeGraph guards (src/optimal_planner.cpp:370-382)
@@ -2073,11 +2287,22 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       int ovf = 0;
       if (c.legacy_obstacle_association)
         associate_legacy(c, sc, l, n, assoc_cnt, assoc, bt.assoc_cap, S, &ovf, bt.legacy_idx + (size_t)b * bt.assoc_cap);
-      else
+      else if (mcu_on && (mc.debug_flags & 1)) {   // (diagnostic) this workgroup scans, the helpers of the DIST phases read the lists
+        associate_range<FAST, true>(c, sc, l, n, 0, n, assoc_cnt, assoc, bt.assoc_cap, S, &ovf);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        t.mcu.shared_lists = true;
+      } else if (mcu_on) {   // the helpers scan pose tiles; the lists come back through HBM (agent-scope accesses from here on)
+        mcu_publish(mm, l.sx, l.sy, l.cs, l.sn, l.tdyn, n, S);
+        mcu_issue(mm, MCU_KIND_ASSOC, n);
+        t.mcu.shared_lists = true;
+        if (!mcu_wait(mm, l.ired + 26)) { status = TEB_AMD_TEB_FAILED; if (tid == 0) or_agent_i32(bt.assoc_overflow + b, 4); break; }
+      } else
         associate<FAST>(c, sc, l, n, assoc_cnt, assoc, bt.assoc_cap, S, &ovf);
-      if (ovf && tid < kThreads) bt.assoc_overflow[b] |= 1;
+      if (ovf && tid < kThreads) { if (mcu_on) { if (tid == 0) or_agent_i32(bt.assoc_overflow + b, 1); } else bt.assoc_overflow[b] |= 1; }
     } else {
       for (int i = tid; i < n; i += kThreads) assoc_cnt[i] = 0;
+      t.mcu.shared_lists = false;
     }
     LNP(9);
     if (tid == 0) {   // :662-670, sequential left-to-right sum like the reference
@@ -2125,6 +2350,15 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     near_cache.invalidate();   // the graph was rebuilt: new pose numbering, new time stamps
     // ---- optimize(): Levenberg-Marquardt
     if (args.inner <= 0 && !args.debug_linearize) { status = TEB_AMD_TEB_FAILED; break; }   // optimize(0) returns 0
+    // multi-CU mode: the distance records of the freshly built graph for the first linearisation; the later ones find the records
+    // of the error evaluation that accepted their state
+    t.mcu.items = nullptr;
+    if (mcu_on && obst_edges && !(mc.debug_flags & 2)) {
+      mcu_publish(mm, l.sx, l.sy, l.cs, l.sn, l.tdyn, n, S);   // (refresh_trig above: cos / sin are those of the current headings)
+      mcu_issue(mm, MCU_KIND_DIST, n);
+      if (!mcu_wait(mm, l.ired + 26)) { status = TEB_AMD_TEB_FAILED; if (tid == 0) or_agent_i32(bt.assoc_overflow + b, 4); break; }
+      t.mcu.items = mcu_items;
+    }
     double ni = 2;
     bool lm_ok = true;
     for (int it = 0; it < args.inner && lm_ok; ++it) {
@@ -2214,7 +2448,10 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
         __syncthreads();
         double tc[5];
         tc[4] = sc_part;
-        evaluate<FAST>(c, sc, t, l, near_cache, tc);
+        if (MCU && t.mcu.items != nullptr) {
+          if (!evaluate_mcu(c, sc, t, l, near_cache, mm, S, tc)) { status = TEB_AMD_TEB_FAILED; if (tid == 0) or_agent_i32(bt.assoc_overflow + b, 4); done = true; lm_ok = false; break; }
+        } else
+          evaluate<FAST>(c, sc, t, l, near_cache, tc);
         last_cats[0] = tc[0]; last_cats[1] = tc[1]; last_cats[2] = tc[2]; last_cats[3] = tc[3];
         double tempChi = ((tc[0] + tc[1]) + tc[2]) + tc[3];
         double scv[1] = {tc[4]};
@@ -2261,7 +2498,10 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       if (c.divergence_detection_enable) {   // setComputeBatchStatistics -> computeActiveErrors after each solve
         double fc[5];
         fc[4] = 0;
-        evaluate<FAST>(c, sc, t, l, near_cache, fc);
+        if (MCU && t.mcu.items != nullptr) {
+          if (!evaluate_mcu(c, sc, t, l, near_cache, mm, S, fc)) { status = TEB_AMD_TEB_FAILED; if (tid == 0) or_agent_i32(bt.assoc_overflow + b, 4); done = true; break; }
+        } else
+          evaluate<FAST>(c, sc, t, l, near_cache, fc);
         last_cats[0] = fc[0]; last_cats[1] = fc[1]; last_cats[2] = fc[2]; last_cats[3] = fc[3];
         chi2_final = ((fc[0] + fc[1]) + fc[2]) + fc[3];
       }
@@ -2287,6 +2527,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   }
 
   // ---- K0: strip store + results
+  if (MCU && mm.H > 0) mcu_exit(mm);   // every way out of the loops above ends here: the helpers leave
   __syncthreads();
   int nonfinite = 0;
   for (int i = tid; i < n; i += kThreads) {
