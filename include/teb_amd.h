@@ -253,7 +253,12 @@ typedef struct teb_amd_options {
                                   /* n > 0 = at most n helper workgroups per band, whatever the size of the scene                  */
   int32_t multi_cu_timeout_us;    /* how long a band waits for its helper workgroups before it gives the launch up (it is then     */
                                   /* repeated on one CU per band); 0 = 50 000 (50 ms)                                            */
-  int32_t reserved[7];            /* must be 0                                                                                  */
+  int32_t speculative_trials;     /* small batches: the damped systems of the first retries of an LM iteration (lambda x 2, x 8,  */
+                                  /* x 64) are solved on spare CUs while the band solves and evaluates its first trial, so that a  */
+                                  /* rejected trial finds its step ready (bit-identical results): 0 = automatic (<= 16 bands,      */
+                                  /* closed-form Jacobians, blocks-in-LDS or hybrid layout: 3 solver workgroups per band),         */
+                                  /* -1 = never, k = 1 .. 3: that many                                                             */
+  int32_t reserved[6];            /* must be 0                                                                                  */
 } teb_amd_options_t;
 void teb_amd_options_default(teb_amd_options_t* opt);
 
@@ -320,9 +325,11 @@ int  teb_amd_get_iteration_log(teb_amd_handle_t* h, int32_t b, double* rows, int
 int  teb_amd_select_best(teb_amd_handle_t* h, int32_t last_best, int32_t initial_plan,
                          int32_t* best, double* best_cost);
 
-/* How the last teb_amd_optimize_batch ran: helper workgroups per band of the multi-CU mode (0 = one CU per band), and whether the
- * launch had to be repeated on one CU per band because the helpers did not arrive in time (a device busy with other work). */
-int  teb_amd_last_launch_info(teb_amd_handle_t* h, int32_t* helpers_per_band, int32_t* repeated_single_cu);
+/* How the last teb_amd_optimize_batch ran: distance-helper and solver-helper workgroups per band of the multi-CU mode (0, 0 = one CU
+ * per band), and whether the launch had to be repeated on one CU per band because the distance helpers did not arrive in time (a
+ * device busy with other work). */
+int  teb_amd_last_launch_info(teb_amd_handle_t* h, int32_t* distance_helpers_per_band, int32_t* solver_helpers_per_band,
+                              int32_t* repeated_single_cu);
 
 /* -- zero-copy access for callers that already live on the GPU (benchmarks, torch interop) ---------- */
 /*

@@ -38,7 +38,7 @@ def _units(variant):
     units = [("teb_amd.o", "teb_amd.hip", [])]
     for jm in v["jmodes"]:
         for sv in (0, 1, 2):
-            for sk in (0, 1):
+            for sk in ((0, 1, 2, 3) if jm == 0 else (0, 1)):   # the small-batch scene kinds (helper workgroups) exist for closed-form Jacobians
                 units.append(("opt_%d_%d_%d.o" % (sv, jm, sk), "teb_opt_inst.hip",
                               ["-DTEB_INST_SOLVER=%d" % sv, "-DTEB_INST_JMODE=%d" % jm, "-DTEB_INST_SCENE=%d" % sk]))
     return units

@@ -16,6 +16,7 @@
 
 #include "../../include/teb_amd.h"
 #include "../../include/teb_amd_debug.h"
+#define TEB_AMD_MAIN_TU   // (non-template kernels of the shared headers are defined here only)
 #include "teb_kernel.hpp"
 #include "teb_opt_launch.hpp"
 #include "teb_strip.hpp"
@@ -174,9 +175,10 @@ struct teb_amd_handle {
   DevBuf<int> ob_n;
   // multi-CU mode (teb_multicu.hpp): control words, published poses, distance records; sized on first use
   DevBuf<unsigned> mcu_ctl;
-  DevBuf<double> mcu_pub, mcu_items;
+  DevBuf<double> mcu_pub, mcu_items, mcu_spec;
   size_t mcu_items_have = 0;
-  int mcu_last_helpers = 0;   // helper workgroups per band of the last launch (0: single-CU), teb_amd_last_launch_info
+  int mcu_last_helpers = 0;   // distance helpers per band of the last launch (0: none), teb_amd_last_launch_info
+  int mcu_last_solvers = 0;   // solver helpers per band of the last launch
   int mcu_last_repeated = 0;  // that launch timed out waiting for its helpers and was repeated on one CU per band
   unsigned* mcu_trace = nullptr;   // teb_amd_debug_mcu_watchdog: host-pinned breadcrumbs of the multi-CU launch, one word per workgroup
   int mcu_watchdog_ms = 0;
@@ -282,32 +284,42 @@ const void* opt_kernel(int solver, int jmode, int scene) {
 }
 hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const BatchDev& bt, const OptArgs& a, int solver, const LdsPlan& plan,
                       const McuDev* mcu = nullptr) {
-  const void* k = opt_kernel(solver, h->cfg.jacobian_mode, sc.fast_points ? SCENE_POINTS : SCENE_GENERIC);
-  if (!k) return hipErrorInvalidDeviceFunction;
   McuDev none;
   std::memset(&none, 0, sizeof none);
   const McuDev* mc = mcu ? mcu : &none;
+  const bool small = mc->K + mc->D > 0;   // helper workgroups: the small-batch instantiation of the scene kind
+  const void* k = opt_kernel(solver, h->cfg.jacobian_mode, sc.fast_points ? (small ? SCENE_POINTS_SMALL : SCENE_POINTS) : (small ? SCENE_GENERIC_SMALL : SCENE_GENERIC));
+  if (!k) return hipErrorInvalidDeviceFunction;
   void* params[] = {const_cast<teb_amd_config_t*>(&h->cfg), const_cast<SceneDev*>(&sc), const_cast<BatchDev*>(&bt), const_cast<OptArgs*>(&a),
                     const_cast<LdsPlan*>(&plan), const_cast<McuDev*>(mc)};
-  return hipLaunchKernel(k, dim3(grid * (1 + mc->H)), dim3(kThreads), params, plan.total_bytes, h->stream);
+  return hipLaunchKernel(k, dim3(grid * (1 + mc->K + mc->D)), dim3(kThreads), params, plan.total_bytes, h->stream);
 }
 hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const BatchDev& bt, const OptArgs& a) {
   return launch_opt(h, grid, sc, bt, a, h->solver, h->plan);
 }
 
-// Multi-CU mode (teb_multicu.hpp): how many helper workgroups each band of this launch gets, 0 = none. Generic scenes only (the
-// point-like path has no per-pair work worth a hand-off), closed-form Jacobians, new association; one workgroup per CU (the LDS
-// footprint of the layouts) means B (1 + H) <= number of CUs keeps every workgroup resident.
-int mcu_helpers_for(teb_amd_handle* h, const OptArgs& args) {
-  if (h->opt.multi_cu < 0 || h->fast_points || args.debug_linearize || h->cfg.jacobian_mode != TEB_AMD_JACOBIAN_ANALYTIC ||
-      h->cfg.legacy_obstacle_association || h->M <= 0)
-    return 0;
+// Multi-CU mode (teb_multicu.hpp): helper workgroups per band of this launch - K solver helpers (speculative LM trials, any scene kind)
+// and D distance helpers (generic scenes: association + distance records). Small batches only: one workgroup per CU (the LDS footprint
+// of the layouts) means B (1 + K + D) <= number of CUs keeps every workgroup resident. Closed-form Jacobians (the small-batch
+// instantiations); the solver helpers need a layout whose normal matrix another workgroup can pick up (blocks in LDS with their HBM
+// backup, or the band copy of the hybrid solve), the distance helpers the new association.
+void mcu_helpers_for(teb_amd_handle* h, const OptArgs& args, int eff_solver, int* K_out, int* D_out) {
+  *K_out = 0; *D_out = 0;
+  if (args.debug_linearize || h->cfg.jacobian_mode != TEB_AMD_JACOBIAN_ANALYTIC || h->B <= 0) return;
   const int cus = h->num_cus > 0 ? h->num_cus : 256;
-  int H = cus / h->B - 1;
-  if (H > 63) H = 63;                                     // beyond ~ 4 poses per helper the hand-off costs more than the tile
-  if (h->opt.multi_cu > 0) H = std::min(H, (int)h->opt.multi_cu);
-  else if (h->B > 16 || (size_t)h->M * (size_t)(h->nmax_known > 0 ? h->nmax_known : h->stride) < 4096) return 0;   // auto: small batches with enough (pose, obstacle) work
-  return H >= 2 ? H : 0;
+  const int room = cus / h->B - 1;   // helper workgroups per band that still leave every workgroup its own CU
+  int K = 0, D = 0;
+  if (h->opt.speculative_trials >= 0 && eff_solver != SOLVER_BANDG && !(eff_solver == SOLVER_BAND && h->band_ldlt) && args.inner > 0) {
+    K = h->opt.speculative_trials > 0 ? std::min((int)h->opt.speculative_trials, kMcuMaxSpec) : (h->B <= 16 ? kMcuMaxSpec : 0);
+    K = std::max(0, std::min(K, room));
+  }
+  if (h->opt.multi_cu >= 0 && !h->fast_points && !h->cfg.legacy_obstacle_association && h->M > 0) {
+    D = std::min(room - K, 60);                               // beyond ~ 5 poses per helper the hand-off costs more than the tile
+    if (h->opt.multi_cu > 0) D = std::min(D, (int)h->opt.multi_cu);
+    else if (h->B > 16 || (size_t)h->M * (size_t)(h->nmax_known > 0 ? h->nmax_known : h->stride) < 4096) D = 0;   // auto: enough (pose, obstacle) work
+    if (D < 2) D = 0;
+  }
+  *K_out = K; *D_out = D;
 }
 
 // largest pose capacity whose LDS plan (with the obstacle cache of this scene, if it is in use) fits
@@ -367,27 +379,32 @@ int launch(teb_amd_handle* h, const OptArgs& args) {
     if (s_cr > 0 && need <= s_cr) { eff_solver = SOLVER_CR; eff_plan = make_lds_plan(s_cr, SOLVER_CR, ob); optimistic = true; }
     else if (s_band > 0 && need <= s_band) { eff_solver = SOLVER_BAND; eff_plan = make_lds_plan(s_band, SOLVER_BAND, ob); optimistic = true; }
   }
-  // multi-CU mode: helper workgroups per band (0 = off); its buffers, and the control words zeroed on the stream before the launch
-  const int H = mcu_helpers_for(h, args);
+  // multi-CU mode: helper workgroups per band (0 = none); its buffers, and the control words zeroed on the stream before the launch
+  int K = 0, D = 0;
+  mcu_helpers_for(h, args, eff_solver, &K, &D);
+  const int H = K + D;
   McuDev mcu;
   std::memset(&mcu, 0, sizeof mcu);
   if (H > 0) {
-    const size_t need_items = (size_t)h->B * h->M * 4 * h->stride;
-    if (!h->mcu_ctl.p) { HIPCHK(h->mcu_ctl.alloc((size_t)h->max_tebs * kMcuCtlWords)); HIPCHK(h->mcu_pub.alloc((size_t)h->max_tebs * kMcuPubArrays * h->stride)); }
+    if (!h->mcu_ctl.p) {
+      HIPCHK(h->mcu_ctl.alloc((size_t)h->max_tebs * kMcuCtlWords)); HIPCHK(h->mcu_pub.alloc((size_t)h->max_tebs * kMcuPubArrays * h->stride));
+      HIPCHK(h->mcu_spec.alloc((size_t)h->max_tebs * (kMcuMaxSpec + 1) * mcu_spec_slot(h->stride)));
+    }
+    const size_t need_items = D > 0 ? (size_t)h->B * h->M * 4 * h->stride : 0;
     if (h->mcu_items_have < need_items) {
       h->mcu_items.free(); h->mcu_items_have = 0;
       HIPCHK(h->mcu_items.alloc(need_items));
       h->mcu_items_have = need_items;
     }
     HIPCHK(hipMemsetAsync(h->mcu_ctl.p, 0, (size_t)h->B * kMcuCtlWords * sizeof(unsigned), h->stream));
-    mcu.H = H; mcu.ctl = h->mcu_ctl.p; mcu.pub = h->mcu_pub.p; mcu.items = h->mcu_items.p; mcu.item_cap = h->M;
+    mcu.K = K; mcu.D = D; mcu.ctl = h->mcu_ctl.p; mcu.pub = h->mcu_pub.p; mcu.items = h->mcu_items.p; mcu.item_cap = h->M; mcu.spec = h->mcu_spec.p;
     mcu.timeout_ticks = (long long)(h->opt.multi_cu_timeout_us > 0 ? h->opt.multi_cu_timeout_us : 50000) * 100LL;   // 100 MHz real-time counter
     mcu.trace = h->mcu_trace;
     mcu.debug_flags = h->mcu_debug_flags;
     if (h->mcu_trace) std::memset(h->mcu_trace, 0, 1024 * sizeof(unsigned));
   }
-  h->mcu_last_helpers = H; h->mcu_last_repeated = 0;
-  const bool checked = optimistic || H > 0;   // the launch is followed by a look at the per-band flags (and possibly repeated)
+  h->mcu_last_helpers = D; h->mcu_last_solvers = K; h->mcu_last_repeated = 0;
+  const bool checked = optimistic || D > 0;   // (solver helpers alone cannot fail a band: a late one just means the band solves itself)   // the launch is followed by a look at the per-band flags (and possibly repeated)
   if (checked) {   // strips as they are now, for the repeat
     if (!h->opt_backup_ready) {
       const size_t BS = (size_t)h->max_tebs * h->stride;
@@ -596,7 +613,7 @@ int teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max
   if (ok && hipEventCreate(&h->ev1) != hipSuccess) ok = false;
   for (int sv : {SOLVER_BAND, SOLVER_CR, SOLVER_BANDG})   // every layout may be launched (teb_amd_set_obstacles / per-launch choice)
     for (int jm : {TEB_AMD_JACOBIAN_ANALYTIC, TEB_AMD_JACOBIAN_G2O_NUMERIC})
-      for (int sk : {SCENE_POINTS, SCENE_GENERIC}) {
+      for (int sk : {SCENE_POINTS, SCENE_GENERIC, SCENE_POINTS_SMALL, SCENE_GENERIC_SMALL}) {
         const void* k = opt_kernel(sv, jm, sk);
         if (ok && k && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit) != hipSuccess) ok = false;
       }
@@ -630,7 +647,7 @@ void teb_amd_destroy(teb_amd_handle_t* h) {
   for (auto* q : gi) q->free();
   h->ob_n.free();
   h->iter_log.free();
-  h->mcu_ctl.free(); h->mcu_pub.free(); h->mcu_items.free();
+  h->mcu_ctl.free(); h->mcu_pub.free(); h->mcu_items.free(); h->mcu_spec.free();
   if (h->mcu_trace) (void)hipHostFree(h->mcu_trace);
   h->g_adj.free();
   h->cm_cells.free(); h->cm_fp.free(); h->cm_out.free();
@@ -1982,10 +1999,11 @@ int teb_amd_restore_state(teb_amd_handle_t* h) {
   return TEB_AMD_OK;
 }
 
-int teb_amd_last_launch_info(teb_amd_handle_t* h, int32_t* helpers_per_band, int32_t* repeated_single_cu) {
+int teb_amd_last_launch_info(teb_amd_handle_t* h, int32_t* distance_helpers_per_band, int32_t* solver_helpers_per_band, int32_t* repeated_single_cu) {
   int rc = check_handle(h);
   if (rc) return rc;
-  if (helpers_per_band) *helpers_per_band = h->mcu_last_helpers;
+  if (distance_helpers_per_band) *distance_helpers_per_band = h->mcu_last_helpers;
+  if (solver_helpers_per_band) *solver_helpers_per_band = h->mcu_last_solvers;
   if (repeated_single_cu) *repeated_single_cu = h->mcu_last_repeated;
   return TEB_AMD_OK;
 }

@@ -1116,6 +1116,8 @@ __device__ __forceinline__ bool cr_forward_mfma(double* __restrict__ D, double* 
   return ok;
 }
 // A(16 x 8) B(8 x 16) with the operand maps used above -> C (16 x 16); also times `reps` dependent-free issues per wave (clock64 ticks)
+// (one definition: the host translation unit's)
+#ifdef TEB_AMD_MAIN_TU
 __global__ void mfma_selftest_kernel(const double* A, const double* B, double* Cout, int reps, long long* ticks) {
   const int lane = threadIdx.x & 63, am = lane & 15, ak = lane >> 4;
   const double a0 = A[am * 8 + ak], a1 = A[am * 8 + ak + 4], b0 = B[ak * 16 + am], b1 = B[(ak + 4) * 16 + am];
@@ -1134,6 +1136,7 @@ __global__ void mfma_selftest_kernel(const double* A, const double* B, double* C
   const long long c1 = clock64();
   if (threadIdx.x == 0 && blockIdx.x == 0) { ticks[0] = c1 - c0; ticks[1] = (long long)(t0[0] + t1[1] + t2[2] + t3[3]); }
 }
+#endif
 #define TEB_CR_FORWARD cr_forward_mfma
 #else
 #define TEB_CR_FORWARD cr_forward
@@ -1355,13 +1358,22 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, const SceneDev&
 // gbuf: the band copy, [8 Nb][kBand]
 // the band as it stands in LDS -> the band's HBM scratch, rows [0, 8 Nb): a coalesced copy (101 KB at 287 poses; 32 bands per XCD stay
 // inside the 4 MB L2); the padding rows of an odd pose count become identity rows
-__device__ __forceinline__ void cr_copy_band(const Lds& l, int n, double* __restrict__ gband) {
+// shared: solver helpers on other CUs read the copy as well (speculative trials, teb_multicu.hpp): written through, agent scope
+__device__ __forceinline__ void cr_copy_band(const Lds& l, int n, double* __restrict__ gband, bool shared = false) {
   const int tid = threadIdx.x;
   const int Nt = 4 * n, Nb = (Nt + 7) >> 3;
   const double* Hb = l.Hb;
-  for (int q = tid; q < Nb * 8 * kBand; q += kThreads) {
-    const int r = q / kBand;
-    gband[q] = r < Nt ? Hb[q] : ((q - r * kBand) == 0 ? 1.0 : 0.0);
+  if (shared) {
+    for (int q = tid; q < Nb * 8 * kBand; q += kThreads) {
+      const int r = q / kBand;
+      st_agent_f64(gband + q, r < Nt ? Hb[q] : ((q - r * kBand) == 0 ? 1.0 : 0.0));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    for (int q = tid; q < Nb * 8 * kBand; q += kThreads) {
+      const int r = q / kBand;
+      gband[q] = r < Nt ? Hb[q] : ((q - r * kBand) == 0 ? 1.0 : 0.0);
+    }
   }
   __threadfence_block();
   __syncthreads();
@@ -2004,7 +2016,7 @@ __device__ inline void associate(const teb_amd_config_t& c, const SceneDev& sc, 
 }
 
 // ---- multi-CU mode: the helper workgroups of a band (teb_multicu.hpp) ---------------------------------------------------------------
-// Helper j of H serves the pose tile [j P, (j + 1) P), P = ceil(n / H), of every phase the master issues, until MCU_KIND_EXIT, an abort
+// Distance helper j of D serves the pose tile [j P, (j + 1) P), P = ceil(n / D), of every phase the master issues, until MCU_KIND_EXIT, an abort
 // or the timeout. The published poses are staged into the helper's own LDS strips (same layout as the master's), so the device
 // functions of the single-CU path (association scan, footprint_distance) run here unchanged.
 __device__ inline void mcu_helper(const teb_amd_config_t& c, const SceneDev& sc, const BatchDev& bt, const McuDev& mc, const LdsPlan& plan, int b, int j) {
@@ -2042,7 +2054,7 @@ __device__ inline void mcu_helper(const teb_amd_config_t& c, const SceneDev& sc,
     const int kind = (int)(cmd & 0xffu);
     mcu_trace(mc.trace, epoch, 0x20 + (unsigned)kind);
     if (kind == MCU_KIND_EXIT || n < 2 || n > plan.S) return;
-    const int P = (n + mc.H - 1) / mc.H;
+    const int P = (n + mc.D - 1) / mc.D;
     const int p_lo = j * P < n ? j * P : n, p_hi = p_lo + P < n ? p_lo + P : n;
     // stage the poses of the tile (agent-scope loads: the lines were written through by the master)
     for (int i = p_lo + tid; i < p_hi; i += kThreads) {
@@ -2173,31 +2185,98 @@ __device__ inline void associate_legacy(const teb_amd_config_t& c, const SceneDe
 }
 
 // =================================================================================================================
+// ---- multi-CU mode: solver helper k of a band (speculative LM trials, teb_multicu.hpp) ------------------------------------------------
+// Per LM iteration: wait for the command, take the right-hand side and lambda_k, (blocks-in-LDS layout: load the normal matrix from the
+// band's HBM backup into this workgroup's own LDS), run the band's damped solve, write the step back through. The data were written
+// through (sc1) by the band's workgroup: ONE agent-scope acquire after the poll drops this CU's stale lines, then plain loads.
+template <int SOLVER>
+__device__ inline void mcu_solver_helper(const SceneDev& sc, const BatchDev& bt, const McuDev& mc, const LdsPlan& plan, int b, int k) {
+  extern __shared__ __attribute__((aligned(16))) double lds_base[];
+  const Lds l = carve(lds_base, plan);
+  const int tid = threadIdx.x, S = bt.stride;
+  unsigned* ctl = mc.ctl + (size_t)b * kMcuCtlWords;
+  const size_t slot = mcu_spec_slot(S);
+  const double* in = mc.spec + (size_t)b * (mc.K + 1) * slot;
+  double* out = mc.spec + ((size_t)b * (mc.K + 1) + k) * slot;
+  double* Hbk = bt.Hbackup + (size_t)b * bt.hmat_stride;
+  unsigned epoch = 0;
+  for (;;) {
+    mcu_trace(mc.trace, epoch, 0x60);
+    if (tid == 0) {
+      unsigned cmd = 0;
+      const long long t0 = realtime_ticks();
+      for (;;) {
+        cmd = ld_agent_u32(ctl + MCU_SCMD);
+        if (cmd > epoch) break;
+        if (ld_agent_u32(ctl + MCU_SABORT) != 0 || realtime_ticks() - t0 > 4 * mc.timeout_ticks + 100000) { cmd = kMcuSpecExit; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      l.ired[24] = (int)cmd;
+      l.ired[25] = (int)ld_agent_u32(ctl + MCU_SN);
+      if (cmd != kMcuSpecExit) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    const unsigned cmd = (unsigned)l.ired[24];
+    const int n = l.ired[25];
+    __syncthreads();
+    if (cmd == kMcuSpecExit || n < 2 || n > plan.S) return;
+    epoch = cmd;
+    mcu_trace(mc.trace, epoch, 0x61);
+    const int Nt = 4 * n;
+    const double lambda = in[4 * S + 8 + k];
+    for (int r = tid; r < Nt + 8; r += kThreads) l.bv[r] = r < Nt ? in[r] : 0.0;
+    if constexpr (SOLVER == SOLVER_CR) {
+      const int hsz = ((Nt + 7) >> 3) * 2 * kBlk;
+      for (int q = tid; q < hsz; q += kThreads) *hmat_ptr<SOLVER_CR>(l, q, Nt) = Hbk[q];
+    }
+    __syncthreads();
+    if constexpr (SOLVER == SOLVER_CR) cr_solve_t<false, false>(plan, sc, n, lambda, nullptr, nullptr);
+    else cr_solve_hybrid(plan, n, lambda, Hbk);
+    for (int r = tid; r < Nt; r += kThreads) st_agent_f64(out + r, l.dxv[r]);
+    if (tid == 0) st_agent_f64(out + 4 * S + 8, l.ired[0] != 0 ? 1.0 : 0.0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) st_agent_u32(ctl + MCU_SDONE + k, epoch);
+    mcu_trace(mc.trace, epoch, 0x62);
+  }
+}
+
 // SCENE: SCENE_POINTS = every obstacle and the footprint are point-like and the obstacle table is cached in LDS (SceneDev::fast_points),
 // SCENE_GENERIC = any shapes (segment / polygon distance loops, bounding-circle culling). One instantiation each, so that neither pays
 // for the other's code (placement, registers).
-enum { SCENE_POINTS = 0, SCENE_GENERIC = 1 };
+// The _SMALL kinds are the same two for SMALL BATCHES (teb_multicu.hpp): launched with helper workgroups on the CUs the batch leaves idle -
+// K solver helpers per band (speculative LM trials) and, for generic scenes, D distance helpers. Closed-form Jacobians only.
+enum { SCENE_POINTS = 0, SCENE_GENERIC = 1, SCENE_POINTS_SMALL = 2, SCENE_GENERIC_SMALL = 3 };
 template <int SOLVER, int JMODE, int SCENE>
 __global__ void __launch_bounds__(kThreads)
 teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev bt, const OptArgs args,
                     const LdsPlan plan, const McuDev mc) {
   extern __shared__ __attribute__((aligned(16))) double lds_base[];
-  constexpr bool FAST = SCENE == SCENE_POINTS;
-  constexpr bool MCU = !FAST && JMODE == TEB_AMD_JACOBIAN_ANALYTIC;   // the multi-CU mode exists for generic scenes with closed-form Jacobians
+  constexpr bool FAST = SCENE == SCENE_POINTS || SCENE == SCENE_POINTS_SMALL;
+  constexpr bool MCU = SCENE == SCENE_POINTS_SMALL || SCENE == SCENE_GENERIC_SMALL;   // small-batch instantiation: helper workgroups possible
+  static_assert(!MCU || JMODE == TEB_AMD_JACOBIAN_ANALYTIC, "the small-batch kinds exist for closed-form Jacobians");
   if constexpr (MCU) {
-    if (mc.H > 0 && (int)blockIdx.x >= bt.B) {   // workgroups B .. B (1 + H) - 1: helpers of band (x - B) / H
-      const int hb = ((int)blockIdx.x - bt.B) / mc.H;
-      mcu_helper(c, sc, bt, mc, plan, hb, ((int)blockIdx.x - bt.B) - hb * mc.H);
+    if (mc.K + mc.D > 0 && (int)blockIdx.x >= bt.B) {   // workgroups B .. B (1 + K + D) - 1: helpers of band (x - B) / (K + D)
+      const int per = mc.K + mc.D;
+      const int hb = ((int)blockIdx.x - bt.B) / per, j = ((int)blockIdx.x - bt.B) - hb * per;
+      if (j < mc.K) {
+        if constexpr (SOLVER != SOLVER_BANDG) mcu_solver_helper<SOLVER>(sc, bt, mc, plan, hb, j + 1);
+      } else {
+        if constexpr (!FAST) mcu_helper(c, sc, bt, mc, plan, hb, j - mc.K);
+      }
       return;
     }
   }
   const int b = blockIdx.x, tid = threadIdx.x, S = bt.stride;
   const Lds l = carve(lds_base, plan, SOLVER == SOLVER_BANDG ? args.Hband + (size_t)b * args.hband_stride : nullptr, SOLVER == SOLVER_BANDG);
   McuMaster mm;
-  mm.H = MCU ? mc.H : 0; mm.epoch = 0; mm.failed = false; mm.timeout = mc.timeout_ticks; mm.trace = mc.trace;
-  mm.ctl = mm.H > 0 ? mc.ctl + (size_t)b * kMcuCtlWords : nullptr;
+  mm.H = (MCU && !FAST) ? mc.D : 0; mm.K = (MCU && SOLVER != SOLVER_BANDG) ? mc.K : 0;
+  mm.epoch = 0; mm.sepoch = 0; mm.failed = false; mm.spec_failed = false; mm.timeout = mc.timeout_ticks; mm.trace = mc.trace;
+  mm.ctl = (mm.H > 0 || mm.K > 0) ? mc.ctl + (size_t)b * kMcuCtlWords : nullptr;
   mm.pub = mm.H > 0 ? mc.pub + (size_t)b * kMcuPubArrays * S : nullptr;
+  mm.spec = mm.K > 0 ? mc.spec + (size_t)b * (mc.K + 1) * mcu_spec_slot(S) : nullptr;
   const bool mcu_on = MCU && mm.H > 0 && !args.debug_linearize && !c.legacy_obstacle_association;
+  const bool spec_on = MCU && mm.K > 0 && !args.debug_linearize && !(SOLVER == SOLVER_BAND && args.band_ldlt) && !(mc.debug_flags & 4);
   if constexpr (FAST) {   // stage the point-like obstacle table once: static list first, then the dynamic list
     const int tot = sc.n_static + sc.n_dyn;
     for (int k = tid; k < tot; k += kThreads) {
@@ -2217,7 +2296,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       bt.status[b] = TEB_AMD_TEB_FAILED; bt.iters[b] = 0; bt.trials[b] = 0;
       bt.chi2[b] = 0; bt.cost[b] = __longlong_as_double(0x7ff8000000000000LL); bt.lambda[b] = 0;
     }
-    if (MCU && mm.H > 0) mcu_exit(mm);   // the helpers of this band must not wait for a master that has left
+    if (MCU && mm.H + mm.K > 0) mcu_exit(mm);   // the helpers of this band must not wait for a master that has left
     return;
   }
 
@@ -2397,15 +2476,39 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       PROF_START();
       const int hsz = (SOLVER != SOLVER_CR) ? Nt * kBand : ((Nt + 7) >> 3) * 2 * kBlk;
       const bool keep_copy = !(SOLVER != SOLVER_CR && !args.band_ldlt);   // the HBM-block reductions never touch the band
-      if (keep_copy)
-        for (int q = tid; q < hsz; q += kThreads) Hbk[q] = *hmat_ptr<SOLVER>(l, q, Nt);   // saved for rejected trials
-      if (SOLVER == SOLVER_BAND && !args.band_ldlt) cr_copy_band(l, n, Hbk);   // hybrid solve: the band to HBM once per iteration
+      if constexpr (MCU) {
+        if (spec_on) spec_wait_idle(mm, l.ired + 26);   // the solver helpers are done with the buffers of the previous iteration
+      }
+      const bool spec_now = MCU && spec_on && !mm.spec_failed;
+      if (keep_copy) {
+        if (spec_now) {   // (the solver helpers load the same backup: written through)
+          for (int q = tid; q < hsz; q += kThreads) st_agent_f64(Hbk + q, *hmat_ptr<SOLVER>(l, q, Nt));
+        } else {
+          for (int q = tid; q < hsz; q += kThreads) Hbk[q] = *hmat_ptr<SOLVER>(l, q, Nt);   // saved for rejected trials
+        }
+      }
+      if (SOLVER == SOLVER_BAND && !args.band_ldlt) cr_copy_band(l, n, Hbk, spec_now);   // hybrid solve: the band to HBM once per iteration
+      if constexpr (MCU) {
+        if (spec_now) spec_issue(mm, l.bv, Nt, n, S, lambda, ni);   // retries 1 .. K start on their CUs now
+      }
       PROF_END(3);
       double rho = 0;
       int qmax = 0;
+      bool h_spent = false;   // blocks-in-LDS layout: the in-place solve has consumed H
       do {
         // --- damped solve
         PROF_START();
+        bool taken = false;
+        if constexpr (MCU) {
+          if (spec_now && !mm.spec_failed && qmax >= 1 && qmax <= mm.K)
+            taken = spec_take(mm, qmax, l.dxv, l.ired, Nt, S, l.ired + 26);   // the step of this retry was solved on a spare CU meanwhile
+        }
+        if (!taken) {
+        if (keep_copy && h_spent) {   // bring back the un-factored H (lazily: a retry whose step came from a helper needs no H at all)
+          for (int q = tid; q < hsz; q += kThreads) *hmat_ptr<SOLVER>(l, q, Nt) = Hbk[q];
+          __syncthreads();
+        }
+        h_spent = true;
         if constexpr (SOLVER == SOLVER_BAND) {
           if (args.band_ldlt) {
             if (tid < 64) {
@@ -2421,6 +2524,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
         } else {
           cr_solve_t<false, false>(plan, sc, n, lambda, nullptr, nullptr);
         }
+        }   // !taken
         PROF_END(4);
         PROF_START();
         const bool ok2 = l.ired[0] != 0;
@@ -2479,8 +2583,6 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
             if (i < n) { l.sx[i] = bx_[kk]; l.sy[i] = by_[kk]; l.sth[i] = bth_[kk]; l.sdt[i] = bdt_[kk]; }
           }
           if (!isfinite(lambda)) { ++qmax; __syncthreads(); break; }
-          if (keep_copy && rho < 0 && qmax + 1 < 10)   // another trial follows: bring back the un-factored H
-            for (int q = tid; q < hsz; q += kThreads) *hmat_ptr<SOLVER>(l, q, Nt) = Hbk[q];
         }
         __syncthreads();
         PROF_END(6);
@@ -2527,7 +2629,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   }
 
   // ---- K0: strip store + results
-  if (MCU && mm.H > 0) mcu_exit(mm);   // every way out of the loops above ends here: the helpers leave
+  if (MCU && mm.H + mm.K > 0) mcu_exit(mm);   // every way out of the loops above ends here: the helpers leave
   __syncthreads();
   int nonfinite = 0;
   for (int i = tid; i < n; i += kThreads) {

@@ -56,21 +56,28 @@ __device__ __forceinline__ int ld_list(bool shared, const int* p) { return share
 
 __device__ __forceinline__ long long realtime_ticks() { return (long long)__builtin_amdgcn_s_memrealtime(); }   // 100 MHz, independent of the shader clock
 
-// control block of one band: 64 words, the two contended ones on cache lines of their own
+// control block of one band: 64 words, the contended ones on cache lines of their own
 constexpr int kMcuCtlWords = 64;
-enum { MCU_CMD = 0, MCU_DONE = 16, MCU_N = 32, MCU_ABORT = 33 };
+enum { MCU_CMD = 0, MCU_DONE = 16, MCU_N = 32, MCU_ABORT = 33, MCU_SABORT = 34, MCU_SCMD = 48, MCU_SN = 49, MCU_SDONE = 52 /* + k, k = 1 .. kMcuMaxSpec */ };
 enum { MCU_KIND_ASSOC = 1, MCU_KIND_DIST = 2, MCU_KIND_EXIT = 3 };
+constexpr unsigned kMcuSpecExit = 0xffffffffu;
 constexpr int kMcuPubArrays = 5;     // x, y, cos, sin, time stamp of the dynamic edges
+constexpr int kMcuMaxSpec = 3;       // speculative damped solves per LM iteration: lambda * 2, * 8, * 64 (the first three rejections)
+__host__ __device__ inline size_t mcu_spec_slot(int S) { return (size_t)4 * S + 16; }   // doubles per slot: 4 S + 8 values, then 8 meta
 
-struct McuDev {            // kernel argument; H == 0: single-CU launch, the pointers are not touched
-  int H;                   // helper workgroups per band
+// A launch of the small-batch instantiations has B x (1 + K + D) workgroups: per band its own workgroup, K solver helpers (speculative LM
+// trials, below) and D distance helpers (generic scenes: association + distance records, above).
+struct McuDev {            // kernel argument; K == D == 0: single-CU launch, the pointers are not touched
+  int K;                   // solver helpers per band
+  int D;                   // distance helpers per band (generic scenes only)
   unsigned* ctl;           // [B][kMcuCtlWords], zeroed by the host before every launch
   double* pub;             // [B][kMcuPubArrays][S]
   double* items;           // [B][item_cap][4][S]: record q of item k of pose i at ((k * 4 + q) * S + i)
   int item_cap;            // >= association entries + dynamic obstacles of a pose
+  double* spec;            // [B][1 + K][mcu_spec_slot(S)]: slot 0 = right-hand side b (+ the lambdas at 4 S + 8 + k), slot k = step of solver helper k (+ "factorisation ok" at 4 S + 8)
   long long timeout_ticks; // of the real-time counter (100 MHz)
   unsigned* trace;         // diagnostic (teb_amd_debug_mcu_watchdog): host-visible breadcrumbs, one word per workgroup, or nullptr
-  int debug_flags;         // diagnostic (teb_amd_debug_mcu_flags): 1 = the master associates itself, 2 = the master computes the distances itself
+  int debug_flags;         // diagnostic (teb_amd_debug_mcu_flags): 1 = the master associates itself, 2 = it computes the distances itself, 4 = it solves every trial itself
 };
 // breadcrumb of this workgroup: (epoch << 8) | code, system scope so that the host can read it while the kernel runs
 __device__ __forceinline__ void mcu_trace(unsigned* trace, unsigned epoch, unsigned code) {
@@ -85,7 +92,11 @@ struct McuView {
 
 // ---- master side ----------------------------------------------------------------------------------------------------------------
 struct McuMaster {
-  int H;
+  int H;                   // distance helpers of the band
+  int K;                   // solver helpers of the band
+  unsigned sepoch;         // speculative solves issued so far (one per LM iteration)
+  bool spec_failed;        // a solver helper did not deliver in time: this workgroup solves every further trial itself
+  double* spec;
   unsigned* ctl;
   double* pub;
   unsigned epoch;          // phases issued so far
@@ -139,9 +150,70 @@ __device__ __forceinline__ bool mcu_wait(McuMaster& m, int* lds_flag) {
 __device__ __forceinline__ void mcu_exit(McuMaster& m) {
   if (threadIdx.x == 0) {
     ++m.epoch;
-    st_agent_u32(m.ctl + MCU_CMD, (m.epoch << 8) | (unsigned)MCU_KIND_EXIT);
+    if (m.H > 0) st_agent_u32(m.ctl + MCU_CMD, (m.epoch << 8) | (unsigned)MCU_KIND_EXIT);
+    if (m.K > 0) st_agent_u32(m.ctl + MCU_SCMD, kMcuSpecExit);
   }
   mcu_trace(m.trace, m.epoch, 9);
+}
+
+// ---- speculative LM trials ------------------------------------------------------------------------------------------------------
+// OptimizationAlgorithmLevenberg::solve retries a rejected step with lambda * 2, * 4, * 8 ..: the damped systems
+// of the first K retries are known as soon as the iteration is linearised. The band's workgroup publishes the right-hand side (the
+// normal matrix is in its HBM backup / band copy anyway, written through in this mode) and the K lambdas; solver helper k solves
+// (H + lambda_k I) dx = b with the SAME routine on a spare CU while this workgroup solves and evaluates trial 0. A rejected trial then
+// finds its step ready instead of spending another solve - the accepted step, and every bit of it, is what the sequential loop computes.
+__device__ __forceinline__ void spec_wait_idle(McuMaster& m, int* lds_flag) {   // the helpers have left the buffers of the previous iteration
+  if (m.sepoch == 0 || m.spec_failed) return;
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    const long long t0 = realtime_ticks();
+    for (int k = 1; k <= m.K && ok; ++k)
+      while (ld_agent_u32(m.ctl + MCU_SDONE + k) < m.sepoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (realtime_ticks() - t0 > m.timeout) { ok = 0; st_agent_u32(m.ctl + MCU_SABORT, 1u); break; }
+      }
+    *lds_flag = ok;
+  }
+  __syncthreads();
+  if (*lds_flag == 0) m.spec_failed = true;
+  __syncthreads();
+}
+// right-hand side b (Nt values) and the lambdas of the retries, then the command; lambda0 / ni0: the damping of trial 0 and its multiplier
+__device__ __forceinline__ void spec_issue(McuMaster& m, const double* bv, int Nt, int n, int S, double lambda0, double ni0) {
+  for (int r = threadIdx.x; r < Nt; r += kThreads) st_agent_f64(m.spec + r, bv[r]);
+  if (threadIdx.x == 0) {
+    double lam = lambda0, ni = ni0;
+    for (int k = 1; k <= m.K; ++k) { lam *= ni; ni *= 2; st_agent_f64(m.spec + 4 * S + 8 + k, lam); }   // exactly the products of the retry loop
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  ++m.sepoch;
+  if (threadIdx.x == 0) {
+    st_agent_u32(m.ctl + MCU_SN, (unsigned)n);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st_agent_u32(m.ctl + MCU_SCMD, m.sepoch);
+  }
+}
+// the step of retry k into dxv; returns false when the helper did not deliver in time (the caller solves itself from then on)
+__device__ __forceinline__ bool spec_take(McuMaster& m, int k, double* dxv, int* ok_flag, int Nt, int S, int* lds_flag) {
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    const long long t0 = realtime_ticks();
+    while (ld_agent_u32(m.ctl + MCU_SDONE + k) < m.sepoch) {
+      __builtin_amdgcn_s_sleep(1);
+      if (realtime_ticks() - t0 > m.timeout) { ok = 0; st_agent_u32(m.ctl + MCU_SABORT, 1u); break; }
+    }
+    *lds_flag = ok;
+  }
+  __syncthreads();
+  const bool ok = *lds_flag != 0;
+  __syncthreads();
+  if (!ok) { m.spec_failed = true; return false; }
+  const double* out = m.spec + (size_t)k * mcu_spec_slot(S);
+  for (int r = threadIdx.x; r < Nt; r += kThreads) dxv[r] = ld_agent_f64(out + r);
+  if (threadIdx.x == 0) *ok_flag = ld_agent_f64(out + 4 * S + 8) != 0.0 ? 1 : 0;
+  __syncthreads();
+  return true;
 }
 
 }  // namespace tebamd

@@ -1,5 +1,5 @@
 // teb_opt_inst.hip — ONE instantiation of teb_optimize_kernel per translation unit (see teb_opt_launch.hpp):
-//   hipcc -c -DTEB_INST_SOLVER=<0|1|2> -DTEB_INST_JMODE=<0|1> -DTEB_INST_SCENE=<0|1> teb_opt_inst.hip
+//   hipcc -c -DTEB_INST_SOLVER=<0|1|2> -DTEB_INST_JMODE=<0|1> -DTEB_INST_SCENE=<0|1|2|3> teb_opt_inst.hip
 #include <hip/hip_runtime.h>
 
 #include "teb_kernel.hpp"
@@ -10,6 +10,7 @@
 #endif
 static_assert(tebamd::SOLVER_BAND == 0 && tebamd::SOLVER_CR == 1 && tebamd::SOLVER_BANDG == 2, "teb_opt_launch.hpp numbers the layouts");
 static_assert(TEB_AMD_JACOBIAN_ANALYTIC == 0 && TEB_AMD_JACOBIAN_G2O_NUMERIC == 1, "teb_opt_launch.hpp numbers the Jacobian modes");
-static_assert(tebamd::SCENE_POINTS == 0 && tebamd::SCENE_GENERIC == 1, "teb_opt_launch.hpp numbers the scene kinds");
+static_assert(tebamd::SCENE_POINTS == 0 && tebamd::SCENE_GENERIC == 1 && tebamd::SCENE_POINTS_SMALL == 2 && tebamd::SCENE_GENERIC_SMALL == 3,
+              "teb_opt_launch.hpp numbers the scene kinds");
 
 TEB_OPT_DEFINE(TEB_INST_SOLVER, TEB_INST_JMODE, TEB_INST_SCENE)

@@ -14,9 +14,11 @@
   __attribute__((visibility("hidden"))) const void* TEB_OPT_KERNEL_FN(S, J, P)() {                                   \
     return reinterpret_cast<const void*>(&tebamd::teb_optimize_kernel<S, J, P>);                                     \
   }
-// solver: 0 SOLVER_BAND, 1 SOLVER_CR, 2 SOLVER_BANDG; jmode: 0 analytic, 1 g2o numeric; scene: 0 SCENE_POINTS, 1 SCENE_GENERIC
+// solver: 0 SOLVER_BAND, 1 SOLVER_CR, 2 SOLVER_BANDG; jmode: 0 analytic, 1 g2o numeric; scene: 0 SCENE_POINTS, 1 SCENE_GENERIC,
+// 2 SCENE_POINTS_SMALL, 3 SCENE_GENERIC_SMALL (small batches with helper workgroups, closed-form Jacobians only)
+#define TEB_OPT_FOR_ANALYTIC(X) X(0, 0, 0) X(1, 0, 0) X(2, 0, 0) X(0, 0, 1) X(1, 0, 1) X(2, 0, 1) X(0, 0, 2) X(1, 0, 2) X(2, 0, 2) X(0, 0, 3) X(1, 0, 3) X(2, 0, 3)
 #ifdef TEB_AMD_ANALYTIC_ONLY
-#define TEB_OPT_FOR_ALL(X) X(0, 0, 0) X(1, 0, 0) X(2, 0, 0) X(0, 0, 1) X(1, 0, 1) X(2, 0, 1)
+#define TEB_OPT_FOR_ALL(X) TEB_OPT_FOR_ANALYTIC(X)
 #else
-#define TEB_OPT_FOR_ALL(X) X(0, 0, 0) X(1, 0, 0) X(2, 0, 0) X(0, 0, 1) X(1, 0, 1) X(2, 0, 1) X(0, 1, 0) X(1, 1, 0) X(2, 1, 0) X(0, 1, 1) X(1, 1, 1) X(2, 1, 1)
+#define TEB_OPT_FOR_ALL(X) TEB_OPT_FOR_ANALYTIC(X) X(0, 1, 0) X(1, 1, 0) X(2, 1, 0) X(0, 1, 1) X(1, 1, 1) X(2, 1, 1)
 #endif

@@ -55,7 +55,7 @@ def lib():
         L.teb_amd_get_results.argtypes = [vp, C.POINTER(_abi.Results)]
         L.teb_amd_select_best.argtypes = [vp, C.c_int32, C.c_int32, _abi.p_i32, _abi.p_f64]
         if hasattr(L, "teb_amd_last_launch_info"):
-            L.teb_amd_last_launch_info.argtypes = [vp, _abi.p_i32, _abi.p_i32]
+            L.teb_amd_last_launch_info.argtypes = [vp, _abi.p_i32, _abi.p_i32, _abi.p_i32]
         if hasattr(L, "teb_amd_set_iteration_log"):   # (absent from the older builds tools/ compares against through TEB_AMD_LIB)
             L.teb_amd_set_iteration_log.argtypes = [vp, C.c_int32]
             L.teb_amd_get_iteration_log.argtypes = [vp, C.c_int32, _abi.p_f64, C.c_int32, _abi.p_i32]
@@ -234,10 +234,10 @@ class TebBatchSolver:
         return ms.value
 
     def last_launch_info(self):
-        """(helper workgroups per band of the last optimize() - 0 = one CU per band -, repeated on one CU per band after a timeout)"""
-        a = C.c_int32(0); b = C.c_int32(0)
-        _chk(lib().teb_amd_last_launch_info(self._h, C.byref(a), C.byref(b)), "teb_amd_last_launch_info")
-        return a.value, bool(b.value)
+        """(distance helpers per band of the last optimize(), solver helpers per band, repeated on one CU per band after a timeout)"""
+        a = C.c_int32(0); k = C.c_int32(0); b = C.c_int32(0)
+        _chk(lib().teb_amd_last_launch_info(self._h, C.byref(a), C.byref(k), C.byref(b)), "teb_amd_last_launch_info")
+        return a.value, k.value, bool(b.value)
 
     def capacity(self):
         a = C.c_int32(0)

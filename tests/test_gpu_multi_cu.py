@@ -1,8 +1,11 @@
-"""Multi-CU mode (teb_local_planner_amd/csrc/teb_multicu.hpp): small batches of generic-shape scenes spread the obstacle association
-and the robot <-> obstacle distances over helper workgroups on the otherwise idle CUs. The contract: the bands are BIT-IDENTICAL to the
-single-CU launch (same device functions on the same inputs, rows accumulated in the same order) - for every footprint kind, with
-dynamic obstacles, via-points, the velocity-obstacle-ratio edges, any number of helpers, bands longer than the workgroup; and when the
-helpers do not arrive in time the launch is repeated on one CU per band with the same result."""
+"""Multi-CU mode (teb_local_planner_amd/csrc/teb_multicu.hpp): small batches use the CUs they leave idle.
+  * distance helpers (generic-shape scenes): the obstacle association and the robot <-> obstacle distances of every (pose, obstacle) pair;
+  * solver helpers (any scene): the damped systems of the first retries of an LM iteration, solved speculatively while the band
+    evaluates its first trial.
+The contract: the bands are BIT-IDENTICAL to the single-CU launch (same device functions on the same inputs, rows accumulated in the
+same order, the same solve routine on the same system) - for every footprint kind, with dynamic obstacles, via-points, the
+velocity-obstacle-ratio edges, any number of helpers, bands longer than the workgroup, every layout of the normal matrix; and when
+the distance helpers do not arrive in time the launch is repeated on one CU per band with the same result."""
 import numpy as np
 import pytest
 
@@ -34,13 +37,13 @@ def _assert_identical(a, ra, b, rb):
 
 def test_c5_full_size_is_bit_identical_and_uses_helpers():
     cfg, obst, via, batch = scenes.scene_c5(stride=320)
-    one, r1, info1, f1, ms1 = _run(cfg, obst, via, batch, multi_cu=-1)
+    one, r1, info1, f1, ms1 = _run(cfg, obst, via, batch, multi_cu=-1, speculative_trials=-1)
     many, rm, infom, fm, msm = _run(cfg, obst, via, batch)        # automatic: one band, 300 polygons x 300 poses
-    assert info1 == (0, False)
-    assert infom[0] >= 16 and not infom[1], infom
+    assert info1 == (0, 0, False)
+    assert infom[0] >= 16 and infom[1] == 3 and not infom[2], infom
     assert not f1.any() and not fm.any()
     _assert_identical(many, rm, one, r1)
-    print("C5: one CU %.3f ms, %d helpers %.3f ms" % (ms1, infom[0], msm))
+    print("C5: one CU %.3f ms, %d distance + %d solver helpers %.3f ms" % (ms1, infom[0], infom[1], msm))
     assert msm < ms1
 
 
@@ -48,9 +51,9 @@ def test_c5_full_size_is_bit_identical_and_uses_helpers():
 @pytest.mark.parametrize("helpers", [2, 7, 40])
 def test_small_mixed_scenes_every_footprint(footprint, helpers):
     cfg, obst, via, batch = scenes.scene_small_mixed(footprint=footprint)   # every obstacle type, dynamic obstacles, via-points; 3 bands
-    one, r1, info1, _, _ = _run(cfg, obst, via, batch, multi_cu=-1, generic_distance_path=True)
-    many, rm, infom, fm, _ = _run(cfg, obst, via, batch, multi_cu=helpers, generic_distance_path=True)
-    assert info1[0] == 0 and infom == (helpers, False), (info1, infom)
+    one, r1, info1, _, _ = _run(cfg, obst, via, batch, multi_cu=-1, speculative_trials=-1, generic_distance_path=True)
+    many, rm, infom, fm, _ = _run(cfg, obst, via, batch, multi_cu=helpers, speculative_trials=-1, generic_distance_path=True)
+    assert info1 == (0, 0, False) and infom == (helpers, 0, False), (info1, infom)
     assert not fm.any()
     _assert_identical(many, rm, one, r1)
 
@@ -58,9 +61,9 @@ def test_small_mixed_scenes_every_footprint(footprint, helpers):
 def test_velocity_obstacle_ratio_edges_read_the_records():
     cfg, obst, via, batch = scenes.scene_small_mixed(footprint="polygon")
     cfg.optim.weight_velocity_obstacle_ratio = 3.0
-    one, r1, _, _, _ = _run(cfg, obst, via, batch, multi_cu=-1)
+    one, r1, _, _, _ = _run(cfg, obst, via, batch, multi_cu=-1, speculative_trials=-1)
     many, rm, infom, _, _ = _run(cfg, obst, via, batch, multi_cu=9)
-    assert infom == (9, False)
+    assert infom == (9, 3, False)
     _assert_identical(many, rm, one, r1)
 
 
@@ -68,27 +71,27 @@ def test_divergence_detection_and_cost_exponent():
     cfg, obst, via, batch = scenes.scene_small_mixed(footprint="two_circles")
     cfg.recovery.divergence_detection_enable = True
     cfg.optim.obstacle_cost_exponent = 1.5
-    one, r1, _, _, _ = _run(cfg, obst, via, batch, multi_cu=-1)
-    many, rm, infom, _, _ = _run(cfg, obst, via, batch, multi_cu=5)
-    assert infom == (5, False)
+    one, r1, _, _, _ = _run(cfg, obst, via, batch, multi_cu=-1, speculative_trials=-1)
+    many, rm, infom, _, _ = _run(cfg, obst, via, batch, multi_cu=5, speculative_trials=2)
+    assert infom == (5, 2, False)
     _assert_identical(many, rm, one, r1)
 
 
 def test_long_band_beyond_the_workgroup():
     """more poses than the 256 lanes of a workgroup: the second (sliced) pass of the single-CU path against helper tiles"""
     cfg, obst, via, batch = scenes.scene_c5(n=300, M=100, stride=400)
-    one, r1, _, f1, _ = _run(cfg, obst, via, batch, multi_cu=-1)
+    one, r1, _, f1, _ = _run(cfg, obst, via, batch, multi_cu=-1, speculative_trials=-1)
     many, rm, infom, fm, _ = _run(cfg, obst, via, batch, multi_cu=32)
-    assert infom == (32, False) and not f1.any() and not fm.any()
+    assert infom == (32, 3, False) and not f1.any() and not fm.any()
     assert one.n[0] > 256
     _assert_identical(many, rm, one, r1)
 
 
 def test_helpers_that_do_not_arrive_in_time_mean_a_repeat_on_one_cu():
     cfg, obst, via, batch = scenes.scene_small_mixed(footprint="polygon")
-    one, r1, _, _, _ = _run(cfg, obst, via, batch, multi_cu=-1)
+    one, r1, _, _, _ = _run(cfg, obst, via, batch, multi_cu=-1, speculative_trials=-1)
     many, rm, infom, fm, _ = _run(cfg, obst, via, batch, multi_cu=6, multi_cu_timeout_us=1)   # 1 us: no phase can make it
-    assert infom == (6, True), infom
+    assert infom == (6, 3, True), infom
     assert not fm.any()
     _assert_identical(many, rm, one, r1)
 
@@ -97,21 +100,60 @@ def test_numeric_mode_and_legacy_association_stay_on_one_cu():
     cfg, obst, via, batch = scenes.scene_small_mixed(footprint="polygon")
     cfg.jacobian_mode = _abi.JACOBIAN_G2O_NUMERIC
     _, _, info, _, _ = _run(cfg, obst, via, batch, multi_cu=8)
-    assert info == (0, False)
+    assert info == (0, 0, False)
     cfg.jacobian_mode = _abi.JACOBIAN_ANALYTIC
     cfg.obstacles.legacy_obstacle_association = True
-    _, _, info, _, _ = _run(cfg, obst, via, batch, multi_cu=8)
-    assert info == (0, False)
+    one, r1, info1, _, _ = _run(cfg, obst, via, batch, multi_cu=-1, speculative_trials=-1)
+    many, rm, info, _, _ = _run(cfg, obst, via, batch, multi_cu=8)
+    assert info == (0, 3, False)           # the legacy association stays with the band, the speculative trials do not depend on it
+    _assert_identical(many, rm, one, r1)
 
 
 def test_matches_the_oracle(oracle):
     cfg, obst, via, batch = scenes.scene_small_mixed(footprint="polygon")
     many, rm, infom, _, _ = _run(cfg, obst, via, batch, multi_cu=12)
     ref, rres = oracle.optimize_batch(cfg, obst, via, batch)
-    assert infom == (12, False)
+    assert infom == (12, 3, False)
     np.testing.assert_array_equal(many.n, ref.n)
     np.testing.assert_array_equal(rm.lm_trials, rres.lm_trials)
     for b in range(batch.count):
         for u, v in zip(many.get_teb(b), ref.get_teb(b)):
             assert np.abs(u - v).max() < 1e-7
     np.testing.assert_allclose(rm.cost, rres.cost, rtol=1e-8)
+
+
+# ---- speculative LM trials (solver helpers), point-like scenes included ---------------------------------------------------------------
+@pytest.mark.parametrize("k", [1, 2, 3])
+@pytest.mark.parametrize("layout", ["cr", "band"])
+def test_speculative_trials_every_layout(layout, k):
+    """C2-like single band in the blocks-in-LDS layout (in-place solve, H restored lazily) and in the hybrid layout (band copy in HBM)."""
+    cfg, obst, via, batch = scenes.scene_c2(n=120, M=60, stride=208 if layout == "cr" else 288)
+    one, r1, info1, _, _ = _run(cfg, obst, via, batch, speculative_trials=-1, layout=layout)
+    many, rm, infom, _, _ = _run(cfg, obst, via, batch, speculative_trials=k, layout=layout)
+    assert info1 == (0, 0, False) and infom == (0, k, False), (info1, infom)
+    assert r1.lm_trials[0] > r1.lm_iterations[0]          # there are rejected trials to speculate on
+    _assert_identical(many, rm, one, r1)
+
+
+def test_c2_full_size_is_bit_identical_and_faster():
+    cfg, obst, via, batch = scenes.scene_c2(stride=208)
+    one, r1, info1, _, ms1 = _run(cfg, obst, via, batch, speculative_trials=-1)
+    many, rm, infom, _, msm = _run(cfg, obst, via, batch)          # automatic: one band -> three solver helpers
+    assert info1 == (0, 0, False) and infom == (0, 3, False), (info1, infom)
+    _assert_identical(many, rm, one, r1)
+    print("C2: one CU %.3f ms, with 3 solver helpers %.3f ms (%d trials for %d iterations)" % (ms1, msm, r1.lm_trials[0], r1.lm_iterations[0]))
+    assert msm < ms1
+
+
+def test_small_batch_of_point_like_bands_with_dynamic_obstacles():
+    cfg, obst, via, batch = scenes.scene_c4(B=6, n=150, stride=288)       # hybrid layout, LDS obstacle cache, autoResize, dynamic obstacles
+    one, r1, _, _, _ = _run(cfg, obst, via, batch, speculative_trials=-1)
+    many, rm, infom, _, _ = _run(cfg, obst, via, batch)
+    assert infom == (0, 3, False)
+    _assert_identical(many, rm, one, r1)
+
+
+def test_large_batches_stay_on_one_workgroup_per_band():
+    cfg, obst, via, batch = scenes.scene_c3(B=40, n=60, M=40, stride=208)
+    _, _, info, _, _ = _run(cfg, obst, via, batch)
+    assert info == (0, 0, False)
