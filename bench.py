@@ -41,6 +41,59 @@ def alg_bytes_per_unit(n, M, e_assoc, inner):
     return 64 * n + r_obst + 4 * e_assoc + 32 + (32 * n + r_obst + 4 * e_assoc) / inner
 
 
+def latency_model(probe, n, inner_trials, static_edges_per_pose, dyn_near_per_pose, hybrid=True):
+    """Dependency-latency model of ONE LM iteration of one band (the HBM fraction is reported
+    'alongside the dependency-latency model'): the cycles the iteration would take if only its dependent-instruction chains remained
+    (unbounded issue width, no contention) - levels x per-round chain of the block cyclic reduction + linearisation + error
+    evaluation - built from the primitive latencies measured on this chip at one wave per SIMD (tools/micro/latency_probe.hip ->
+    profiles/latency_probe_r03.json) times the chain lengths read off the kernel source (DESIGN.md section 4 lists them).
+    n = poses, inner_trials = damped solves + error evaluations per LM iteration (measured), hybrid = band-in-LDS layout."""
+    L = probe
+    fma, rcp, sqrt_, div, sincos, lds, l2, bar, dpp = (L["fma_f64"], L["fast_rcp_f64_plus_add"], L["sqrt_f64_plus_add"], L["div_f64_plus_add"],
+                                                         L["sincos_f64_plus_add"], L["lds_load"], L["l2_load"], L["syncthreads_4_waves"], L["dpp_move_f64_plus_add"])
+    nb = (4 * n + 7) // 8
+    # one round of the reduction: load D_i (LDS or L2), LDL^T of an 8x8 block = 8 pivots x (reciprocal + scale + update), three right-hand
+    # sides through it (7 forward + 1 scale + 7 backward dependent steps), 8-term Schur dot products, read-modify-write of the
+    # neighbours in two barrier-separated phases
+    factor = 8 * (rcp + 2 * fma)
+    round_lds = lds + factor + 15 * fma + 8 * fma + 2 * (lds + bar)
+    round_l2 = l2 + factor + 15 * fma + 8 * fma + lds + 2 * (lds + bar)          # level 0 of the hybrid solve gathers from the band copy (L2)
+    rounds = 0
+    e = nb // 2                                                                  # eliminations of level 0
+    solve = 0.0
+    if hybrid:
+        solve += l2 + lds + bar                                                  # compact system of the even rows
+        solve += ((e + 31) // 32) * round_l2
+        rounds += (e + 31) // 32
+        m = (nb + 1) // 2                                                        # rows of the compact system
+    else:
+        m = nb
+    s_ = 1
+    levels = 0
+    while s_ < m:
+        el = (m - 1 - s_) // (2 * s_) + 1
+        solve += ((el + 31) // 32) * round_lds
+        rounds += (el + 31) // 32
+        levels += 1
+        s_ *= 2
+    solve += lds + factor + 15 * fma                                             # top block
+    solve += levels * (lds + 8 * fma + lds + bar)                                # back substitution, one level after the other
+    if hybrid:
+        solve += 8 * (fma + 3 * dpp) + lds                                       # odd rows from the records in registers (butterfly over 8 lanes)
+    # linearisation: zero H | barrier | sin, cos of the headings | barrier | the lane's longest edge chain | three scatter phases | chi^2 sum
+    static_chain = ((static_edges_per_pose + 3) // 4) * (l2 + lds + sqrt_ + div + 6 * fma)      # association entries four at a time
+    dyn_chain = lds + 8 * fma + dyn_near_per_pose * (sqrt_ + div + 8 * fma)                     # cached near mask, then the near obstacles
+    accel_chain = 2 * sqrt_ + 4 * div + 24 * fma                                                # EdgeAcceleration: two signed velocities (sqrt, sigmoid, /dt) -> /T
+    edges = max(static_chain + dyn_chain, accel_chain)                                          # independent chains of one lane overlap
+    blocksum = 6 * dpp + lds + 2 * bar
+    linearise = lds + bar + sincos + bar + edges + 3 * (2 * lds + bar) + blocksum
+    evaluate = lds + sincos + bar + edges + blocksum                                            # update, then the same chains without Jacobians
+    per_iteration = linearise + lds + inner_trials * (solve + evaluate) + l2                   # + band copy / backup once per iteration
+    return {"cycles_per_lm_iteration": per_iteration, "solve_cycles": solve, "solve_rounds": rounds, "linearise_cycles": linearise,
+            "evaluate_cycles": evaluate, "trials_per_iteration": inner_trials, "poses": n,
+            "primitives": {k: L[k] for k in sorted(L)}}
+
+
 def kernel_source_hash(root=None):
     """sha256 over the device sources with comments and white space stripped (a comment edit does not make a new binary): ties a
     committed rocprof summary to the binary it was taken from."""
@@ -112,6 +165,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=256, help="TEBs in the CPU-oracle sample")
     ap.add_argument("--parity-bands", type=int, default=16)
     ap.add_argument("--latency-reps", type=int, default=20)
+    ap.add_argument("--sustain-seconds", type=float, default=3.0, help="length of the sustained segment after the timed steps (N = 1 only; 0 = off)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -237,6 +291,19 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     res = s.results()
+    # a sustained segment of the SAME step (>= 3 s): long enough for an external sampler (rocm-smi) to see the device busy; its
+    # per-step time has to agree with the K timed steps above
+    sustained = None
+    if not distributed and args.sustain_seconds > 0:
+        ts0 = time.perf_counter()
+        ks = 0
+        while time.perf_counter() - ts0 < args.sustain_seconds:
+            for _ in range(50):
+                step()
+            ks += 50
+        torch.cuda.synchronize()
+        tsus = time.perf_counter() - ts0
+        sustained = {"seconds": tsus, "steps": ks, "ms_per_step": 1e3 * tsus / ks}
     units_step = int(res.lm_iterations.sum())
     n_after = s.pose_counts()
     tebs_ok = int((res.status == 0).sum())
@@ -316,6 +383,29 @@ def main():
                          "kernel": "teb_optimize_kernel", "kernel_ms": kms,
                          "alg_bytes_per_unit": abu, "alg_bytes_per_launch": alg_bytes_launch},
         }
+        if sustained:
+            sustained["agrees_with_timed_steps_within_3_percent"] = bool(abs(sustained["ms_per_step"] / out["ms_per_step"] - 1.0) <= 0.03)
+            out["sustained"] = sustained
+        # dependency-latency model (primitive latencies measured on this chip x chain lengths of one LM iteration, see latency_model)
+        try:
+            import glob
+            pr = sorted(glob.glob(os.path.join(ROOT, "profiles", "latency_probe_r*.json")))
+            if pr:
+                probe = json.load(open(pr[-1]))["workgroups_256"]
+                tr_per_it = float(res.lm_trials.sum()) / max(1.0, float(res.lm_iterations.sum()))
+                lm = latency_model(probe, int(round(float(n_after.max()))), tr_per_it, e_assoc / max(1.0, n_eff), 0.3)
+                # the launch ends with its slowest band: its LM iterations x the model against the kernel's cycles at the clock the probe ran at
+                clock_hz = 2.06e9     # shader clock with all 256 CUs busy (clock64 ticks per second of kernel time)
+                its = int(res.lm_iterations.max())
+                model_ms = 1e3 * its * lm["cycles_per_lm_iteration"] / clock_hz
+                lm.update({"lm_iterations_of_a_band": its, "model_ms_per_launch": model_ms, "kernel_ms": kms, "achieved_over_model": kms / model_ms,
+                           "shader_clock_hz": clock_hz, "source": os.path.basename(pr[-1]),
+                           "note": "critical path only (dependent-instruction chains of the longest band at one wave per SIMD, unbounded issue width, "
+                                   "no LDS / L2 contention, autoResize and association left out): what remains between it and the kernel is issue "
+                                   "bandwidth (fp64 at 16 lanes / cycle / SIMD), LDS pipe sharing between the four waves and barrier skew"})
+                out["roofline"]["latency_model"] = lm
+        except Exception as e:   # noqa: BLE001
+            out["roofline"]["latency_model"] = {"error": str(e)[:200]}
         if traffic_note:
             out["roofline"]["traffic_note"] = traffic_note
         if fp64:
@@ -361,9 +451,38 @@ def main():
                                        "against": "oracle/teb_oracle.cpp, closed-form Jacobians, same inputs; all 256 bands: tests/test_gpu_measured_configs.py"}
             except Exception as e:   # noqa: BLE001
                 out["parity_check"] = {"error": str(e)[:200]}
+            # ---- the same batch, ALL bands, against the reference's OWN code (oracle/_ref = src/optimal_planner.cpp compiled in place,
+            #      its LM trace from the stand-in optimiser): SURVEY 8(c) tolerance T3, checker only, outside the timed region
+            try:
+                from oracle import ref_py, refcode_compare as RC
+                if os.path.exists(ref_py.SO):
+                    t1 = time.perf_counter()
+                    ref_pack = ref_py.optimize_batch(cfg, obst, via, batch, threads=min(B, os.cpu_count() or 1), trace=True)
+                    t_ref = time.perf_counter() - t1
+                    s.set_iteration_log(True)
+                    s.restore()
+                    hp.optimizeAllTEBs(inner, outer)
+                    res_r = s.results()
+                    out_r = s.download(batch.copy())
+                    tr_r = [s.iteration_log(b) for b in range(B)]
+                    s.set_iteration_log(False)
+                    rep = RC.compare_with_reference_code(out_r, res_r, tr_r, ref_pack[0], ref_pack[1], ref_pack[2], ref_pack[4])
+                    rep["outside"] = rep["outside"][:8]; rep["pose_count_mismatch"] = rep["pose_count_mismatch"][:8]
+                    rep.update({"mode": "analytic (closed-form Jacobians; the reference differentiates numerically)",
+                                "against": "oracle/_ref/libteb_ref.so: TebOptimalPlanner::optimizeTEB of the reference on every band, %.1f s on the host" % t_ref,
+                                "tolerance_T3": {"state": RC.T3_STATE, "chi2_rel": RC.T3_CHI2_REL},
+                                "tests": "tests/test_gpu_reference_code.py (C4 headline, C2, C3, C5; both Jacobian modes)"})
+                    out.setdefault("parity_check", {})["vs_reference_code"] = rep
+                else:
+                    ref_pack = None
+            except Exception as e:   # noqa: BLE001
+                ref_pack = None
+                out.setdefault("parity_check", {})["vs_reference_code"] = {"error": str(e)[:200]}
 
         # ---- p50 plan()-equivalent latency on the 200-pose band: upload -> 4x5 iterations incl. autoResize,
         #      association, cost -> select -> download (single TEB, config C2, and the C4 batch)
+        if args.no_parity_check:
+            ref_pack = None
         lat = {}
         for name, (c2, o2, v2, b2) in ((("c2_single_teb", scenes.scene_c2(stride=208)),
                                         ("c4_batch", scenes.scene_c4(B=B, n=n, stride=STRIDE))) if args.latency_reps > 0 else ()):
@@ -379,6 +498,7 @@ def main():
                 s2.download(hb)
                 ts.append(time.perf_counter() - t1)
             lat[name + "_p50_ms"] = 1e3 * float(np.median(ts))
+            lat[name + "_p95_ms"] = 1e3 * float(np.percentile(ts, 95))
             # the same tick with the bands resident in HBM: warm start on the device, optimise,
             # select, velocity command of the winner; only a start pose, a goal pose and two twists cross PCIe
             s2.upload(b2)
@@ -398,6 +518,8 @@ def main():
                 s2.velocity_command(best, 1, 0)
                 ts.append(time.perf_counter() - t1)
             lat[name + "_device_resident_p50_ms"] = 1e3 * float(np.median(ts))
+            lat[name + "_device_resident_p95_ms"] = 1e3 * float(np.percentile(ts, 95))
+            lat[name + "_helpers"] = dict(zip(("distance_helpers_per_band", "solver_helpers_per_band", "repeated_on_one_cu"), s2.last_launch_info()))
             s2.close()
         if args.latency_reps > 0:
             # whole HomotopyClassPlanner::plan() tick on device-resident bands: updateAllTEBs, H-signatures +
@@ -422,6 +544,7 @@ def main():
                 nb.append(hpt.solver.count)
             hpt.solver.close()
             lat["hcp_plan_tick_p50_ms"] = 1e3 * float(np.median(ts[1:]))
+            lat["hcp_plan_tick_p95_ms"] = 1e3 * float(np.percentile(ts[1:], 95))
             lat["hcp_plan_tick"] = {"workload": "HomotopyClassPlanner::plan() ticks on one planner: 16 m straight task, 12 point obstacles, "
                                                 "roadmap graph (15 samples), max_number_classes 5, 4x5 iterations, teb_autosize on, pose capacity 224",
                                     "ticks": ticks, "first_tick_ms": 1e3 * ts[0], "bands_per_tick": [int(min(nb)), int(max(nb))]}
@@ -457,13 +580,26 @@ def main():
             s4n = planner.make_solver(c4n, o4n, v4n, b4n)
             s4n.snapshot()
             kn, wn, rn = time_solver(torch, s4n, c4n, 3)
+            num_vs_ref = None
+            try:   # the number above is only worth quoting if its results are right: the same comparison with the reference's own code
+                if ref_pack is not None and B == b4n.count:
+                    from oracle import refcode_compare as RC
+                    s4n.set_iteration_log(True)
+                    s4n.restore()
+                    s4n.optimize(inner, outer, True, c4n.hcp.selection_obst_cost_scale, c4n.hcp.selection_viapoint_cost_scale, c4n.hcp.selection_alternative_time_cost)
+                    res_n = s4n.results(); out_n = s4n.download(b4n.copy()); tr_n = [s4n.iteration_log(b) for b in range(B)]
+                    num_vs_ref = RC.compare_with_reference_code(out_n, res_n, tr_n, ref_pack[0], ref_pack[1], ref_pack[2], ref_pack[4])
+                    num_vs_ref["outside"] = num_vs_ref["outside"][:8]; num_vs_ref["pose_count_mismatch"] = num_vs_ref["pose_count_mismatch"][:8]
+                    num_vs_ref["mode"] = "g2o_numeric (the reference's own linearisation scheme)"
+            except Exception as e:   # noqa: BLE001
+                num_vs_ref = {"error": str(e)[:200]}
             s4n.close()
             un = int(rn.lm_iterations.sum())
             sec["c4_g2o_numeric_jacobians"] = {
                 "workload": "the headline workload with jacobian_mode = g2o central differences (delta 1e-9), the reference's own linearisation "
                             "scheme: 1 + 2 x #columns residual evaluations per edge",
                 "kernel_ms": kn, "ms_per_step": wn, "units_per_step": un, "value": un / (wn * 1e-3), "unit": "TEB.LM-iterations/s",
-                "tebs_ok": int((rn.status == 0).sum())}
+                "tebs_ok": int((rn.status == 0).sum()), "vs_reference_code": num_vs_ref}
             for nm, mk, what in (("c3_autosize_on", lambda: scenes.scene_c3(stride=208), "C3: 64 candidate TEBs x 150 poses, 200 point obstacles"),
                                  ("c2_autosize_on", lambda: scenes.scene_c2(stride=232), "C2: 1 TEB x 200 poses, 100 point obstacles"),
                                  ("c5_carlike_polygons", lambda: scenes.scene_c5(stride=343),
@@ -471,13 +607,21 @@ def main():
                 cc, oo, vv, bb = mk()
                 sx = planner.make_solver(cc, oo, vv, bb)
                 sx.snapshot()
-                kx, wx, rx = time_solver(torch, sx, cc, 3 if nm.startswith("c5") else max(3, args.latency_reps // 4))
+                kx, wx, rx = time_solver(torch, sx, cc, max(3, args.latency_reps // 4))
                 nx = sx.pose_counts()
+                hx = sx.last_launch_info()
                 sx.close()
                 ux = int(rx.lm_iterations.sum())
                 sec[nm] = {"workload": what + ", teb_autosize on, 4 outer x 5 inner", "kernel_ms": kx, "ms_per_step": wx, "units_per_step": ux,
                            "value": ux / (wx * 1e-3), "unit": "TEB.LM-iterations/s", "poses_after": [int(nx.min()), int(nx.max())],
-                           "tebs_ok": int((rx.status == 0).sum())}
+                           "tebs_ok": int((rx.status == 0).sum()),
+                           "helpers": {"distance_helpers_per_band": hx[0], "solver_helpers_per_band": hx[1], "repeated_on_one_cu": hx[2]}}
+                if hx[0] or hx[1]:   # small batch: the same launch confined to one CU per band (multi-CU mode off), bit-identical results
+                    s1 = planner.make_solver(cc, oo, vv, bb, options=_abi.Options(multi_cu=-1, speculative_trials=-1))
+                    s1.snapshot()
+                    k1, w1, _ = time_solver(torch, s1, cc, 3)
+                    s1.close()
+                    sec[nm]["one_cu_per_band"] = {"kernel_ms": k1, "ms_per_step": w1}
             out["secondary"] = sec
 
         # ---- CPU baseline: the oracle in the reference-faithful mode (g2o central differences), thread per TEB

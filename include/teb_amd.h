@@ -255,9 +255,10 @@ typedef struct teb_amd_options {
                                   /* repeated on one CU per band); 0 = 50 000 (50 ms)                                            */
   int32_t speculative_trials;     /* small batches: the damped systems of the first retries of an LM iteration (lambda x 2, x 8,  */
                                   /* x 64) are solved on spare CUs while the band solves and evaluates its first trial, so that a  */
-                                  /* rejected trial finds its step ready (bit-identical results): 0 = automatic (<= 16 bands,      */
-                                  /* closed-form Jacobians, blocks-in-LDS or hybrid layout: 3 solver workgroups per band),         */
-                                  /* -1 = never, k = 1 .. 3: that many                                                             */
+                                  /* rejected trial finds its step ready (bit-identical results): 0 = automatic (closed-form       */
+                                  /* Jacobians, blocks-in-LDS or hybrid layout; as many of the three as the batch leaves CUs for:  */
+                                  /* 3 solver workgroups per band up to 64 bands, 1 up to 128, none beyond), -1 = never,           */
+                                  /* k = 1 .. 3: at most that many                                                                 */
   int32_t reserved[6];            /* must be 0                                                                                  */
 } teb_amd_options_t;
 void teb_amd_options_default(teb_amd_options_t* opt);

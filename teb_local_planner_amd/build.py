@@ -72,14 +72,17 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def build(force=False, verbose=False, variant="product", jobs=None, extra_defines=(), out=None):
-    """Compile the variant if its sources are newer than the library. Returns the library path."""
+def build(force=False, verbose=False, variant="product", jobs=None, extra_defines=(), out=None, unit_flags=None):
+    """Compile the variant if its sources are newer than the library. Returns the library path.
+    unit_flags: {object name: [extra compiler flags]} for single translation units (compiler-flag experiments of tools/)."""
     v = VARIANTS[variant]
     lib = os.path.abspath(out or v["lib"])
     if not (force or _stale(lib)):
         return lib
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    tag = variant if not extra_defines else variant + "_" + hashlib.sha256(" ".join(extra_defines).encode()).hexdigest()[:8]
+    unit_flags = unit_flags or {}
+    salt = " ".join(extra_defines) + "".join("|%s:%s" % (k, " ".join(v)) for k, v in sorted(unit_flags.items()))
+    tag = variant if not salt else variant + "_" + hashlib.sha256(salt.encode()).hexdigest()[:8]
     bdir = os.path.join(HERE, "build", tag)
     os.makedirs(bdir, exist_ok=True)
     jobs = jobs or int(os.environ.get("TEB_AMD_BUILD_JOBS", "0")) or min(os.cpu_count() or 1, 8)
@@ -91,7 +94,7 @@ def build(force=False, verbose=False, variant="product", jobs=None, extra_define
         newest = newest_kernel if src == "teb_opt_inst.hip" else newest_all
         if not force and os.path.exists(o) and os.path.getmtime(o) >= newest:
             return o
-        cmd = [hipcc] + HIPCC_FLAGS + v["defines"] + list(extra_defines) + defs + ["-c", os.path.join(CSRC, src), "-o", o]
+        cmd = [hipcc] + HIPCC_FLAGS + v["defines"] + list(extra_defines) + defs + list(unit_flags.get(obj, [])) + ["-c", os.path.join(CSRC, src), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=CSRC)

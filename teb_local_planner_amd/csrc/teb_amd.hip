@@ -310,7 +310,8 @@ void mcu_helpers_for(teb_amd_handle* h, const OptArgs& args, int eff_solver, int
   const int room = cus / h->B - 1;   // helper workgroups per band that still leave every workgroup its own CU
   int K = 0, D = 0;
   if (h->opt.speculative_trials >= 0 && eff_solver != SOLVER_BANDG && !(eff_solver == SOLVER_BAND && h->band_ldlt) && args.inner > 0) {
-    K = h->opt.speculative_trials > 0 ? std::min((int)h->opt.speculative_trials, kMcuMaxSpec) : (h->B <= 16 ? kMcuMaxSpec : 0);
+    // automatic: as many of the three retries as the batch leaves CUs for (<= 64 bands: all three, <= 128: the first - the common - one)
+    K = h->opt.speculative_trials > 0 ? std::min((int)h->opt.speculative_trials, kMcuMaxSpec) : kMcuMaxSpec;
     K = std::max(0, std::min(K, room));
   }
   if (h->opt.multi_cu >= 0 && !h->fast_points && !h->cfg.legacy_obstacle_association && h->M > 0) {

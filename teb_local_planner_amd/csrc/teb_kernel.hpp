@@ -47,6 +47,15 @@ __device__ long long g_lin_prof[16];  // thread 0 of workgroup 0: sections of li
 #define LNP_DECL
 #define LNP(k)
 #endif
+// (experiment, -DTEB_AMD_POINTS_KEEP_GENERIC: the point-like instantiations branch on SceneDev::fast_points at run time and so keep the
+// generic-shape code they never execute - the code round 2's single kernel carried)
+#ifdef TEB_AMD_POINTS_KEEP_GENERIC
+#define TEB_IF_FAST(F) if ((F) && sc.fast_points)
+#define TEB_IF_NOT_FAST(F) if (!((F) && sc.fast_points))
+#else
+#define TEB_IF_FAST(F) if constexpr (F)
+#define TEB_IF_NOT_FAST(F) if constexpr (!(F))
+#endif
 // Storage formats of the normal matrix (selected per handle by the pose capacity S and the obstacle cache):
 //   SOLVER_BAND : Hb[4S][11] lower band in LDS (S <= 343); solved by the hybrid cyclic reduction (cr_solve_hybrid: level 0 from a
 //                 band-form copy in HBM into a compact even-row system in LDS) or, teb_amd_options_t::band_ldlt, by the sequential
@@ -367,7 +376,7 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
   EVP_DECL
   if (i >= 1) {
    if constexpr (PART != 2) {
-    if constexpr (FAST) {
+    TEB_IF_FAST(FAST) {
       if (!c.legacy_obstacle_association) {
         // The association lists live in HBM (pose-major, coalesced over the lanes); a lane walks its list in order and at one wave per
         // SIMD every dependent load is a full round trip (L2 for the entry, LDS for the obstacle, then the sqrt chain: ~ 1.1 k cycles per
@@ -568,7 +577,7 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
         TEB_EDGE(M_SEG, CAT_OTHER, {
           double gr[3] = {0, 0, 0};
           double dobs;
-          if constexpr (FAST) dobs = pointlike_distance<J_>(c, W.x0, W.y0, l.obx[p], l.oby[p], l.obr[p], gr);
+          TEB_IF_FAST(FAST) dobs = pointlike_distance<J_>(c, W.x0, W.y0, l.obx[p], l.oby[p], l.obr[p], gr);
           else dobs = footprint_distance(c, sc, sc.static_idx[p & kAssocMask], W.x0, W.y0, W.c0, W.s0, false, 0.0, J_ ? gr : nullptr);
           edge_velocity_obstacle_ratio<J_>(c, dobs, gr, W, ACC_);
         });
@@ -1863,7 +1872,7 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
     else { if (dist < r.right_min) { r.right_min = dist; r.right = k; } }
   };
   int k0 = k_lo;
-  if constexpr (FAST) {
+  TEB_IF_FAST(FAST) {
     // Far-field culling, exact: an obstacle beyond max(cutoff, force) (+ a relative guard band of 1e-12 against the rounding of the
     // distance) from the pose is neither included nor a left / right candidate. Pass 1 (uniform over the wave): squared distances, one
     // bit per obstacle; pass 2: each lane visits the set bits of its own mask in list order - the decisions of the sequential scan,
@@ -1889,7 +1898,7 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
     }
     k0 = k_hi;
   }
-  if constexpr (!FAST) {
+  TEB_IF_NOT_FAST(FAST) {
     // Generic shapes: the same two passes with bounding circles. The robot lies within frad of the pose, the obstacle within brad of its
     // centroid, so their distance is at least |centroid - pose| - brad - frad; beyond max(cutoff, force) (+ guard band) the obstacle
     // cannot matter and its exact distance (segment / polygon loops, the expensive part: 75 % of BASELINE C5 before) is never computed.

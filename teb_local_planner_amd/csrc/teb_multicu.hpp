@@ -194,14 +194,18 @@ __device__ __forceinline__ void spec_issue(McuMaster& m, const double* bv, int N
     st_agent_u32(m.ctl + MCU_SCMD, m.sepoch);
   }
 }
-// the step of retry k into dxv; returns false when the helper did not deliver in time (the caller solves itself from then on)
+// the step of retry k into dxv; returns false when the helper did not deliver in time (the caller solves itself from then on). The
+// patience here is short - a few solve times, kMcuSpecPatienceTicks: a helper that has not finished by the time its step is wanted is
+// a helper without a CU (a busy device, or a batch that fills the chip exactly), and waiting for it would cost more than solving.
+constexpr long long kMcuSpecPatienceTicks = 20000;   // 200 us of the 100 MHz counter
 __device__ __forceinline__ bool spec_take(McuMaster& m, int k, double* dxv, int* ok_flag, int Nt, int S, int* lds_flag) {
   if (threadIdx.x == 0) {
     int ok = 1;
     const long long t0 = realtime_ticks();
+    const long long patience = m.timeout < kMcuSpecPatienceTicks ? m.timeout : kMcuSpecPatienceTicks;
     while (ld_agent_u32(m.ctl + MCU_SDONE + k) < m.sepoch) {
       __builtin_amdgcn_s_sleep(1);
-      if (realtime_ticks() - t0 > m.timeout) { ok = 0; st_agent_u32(m.ctl + MCU_SABORT, 1u); break; }
+      if (realtime_ticks() - t0 > patience) { ok = 0; st_agent_u32(m.ctl + MCU_SABORT, 1u); break; }
     }
     *lds_flag = ok;
   }

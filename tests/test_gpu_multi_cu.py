@@ -153,7 +153,11 @@ def test_small_batch_of_point_like_bands_with_dynamic_obstacles():
     _assert_identical(many, rm, one, r1)
 
 
-def test_large_batches_stay_on_one_workgroup_per_band():
-    cfg, obst, via, batch = scenes.scene_c3(B=40, n=60, M=40, stride=208)
-    _, _, info, _, _ = _run(cfg, obst, via, batch)
-    assert info == (0, 0, False)
+def test_helper_count_follows_the_room_the_batch_leaves():
+    """256 CUs, one workgroup per CU: B (1 + K + D) <= 256. 64 bands: all three retries; 100 bands: the first one; 200 bands: none."""
+    for B, want in ((64, 3), (100, 1), (200, 0)):
+        cfg, obst, via, batch = scenes.scene_c3(B=B, n=60, M=40, stride=208)
+        one, r1, info1, _, _ = _run(cfg, obst, via, batch, speculative_trials=-1)
+        many, rm, info, _, _ = _run(cfg, obst, via, batch)
+        assert info1 == (0, 0, False) and info == (0, want, False), (B, info)
+        _assert_identical(many, rm, one, r1)

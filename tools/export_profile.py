@@ -75,7 +75,7 @@ def main():
         lines.append("")
         lines.append("# shares of SQ_WAVE_CYCLES (WAIT_ANY = parked at s_waitcnt / s_barrier, WAIT_INST_ANY = issue stalls, ACTIVE_INST_ANY = issuing)")
         lines.append("  ".join("%s %.1f %%" % (k, 100 * v) for k, v in att.items()))
-    # matrix-core counters of the -DTEB_AMD_MFMA_SCHUR build (profiled with TEB_AMD_LIB=tools/libteb_amd_mfma.so)
+    # matrix-core counters of the -DTEB_AMD_MFMA_SCHUR build (profiled with TEB_AMD_LIB=teb_local_planner_amd/libteb_amd_mfma.so)
     db = os.path.join(SRC, "pmc_mfma", "mfma_results.db")
     mt = os.path.join(SRC, "mfma_trace", "mtrace_results.db")
     if os.path.exists(db) and os.path.exists(mt):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): rocprofv3 kernel trace + PMC passes of the bench command (each counter group in its own run, with
 # --kernel-trace only, as gpurun requires). Outputs land in gpurun_out/$PROF_DIR (default prof); tools/export_profile.py <tag> turns them
-# into profiles/rocprof_<tag>_summary.{txt,json}. The last two passes profile the -DTEB_AMD_MFMA_SCHUR build (tools/libteb_amd_mfma.so,
+# into profiles/rocprof_<tag>_summary.{txt,json}. The last two passes profile the -DTEB_AMD_MFMA_SCHUR build (teb_local_planner_amd/libteb_amd_mfma.so,
 # if present) for the matrix-core counters of the Schur update.
 set -u
 ROOT=$(pwd)
@@ -16,10 +16,10 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o write -- $CMD > $
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace -d $OUT/pmc_sq -o sq -- $CMD > $OUT/bench_sq.json 2> $OUT/sq.log
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES --kernel-trace -d $OUT/pmc_sq2 -o sq2 -- $CMD > /dev/null 2> $OUT/sq2.log
 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 --kernel-trace -d $OUT/pmc_f64 -o f64 -- $CMD > $OUT/bench_f64.json 2> $OUT/f64.log
-if [ -f $ROOT/tools/libteb_amd_mfma.so ]; then
-  TEB_AMD_LIB=$ROOT/tools/libteb_amd_mfma.so rocprofv3 --kernel-trace --stats -d $OUT/mfma_trace -o mtrace -- $CMD > $OUT/bench_mfma_trace.json 2> $OUT/mfma_trace.log
-  TEB_AMD_LIB=$ROOT/tools/libteb_amd_mfma.so rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace -d $OUT/pmc_mfma -o mfma -- $CMD > /dev/null 2> $OUT/mfma.log
-  TEB_AMD_LIB=$ROOT/tools/libteb_amd_mfma.so python $ROOT/tools/mfma_probe.py > $OUT/mfma_probe.txt 2>&1
+if [ -f $ROOT/teb_local_planner_amd/libteb_amd_mfma.so ]; then
+  TEB_AMD_LIB=$ROOT/teb_local_planner_amd/libteb_amd_mfma.so rocprofv3 --kernel-trace --stats -d $OUT/mfma_trace -o mtrace -- $CMD > $OUT/bench_mfma_trace.json 2> $OUT/mfma_trace.log
+  TEB_AMD_LIB=$ROOT/teb_local_planner_amd/libteb_amd_mfma.so rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace -d $OUT/pmc_mfma -o mfma -- $CMD > /dev/null 2> $OUT/mfma.log
+  TEB_AMD_LIB=$ROOT/teb_local_planner_amd/libteb_amd_mfma.so python $ROOT/tools/mfma_probe.py > $OUT/mfma_probe.txt 2>&1
 fi
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/cal_fetch -o calf -- python $ROOT/tools/calib_stream.py > /dev/null 2> $OUT/calf.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/cal_write -o calw -- python $ROOT/tools/calib_stream.py > /dev/null 2> $OUT/calw.log
