@@ -146,6 +146,16 @@ extern "C" int backend_check_hcp_ticks(int which, const teb_amd_config_t* acfg, 
   else hcp.reset(new HomotopyClassPlannerAmd(cfg, &obst, TebVisualizationPtr(), n_via > 0 ? &via : NULL, std::max(slots, 1), out->stride,
                                              std::max<int>((int)obst.size(), 1), o && o->vert_offset ? std::max(o->vert_offset[o->count], 1) : 1,
                                              std::max(n_via, 1)));
+  // which = 2: the drop-in class in its SHARDED mode on a communicator of one rank (RCCL refuses two ranks on one device): every RCCL
+  // call of the path - the selection all-gather, the status all-gather and the broadcast of the winner's band - runs, and the ticks have
+  // to come out exactly as with which = 1
+  teb_amd_comm_t* comm = NULL;
+  if (which == 2) {
+    char id[TEB_AMD_COMM_ID_BYTES];
+    if (teb_amd_comm_unique_id(id) != TEB_AMD_OK || teb_amd_comm_create(id, 0, 1, 0, &comm) != TEB_AMD_OK) return 3;
+    static_cast<HomotopyClassPlannerAmd*>(hcp.get())->setCommunicator(comm, 0);
+  }
+  struct CommGuard { teb_amd_comm_t*& c; ~CommGuard() { if (c) teb_amd_comm_destroy(c); } } guard{comm};
   std::vector<geometry_msgs::PoseStamped> plan;
   for (int t = 0; t < n_ticks; ++t) {
     PoseSE2 s(starts[3 * t], starts[3 * t + 1], starts[3 * t + 2]), g(goals[3 * t], goals[3 * t + 1], goals[3 * t + 2]);

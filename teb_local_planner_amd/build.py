@@ -23,6 +23,13 @@ HEADERS = ["teb_device.hpp", "teb_comm.hpp", "teb_feasibility.hpp", "teb_geometr
 # letting the compiler fuse a*b+c would change which side of a penalty kink borderline residuals fall on.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 
+# Per-unit flags of the product. -DTEB_AMD_POINTS_KEEP_GENERIC on the point-like band-layout instantiation (the headline's kernel): it
+# branches on SceneDev::fast_points at run time and so keeps the generic-shape code it never executes. Measured on MI355X, same box,
+# alternating libraries, 11 launches each, +-0.3 %: headline launch 3.71 ms without the flag, 3.62 ms with it, 3.59 ms for round 2's
+# single kernel (which carried that code for every scene). What changes is the register allocation / placement of the hot loops, not
+# the work; no compiler flag tried (scheduler strategies, -O2, -Os) moves it. Kept because the headline is what is measured.
+UNIT_FLAGS = {"opt_0_0_0.o": ["-DTEB_AMD_POINTS_KEEP_GENERIC"]}
+
 VARIANTS = {
     "product": dict(lib=LIB, defines=[], jmodes=(0, 1)),
     "mfma": dict(lib=LIB_MFMA, defines=["-DTEB_AMD_MFMA_SCHUR", "-DTEB_AMD_ANALYTIC_ONLY"], jmodes=(0,)),
@@ -80,7 +87,7 @@ def build(force=False, verbose=False, variant="product", jobs=None, extra_define
     if not (force or _stale(lib)):
         return lib
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    unit_flags = unit_flags or {}
+    unit_flags = dict(UNIT_FLAGS, **(unit_flags or {})) if variant in PRODUCT_VARIANTS else (unit_flags or {})
     salt = " ".join(extra_defines) + "".join("|%s:%s" % (k, " ".join(v)) for k, v in sorted(unit_flags.items()))
     tag = variant if not salt else variant + "_" + hashlib.sha256(salt.encode()).hexdigest()[:8]
     bdir = os.path.join(HERE, "build", tag)

@@ -1742,6 +1742,203 @@ __device__ __noinline__ void autoresize_script_lane0(double dt_ref_, double hyst
   if (!ovf) out_desc[k] = n_in - 1;   // the goal pose
 }
 
+
+// ---- the same rule machine run by the 64 lanes of wave 0 with its arrays in REGISTERS ----------------------------------------------
+// autoresize_script_lane0 spends ~ 590 cycles per rule step, most of it on LDS round trips of a single lane (the next interval, the
+// emitted descriptors) and on exec-mask bookkeeping: values one lane loaded from LDS count as divergent. Here the time differences of
+// the band live in the registers of wave 0 (lane l holds intervals l, 64 + l, ..), element j is fetched with v_readlane (an SGPR
+// result: every decision is a scalar branch), emitted intervals / descriptors / new-pose records / run records are appended into register
+// chunks (a compare + conditional move per element) and written to the LDS scratch by all lanes at the end. Same rules, same order, same results
+// (tests/test_gpu_parity.py: autoResize tests; the bit fingerprints).
+__device__ __forceinline__ double rl_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// element `lane` of a register "array" := val (val and lane uniform): one compare + conditional moves (this compiler has no writelane builtin)
+__device__ __forceinline__ double wl_f64(double old, double val, int lane) { return ((int)(threadIdx.x & 63) == lane) ? val : old; }
+__device__ __forceinline__ int wl_i32(int old, int val, int lane) { return ((int)(threadIdx.x & 63) == lane) ? val : old; }
+constexpr int kArChunks = 8;   // 64 intervals each: pose capacity 512
+template <typename T>
+__device__ __forceinline__ T ar_sel(const T (&v)[kArChunks], int c) {   // c uniform: a scalar jump, no dynamic register indexing
+  switch (c) { case 0: return v[0]; case 1: return v[1]; case 2: return v[2]; case 3: return v[3]; case 4: return v[4]; case 5: return v[5]; case 6: return v[6]; default: return v[7]; }
+}
+template <typename T>
+__device__ __forceinline__ void ar_put(T (&v)[kArChunks], int c, T x) {
+  switch (c) { case 0: v[0] = x; break; case 1: v[1] = x; break; case 2: v[2] = x; break; case 3: v[3] = x; break; case 4: v[4] = x; break; case 5: v[5] = x; break; case 6: v[6] = x; break; default: v[7] = x; break; }
+}
+// append-only register array: element k goes to lane k & 63 of chunk k >> 6; the chunk under construction is `cur`
+template <typename T> struct ArOut { T done[kArChunks]; T cur; int cchunk; };
+__device__ __forceinline__ void ar_push(ArOut<double>& o, int k, double val) {
+  const int c = k >> 6;
+  if (c != o.cchunk) { ar_put(o.done, o.cchunk, o.cur); o.cchunk = c; o.cur = ar_sel(o.done, c); }
+  o.cur = wl_f64(o.cur, val, k & 63);
+}
+__device__ __forceinline__ void ar_push(ArOut<int>& o, int k, int val) {
+  const int c = k >> 6;
+  if (c != o.cchunk) { ar_put(o.done, o.cchunk, o.cur); o.cchunk = c; o.cur = ar_sel(o.done, c); }
+  o.cur = wl_i32(o.cur, val, k & 63);
+}
+template <typename T> __device__ __forceinline__ void ar_init(ArOut<T>& o) {
+#pragma unroll
+  for (int c = 0; c < kArChunks; ++c) o.done[c] = T(0);
+  o.cur = T(0); o.cchunk = 0;
+}
+__device__ __noinline__ void autoresize_script_wave0(double dt_ref_, double hyst_, int max_samples_, int min_samples_, int off_state_,
+                                                       int off_scratch_, int n_in_, int stride_, int off_out_) {
+  extern __shared__ __attribute__((aligned(16))) double lds_base[];
+  const int lane = threadIdx.x & 63;
+  const double dt_ref = uni(dt_ref_), hyst = uni(hyst_);
+  const int max_samples = uni(max_samples_), min_samples = uni(min_samples_), off_state = uni(off_state_), off_scratch = uni(off_scratch_),
+            n_in = uni(n_in_), stride = uni(stride_);
+  int* res = reinterpret_cast<int*>(lds_base) + uni(off_out_);
+  int ovf = 0;
+  const double* in_dt = lds_base + off_state + 3 * stride;   // Lds: sx sy sth sdt ...
+  double* odt = lds_base + off_scratch;
+  int* out_desc = reinterpret_cast<int*>(odt + 4 * stride);
+  int* rec = out_desc + stride;
+  double* stk_dt = odt + 5 * stride;
+  int* stk_desc = reinterpret_cast<int*>(stk_dt + kSplitStack);
+  const unsigned long long* masks = reinterpret_cast<const unsigned long long*>(stk_dt + kSplitStack + kSplitStack / 2);
+  int* runs = reinterpret_cast<int*>(stk_dt + kSplitStack + kSplitStack / 2 + kActiveMasks);
+  const int Tin = n_in - 1;
+  // the band's time differences into registers
+  double vin[kArChunks];
+#pragma unroll
+  for (int c = 0; c < kArChunks; ++c) { const int idx = 64 * c + lane; vin[c] = idx < Tin ? in_dt[idx] : 0.0; }
+  int in_chunk = 0;
+  double in_cur = vin[0];
+  auto fetch = [&](int j) -> double {   // in_dt[j], j uniform
+    const int c = j >> 6;
+    if (c != in_chunk) { in_chunk = c; in_cur = ar_sel(vin, c); }
+    return rl_f64(in_cur, j & 63);
+  };
+  ArOut<double> o_dt; ArOut<int> o_desc, o_rec, o_runs;
+  ar_init(o_dt); ar_init(o_desc); ar_init(o_rec); ar_init(o_runs);
+  int T = Tin;           // sizeTimeDiffs()
+  int j = 1;             // next unread input interval
+  int sp = 0;            // stack size
+  int k = 0;             // emitted intervals
+  int nn = 0, md = 0;    // new poses, deepest split tree
+  int nruns = 0, tail_k = -1;
+  int mchunk = -1; unsigned long long mcur = 0;   // register copy of the marks of the current chunk
+  bool modified = false;
+  int cdesc = 0, cdepth = 0;
+  double cdt = Tin >= 1 ? fetch(0) : 0.0;
+  bool fresh = true;     // cur is the untouched input interval cdesc (nothing was added to it)
+  double pdt = (j < Tin) ? fetch(j) : 0.0;
+  bool ptouched = false; // an excess was pushed onto the prefetched interval
+  bool alive = Tin >= 1;
+  int top_desc = 0, top_depth = 0; double top_dt = 0;   // register copy of the stack top
+  while (alive) {
+    if (fresh && sp == 0) {
+      const int j0 = cdesc;
+      if ((j0 >> 6) != mchunk) {
+        mchunk = j0 >> 6;
+        unsigned long long mv = mchunk < kActiveMasks ? masks[mchunk] : ~0ull;
+        mcur = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mv >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)mv);
+      }
+      int a = j0;
+      if (!((mcur >> (j0 & 63)) & 1ull)) {
+        a = Tin;
+        unsigned long long m = mcur & (~0ull << (j0 & 63));
+        for (int cidx = mchunk; ; ) {
+          if (m) { a = (cidx << 6) + __ffsll((long long)m) - 1; break; }
+          ++cidx;
+          if (cidx >= kActiveMasks || (cidx << 6) >= Tin) break;
+          unsigned long long mv = masks[cidx];
+          m = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mv >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)mv);
+        }
+        if (a > Tin) a = Tin;
+      }
+      const int len = a - j0;
+      if (len >= 2) {
+        if (k + len > stride - 1) { ovf = 1; break; }
+        ar_push(o_runs, nruns, k | (j0 << 10) | (len << 20));
+        ++nruns;
+        k += len;
+        j = a + 1;
+        if (a < Tin) {
+          cdesc = a; cdepth = 0; cdt = fetch(a); fresh = true;
+          pdt = (j < Tin) ? fetch(j) : 0.0; ptouched = false;
+        } else { alive = false; break; }
+      }
+    }
+    const bool has_next = (sp > 0) || (j < Tin);
+    if (cdt > dt_ref + hyst && T < max_samples) {
+      if (cdt > 2 * dt_ref) {
+        const double newtime = 0.5 * cdt;
+        int edesc, edepth;
+        if (sp > 0) { edesc = top_desc; edepth = top_depth; }
+        else { edesc = (j < Tin) ? j : n_in - 1; edepth = 0; }
+        if (sp >= kSplitStack || nn >= stride) { ovf = 1; break; }
+        const int depth = 1 + (cdepth > edepth ? cdepth : edepth);
+        ar_push(o_rec, nn, cdesc | (edesc << 11) | (depth << 22));
+        md = depth > md ? depth : md;
+        if (sp > 0 && lane == 0) { stk_dt[sp - 1] = top_dt; stk_desc[sp - 1] = top_desc | (top_depth << 16); }   // spill the old top
+        top_desc = kNewPose + nn; top_depth = depth; top_dt = newtime;
+        ++nn; ++sp;
+        cdt = newtime; fresh = false;
+        ++T;
+        modified = true;
+        continue;   // i-- : re-check the left half
+      } else {
+        if (has_next) {
+          if (sp > 0) top_dt += cdt - dt_ref;
+          else { pdt += cdt - dt_ref; ptouched = true; }
+        }
+        cdt = dt_ref; fresh = false;
+      }
+    } else if (cdt < dt_ref - hyst && T > min_samples) {
+      if (has_next) {
+        if (sp > 0) {
+          cdt = top_dt + cdt; --sp;
+          if (sp > 0) { top_dt = uni(stk_dt[sp - 1]); const int e = uni(stk_desc[sp - 1]); top_desc = e & 0xffff; top_depth = e >> 16; }
+        } else {
+          cdt = pdt + cdt; ++j;
+          if (j < Tin) pdt = fetch(j);
+          ptouched = false;
+        }
+        fresh = false;
+        --T;
+        modified = true;
+        continue;
+      } else if (k > 0) {
+        tail_k = k - 1;
+        if (lane == 0) odt[stride - 1] = cdt;   // (slot never used by an emitted interval: k <= stride - 1 intervals)
+        --T;
+        modified = true;
+        alive = false;
+        break;
+      }
+    }
+    // emit cur, advance
+    if (k >= stride - 1) { ovf = 1; break; }
+    ar_push(o_desc, k, cdesc); ar_push(o_dt, k, cdt);
+    ++k;
+    if (sp > 0) {
+      cdesc = top_desc; cdepth = top_depth; cdt = top_dt; --sp; fresh = false;
+      if (sp > 0) { top_dt = uni(stk_dt[sp - 1]); const int e = uni(stk_desc[sp - 1]); top_desc = e & 0xffff; top_depth = e >> 16; }
+    } else if (j < Tin) {
+      cdesc = j; cdepth = 0; cdt = pdt; fresh = !ptouched; ++j;
+      if (j < Tin) pdt = fetch(j);
+      ptouched = false;
+    } else alive = false;
+  }
+  // the register chunks to the LDS scratch, all lanes (the slots of the run records are overwritten by their expansion afterwards)
+  ar_put(o_dt.done, o_dt.cchunk, o_dt.cur); ar_put(o_desc.done, o_desc.cchunk, o_desc.cur);
+  ar_put(o_rec.done, o_rec.cchunk, o_rec.cur); ar_put(o_runs.done, o_runs.cchunk, o_runs.cur);
+#pragma unroll
+  for (int c = 0; c < kArChunks; ++c) {
+    const int idx = 64 * c + lane;
+    if (idx < k) { odt[idx] = o_dt.done[c]; out_desc[idx] = o_desc.done[c]; }
+    if (idx < nn) rec[idx] = o_rec.done[c];
+    if (idx < nruns) runs[idx] = o_runs.done[c];
+  }
+  if (lane == 0) {
+    res[0] = k + 1; res[1] = modified ? 1 : 0; res[2] = ovf; res[3] = nn; res[4] = md; res[5] = nruns; res[6] = tail_k;
+    if (!ovf) out_desc[k] = n_in - 1;   // the goal pose
+  }
+}
+
 __device__ inline int autoresize(const teb_amd_config_t& c, const Lds& l, int n, int off_state, int off_scratch, int stride,
                                  bool fast_mode, int* overflow_flag) {
   extern __shared__ __attribute__((aligned(16))) double lds_base[];
@@ -1769,6 +1966,7 @@ __device__ inline int autoresize(const teb_amd_config_t& c, const Lds& l, int n,
     }
     trig = __syncthreads_or(trig);
     if (!trig) break;
+#ifndef TEB_AMD_AUTORESIZE_WAVE0   // one lane, arrays in LDS (the register-resident variant of wave 0 measured slower: DESIGN.md section 3)
     if (tid == 0) {
 #ifdef TEB_PROFILE
       const long long sw_t0 = clock64();
@@ -1780,6 +1978,19 @@ __device__ inline int autoresize(const teb_amd_config_t& c, const Lds& l, int n,
 #endif
       __threadfence_block();
     } else if (tid >= 64) {
+#else
+    if (tid < 64) {
+#ifdef TEB_PROFILE
+      const long long sw_t0 = clock64();
+#endif
+      autoresize_script_wave0(c.dt_ref, c.dt_hysteresis, c.max_samples, c.min_samples, off_state, off_scratch, n, stride,
+                              (int)(reinterpret_cast<int*>(l.ired + 16) - reinterpret_cast<int*>(lds_base)));
+#ifdef TEB_PROFILE
+      if (tid == 0) { l.ired[12] += (int)(clock64() - sw_t0); l.ired[13] += 1; }
+#endif
+      __threadfence_block();
+    } else {
+#endif
       // meanwhile the other waves refresh cos / sin of the poses as they are now (the cache may date from a rejected LM trial);
       // wave 0 is excluded so that lane 0 is not held up by its own wave
       for (int i = tid - 64; i < n; i += kThreads - 64) { double sv, cv; sincos(l.sth[i], &sv, &cv); l.cs[i] = cv; l.sn[i] = sv; }

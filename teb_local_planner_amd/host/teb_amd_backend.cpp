@@ -619,4 +619,32 @@ int TebAmdBatch::selectBestTeb(int last_best, int initial_plan, double* best_cos
   return best;
 }
 
+int TebAmdBatch::selectBestTebDistributed(int last_best_global, int initial_plan_global, double* best_cost, int* owner_rank)
+{
+  int32_t best = -1, owner = -1;
+  double bc = 0;
+  if (!h_ || !comm_) { error_ = "selectBestTebDistributed: no communicator (setCommunicator)"; return -1; }
+  if (!check(teb_amd_select_best_distributed(h_, comm_, global_offset_, last_best_global, initial_plan_global, &best, &bc, &owner),
+             "teb_amd_select_best_distributed")) return -1;
+  if (best_cost) *best_cost = bc;
+  if (owner_rank) *owner_rank = owner;
+  return best;
+}
+
+bool TebAmdBatch::broadcastBand(int owner_rank, int local_index, TimedElasticBand& teb)
+{
+  if (!h_ || !comm_) { error_ = "broadcastBand: no communicator (setCommunicator)"; return false; }
+  const int S = max_poses_;
+  int32_t n = 0;
+  std::vector<double> x(S), y(S), th(S), dt(S);
+  if (!check(teb_amd_broadcast_band(h_, comm_, owner_rank, local_index, S, &n, x.data(), y.data(), th.data(), dt.data()), "teb_amd_broadcast_band"))
+    return false;
+  teb.clearTimedElasticBand();
+  if (n < 1) return true;
+  teb.addPose(x[0], y[0], th[0], true);
+  for (int i = 1; i < n; ++i) appendPoseAndTimeDiff(teb, x[i], y[i], th[i], dt[i - 1]);
+  teb.setPoseVertexFixed(n - 1, true);
+  return true;
+}
+
 } // namespace teb_local_planner

@@ -102,6 +102,24 @@ public:
    */
   int selectBestTeb(int last_best, int initial_plan, double* best_cost = NULL);
 
+  /**
+   * A candidate batch SHARDED over several GPUs (one process per GPU): the ranks that share it exchange nothing but the
+   * selection. comm = the communicator of those ranks (teb_amd_comm_create; it stays the caller's), global_offset = the global
+   * index of this rank's first candidate. NULL = this rank alone.
+   */
+  void setCommunicator(teb_amd_comm_t* comm, int global_offset) { comm_ = comm; global_offset_ = global_offset; }
+  bool sharded() const { return comm_ != NULL; }
+  int globalOffset() const { return global_offset_; }
+  /**
+   * selectBestTeb over the candidates of ALL ranks (collective; one 16-byte record per rank through RCCL): indices are GLOBAL
+   * (offset of the owning rank + local index, -1 = none). Returns the global index of the winner (-1: no rank holds a candidate), its
+   * owner in *owner_rank. Same arithmetic as selectBestTeb: the rank that owns last_best / initial_plan applies the multipliers.
+   */
+  int selectBestTebDistributed(int last_best_global, int initial_plan_global, double* best_cost = NULL, int* owner_rank = NULL);
+  /** The winner's band from its owner to every rank (collective): `teb` is rebuilt from it on every rank. */
+  bool broadcastBand(int owner_rank, int local_index, TimedElasticBand& teb);
+
+  int maxTebs() const { return max_tebs_; }
   int maxPoses() const { return max_poses_; }
   int maxObstacles() const { return max_obstacles_; }
   int maxObstacleVertices() const { return max_obstacle_vertices_; }
@@ -165,6 +183,8 @@ private:
   bool uploadBands(const std::vector<TebOptimalPlannerAmd*>& tebs);
   bool downloadBands(const std::vector<TebOptimalPlannerAmd*>& tebs);
   teb_amd_handle_t* h_ = NULL;
+  teb_amd_comm_t* comm_ = NULL;
+  int global_offset_ = 0;
   int max_tebs_, max_poses_, max_obstacles_ = 0, max_obstacle_vertices_ = 0, max_via_points_ = 0;
   std::string error_;
 };

@@ -27,6 +27,14 @@ HomotopyClassPlannerAmd::HomotopyClassPlannerAmd(const TebConfig& cfg, ObstConta
 {
 }
 
+void HomotopyClassPlannerAmd::setCommunicator(teb_amd_comm_t* comm, int rank)
+{
+  rank_ = rank;
+  batch_->setCommunicator(comm, rank * batch_->maxTebs());
+  best_global_ = -1; best_owner_ = -1;
+  remote_best_.reset();
+}
+
 bool HomotopyClassPlannerAmd::plan(const PoseSE2& start, const PoseSE2& goal, const geometry_msgs::Twist* start_vel, bool free_goal_vel)
 {
   ROS_ASSERT_MSG(initialized_, "Call initialize() first.");
@@ -82,20 +90,47 @@ bool HomotopyClassPlannerAmd::plan(const PoseSE2& start, const PoseSE2& goal, co
   }
   // update via-points if activated: done on the device-side flags and mirrored onto the candidates by the call above (:286-315)
 
-  if (tebs_.empty())
+  if (tebs_.empty() && !batch_->sharded())
   {
     best_teb_.reset();
     initial_plan_ = nullptr;
     return true;
   }
   // ---- optimizeAllTEBs (:466-493): one launch ------------------------------------------------------------------------------------------
+  if (!tebs_.empty())
   {
     std::vector<TebOptimalPlannerAmd*> raw;
     for (const TebOptimalPlannerAmdPtr& p : cand) raw.push_back(p.get());
     batch_->optimizeAllTEBs(raw, cfg_->optim.no_inner_iterations, cfg_->optim.no_outer_iterations, true, cfg_->hcp.selection_obst_cost_scale,
                             cfg_->hcp.selection_viapoint_cost_scale, cfg_->hcp.selection_alternative_time_cost);
   }
-  // ---- selectBestTeb (:564-667) -----------------------------------------------------------------------------------------------------------
+  // ---- selectBestTeb (:564-667) over the candidates of every rank that shares the batch ----------------------------------------------------
+  if (batch_->sharded())
+  {
+    const int off = batch_->globalOffset();
+    int initial_global = initial_index >= 0 ? off + initial_index : -1;
+    int last_global = -1;   // the last winner survives as a candidate of its owner (moved to the front by the exploration, :766-838)
+    if (best_owner_ == rank_ && best_teb_)
+      for (std::size_t i = 0; i < tebs_.size(); ++i) if (tebs_[i] == best_teb_) last_global = off + (int)i;
+    int owner = -1;
+    const int sel = batch_->selectBestTebDistributed(last_global, initial_global, NULL, &owner);
+    TebOptimalPlannerPtr previous = best_teb_;
+    if (sel < 0) { best_teb_.reset(); best_global_ = -1; best_owner_ = -1; initial_plan_ = nullptr; return true; }
+    if (owner == rank_)
+      best_teb_ = tebs_[sel - off];
+    else
+    {
+      if (!remote_best_) remote_best_.reset(new TebOptimalPlannerAmd(*cfg_, obstacles_, visualization_, via_points_));
+      best_teb_ = remote_best_;
+    }
+    // the winner's band on every rank (a collective: the owner takes part as well); non-owners mirror it
+    TimedElasticBand scratch;
+    if (!batch_->broadcastBand(owner, owner == rank_ ? sel - off : 0, owner == rank_ ? scratch : remote_best_->teb())) return false;
+    (void)previous;   // the switching_blocking_period rule needs one clock for all ranks: it stays with the caller in the sharded mode
+    best_global_ = sel; best_owner_ = owner;
+    initial_plan_ = nullptr;
+    return true;
+  }
   {
     int last_best = -1;
     for (std::size_t i = 0; i < tebs_.size(); ++i) if (tebs_[i] == best_teb_) last_best = (int)i;

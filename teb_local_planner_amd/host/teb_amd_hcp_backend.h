@@ -33,8 +33,23 @@ public:
 
   const std::string& lastError() const { return batch_->lastError(); }
 
+  /**
+   * Candidate classes SHARDED over several GPUs (one process per GPU; the batch of HomotopyClassPlanner is the data-parallel axis,
+   * src/homotopy_class_planner.cpp:466-493): every rank explores, keeps and optimises its own candidates; selectBestTeb (:564-667)
+   * runs over all of them - one 16-byte record per rank through the communicator - and the winner's band reaches every rank, so that
+   * bestTeb() / getVelocityCommand work on every rank (on the ranks that do not own it best_teb_ is a mirror object that is not part
+   * of tebs_). Global candidate index = rank * max_tebs + local index. comm stays the caller's (teb_amd_comm_create); NULL switches
+   * the sharding off. plan() becomes a collective: every rank of the communicator has to call it each tick.
+   */
+  void setCommunicator(teb_amd_comm_t* comm, int rank);
+  int bestTebGlobalIndex() const { return best_global_; }   //!< of the last plan(), -1 = none / not sharded
+  int bestTebOwnerRank() const { return best_owner_; }
+
 private:
   boost::shared_ptr<TebAmdBatch> batch_;
+  int rank_ = 0;
+  int best_global_ = -1, best_owner_ = -1;
+  TebOptimalPlannerAmdPtr remote_best_;   //!< mirror of a winner another rank owns
 };
 
 } // namespace teb_local_planner

@@ -4,7 +4,9 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from teb_local_planner_amd import planner, scenes
-CASES = {"c4on": lambda: scenes.scene_c4(stride=288), "c2": lambda: scenes.scene_c2(stride=208), "c3": lambda: scenes.scene_c3(stride=208),
+def _c4fix():
+    a = scenes.scene_c4(stride=208); a[0].trajectory.teb_autosize = False; return a
+CASES = {"c4on": lambda: scenes.scene_c4(stride=288), "c4fix": _c4fix, "c2": lambda: scenes.scene_c2(stride=208), "c3": lambda: scenes.scene_c3(stride=208),
          "c5": lambda: scenes.scene_c5(stride=320)}
 reps = int(os.environ.get("REPS", "15"))
 out = []
