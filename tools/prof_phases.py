@@ -1,27 +1,15 @@
-"""Phase breakdown of teb_optimize_kernel (workgroup 0) using a -DTEB_PROFILE build of the library."""
+"""Phase breakdown of teb_optimize_kernel (workgroup 0) with a -DTEB_PROFILE build of the library:
+   tools/build_prof.sh && TEB_AMD_LIB=$PWD/tools/libteb_amd_prof.so python tools/prof_phases.py [c4on c4 c3 c2 c5] [--one-cu]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from teb_local_planner_amd import planner, scenes, _abi
-so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libteb_amd_prof.so")
-planner._HERE = os.path.dirname(so)
-import shutil
-# load the profiling build instead of the product library
-L = C.CDLL(so)
-planner._LIB = None
-orig = planner.os.path.join
-def lib_prof():
-    if planner._LIB is None:
-        real = planner._HERE
-        planner._HERE = os.path.dirname(so)
-        os.symlink(so, os.path.join(os.path.dirname(so), "libteb_amd.so")) if not os.path.exists(os.path.join(os.path.dirname(so), "libteb_amd.so")) else None
-    return None
-if not os.path.exists(os.path.join(os.path.dirname(so), "libteb_amd.so")):
-    os.symlink(so, os.path.join(os.path.dirname(so), "libteb_amd.so"))
 Lb = planner.lib()
 Lb.teb_amd_debug_profile.argtypes = [C.c_void_p, _abi.p_f64]
+ONE_CU = "--one-cu" in sys.argv
+OPT = _abi.Options(multi_cu=-1, speculative_trials=-1) if ONE_CU else None
 names = ["autoresize", "assoc+via+tdyn", "linearize", "H backup", "solve", "update+evaluate", "accept/restore"]
-for which in sys.argv[1:] or ["c4", "c2", "c5"]:
+for which in [a for a in sys.argv[1:] if not a.startswith("--")] or ["c4", "c2", "c5"]:
     if which == "c4":
         cfg, obst, via, batch = scenes.scene_c4(); cfg.trajectory.teb_autosize = False
     elif which == "c4on":
@@ -32,7 +20,7 @@ for which in sys.argv[1:] or ["c4", "c2", "c5"]:
         cfg, obst, via, batch = scenes.scene_c2(stride=208)
     else:
         cfg, obst, via, batch = scenes.scene_c5(stride=320)
-    s = planner.make_solver(cfg, obst, via, batch)
+    s = planner.make_solver(cfg, obst, via, batch, options=OPT)
     for rep in range(2):
         s.upload(batch)
         s.optimize(5, 4, True, 100.0, 1.0, False)
@@ -40,7 +28,7 @@ for which in sys.argv[1:] or ["c4", "c2", "c5"]:
     cyc = np.zeros(8)
     rc = Lb.teb_amd_debug_profile(s._h, _abi._ptr(cyc, C.c_double))
     ms = s.last_kernel_ms()
-    print("== %s kernel %.3f ms, TEB0: iters %d trials %d" % (which, ms, res.lm_iterations[0], res.lm_trials[0]))
+    print("== %s kernel %.3f ms, TEB0: iters %d trials %d, helpers (distance, solver, repeated) %s" % (which, ms, res.lm_iterations[0], res.lm_trials[0], s.last_launch_info()))
     tot = cyc[:7].sum()
     for k, nm in enumerate(names):
         print("   %-18s %12.0f cycles  %5.1f %%   (%.1f us @100MHz-clock64?)" % (nm, cyc[k], 100 * cyc[k] / tot, cyc[k] / 100.0))
