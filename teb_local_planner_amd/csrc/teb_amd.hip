@@ -578,6 +578,7 @@ int teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max
   // per-band HBM buffer: the copy of H for rejected trials (SOLVER_CR, banded LDL^T) or the blocks the cyclic reduction of a
   // SOLVER_BAND handle works on (D, L, f: nb * (2 * kBlk + 8) doubles)
   h->hmat_stride = std::max(hbm_scratch_doubles(max_poses, SOLVER_BAND), hbm_scratch_doubles(max_poses, solver));   // every layout may be launched
+  h->hmat_stride = (h->hmat_stride + 1) & ~(size_t)1;   // every band's slice 16-byte aligned (the multi-CU mode writes it with 16-byte stores)
   h->band_ldlt = opt.band_ldlt != 0;
   if (solver == SOLVER_BANDG) h->band_ldlt = 0;   // the sequential LDL^T works in place on an LDS band only
   if (stream) { h->stream = reinterpret_cast<hipStream_t>(stream); h->own_stream = false; }

@@ -1372,7 +1372,7 @@ __device__ __forceinline__ void cr_copy_band(const Lds& l, int n, double* __rest
   const int tid = threadIdx.x;
   const int Nt = 4 * n, Nb = (Nt + 7) >> 3;
   const double* Hb = l.Hb;
-  if (shared) {
+  if (shared) {   // (8-byte write-through stores; 16-byte ones through inline asm measured 7 - 10 % slower end to end on C2 / C3 / C5)
     for (int q = tid; q < Nb * 8 * kBand; q += kThreads) {
       const int r = q / kBand;
       st_agent_f64(gband + q, r < Nt ? Hb[q] : ((q - r * kBand) == 0 ? 1.0 : 0.0));
@@ -2156,8 +2156,10 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
 // Poses [p_begin, p_end) of a band of n poses. SHARED: the lists are read by other workgroups (multi-CU mode: a helper scans its pose
 // tile, always sliced) and are written with agent-scope stores.
 template <bool FAST, bool SHARED>
+// stage / stage_ints: LDS scratch a helper lends its lanes for the forced inclusions of their slices (kThreads x chunk ints; a pose in a
+// cluster of obstacles has more of them than the registers of kSliceForced hold, and the sequential fallback is the slow path).
 __device__ inline void associate_range(const teb_amd_config_t& c, const SceneDev& sc, const Lds& l, int n, int p_begin, int p_end, int* assoc_cnt,
-                                       int* assoc, int cap, int stride, int* overflow) {
+                                       int* assoc, int cap, int stride, int* overflow, int* stage = nullptr, int stage_ints = 0) {
   const int first_vertex = c.weight_velocity_obstacle_ratio == 0 ? 1 : 0;
   const double kMax = 1.7976931348623157e308;
   const int tid = threadIdx.x;
@@ -2186,14 +2188,20 @@ __device__ inline void associate_range(const teb_amd_config_t& c, const SceneDev
       int forced[kSliceForced];
 #pragma unroll
       for (int q = 0; q < kSliceForced; ++q) forced[q] = 0;
+      const bool staged = SHARED && stage != nullptr && kThreads * chunk <= stage_ints;   // (a slice holds at most `chunk` entries)
+      int* mine = stage + tid * chunk;
       if (scans) {
-        assoc_scan<FAST>(c, sc, l, i, k_lo, k_hi, r, [&](int k) {
+        if (staged) {
+          assoc_scan<FAST>(c, sc, l, i, k_lo, k_hi, r, [&](int k) { mine[r.cnt] = k; });
+        } else {
+          assoc_scan<FAST>(c, sc, l, i, k_lo, k_hi, r, [&](int k) {
 #pragma unroll
-          for (int q = 0; q < kSliceForced; ++q) if (r.cnt == q) forced[q] = k;   // register file: no dynamic indexing
-        });
+            for (int q = 0; q < kSliceForced; ++q) if (r.cnt == q) forced[q] = k;   // register file: no dynamic indexing
+          });
+        }
       }
       // over the G slices of the pose (adjacent lanes): offset of this slice's forced entries, total, first minima, "registers overflowed"
-      int before = 0, total = r.cnt, spilled = r.cnt > kSliceForced;
+      int before = 0, total = r.cnt, spilled = !staged && r.cnt > kSliceForced;
       for (int off = 1; off < G; off <<= 1) {
         const int up = __shfl_up(total, off, 64);
         if (sl >= off) total += up;   // inclusive scan over sl
@@ -2213,8 +2221,12 @@ __device__ inline void associate_range(const teb_amd_config_t& c, const SceneDev
         if (spilled || full > cap) {
           if (sl == 0) sequential();
         } else {
+          if (staged) {
+            for (int q = 0; q < r.cnt; ++q) st_list<SHARED>(&assoc[(size_t)(before + q) * stride + i], mine[q]);
+          } else {
 #pragma unroll
-          for (int q = 0; q < kSliceForced; ++q) if (q < r.cnt) st_list<SHARED>(&assoc[(size_t)(before + q) * stride + i], forced[q]);
+            for (int q = 0; q < kSliceForced; ++q) if (q < r.cnt) st_list<SHARED>(&assoc[(size_t)(before + q) * stride + i], forced[q]);
+          }
           if (sl == 0) {
             int cnt = total;
             if (r.left >= 0) { st_list<SHARED>(&assoc[(size_t)cnt * stride + i], r.left); ++cnt; }
@@ -2285,7 +2297,9 @@ __device__ inline void mcu_helper(const teb_amd_config_t& c, const SceneDev& sc,
     mcu_trace(mc.trace, epoch, 0x30);
     if (kind == MCU_KIND_ASSOC) {
       int ovf = 0;
-      if (p_lo < p_hi) associate_range<false, true>(c, sc, l, n, p_lo, p_hi, assoc_cnt, assoc, bt.assoc_cap, S, &ovf);
+      if (p_lo < p_hi)
+        associate_range<false, true>(c, sc, l, n, p_lo, p_hi, assoc_cnt, assoc, bt.assoc_cap, S, &ovf, reinterpret_cast<int*>(lds_base + plan.off_H),
+                                     2 * (int)hmat_doubles(plan.S, plan.solver));
       if (ovf) or_agent_i32(bt.assoc_overflow + b, 1);
     } else {   // MCU_KIND_DIST: one (pose, record) pair per lane
       const bool dyn_on = c.include_dynamic_obstacles && c.weight_obstacle != 0;
