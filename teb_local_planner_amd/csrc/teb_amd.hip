@@ -122,7 +122,7 @@ __global__ void select_best_kernel(const double* cost, int count, int last_best,
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { *out_cost = sv[0]; *out_idx = si[0]; }
+  if (threadIdx.x == 0) { out_cost[0] = sv[0]; out_cost[1] = (double)si[0]; *out_idx = si[0]; }   // (cost, index) also as one 16-byte record
 }
 
 // debug: known-byte-count stream with the kernel's own global access pattern (8 B per lane, coalesced) used to
@@ -175,6 +175,8 @@ struct teb_amd_handle {
   DevBuf<int> ob_n;
   // multi-CU mode (teb_multicu.hpp): control words, published poses, distance records; sized on first use
   DevBuf<unsigned> mcu_ctl;
+  DevBuf<double> pack_dev;          // packed messages of small batches (kPackMaxDoubles)
+  double* pack_host = nullptr;      // its pinned host side
   DevBuf<double> mcu_pub, mcu_items, mcu_spec;
   size_t mcu_items_have = 0;
   int mcu_last_helpers = 0;   // distance helpers per band of the last launch (0: none), teb_amd_last_launch_info
@@ -342,6 +344,41 @@ __global__ void __launch_bounds__(256) copy_state_kernel(double* __restrict__ x,
     if (i < (size_t)B) n[i] = sn[i];
   }
 }
+// Small batches (a planner tick, one TebOptimalPlanner): a dozen tiny copies cost more in host calls than in bytes. The bands and their
+// attributes travel as ONE packed message through a pinned host buffer and ONE copy; these kernels scatter / gather it on the device.
+// Message (doubles; the integer attributes are exact as doubles): [n | has_vs | has_vg | rotdir | via_en] B each, [vs | vg] 3 B each,
+// then x | y | theta | dt, B rows of w columns each.
+constexpr size_t kPackMaxDoubles = 65536;   // 512 KB: beyond that the strided copies win
+__global__ void __launch_bounds__(256) unpack_bands_kernel(const double* __restrict__ msg, int B, int w, int S, int* n, int* hvs, int* hvg, int* rd, int* ve,
+                                                           double* vs, double* vg, double* x, double* y, double* th, double* dt, int* optimized) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < B) { n[t] = (int)msg[t]; hvs[t] = (int)msg[B + t]; hvg[t] = (int)msg[2 * B + t]; rd[t] = (int)msg[3 * B + t]; ve[t] = (int)msg[4 * B + t]; optimized[t] = 0; }
+  if (t < 3 * B) { vs[t] = msg[5 * B + t]; vg[t] = msg[8 * B + t]; }
+  const double* body = msg + 11 * (size_t)B;
+  const size_t plane = (size_t)B * w;
+  for (size_t q = t; q < plane; q += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = q / w, i = q - b * w, o = b * S + i;
+    x[o] = body[q]; y[o] = body[plane + q]; th[o] = body[2 * plane + q]; dt[o] = body[3 * plane + q];
+  }
+}
+__global__ void __launch_bounds__(256) pack_bands_kernel(double* __restrict__ msg, int B, int w, int S, const int* n, const double* x, const double* y,
+                                                         const double* th, const double* dt) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < B) msg[t] = (double)n[t];
+  double* body = msg + B;
+  const size_t plane = (size_t)B * w;
+  for (size_t q = t; q < plane; q += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = q / w, i = q - b * w, o = b * S + i;
+    body[q] = x[o]; body[plane + q] = y[o]; body[2 * plane + q] = th[o]; body[3 * plane + q] = dt[o];
+  }
+}
+// [status | lm_iterations | lm_trials | chi2 | cost | lambda] B each
+__global__ void __launch_bounds__(256) pack_results_kernel(double* __restrict__ msg, int B, const int* status, const int* iters, const int* trials, const double* chi2,
+                                                           const double* cost, const double* lambda) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < B) { msg[t] = (double)status[t]; msg[B + t] = (double)iters[t]; msg[2 * B + t] = (double)trials[t]; msg[3 * B + t] = chi2[t]; msg[4 * B + t] = cost[t]; msg[5 * B + t] = lambda[t]; }
+}
+
 struct Strips { double *x, *y, *th, *dt; int* n; };
 static int copy_strips(teb_amd_handle_t* h, const Strips& dst, const Strips& src, int bands) {
   const size_t count = (size_t)bands * h->stride;   // >= bands
@@ -607,7 +644,9 @@ int teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max
   A(h->Hband.alloc((size_t)max_tebs * h->hband_stride));
   A(h->snap_n.alloc(max_tebs)); A(h->snap_x.alloc(BS)); A(h->snap_y.alloc(BS)); A(h->snap_th.alloc(BS)); A(h->snap_dt.alloc(BS));
   A(h->dbg_H.alloc((size_t)4 * max_poses * kBand)); A(h->dbg_b.alloc((size_t)4 * max_poses)); A(h->dbg_chi2.alloc(4));
-  A(h->sel_cost.alloc(1)); A(h->sel_idx.alloc(1)); A(h->err_flag.alloc(1));
+  A(h->sel_cost.alloc(2)); A(h->sel_idx.alloc(1)); A(h->err_flag.alloc(1));
+  A(h->pack_dev.alloc(kPackMaxDoubles));
+  if (ok && hipHostMalloc(reinterpret_cast<void**>(&h->pack_host), kPackMaxDoubles * sizeof(double), hipHostMallocDefault) != hipSuccess) h->pack_host = nullptr;   // (optional: without it the strided copies are used)
   A(h->stage_x.alloc((size_t)max_poses + 2)); A(h->stage_y.alloc((size_t)max_poses + 2)); A(h->stage_yaw.alloc((size_t)max_poses + 2));
   A(h->out_cmd.alloc(4 * (size_t)max_tebs)); A(h->out_prof.alloc((size_t)max_tebs * (max_poses + 1) * 3)); A(h->out_traj.alloc(BS * 7));
   A(h->hsig.alloc((size_t)max_tebs * (Mo > 2 ? Mo : 2))); A(h->hs_pre.alloc(Mo)); A(h->hs_pim.alloc(Mo)); A(h->hs_pex.alloc(Mo));
@@ -651,6 +690,8 @@ void teb_amd_destroy(teb_amd_handle_t* h) {
   h->iter_log.free();
   h->mcu_ctl.free(); h->mcu_pub.free(); h->mcu_items.free(); h->mcu_spec.free();
   if (h->mcu_trace) (void)hipHostFree(h->mcu_trace);
+  if (h->pack_host) (void)hipHostFree(h->pack_host);
+  h->pack_dev.free();
   h->g_adj.free();
   h->cm_cells.free(); h->cm_fp.free(); h->cm_out.free();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -805,6 +846,40 @@ int teb_amd_upload_tebs(teb_amd_handle_t* h, const teb_amd_teb_batch_t* bt) {
     nmax = bt->n[b] > nmax ? bt->n[b] : nmax;
   }
   if (nmax > h->stride) return fail(TEB_AMD_ERR_CAPACITY, "a TEB has more poses than max_poses");
+  const int wc_pack = bt->stride < h->stride ? bt->stride : h->stride;   // whole rows, like the strided copies: the padding stays the caller's
+  if (h->pack_host && 11 * (size_t)B + 4 * (size_t)B * wc_pack <= kPackMaxDoubles) {   // small batch: one packed message, one copy, one kernel
+    double* m = h->pack_host;
+    const int wc = wc_pack;
+    for (int b = 0; b < B; ++b) {
+      m[b] = bt->n[b];
+      m[B + b] = bt->has_vel_start ? (bt->has_vel_start[b] != 0) : 1;
+      m[2 * B + b] = bt->has_vel_goal ? (bt->has_vel_goal[b] != 0) : 1;
+      m[3 * B + b] = bt->prefer_rotdir ? bt->prefer_rotdir[b] : TEB_AMD_ROT_NONE;
+      m[4 * B + b] = bt->via_points_enabled ? (bt->via_points_enabled[b] != 0) : 1;
+      for (int q = 0; q < 3; ++q) {
+        m[5 * B + 3 * b + q] = bt->vel_start ? bt->vel_start[3 * b + q] : 0.0;
+        m[8 * B + 3 * b + q] = bt->vel_goal ? bt->vel_goal[3 * b + q] : 0.0;
+      }
+    }
+    double* body = m + 11 * (size_t)B;
+    const size_t plane = (size_t)B * wc;
+    for (int b = 0; b < B; ++b) {
+      const size_t so = (size_t)b * bt->stride, q = (size_t)b * wc;
+      std::memcpy(body + q, bt->x + so, wc * sizeof(double)); std::memcpy(body + plane + q, bt->y + so, wc * sizeof(double));
+      std::memcpy(body + 2 * plane + q, bt->theta + so, wc * sizeof(double)); std::memcpy(body + 3 * plane + q, bt->dt + so, wc * sizeof(double));
+    }
+    const size_t count = 11 * (size_t)B + 4 * plane;
+    HIPCHK(hipMemcpyAsync(h->pack_dev.p, m, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const int grid = (int)std::min<size_t>(256, (std::max<size_t>(plane, 3 * (size_t)B) + 255) / 256);
+    hipLaunchKernelGGL(unpack_bands_kernel, dim3(grid), dim3(256), 0, h->stream, h->pack_dev.p, B, wc, h->stride, h->n.p, h->has_vs.p, h->has_vg.p, h->rotdir.p,
+                       h->via_en.p, h->vs.p, h->vg.p, h->x.p, h->y.p, h->th.p, h->dt.p, h->optimized.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));   // (the pinned buffer is reused by the next call)
+    h->B = B;
+    h->consumers_valid = false; h->nmax_known = nmax;
+    h->hsig_mode = 0;
+    return TEB_AMD_OK;
+  }
   const size_t w = (size_t)(bt->stride < h->stride ? bt->stride : h->stride) * sizeof(double);
   const size_t sp = (size_t)bt->stride * sizeof(double), dp = (size_t)h->stride * sizeof(double);
   HIPCHK(hipMemcpy2DAsync(h->x.p, dp, bt->x, sp, w, B, hipMemcpyHostToDevice, h->stream));
@@ -844,6 +919,27 @@ int teb_amd_download_tebs(teb_amd_handle_t* h, teb_amd_teb_batch_t* bt) {
   if (!bt || !bt->n || !bt->x || !bt->y || !bt->theta || !bt->dt) return fail(TEB_AMD_ERR_INVALID_ARG, "bad TEB batch");
   if (bt->count < h->B) return fail(TEB_AMD_ERR_INVALID_ARG, "batch too small for the resident TEBs");
   const int B = h->B;
+  {
+    const int wc = bt->stride < h->stride ? bt->stride : h->stride;
+    const size_t plane = (size_t)B * wc, count = (size_t)B + 4 * plane;
+    if (h->pack_host && count <= kPackMaxDoubles) {   // small batch: one gather kernel, one copy
+      const int grid = (int)std::min<size_t>(256, (plane + 255) / 256);
+      hipLaunchKernelGGL(pack_bands_kernel, dim3(grid), dim3(256), 0, h->stream, h->pack_dev.p, B, wc, h->stride, h->n.p, h->x.p, h->y.p, h->th.p, h->dt.p);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(h->pack_host, h->pack_dev.p, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      const double* m = h->pack_host;
+      for (int b = 0; b < B; ++b) if ((int)m[b] > bt->stride) return fail(TEB_AMD_ERR_CAPACITY, "host batch stride too small for the resized TEB");
+      const double* body = m + B;
+      for (int b = 0; b < B; ++b) {
+        const size_t so = (size_t)b * bt->stride, q = (size_t)b * wc;
+        std::memcpy(bt->x + so, body + q, wc * sizeof(double)); std::memcpy(bt->y + so, body + plane + q, wc * sizeof(double));
+        std::memcpy(bt->theta + so, body + 2 * plane + q, wc * sizeof(double)); std::memcpy(bt->dt + so, body + 3 * plane + q, wc * sizeof(double));
+        bt->n[b] = (int)m[b];
+      }
+      return TEB_AMD_OK;
+    }
+  }
   std::vector<int> n(B);
   HIPCHK(hipMemcpyAsync(n.data(), h->n.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -919,6 +1015,23 @@ int teb_amd_get_results(teb_amd_handle_t* h, teb_amd_results_t* out) {
   if (rc) return rc;
   if (!out) return fail(TEB_AMD_ERR_INVALID_ARG, "null results");
   const int B = h->B;
+  if (h->pack_host && 6 * (size_t)B <= kPackMaxDoubles) {   // six result columns in one gather + one copy
+    hipLaunchKernelGGL(pack_results_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->pack_dev.p, B, h->status.p, h->iters.p, h->trials.p, h->chi2.p, h->cost.p,
+                       h->lambda.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h->pack_host, h->pack_dev.p, 6 * (size_t)B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const double* m = h->pack_host;
+    for (int b = 0; b < B; ++b) {
+      if (out->status) out->status[b] = (int32_t)m[b];
+      if (out->lm_iterations) out->lm_iterations[b] = (int32_t)m[B + b];
+      if (out->lm_trials) out->lm_trials[b] = (int32_t)m[2 * B + b];
+      if (out->chi2) out->chi2[b] = m[3 * B + b];
+      if (out->cost) out->cost[b] = m[4 * B + b];
+      if (out->lambda) out->lambda[b] = m[5 * B + b];
+    }
+    return TEB_AMD_OK;
+  }
   if (out->status) HIPCHK(hipMemcpyAsync(out->status, h->status.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   if (out->lm_iterations) HIPCHK(hipMemcpyAsync(out->lm_iterations, h->iters.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   if (out->lm_trials) HIPCHK(hipMemcpyAsync(out->lm_trials, h->trials.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -939,12 +1052,11 @@ int teb_amd_select_best(teb_amd_handle_t* h, int32_t last_best, int32_t initial_
   hipLaunchKernelGGL(select_best_kernel, dim3(1), dim3(kThreads), 0, h->stream, h->cost.p, h->B, last_best, initial_plan,
                      h->cfg.selection_cost_hysteresis, h->cfg.selection_prefer_initial_plan, h->sel_cost.p, h->sel_idx.p);
   HIPCHK(hipGetLastError());
-  double c; int i;
-  HIPCHK(hipMemcpyAsync(&c, h->sel_cost.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(&i, h->sel_idx.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  double rec[2];   // one 16-byte copy
+  HIPCHK(hipMemcpyAsync(rec, h->sel_cost.p, sizeof(rec), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  *best = i;
-  if (best_cost) *best_cost = c;
+  *best = (int32_t)rec[1];
+  if (best_cost) *best_cost = rec[0];
   return TEB_AMD_OK;
 }
 
