@@ -252,7 +252,8 @@ typedef struct teb_amd_options {
                                   /* bands, closed-form Jacobians, new association, enough obstacles x poses), -1 = never,         */
                                   /* n > 0 = at most n helper workgroups per band, whatever the size of the scene                  */
   int32_t multi_cu_timeout_us;    /* how long a band waits for its helper workgroups before it gives the launch up (it is then     */
-                                  /* repeated on one CU per band); 0 = 50 000 (50 ms)                                            */
+                                  /* repeated on one CU per band); 0 = 2000 (2 ms: a phase takes some 10 us when the helpers have */
+                                  /* CUs - they do unless other work occupies the device)                                          */
   int32_t speculative_trials;     /* small batches: the damped systems of the first retries of an LM iteration (lambda x 2, x 8,  */
                                   /* x 64) are solved on spare CUs while the band solves and evaluates its first trial, so that a  */
                                   /* rejected trial finds its step ready (bit-identical results): 0 = automatic (closed-form       */
@@ -296,7 +297,9 @@ int  teb_amd_download_tebs(teb_amd_handle_t* h, teb_amd_teb_batch_t* batch);
 /*
  * The hot path: B x optimizeTEB (src/optimal_planner.cpp:182-231), i.e. optimizeAllTEBs
  * (src/homotopy_class_planner.cpp:466-493) when called with compute_cost=1 and the selection_* scales.
- * Asynchronous on the handle's stream; results are valid after teb_amd_synchronize / get_results.
+ * Asynchronous on the handle's stream; results are valid after teb_amd_synchronize / get_results. Two cases return only after the
+ * launch has finished, because its per-band flags decide whether it has to be repeated: a handle launched in a faster layout than its
+ * capacity's own (see teb_amd_create), and a launch with distance helpers (teb_amd_options_t::multi_cu).
  */
 int  teb_amd_optimize_batch(teb_amd_handle_t* h, int32_t iterations_innerloop, int32_t iterations_outerloop,
                             int32_t compute_cost_afterwards, double obst_cost_scale,

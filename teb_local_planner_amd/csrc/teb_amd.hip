@@ -169,6 +169,7 @@ struct teb_amd_handle {
   // scene
   DevBuf<int> o_type, o_dyn, o_voff, o_static, o_dynidx;
   DevBuf<double> o_ax, o_ay, o_bx, o_by, o_rad, o_vx, o_vy, o_cx, o_cy, o_brad, o_pvx, o_pvy, viax, viay;
+  DevBuf<double> o_list;   // [5][max_obst]: x, y, radius, vx, vy in the order of the LDS obstacle cache (SceneDev::lox ..)
   // batch
   DevBuf<int> n, has_vs, has_vg, rotdir, via_en, status, optimized, iters, trials, assoc_cnt, assoc, assoc_ovf, via_pose, legacy_idx;
   DevBuf<double> x, y, th, dt, vs, vg, chi2, cost, lambda, Hbackup, Hband, ob_x, ob_y, ob_th, ob_dt;   // ob_*: strips before an optimistic launch
@@ -247,6 +248,8 @@ SceneDev scene_of(teb_amd_handle* h) {
   s.dyn = h->o_dyn.p; s.voff = h->o_voff.p; s.pvx = h->o_pvx.p; s.pvy = h->o_pvy.p;
   s.n_static = h->n_static; s.static_idx = h->o_static.p; s.n_dyn = h->n_dyn; s.dyn_idx = h->o_dynidx.p;
   s.nvia = h->nvia; s.viax = h->viax.p; s.viay = h->viay.p;
+  const size_t mo = (size_t)(h->max_obst > 0 ? h->max_obst : 1);
+  s.lox = h->o_list.p; s.loy = h->o_list.p + mo; s.lor = h->o_list.p + 2 * mo; s.lovx = h->o_list.p + 3 * mo; s.lovy = h->o_list.p + 4 * mo;
   return s;
 }
 
@@ -436,7 +439,7 @@ int launch(teb_amd_handle* h, const OptArgs& args) {
     }
     HIPCHK(hipMemsetAsync(h->mcu_ctl.p, 0, (size_t)h->B * kMcuCtlWords * sizeof(unsigned), h->stream));
     mcu.K = K; mcu.D = D; mcu.ctl = h->mcu_ctl.p; mcu.pub = h->mcu_pub.p; mcu.items = h->mcu_items.p; mcu.item_cap = h->M; mcu.spec = h->mcu_spec.p;
-    mcu.timeout_ticks = (long long)(h->opt.multi_cu_timeout_us > 0 ? h->opt.multi_cu_timeout_us : 50000) * 100LL;   // 100 MHz real-time counter
+    mcu.timeout_ticks = (long long)(h->opt.multi_cu_timeout_us > 0 ? h->opt.multi_cu_timeout_us : 2000) * 100LL;   // 100 MHz real-time counter
     mcu.trace = h->mcu_trace;
     mcu.debug_flags = h->mcu_debug_flags;
     if (h->mcu_trace) std::memset(h->mcu_trace, 0, 1024 * sizeof(unsigned));
@@ -628,6 +631,7 @@ int teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max
   bool ok = true;
   auto A = [&](hipError_t e) { if (e != hipSuccess) ok = false; };
   A(h->o_type.alloc(Mo)); A(h->o_dyn.alloc(Mo)); A(h->o_voff.alloc(Mo + 1)); A(h->o_static.alloc(Mo)); A(h->o_dynidx.alloc(Mo));
+  A(h->o_list.alloc(5 * (size_t)Mo));
   A(h->o_ax.alloc(Mo)); A(h->o_ay.alloc(Mo)); A(h->o_bx.alloc(Mo)); A(h->o_by.alloc(Mo)); A(h->o_rad.alloc(Mo));
   A(h->o_vx.alloc(Mo)); A(h->o_vy.alloc(Mo)); A(h->o_cx.alloc(Mo)); A(h->o_cy.alloc(Mo)); A(h->o_brad.alloc(Mo));
   A(h->o_pvx.alloc(max_obstacle_vertices)); A(h->o_pvy.alloc(max_obstacle_vertices));
@@ -677,7 +681,7 @@ void teb_amd_destroy(teb_amd_handle_t* h) {
                        &h->snap_n, &h->sel_idx, &h->err_flag, &h->hs_pex};
   for (auto* q : ib) q->free();
   DevBuf<double>* db[] = {&h->o_ax, &h->o_ay, &h->o_bx, &h->o_by, &h->o_rad, &h->o_vx, &h->o_vy, &h->o_cx, &h->o_cy, &h->o_brad, &h->o_pvx,
-                          &h->o_pvy, &h->viax, &h->viay, &h->x, &h->y, &h->th, &h->dt, &h->vs, &h->vg, &h->chi2, &h->cost,
+                          &h->o_pvy, &h->o_list, &h->viax, &h->viay, &h->x, &h->y, &h->th, &h->dt, &h->vs, &h->vg, &h->chi2, &h->cost,
                           &h->lambda, &h->Hbackup, &h->Hband, &h->ob_x, &h->ob_y, &h->ob_th, &h->ob_dt, &h->snap_x, &h->snap_y, &h->snap_th, &h->snap_dt, &h->dbg_H,
                           &h->dbg_b, &h->dbg_chi2, &h->sel_cost, &h->stage_x, &h->stage_y, &h->stage_yaw, &h->out_cmd, &h->out_prof, &h->out_traj, &h->hsig, &h->hs_pre, &h->hs_pim};
   for (auto* q : db) q->free();
@@ -714,6 +718,19 @@ int commit_obstacles(teb_amd_handle* h) {
   }
   auto up_i = [&](DevBuf<int>& d, const std::vector<int>& v) { return v.empty() ? hipSuccess : hipMemcpyAsync(d.p, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, h->stream); };
   HIPCHK(up_i(h->o_static, st)); HIPCHK(up_i(h->o_dynidx, dy));
+  {   // the obstacles in cache order (static list, then dynamic list): what the kernel stages into LDS, readable with scalar loads
+    const size_t mo = (size_t)(h->max_obst > 0 ? h->max_obst : 1);
+    std::vector<double> lo(5 * mo, 0.0);
+    size_t k = 0;
+    for (const std::vector<int>* lst : {&st, &dy})
+      for (int oi : *lst) {
+        lo[k] = o.ax[oi]; lo[mo + k] = o.ay[oi]; lo[2 * mo + k] = o.type[oi] == TEB_AMD_OBST_CIRCULAR ? o.rad[oi] : 0.0;
+        lo[3 * mo + k] = o.vx[oi]; lo[4 * mo + k] = o.vy[oi];
+        ++k;
+      }
+    HIPCHK(hipMemcpyAsync(h->o_list.p, lo.data(), lo.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
   HIPCHK(hipStreamSynchronize(h->stream));   // host vectors go out of scope
   h->n_static = (int)st.size(); h->n_dyn = (int)dy.size();
   h->host_static = st;

@@ -55,6 +55,9 @@ struct SceneDev {
   const int* dyn_idx;
   int nvia;
   const double *viax, *viay;
+  // point-like scenes: x, y, radius (0 for points), velocity of the obstacles in the order of the LDS cache (static list, then dynamic
+  // list). The far-field passes read them with wave-uniform indices, i.e. as scalar loads (no LDS traffic, no VGPR)
+  const double *lox, *loy, *lor, *lovx, *lovy;
 };
 
 constexpr int kAssocTriple = 1 << 30;   // legacy association adds the edge at the closest pose three times (:583-641)
