@@ -836,14 +836,30 @@ __device__ __forceinline__ double fast_rcp(double d) {
 #else
 #define TEB_CR_SCHED_BARRIER __builtin_amdgcn_sched_barrier(0);
 #endif
+// Pairs of consecutive doubles at 16-byte aligned addresses are fetched with one 16-byte access (LDS: ds_read_b128, 256 B/clk, where the
+// 8-byte aligned pair the compiler forms by itself is a ds_read2_b64 at 128 B/clk). Every 8x8 block starts on a 16-byte boundary (kBlk is
+// even, the regions start at even offsets of the 16-byte aligned LDS window / of the hipMalloc'ed scratch) and its rows are 64 bytes.
+typedef double teb_v2d __attribute__((ext_vector_type(2)));
+template <int N>
+__device__ __forceinline__ void ld_row(const double* __restrict__ p, double* out) {   // out[0 .. N) = p[0 .. N), p 16-byte aligned
+#ifdef TEB_AMD_NO_B128
+#pragma unroll
+  for (int t = 0; t < N; ++t) out[t] = p[t];
+#else
+#pragma unroll
+  for (int t = 0; t + 1 < N; t += 2) {
+    const teb_v2d v = *reinterpret_cast<const teb_v2d*>(p + t);
+    out[t] = v.x; out[t + 1] = v.y;
+  }
+  if (N & 1) out[N - 1] = p[N - 1];
+#endif
+}
 struct Ldl8 {   // in-place LDL^T of one 8x8 SPD block: a[r(r+1)/2 + c] holds l_rc (r > c) and 1/d_r on the diagonal
   double a[36];
   __device__ __forceinline__ static constexpr int idx(int r, int c) { return r * (r + 1) / 2 + c; }   // r >= c
-  __device__ __forceinline__ void load(const double* Di) {
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-#pragma unroll
-      for (int cc = 0; cc <= r; ++cc) a[idx(r, cc)] = Di[r * 8 + cc];
+  __device__ __forceinline__ void load(const double* Di) {   // Di 16-byte aligned
+    ld_row<1>(Di, a + idx(0, 0)); ld_row<2>(Di + 8, a + idx(1, 0)); ld_row<3>(Di + 16, a + idx(2, 0)); ld_row<4>(Di + 24, a + idx(3, 0));
+    ld_row<5>(Di + 32, a + idx(4, 0)); ld_row<6>(Di + 40, a + idx(5, 0)); ld_row<7>(Di + 48, a + idx(6, 0)); ld_row<8>(Di + 56, a + idx(7, 0));
   }
   __device__ __forceinline__ bool factor() {
     TEB_SOLVER_FMA
@@ -943,11 +959,13 @@ __device__ __forceinline__ bool cr_forward_round(double* __restrict__ D, double*
     F.load(Di);
     ok = F.factor();
     CRR(0);
+    double cu[8];
+    ld_row<8>((hasU ? Lp : Li) + c * 8, cu);   // row c of L_{i+s} (an address inside the blocks even without an upper neighbour)
+    ld_row<8>(f + i * 8, wf);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       wL[k] = Li[k * 8 + c];
-      wU[k] = hasU ? Lp[c * 8 + k] : 0.0;
-      wf[k] = f[i * 8 + k];
+      wU[k] = hasU ? cu[k] : 0.0;
     }
     F.solve3(wL, wU, wf);
     CRR(1);
@@ -955,24 +973,27 @@ __device__ __forceinline__ bool cr_forward_round(double* __restrict__ D, double*
     for (int t = 0; t < R; ++t) { o1[t] = 0; o2[t] = 0; o3[t] = 0; }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
+      double li[R];
+      ld_row<R>(Li + k * 8 + a0, li);
 #pragma unroll
-      for (int t = 0; t < R; ++t) o1[t] += Li[k * 8 + a0 + t] * wL[k];
+      for (int t = 0; t < R; ++t) o1[t] += li[t] * wL[k];
       s1 += Li[k * 8 + c] * wf[k];
       if ((k % TEB_CR_FENCE_EVERY) == TEB_CR_FENCE_EVERY - 1) { TEB_CR_SCHED_BARRIER }
     }
     if (hasU) {
 #pragma unroll
       for (int t = 0; t < R; ++t) {
+        double lp[8];
+        ld_row<8>(Lp + (a0 + t) * 8, lp);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const double lp = Lp[(a0 + t) * 8 + k];
-          o2[t] -= lp * wL[k];
-          o3[t] += lp * wU[k];
+          o2[t] -= lp[k] * wL[k];
+          o3[t] += lp[k] * wU[k];
         }
         if ((t % TEB_CR_FENCE_EVERY) == TEB_CR_FENCE_EVERY - 1) { TEB_CR_SCHED_BARRIER }
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) s2 += Lp[c * 8 + k] * wf[k];
+      for (int k = 0; k < 8; ++k) s2 += cu[k] * wf[k];
     }
   }
   CRR(2);
@@ -1173,8 +1194,7 @@ __device__ __forceinline__ bool cr_top(const double* __restrict__ D, double* __r
   const int tid = threadIdx.x;
   if (tid < 8) {
     double v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = f[k];
+    ld_row<8>(f, v);
     Ldl8 F;
     F.load(D);
     ok = F.factor();
@@ -1197,13 +1217,15 @@ __device__ __forceinline__ void cr_backward(const double* __restrict__ D, const 
       const int e = u >> 3, r = u & 7;
       const int i = s * (2 * e + 1);
       double acc = f[i * 8 + r], acc2 = 0;
-      const double* WL = D + i * kBlk + r * 8;
-      const double* xm = f + (i - s) * 8;
+      double WL[8], xm[8];
+      ld_row<8>(D + i * kBlk + r * 8, WL);
+      ld_row<8>(f + (i - s) * 8, xm);
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc -= WL[k] * xm[k];
       if (i + s < Nb) {
-        const double* WU = L + i * kBlk + r * 8;
-        const double* xp = f + (i + s) * 8;
+        double WU[8], xp[8];
+        ld_row<8>(L + i * kBlk + r * 8, WU);
+        ld_row<8>(f + (i + s) * 8, xp);
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc2 -= WU[k] * xp[k];
       }
@@ -1218,8 +1240,10 @@ __device__ __forceinline__ void cr_backward(const double* __restrict__ D, const 
 // -DTEB_AMD_INLINE_SOLVE builds the inlined variant (4.1 GB per launch, 18 % slower: it spills inside the loops instead).
 #ifdef TEB_AMD_INLINE_SOLVE
 #define TEB_SOLVE_LINKAGE __forceinline__
-#else
+#elif defined(TEB_AMD_SOLVE_CSR)
 #define TEB_SOLVE_LINKAGE __noinline__
+#else
+#define TEB_SOLVE_LINKAGE __noinline__ __attribute__((not_tail_called))
 #endif
 // GLOBAL == false: the blocks are the LDS-resident normal matrix (SOLVER_CR), which the solve destroys.
 // GLOBAL == true : the normal matrix is a band in HBM (SOLVER_BANDG, bands too long for any LDS layout); its 8x8 blocks (+ lambda)
@@ -1327,8 +1351,7 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, const SceneDev&
   // the last surviving block row: x_0 = D_0^{-1} f_0
   if (tid < 8) {
     double v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = f[k];
+    ld_row<8>(f, v);
     Ldl8 F;
     F.load(D);
     ok = F.factor() && ok;
@@ -1350,13 +1373,15 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, const SceneDev&
       const int e = u >> 3, r = u & 7;
       const int i = s * (2 * e + 1);
       double acc = f[i * 8 + r], acc2 = 0;
-      const double* WL = D + i * kBlk + r * 8;
-      const double* xm = f + (i - s) * 8;
+      double WL[8], xm[8];
+      ld_row<8>(D + i * kBlk + r * 8, WL);
+      ld_row<8>(f + (i - s) * 8, xm);
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc -= WL[k] * xm[k];
       if (i + s < Nb) {
-        const double* WU = L + i * kBlk + r * 8;
-        const double* xp = f + (i + s) * 8;
+        double WU[8], xp[8];
+        ld_row<8>(L + i * kBlk + r * 8, WU);
+        ld_row<8>(f + (i + s) * 8, xp);
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc2 -= WU[k] * xp[k];
       }
@@ -1414,7 +1439,9 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, dou
   // Hg: the band copy, entry (r, c), c <= r <= c + 10, at Hg[r * 11 + (r - c)]. In terms of 8x8 blocks:
   //   D_j[a][b] (b <= a)        = Hg[(8 j + a) * 11 + (a - b)]
   //   L_j[a][b] = H(8j+a, 8(j-1)+b) = Hg[(8 j + a) * 11 + (8 + a - b)]   for b >= a - 2, structurally zero otherwise (49 of 64 entries)
-  const double* __restrict__ Hg = gbuf;
+  // (global address space spelled out: a generic pointer would be read with flat_load, which also counts on the LDS counter)
+  typedef const double __attribute__((address_space(1))) gdouble_t;
+  gdouble_t* __restrict__ Hg = (gdouble_t*)gbuf;
   double* __restrict__ Dc = lds_base + plan.off_H;
   double* __restrict__ Lc = Dc + Nc * kBlk;
   double* __restrict__ fc = Lc + Nc * kBlk;
@@ -1462,8 +1489,8 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, dou
     double s1 = 0, s2 = 0;
     if (rr * (kThreads / 8) < E) {   // (uniform) this round has eliminations at all
       if (act) {
-        const double* Hi = Hg + (size_t)(8 * i) * kBand;         // band rows of block row i
-        const double* Hp = Hg + (size_t)(8 * (i + 1)) * kBand;   // ... of block row i + 1 (valid iff hasU)
+        gdouble_t* Hi = Hg + (size_t)(8 * i) * kBand;         // band rows of block row i
+        gdouble_t* Hp = Hg + (size_t)(8 * (i + 1)) * kBand;   // ... of block row i + 1 (valid iff hasU)
         Ldl8 F;
 #pragma unroll
         for (int r = 0; r < 8; ++r)
