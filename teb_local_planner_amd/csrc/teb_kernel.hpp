@@ -14,6 +14,7 @@
 #pragma once
 #include "teb_edges.hpp"
 #include "teb_multicu.hpp"
+#include "teb_autoresize_chain.hpp"
 
 namespace tebamd {
 
@@ -1981,6 +1982,134 @@ __device__ __noinline__ void autoresize_script_wave0(double dt_ref_, double hyst
   }
 }
 
+// ---- one sweep as chains that run side by side (teb_autoresize_chain.hpp) ---------------------------------------------------------------
+// All lanes: pass A (every input interval starts a chain), pointer doubling over next[] from interval 0, prefix sums over the members,
+// pass B (the members write the edit script). Results in ired[16 .. 22] like autoresize_script_lane0 (no run records). Returns 0 when
+// the sweep has to be run by the sequential machine instead: a member chain gave up, or one of the two sample-count guards may bind.
+// Temporaries: 6 int arrays in the region of the new poses (nx ny nth), dead until the script is applied.
+// Out of line, operands addressed from the dynamic LDS base (like autoresize_script_lane0): inlined into the kernel the loop of the chain
+// machine inherited the kernel's register pressure - its constants were reloaded from scratch and from the kernel arguments in every
+// rule evaluation (~ 750 cycles each); on its own it is allocated from an empty register file.
+static_assert(kArNewPose == kNewPose, "descriptor convention");
+__device__ __noinline__ __attribute__((not_tail_called)) int autoresize_chains(double dt_ref_, double hyst_, int max_samples_, int min_samples_,
+                                                                               int n_, int off_state_, int off_scratch_, int stride_, int off_red_) {
+  extern __shared__ __attribute__((aligned(16))) double lds_base[];
+  // (arguments of an out-of-line function arrive in VGPRs: wave-uniform copies keep the addressing and the uniform branches scalar)
+  const double dt_ref = uni(dt_ref_), hyst = uni(hyst_);
+  const int max_samples = uni(max_samples_), min_samples = uni(min_samples_), n = uni(n_), off_state = uni(off_state_),
+            off_scratch = uni(off_scratch_), stride = uni(stride_), off_red = uni(off_red_);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int Tin = n - 1;
+  const double* in_dt = lds_base + off_state + 3 * stride;   // Lds: sx sy sth sdt ...
+  double* odt = lds_base + off_scratch;
+  int* out_desc = reinterpret_cast<int*>(odt + 4 * stride);
+  int* rec = out_desc + stride;
+  int* t_next = reinterpret_cast<int*>(odt + stride);
+  int* t_cnt = t_next + stride; int* t_aux = t_cnt + stride; int* t_jump = t_aux + stride; int* t_reach = t_jump + stride; int* t_off = t_reach + stride;
+  int* wsum = reinterpret_cast<int*>(lds_base + off_red);   // per-wave partial sums of the scans / reductions
+  int* ired = reinterpret_cast<int*>(lds_base + off_red + 64);
+  ArChainOut o;
+  o.odt = odt; o.out_desc = out_desc; o.rec = rec; o.tail_dt = odt + stride - 1; o.k0 = 0; o.nn0 = 0;
+  // pass A
+#pragma unroll 1
+  for (int kk = 0; kk < kMaxPoseIter; ++kk) {
+    const int i = tid + kk * kThreads;
+    if (i < Tin) {
+      const ArChainResult r = ar_chain_run<false>(in_dt, Tin, i, dt_ref, hyst, o);
+      t_next[i] = r.next; t_jump[i] = r.next;
+      t_cnt[i] = r.emitted | (r.new_poses << 16);
+      t_aux[i] = r.splits | (r.merges << 8) | (r.depth << 16) | (r.gave_up << 24) | (r.tail << 25);
+      t_reach[i] = (i == 0) ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  // the members of the sweep: 0, next[0], next[next[0]], .. (pointer doubling; a mark set early by a neighbour only adds members sooner)
+  for (int round = 0; round < 12; ++round) {
+    int marked = 0;
+    int nj[kMaxPoseIter];
+#pragma unroll
+    for (int kk = 0; kk < kMaxPoseIter; ++kk) {
+      const int i = tid + kk * kThreads;
+      nj[kk] = Tin;
+      if (i < Tin) {
+        const int j = t_jump[i];
+        if (j < Tin) {
+          nj[kk] = t_jump[j];
+          if (t_reach[i] && !t_reach[j]) { t_reach[j] = 1; marked = 1; }
+        }
+      }
+    }
+    if (!__syncthreads_or(marked)) break;
+#pragma unroll
+    for (int kk = 0; kk < kMaxPoseIter; ++kk) {
+      const int i = tid + kk * kThreads;
+      if (i < Tin) t_jump[i] = nj[kk];
+    }
+    __syncthreads();
+  }
+  // prefix sums over the members in band order: first emitted interval | first new pose << 16; totals of splits, merges, depth, flags
+  int base = 0, tot_s = 0, tot_m = 0, md = 0, flags = 0;
+#pragma unroll
+  for (int kk = 0; kk < kMaxPoseIter; ++kk) {
+    const int i = tid + kk * kThreads;
+    const bool member = i < Tin && t_reach[i] != 0;
+    const int v = member ? t_cnt[i] : 0;
+    const int a = member ? t_aux[i] : 0;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(inc, off, 64); if (lane >= off) inc += u; }
+    int sm = (a & 0xff) | (((a >> 8) & 0xff) << 16);   // splits | merges << 16
+    int dp = (a >> 16) & 0xff, fl = a >> 24;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      sm += __shfl_down(sm, off, 64);
+      const int d2 = __shfl_down(dp, off, 64); dp = d2 > dp ? d2 : dp;
+      fl |= __shfl_down(fl, off, 64);
+    }
+    if (lane == 63) wsum[wv] = inc;
+    if (lane == 0) { wsum[8 + wv] = sm; wsum[16 + wv] = dp; wsum[24 + wv] = fl; }
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+      const int ws = wsum[w];
+      if (w < wv) before += ws;
+      total += ws;
+      const int s2 = wsum[8 + w];
+      tot_s += s2 & 0xffff; tot_m += s2 >> 16;
+      md = wsum[16 + w] > md ? wsum[16 + w] : md;
+      flags |= wsum[24 + w];
+    }
+    if (i < Tin) t_off[i] = base + before + inc - v;
+    base += total;
+    __syncthreads();
+  }
+  const int K = base & 0xffff, NN = base >> 16;
+  if (flags & 1) return 0;                                                      // a member gave up
+  if (Tin + tot_s >= max_samples || Tin - tot_m <= min_samples) return 0;       // a guard may bind somewhere in the sweep
+  const int ovf = (K > stride - 1 || NN > stride) ? 1 : 0;
+  if (tid == 0) {
+    ired[16] = K + 1; ired[17] = (tot_s + tot_m) > 0 ? 1 : 0; ired[18] = ovf; ired[19] = NN; ired[20] = md; ired[21] = 0;
+    ired[22] = -1;
+  }
+  __syncthreads();
+  if (ovf) return 1;
+  // pass B
+#pragma unroll 1
+  for (int kk = 0; kk < kMaxPoseIter; ++kk) {
+    const int i = tid + kk * kThreads;
+    if (i < Tin && t_reach[i] != 0) {
+      const int off = t_off[i];
+      o.k0 = off & 0xffff; o.nn0 = off >> 16;
+      const ArChainResult r = ar_chain_run<true>(in_dt, Tin, i, dt_ref, hyst, o);
+      if (r.tail) ired[22] = o.k0 + r.emitted - 1;
+    }
+  }
+  if (tid == 0) out_desc[K] = n - 1;   // the goal pose
+  __threadfence_block();
+  return 1;
+}
+
 __device__ inline int autoresize(const teb_amd_config_t& c, const Lds& l, int n, int off_state, int off_scratch, int stride,
                                  bool fast_mode, int* overflow_flag) {
   extern __shared__ __attribute__((aligned(16))) double lds_base[];
@@ -2008,6 +2137,19 @@ __device__ inline int autoresize(const teb_amd_config_t& c, const Lds& l, int n,
     }
     trig = __syncthreads_or(trig);
     if (!trig) break;
+#ifndef TEB_AMD_AUTORESIZE_SEQ
+    // the sweep as parallel chains; the sequential machine below takes over when they decline (uniform decision)
+    bool by_chains = false;
+    if (T < kMaxPoseIter * kThreads) {
+      // cos / sin of the poses as they are now (the cache may date from a rejected LM trial): the new poses average headings through them
+      for (int i = tid; i < n; i += kThreads) { double sv, cv; sincos(l.sth[i], &sv, &cv); l.cs[i] = cv; l.sn[i] = sv; }
+      by_chains = uni(autoresize_chains(c.dt_ref, c.dt_hysteresis, c.max_samples, c.min_samples, n, off_state, off_scratch, stride,
+                                        (int)(l.red - lds_base))) != 0;
+    }
+#else
+    const bool by_chains = false;
+#endif
+    if (!by_chains) {
 #ifndef TEB_AMD_AUTORESIZE_WAVE0   // one lane, arrays in LDS (the register-resident variant of wave 0 measured slower: DESIGN.md section 3)
     if (tid == 0) {
 #ifdef TEB_PROFILE
@@ -2037,6 +2179,7 @@ __device__ inline int autoresize(const teb_amd_config_t& c, const Lds& l, int n,
       // wave 0 is excluded so that lane 0 is not held up by its own wave
       for (int i = tid - 64; i < n; i += kThreads - 64) { double sv, cv; sincos(l.sth[i], &sv, &cv); l.cs[i] = cv; l.sn[i] = sv; }
     }
+    }   // !by_chains
     __syncthreads();
     const int n_out = l.ired[16], mod = l.ired[17], ovf = l.ired[18], n_new = l.ired[19], md = l.ired[20], nruns = l.ired[21], tail_k = l.ired[22];
     if (ovf) { *overflow_flag = 1; return n; }
