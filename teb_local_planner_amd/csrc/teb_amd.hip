@@ -159,6 +159,7 @@ struct teb_amd_handle {
   int num_cus = 0;
   LdsPlan plan;
   int fast_points = 0;
+  int static_radius_zero = 0;   // every obstacle of the static list enters the LDS cache with radius 0 (no circular obstacle among them)
   teb_amd_options_t opt;   // behaviour switches fixed at create (ABI 2; never the process environment)
   int snap_nmax = -1;      // nmax_known at the time of teb_amd_snapshot_state
   int snap_B = -1;         // B at that time (the bound covers those bands only)
@@ -243,6 +244,7 @@ SceneDev scene_of(teb_amd_handle* h) {
   SceneDev s;
   s.M = h->M;
   s.fast_points = h->fast_points;
+  s.static_radius_zero = h->static_radius_zero;
   s.type = h->o_type.p; s.ax = h->o_ax.p; s.ay = h->o_ay.p; s.bx = h->o_bx.p; s.by = h->o_by.p;
   s.rad = h->o_rad.p; s.vx = h->o_vx.p; s.vy = h->o_vy.p; s.cx = h->o_cx.p; s.cy = h->o_cy.p; s.brad = h->o_brad.p;
   s.dyn = h->o_dyn.p; s.voff = h->o_voff.p; s.pvx = h->o_pvx.p; s.pvy = h->o_pvy.p;
@@ -722,6 +724,8 @@ int commit_obstacles(teb_amd_handle* h) {
     const size_t mo = (size_t)(h->max_obst > 0 ? h->max_obst : 1);
     std::vector<double> lo(5 * mo, 0.0);
     size_t k = 0;
+    h->static_radius_zero = 1;
+    for (int oi : st) if (o.type[oi] == TEB_AMD_OBST_CIRCULAR && o.rad[oi] != 0.0) h->static_radius_zero = 0;
     for (const std::vector<int>* lst : {&st, &dy})
       for (int oi : *lst) {
         lo[k] = o.ax[oi]; lo[mo + k] = o.ay[oi]; lo[2 * mo + k] = o.type[oi] == TEB_AMD_OBST_CIRCULAR ? o.rad[oi] : 0.0;

@@ -43,6 +43,7 @@ struct SceneDev {
   int M;
   int fast_points;         // 1: every obstacle is Point/Circular, the footprint is Point/Circular and the
                            //    obstacle cache fits the LDS -> specialised distance path on LDS-resident data
+  int static_radius_zero;  // 1: no obstacle of the static list has a radius (the far-field threshold of the association is one number)
   const int* type;
   const double *ax, *ay, *bx, *by, *rad, *vx, *vy, *cx, *cy;
   const double* brad;      // radius of a circle about the centroid (cx, cy) that contains the obstacle (far-field culling)

@@ -1420,10 +1420,20 @@ __device__ __forceinline__ void cr_copy_band(const Lds& l, int n, double* __rest
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
+#ifndef TEB_AMD_BAND_COPY_V1
+    // rows [0, Nt): a linear copy, two doubles per access (the band starts on a 16-byte boundary in LDS and in the scratch, Nt * kBand is
+    // even); the padding rows [Nt, 8 Nb) of an odd pose count become identity rows
+    typedef double __attribute__((address_space(1))) gdouble_t;
+    typedef teb_v2d __attribute__((address_space(1))) gv2d_t;
+    const int live = Nt * kBand;
+    for (int q = 2 * tid; q < live; q += 2 * kThreads) *reinterpret_cast<gv2d_t*>((gdouble_t*)gband + q) = *reinterpret_cast<const teb_v2d*>(Hb + q);
+    for (int q = live + tid; q < Nb * 8 * kBand; q += kThreads) gband[q] = ((q - live) % kBand) == 0 ? 1.0 : 0.0;
+#else
     for (int q = tid; q < Nb * 8 * kBand; q += kThreads) {
       const int r = q / kBand;
       gband[q] = r < Nt ? Hb[q] : ((q - r * kBand) == 0 ? 1.0 : 0.0);
     }
+#endif
   }
   __threadfence_block();
   __syncthreads();
@@ -2290,12 +2300,38 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
         if (!(d2 > thr * thr) || thr <= 0) near |= 1ull << (k - k0);   // non-finite distances count as near
       }
 #else
+#ifndef TEB_AMD_ASSOC_PASS1_V1
+      if (sc.static_radius_zero) {
+        // no radii in the static list (point obstacles): the threshold is one number, hoisted; the mask is built in its two 32-bit halves
+        // (the bit of obstacle k is a scalar: a conditional move and an OR per obstacle). Same comparisons on the same values.
+        const double thr = (far_d + 0.0) * (1.0 + 1e-12), thr2 = thr * thr;
+        const bool all = thr <= 0;
+        unsigned lo = 0, hi = 0;
+        const int km = k0 + 32 < ke ? k0 + 32 : ke;
+#pragma unroll 4
+        for (int k = k0; k < km; ++k) {
+          const double ddx = x - l.obx[k], ddy = y - l.oby[k];
+          const double d2 = ddx * ddx + ddy * ddy;
+          lo |= !(d2 > thr2) ? 1u << (k - k0) : 0u;
+        }
+#pragma unroll 4
+        for (int k = km; k < ke; ++k) {
+          const double ddx = x - l.obx[k], ddy = y - l.oby[k];
+          const double d2 = ddx * ddx + ddy * ddy;
+          hi |= !(d2 > thr2) ? 1u << (k - km) : 0u;
+        }
+        near = ((unsigned long long)hi << 32) | lo;
+        if (all) near = ke - k0 >= 64 ? ~0ull : ((1ull << (ke - k0)) - 1ull);
+      } else
+#endif
+      {
 #pragma unroll 4
       for (int k = k0; k < ke; ++k) {
         const double ddx = x - l.obx[k], ddy = y - l.oby[k];
         const double d2 = ddx * ddx + ddy * ddy;
         const double thr = (far_d + l.obr[k]) * (1.0 + 1e-12);
         if (!(d2 > thr * thr) || thr <= 0) near |= 1ull << (k - k0);   // non-finite distances count as near
+      }
       }
 #endif
       while (near) {
