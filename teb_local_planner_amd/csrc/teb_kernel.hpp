@@ -66,6 +66,7 @@ __device__ long long g_lin_prof[16];  // thread 0 of workgroup 0: sections of li
 //                 and L_j (coupling to block row j-1), solved by block cyclic reduction with all 256 threads
 //                 (log2(n/2) levels instead of 4n sequential pivots). Needs ~680*S bytes of LDS: S <= 238.
 enum { SOLVER_BAND = 0, SOLVER_CR = 1, SOLVER_BANDG = 2 };   // BANDG: the band lives in HBM (bands too long for the LDS band: up to 512 poses)
+typedef double teb_v2d __attribute__((ext_vector_type(2)));   // two doubles in one 16-byte access
 constexpr int kBlk = 66;   // padded stride (doubles) of one 8x8 block: spreads concurrent eliminations over LDS banks
 
 struct Lds {
@@ -643,6 +644,23 @@ __device__ __forceinline__ double* hmat_ptr(const Lds& l, int q, int Nt) {
   return q < half ? l.Db + q : l.Lb + (q - half);
 }
 
+// the live part of the normal matrix <-> its backup in the band's HBM scratch, two doubles per access (both sides start on 16-byte
+// boundaries, the block / band regions have even lengths: a pair never straddles the D | L boundary)
+template <int SOLVER>
+__device__ __forceinline__ void hmat_save(const Lds& l, int hsz, int Nt, double* __restrict__ g) {
+  typedef double __attribute__((address_space(1))) gdouble_t;
+  typedef teb_v2d __attribute__((address_space(1))) gv2d_t;
+  for (int q = 2 * (int)threadIdx.x; q < hsz; q += 2 * kThreads)
+    *reinterpret_cast<gv2d_t*>((gdouble_t*)g + q) = *reinterpret_cast<const teb_v2d*>(hmat_ptr<SOLVER>(l, q, Nt));
+}
+template <int SOLVER>
+__device__ __forceinline__ void hmat_load(const Lds& l, int hsz, int Nt, const double* __restrict__ g) {
+  typedef const double __attribute__((address_space(1))) gdouble_t;
+  typedef const teb_v2d __attribute__((address_space(1))) gv2d_t;
+  for (int q = 2 * (int)threadIdx.x; q < hsz; q += 2 * kThreads)
+    *reinterpret_cast<teb_v2d*>(hmat_ptr<SOLVER>(l, q, Nt)) = *reinterpret_cast<gv2d_t*>((gdouble_t*)g + q);
+}
+
 // address of the diagonal entry of variable r
 template <int SOLVER>
 __device__ __forceinline__ double* diag_ptr(const Lds& l, int r) {
@@ -840,7 +858,6 @@ __device__ __forceinline__ double fast_rcp(double d) {
 // Pairs of consecutive doubles at 16-byte aligned addresses are fetched with one 16-byte access (LDS: ds_read_b128, 256 B/clk, where the
 // 8-byte aligned pair the compiler forms by itself is a ds_read2_b64 at 128 B/clk). Every 8x8 block starts on a 16-byte boundary (kBlk is
 // even, the regions start at even offsets of the 16-byte aligned LDS window / of the hipMalloc'ed scratch) and its rows are 64 bytes.
-typedef double teb_v2d __attribute__((ext_vector_type(2)));
 template <int N>
 __device__ __forceinline__ void ld_row(const double* __restrict__ p, double* out) {   // out[0 .. N) = p[0 .. N), p 16-byte aligned
 #ifdef TEB_AMD_NO_B128
@@ -2696,7 +2713,7 @@ __device__ inline void mcu_solver_helper(const SceneDev& sc, const BatchDev& bt,
     for (int r = tid; r < Nt + 8; r += kThreads) l.bv[r] = r < Nt ? in[r] : 0.0;
     if constexpr (SOLVER == SOLVER_CR) {
       const int hsz = ((Nt + 7) >> 3) * 2 * kBlk;
-      for (int q = tid; q < hsz; q += kThreads) *hmat_ptr<SOLVER_CR>(l, q, Nt) = Hbk[q];
+      hmat_load<SOLVER_CR>(l, hsz, Nt, Hbk);
     }
     __syncthreads();
     if constexpr (SOLVER == SOLVER_CR) cr_solve_t<false, false>(plan, sc, n, lambda, nullptr, nullptr);
@@ -2953,7 +2970,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
         if (spec_now) {   // (the solver helpers load the same backup: written through)
           for (int q = tid; q < hsz; q += kThreads) st_agent_f64(Hbk + q, *hmat_ptr<SOLVER>(l, q, Nt));
         } else {
-          for (int q = tid; q < hsz; q += kThreads) Hbk[q] = *hmat_ptr<SOLVER>(l, q, Nt);   // saved for rejected trials
+          hmat_save<SOLVER>(l, hsz, Nt, Hbk);   // saved for rejected trials
         }
       }
       if (SOLVER == SOLVER_BAND && !args.band_ldlt) cr_copy_band(l, n, Hbk, spec_now);   // hybrid solve: the band to HBM once per iteration
@@ -2974,7 +2991,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
         }
         if (!taken) {
         if (keep_copy && h_spent) {   // bring back the un-factored H (lazily: a retry whose step came from a helper needs no H at all)
-          for (int q = tid; q < hsz; q += kThreads) *hmat_ptr<SOLVER>(l, q, Nt) = Hbk[q];
+          hmat_load<SOLVER>(l, hsz, Nt, Hbk);
           __syncthreads();
         }
         h_spent = true;
