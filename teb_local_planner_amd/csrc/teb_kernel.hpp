@@ -675,14 +675,14 @@ __device__ __forceinline__ void refresh_trig(const Lds& l, int n) {
 // buildSystem: H = sum J^T Omega J, b = -sum J^T Omega e, and chi^2 per category at the current state.
 template <int SOLVER, int JMODE, bool FAST>
 __device__ inline void linearize(const teb_amd_config_t& c, const SceneDev& sc, const TebCtx& t, const Lds& l, NearCache& nc,
-                                 double* cats /*4, out on all threads*/) {
+                                 double* cats /*4, out on all threads*/, bool trig_is_current = false) {
   const int n = t.n, Nt = 4 * n, tid = threadIdx.x;
   const int hsz = (SOLVER != SOLVER_CR) ? Nt * kBand : ((Nt + 7) >> 3) * 2 * kBlk;
   LNP_DECL
   for (int q = tid; q < hsz; q += kThreads) *hmat_ptr<SOLVER>(l, q, Nt) = 0;
   for (int q = tid; q < Nt + 8; q += kThreads) l.bv[q] = 0;
   LNP(0);
-  refresh_trig(l, n);
+  if (!trig_is_current) refresh_trig(l, n);   // (the LM loop keeps the cos / sin cache current itself: see the update step)
   __syncthreads();
   LNP(1);
   Accum A;
@@ -742,9 +742,11 @@ __device__ __forceinline__ void evaluate_pass(const teb_amd_config_t& c, const S
 }
 template <bool FAST>
 __device__ inline void evaluate(const teb_amd_config_t& c, const SceneDev& sc, const TebCtx& t, const Lds& l, NearCache& nc,
-                                double* cats /*5*/) {
-  refresh_trig(l, t.n);
-  __syncthreads();
+                                double* cats /*5*/, bool trig_is_current = false) {
+  if (!trig_is_current) {   // (callers that changed the headings and refreshed cos / sin themselves, behind a barrier, skip this)
+    refresh_trig(l, t.n);
+    __syncthreads();
+  }
   Accum A;   // only chi[] is live when JAC == false
   A.clear_chi();
   evaluate_pass<FAST, 0>(c, sc, t, l, nc, A);
@@ -2820,6 +2822,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   near_cache.off = args.no_near_cache != 0;
   const bool fast_mode = !c.include_dynamic_obstacles;
   bool done = false;
+  bool trig_stale = true;   // the cos / sin cache (l.cs, l.sn) does not match the headings (uniform)
   PROF_DECL
 #ifdef TEB_PROFILE
   if (threadIdx.x == 0) { l.ired[12] = 0; l.ired[13] = 0; }
@@ -2845,6 +2848,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     PROF_START();
     LNP_DECL
     refresh_trig(l, n);
+    trig_stale = false;
     __syncthreads();
     LNP(8);
     const bool obst_edges = !(c.weight_obstacle == 0 || weight_multiplier == 0);
@@ -2929,7 +2933,10 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     for (int it = 0; it < args.inner && lm_ok; ++it) {
       double cats[4];
       PROF_START();
-      linearize<SOLVER, JMODE, FAST>(c, sc, t, l, near_cache, cats);
+      // cos / sin of the headings are current here: refreshed after autoResize (above), by the update step of the accepted trial, or, after
+      // a rejected last trial, never needed again in this optimize() (the loop ends)
+      linearize<SOLVER, JMODE, FAST>(c, sc, t, l, near_cache, cats, !trig_stale);
+      trig_stale = false;
       PROF_END(2);
       double currentChi = ((cats[0] + cats[1]) + cats[2]) + cats[3];
       if (args.debug_linearize) {
@@ -3025,7 +3032,14 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
             bx_[kk] = l.sx[i]; by_[kk] = l.sy[i]; bth_[kk] = l.sth[i]; bdt_[kk] = l.sdt[i];
             if (i >= 1 && i <= n - 2) {
               l.sx[i] += l.dxv[4 * i]; l.sy[i] += l.dxv[4 * i + 1];
-              l.sth[i] = normalize_theta(l.sth[i] + l.dxv[4 * i + 2]);
+              const double th_new = normalize_theta(l.sth[i] + l.dxv[4 * i + 2]);
+              l.sth[i] = th_new;
+              // the cos / sin cache follows the heading right here (same sincos of the same value as refresh_trig would compute: same
+              // bits), under the latency of the rest of the update, instead of in a pass of its own in front of every error evaluation
+              // and every linearisation
+              double sv, cv;
+              sincos(th_new, &sv, &cv);
+              l.cs[i] = cv; l.sn[i] = sv;
             }
             if (i <= n - 2) l.sdt[i] += l.dxv[4 * i + 3];
 #pragma unroll
@@ -3036,12 +3050,13 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
           }
         }
         __syncthreads();
+        trig_stale = false;   // (the update step above brought the cache along)
         double tc[5];
         tc[4] = sc_part;
         if (MCU && t.mcu.items != nullptr) {
           if (!evaluate_mcu(c, sc, t, l, near_cache, mm, S, tc)) { status = TEB_AMD_TEB_FAILED; if (tid == 0) or_agent_i32(bt.assoc_overflow + b, 4); done = true; lm_ok = false; break; }
         } else
-          evaluate<FAST>(c, sc, t, l, near_cache, tc);
+          evaluate<FAST>(c, sc, t, l, near_cache, tc, true);
         last_cats[0] = tc[0]; last_cats[1] = tc[1]; last_cats[2] = tc[2]; last_cats[3] = tc[3];
         double tempChi = ((tc[0] + tc[1]) + tc[2]) + tc[3];
         double scv[1] = {tc[4]};
@@ -3068,6 +3083,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
             const int i = tid + kk * kThreads;
             if (i < n) { l.sx[i] = bx_[kk]; l.sy[i] = by_[kk]; l.sth[i] = bth_[kk]; l.sdt[i] = bdt_[kk]; }
           }
+          trig_stale = true;   // the cache holds cos / sin of the rejected headings; the next update step (or refresh) overwrites them
           if (!isfinite(lambda)) { ++qmax; __syncthreads(); break; }
         }
         __syncthreads();
@@ -3089,7 +3105,8 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
         if (MCU && t.mcu.items != nullptr) {
           if (!evaluate_mcu(c, sc, t, l, near_cache, mm, S, fc)) { status = TEB_AMD_TEB_FAILED; if (tid == 0) or_agent_i32(bt.assoc_overflow + b, 4); done = true; break; }
         } else
-          evaluate<FAST>(c, sc, t, l, near_cache, fc);
+          evaluate<FAST>(c, sc, t, l, near_cache, fc, !trig_stale);
+          trig_stale = false;
         last_cats[0] = fc[0]; last_cats[1] = fc[1]; last_cats[2] = fc[2]; last_cats[3] = fc[3];
         chi2_final = ((fc[0] + fc[1]) + fc[2]) + fc[3];
       }
