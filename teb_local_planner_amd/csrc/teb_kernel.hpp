@@ -1465,7 +1465,20 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, dou
   CRP_DECL
   const Lds l = carve(lds_base, plan);
   const int tid = threadIdx.x;
-  const int Nt = 4 * n, Nb = (Nt + 7) >> 3, Nc = (Nb + 1) >> 1, E = Nb >> 1;
+  const int Nt = 4 * n, Nb = (Nt + 7) >> 3, E = Nb >> 1;
+  // Level 0 takes two rounds of 32 eliminations. A band of more than 256 poses has up to 8 odd rows beyond them; a third round for those
+  // keeps 24 of the 32 lane groups idle (7 k cycles per solve, and the bands that need it are the ones the launch waits for). Those
+  // rows are not eliminated at level 0 instead: the block rows from 2 E0 on enter the compact system as they are (odd and even,
+  // coupled by their original L blocks) and are reduced by its levels, which need no extra round for them (Nc = 80 instead of 72 rows at
+  // 287 poses: 40 / 20 / 10 / 5 / 2 / 1 eliminations instead of 36 / 18 / 9 / 4 / 2 / 1, seven rounds either way) - as long as
+  // the larger compact system fits the band region. Compact row j is block row 2 j for j <= E0 and block row j + E0 beyond.
+#ifndef TEB_AMD_HYBRID_THREE_ROUNDS
+  const int E0 = (E > 2 * (kThreads / 8) && (size_t)(Nb - 2 * (kThreads / 8)) * (2 * kBlk + 8) <= (size_t)4 * plan.S * kBand) ? 2 * (kThreads / 8) : E;
+#else
+  const int E0 = E;
+#endif
+  const int Nc = Nb - E0;   // (= the even rows alone, (Nb + 1) / 2, when every odd row is eliminated at level 0)
+#define TEB_HYB_ROW(j) ((j) <= E0 ? 2 * (j) : (j) + E0)
   // Hg: the band copy, entry (r, c), c <= r <= c + 10, at Hg[r * 11 + (r - c)]. In terms of 8x8 blocks:
   //   D_j[a][b] (b <= a)        = Hg[(8 j + a) * 11 + (a - b)]
   //   L_j[a][b] = H(8j+a, 8(j-1)+b) = Hg[(8 j + a) * 11 + (8 + a - b)]   for b >= a - 2, structurally zero otherwise (49 of 64 entries)
@@ -1485,7 +1498,7 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, dou
       const int q = q0 + u * kThreads;
       const int j = q >> 6, a8 = (q >> 3) & 7, b8 = q & 7;
       const int hi = a8 > b8 ? a8 : b8, lo = a8 > b8 ? b8 : a8;
-      v[u] = q < Nc * 64 ? Hg[(size_t)(16 * j + hi) * kBand + (hi - lo)] : 0.0;
+      v[u] = q < Nc * 64 ? Hg[(size_t)(8 * TEB_HYB_ROW(j) + hi) * kBand + (hi - lo)] : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < kInitBatch; ++u) {
@@ -1497,8 +1510,13 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, dou
     }
   }
   for (int q = tid; q < Nc * 8; q += kThreads) {
-    const int src = 16 * (q >> 3) + (q & 7);
+    const int src = 8 * TEB_HYB_ROW(q >> 3) + (q & 7);
     fc[q] = src < Nt ? l.bv[src] : 0.0;
+  }
+  // the couplings of the rows that skip level 0 (compact rows E0 + 1 ..): their original L blocks
+  for (int q = (E0 + 1) * 64 + tid; q < Nc * 64; q += kThreads) {
+    const int j = q >> 6, a8 = (q >> 3) & 7, b8 = q & 7;
+    Lc[j * kBlk + (q & 63)] = b8 >= a8 - 2 ? Hg[(size_t)(8 * (j + E0) + a8) * kBand + (8 + a8 - b8)] : 0.0;
   }
   if (tid == 0) l.ired[0] = 1;
   __syncthreads();
@@ -1512,12 +1530,12 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, dou
 #pragma unroll
   for (int rr = 0; rr < kHybridRounds; ++rr) {
     const int e = rr * (kThreads / 8) + grp;
-    const bool act = e < E;
+    const bool act = e < E0;
     const int i = 2 * e + 1;
     const bool hasU = act && (i + 1 < Nb);
     double wL[8], wU[8], wf[8], o1[8], o2[8], o3[8];
     double s1 = 0, s2 = 0;
-    if (rr * (kThreads / 8) < E) {   // (uniform) this round has eliminations at all
+    if (rr * (kThreads / 8) < E0) {   // (uniform) this round has eliminations at all
       if (act) {
         gdouble_t* Hi = Hg + (size_t)(8 * i) * kBand;         // band rows of block row i
         gdouble_t* Hp = Hg + (size_t)(8 * (i + 1)) * kBand;   // ... of block row i + 1 (valid iff hasU)
@@ -1613,13 +1631,13 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, dou
   // x of the even rows, then the odd rows from the records in registers: x_i = P f_i - W_L x_{i-1} - W_U x_{i+1}; lane c holds column c of
   // W_L and W_U, so the 8 lanes of a group add up their column contributions (butterfly over c), then lane r keeps component r
   for (int q = tid; q < Nc * 8; q += kThreads) {
-    const int dst = 16 * (q >> 3) + (q & 7);
+    const int dst = 8 * TEB_HYB_ROW(q >> 3) + (q & 7);
     if (dst < Nt) l.dxv[dst] = fc[q];
   }
 #pragma unroll
   for (int rr = 0; rr < kHybridRounds; ++rr) {
     const int e = rr * (kThreads / 8) + grp;
-    const bool act = e < E;
+    const bool act = e < E0;
     const int i = 2 * e + 1;
     const double xm = act ? fc[e * 8 + c] : 0.0;
     const double xp = (act && i + 1 < Nb) ? fc[(e + 1) * 8 + c] : 0.0;
@@ -1637,6 +1655,7 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, dou
     if (act && 8 * i + c < Nt) l.dxv[8 * i + c] = kf[rr] - mine;
   }
   __syncthreads();  CRP(4);
+#undef TEB_HYB_ROW
 }
 
 // ---- TimedElasticBand::autoResize (src/timed_elastic_band.cpp:227-286) -------------------------------------
