@@ -211,6 +211,46 @@ def test_autoresize_on_device_reproduces_sequential_semantics(oracle):
         assert_full_parity(out, res, ref, rres)
 
 
+def test_autoresize_chains_and_their_fallbacks_on_device(oracle):
+    """The sweep as parallel chains (csrc/teb_autoresize_chain.hpp) on long bands - both slots of a lane in use beyond 256 intervals -
+    and the sweeps it has to hand to the sequential machine: a sample-count guard that may bind (max_samples / min_samples close to
+    the band's size) and a chain of more than 64 rule evaluations (an excess handed on from interval to interval)."""
+    cfg, obst, via, _ = scenes.scene_small_mixed(footprint="point", with_dynamic=False)
+    rng = np.random.default_rng(33)
+    S = 512
+
+    def band(n, dt):
+        x = np.cumsum(rng.uniform(0.02, 0.06, n)); y = rng.normal(0, 0.05, n); th = rng.uniform(-1, 1, n)
+        return x, y, th, dt
+
+    cases = []
+    for n in (150, 230, 257, 300, 340):            # typical: most intervals near the dead band, a few far out
+        dt = rng.normal(0.3, 0.08, n - 1).clip(0.01, None)
+        dt[rng.integers(0, n - 1, 6)] = rng.choice([0.02, 0.9, 1.7], 6)
+        cases.append(band(n, dt))
+    n = 200
+    dt = np.full(n - 1, 0.3); dt[0] = 0.41          # one chain over the whole band: the member gives up
+    cases.append(band(n, dt))
+    dt = np.full(n - 1, 0.3); dt[0] = 0.41; dt[50] = 0.25; dt[120] = 0.05; dt[121] = 1.3   # chains of 51 and ~70 evaluations
+    cases.append(band(n, dt))
+    batch = _abi.TebBatchHost(len(cases), S)
+    for b, cse in enumerate(cases):
+        batch.set_teb(b, *cse)
+    for max_s, min_s in ((500, 3), (262, 3), (500, 228), (345, 150)):
+        cfg.trajectory.max_samples, cfg.trajectory.min_samples = max_s, min_s
+        for fast in (True, False):
+            cfg.obstacles.include_dynamic_obstacles = not fast      # fast_mode = !include_dynamic_obstacles
+            out, res, _ = run_gpu(cfg, obst, via, batch, inner=1, outer=1, compute_cost=False)
+            ref, rres = oracle.optimize_batch(cfg, obst, via, batch, inner=1, outer=1, compute_cost=False, threads=8)
+            np.testing.assert_array_equal(out.n, ref.n)
+            np.testing.assert_array_equal(res.status, rres.status)
+            for b in range(batch.count):
+                if rres.status[b] != _abi.TEB_OK:
+                    continue
+                for u, v in zip(out.get_teb(b), ref.get_teb(b)):
+                    assert np.abs(u - v).max() < 1e-6, (max_s, min_s, fast, b, np.abs(u - v).max())
+
+
 # ---- T4 + BASELINE configs at full size ------------------------------------------------------------------------------
 def test_c3_batch_selection_matches_oracle(oracle):
     cfg, obst, via, batch = scenes.scene_c3(B=16, n=150, M=200, stride=192)
