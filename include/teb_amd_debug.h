@@ -65,6 +65,10 @@ int teb_amd_debug_mcu_watchdog(teb_amd_handle_t* h, int32_t milliseconds);
  * (to bisect a difference between the two modes). */
 int teb_amd_debug_mcu_flags(teb_amd_handle_t* h, int32_t flags);
 
+/* 1 if the last optimise launch ran a kernel instantiation specialised on the TebConfig defaults (teb_amd_options_t::generic_config_path),
+ * 0 if it ran the generic one. */
+int teb_amd_debug_last_config_profile(teb_amd_handle_t* h, int32_t* defaults_profile);
+
 /* per-TEB flags of the last launch: bit0 association list overflow, bit1 autoResize capacity overflow */
 int teb_amd_debug_assoc_overflow(teb_amd_handle_t* h, int32_t* flags);
 

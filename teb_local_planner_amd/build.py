@@ -32,7 +32,7 @@ UNIT_FLAGS = {"opt_0_0_0.o": ["-DTEB_AMD_POINTS_KEEP_GENERIC"]}
 
 VARIANTS = {
     "product": dict(lib=LIB, defines=[], jmodes=(0, 1)),
-    "mfma": dict(lib=LIB_MFMA, defines=["-DTEB_AMD_MFMA_SCHUR", "-DTEB_AMD_ANALYTIC_ONLY"], jmodes=(0,)),
+    "mfma": dict(lib=LIB_MFMA, defines=["-DTEB_AMD_MFMA_SCHUR", "-DTEB_AMD_ANALYTIC_ONLY", "-DTEB_AMD_NO_DEFAULTS_TWINS"], jmodes=(0,)),
     # closed-form Jacobians only: the quick build the tools/ A/B experiments use (build(variant="analytic", extra_defines=[..], out=..))
     "analytic": dict(lib=os.path.join(HERE, "..", "tools", "libteb_amd_ar.so"), defines=["-DTEB_AMD_ANALYTIC_ONLY"], jmodes=(0,)),
 }
@@ -45,7 +45,10 @@ def _units(variant):
     units = [("teb_amd.o", "teb_amd.hip", [])]
     for jm in v["jmodes"]:
         for sv in (0, 1, 2):
-            for sk in ((0, 1, 2, 3) if jm == 0 else (0, 1)):   # the small-batch scene kinds (helper workgroups) exist for closed-form Jacobians
+            # closed-form Jacobians: + the small-batch scene kinds (helper workgroups) and, unless the variant opts out, the point-like
+            # kinds specialised on the TebConfig defaults (4, 5: teb_device.hpp, TEB_CFG)
+            twins = "-DTEB_AMD_NO_DEFAULTS_TWINS" not in v["defines"]
+            for sk in (((0, 1, 2, 3, 4, 5) if twins else (0, 1, 2, 3)) if jm == 0 else (0, 1)):
                 units.append(("opt_%d_%d_%d.o" % (sv, jm, sk), "teb_opt_inst.hip",
                               ["-DTEB_INST_SOLVER=%d" % sv, "-DTEB_INST_JMODE=%d" % jm, "-DTEB_INST_SCENE=%d" % sk]))
     return units

@@ -160,6 +160,7 @@ struct teb_amd_handle {
   LdsPlan plan;
   int fast_points = 0;
   int static_radius_zero = 0;   // every obstacle of the static list enters the LDS cache with radius 0 (no circular obstacle among them)
+  int last_defaults_profile = 0;   // the last optimise launch ran a *_DEFAULTS instantiation (teb_amd_debug_last_config_profile)
   teb_amd_options_t opt;   // behaviour switches fixed at create (ABI 2; never the process environment)
   int snap_nmax = -1;      // nmax_known at the time of teb_amd_snapshot_state
   int snap_B = -1;         // B at that time (the bound covers those bands only)
@@ -289,13 +290,37 @@ const void* opt_kernel(int solver, int jmode, int scene) {
 #undef TEB_OPT_PICK
   return nullptr;   // (a -DTEB_AMD_ANALYTIC_ONLY build asked for the numeric mode)
 }
+// The *_DEFAULTS instantiations fold these flags at compile time (teb_device.hpp: TEB_CFG; the conditions below are exactly the folded
+// ones, in the order they appear in teb_kernel.hpp / teb_edges.hpp): a configuration that satisfies them all - a default TebConfig does -
+// takes the same paths in both instantiations.
+bool config_matches_defaults_profile(const teb_amd_handle* h) {
+  const teb_amd_config_t& c = h->cfg;
+  return h->fast_points && c.jacobian_mode == TEB_AMD_JACOBIAN_ANALYTIC && !h->opt.generic_config_path &&
+         c.max_vel_y == 0 &&                                                         // non-holonomic velocity and acceleration edges
+         !(c.weight_max_vel_x == 0 && c.weight_max_vel_theta == 0) &&
+         !(c.weight_acc_lim_x == 0 && c.weight_acc_lim_theta == 0) &&
+         c.weight_optimaltime != 0 && c.weight_shortest_path == 0 &&
+         (c.min_turning_radius == 0 || c.weight_kinematics_turning_radius == 0) &&    // diff-drive kinematics
+         !(c.weight_kinematics_nh == 0 && c.weight_kinematics_forward_drive == 0) &&
+         !(c.weight_velocity_obstacle_ratio > 0) && !c.legacy_obstacle_association &&
+         c.weight_obstacle != 0 &&                                                   // (dynamic-obstacle edges: the list is empty without include_dynamic_obstacles)
+         h->nvia == 0 &&                                                             // no via-points
+         !c.exact_arc_length && !(c.obstacle_cost_exponent != 1.0 && c.min_obstacle_dist > 0.0) &&
+         c.footprint_type == TEB_AMD_FOOTPRINT_POINT;
+}
 hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const BatchDev& bt, const OptArgs& a, int solver, const LdsPlan& plan,
                       const McuDev* mcu = nullptr) {
   McuDev none;
   std::memset(&none, 0, sizeof none);
   const McuDev* mc = mcu ? mcu : &none;
   const bool small = mc->K + mc->D > 0;   // helper workgroups: the small-batch instantiation of the scene kind
-  const void* k = opt_kernel(solver, h->cfg.jacobian_mode, sc.fast_points ? (small ? SCENE_POINTS_SMALL : SCENE_POINTS) : (small ? SCENE_GENERIC_SMALL : SCENE_GENERIC));
+  const void* k = nullptr;
+  h->last_defaults_profile = 0;
+  if (sc.fast_points && config_matches_defaults_profile(h)) {   // (a build without the twins returns null: generic instantiation)
+    k = opt_kernel(solver, h->cfg.jacobian_mode, small ? SCENE_POINTS_SMALL_DEFAULTS : SCENE_POINTS_DEFAULTS);
+    if (k) h->last_defaults_profile = 1;
+  }
+  if (!k) k = opt_kernel(solver, h->cfg.jacobian_mode, sc.fast_points ? (small ? SCENE_POINTS_SMALL : SCENE_POINTS) : (small ? SCENE_GENERIC_SMALL : SCENE_GENERIC));
   if (!k) return hipErrorInvalidDeviceFunction;
   void* params[] = {const_cast<teb_amd_config_t*>(&h->cfg), const_cast<SceneDev*>(&sc), const_cast<BatchDev*>(&bt), const_cast<OptArgs*>(&a),
                     const_cast<LdsPlan*>(&plan), const_cast<McuDev*>(mc)};
@@ -660,7 +685,7 @@ int teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max
   if (ok && hipEventCreate(&h->ev1) != hipSuccess) ok = false;
   for (int sv : {SOLVER_BAND, SOLVER_CR, SOLVER_BANDG})   // every layout may be launched (teb_amd_set_obstacles / per-launch choice)
     for (int jm : {TEB_AMD_JACOBIAN_ANALYTIC, TEB_AMD_JACOBIAN_G2O_NUMERIC})
-      for (int sk : {SCENE_POINTS, SCENE_GENERIC, SCENE_POINTS_SMALL, SCENE_GENERIC_SMALL}) {
+      for (int sk : {SCENE_POINTS, SCENE_GENERIC, SCENE_POINTS_SMALL, SCENE_GENERIC_SMALL, SCENE_POINTS_DEFAULTS, SCENE_POINTS_SMALL_DEFAULTS}) {
         const void* k = opt_kernel(sv, jm, sk);
         if (ok && k && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit) != hipSuccess) ok = false;
       }
@@ -2386,6 +2411,14 @@ int teb_amd_debug_mcu_watchdog(teb_amd_handle_t* h, int32_t milliseconds) {
 }
 
 // diagnostic of the multi-CU mode: 1 = the association stays with the band's own workgroup, 2 = the distances do (bisecting a difference)
+int teb_amd_debug_last_config_profile(teb_amd_handle_t* h, int32_t* defaults_profile) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!defaults_profile) return fail(TEB_AMD_ERR_INVALID_ARG, "null output");
+  *defaults_profile = h->last_defaults_profile;
+  return TEB_AMD_OK;
+}
+
 int teb_amd_debug_mcu_flags(teb_amd_handle_t* h, int32_t flags) {
   int rc = check_handle(h);
   if (rc) return rc;

@@ -15,6 +15,20 @@
 
 #include "../../include/teb_amd.h"
 
+// ---- instantiations specialised on the configuration ------------------------------------------------------------------------------------
+// Every cost term sits behind run-time flags of teb_amd_config_t (holonomic or not, which weights are zero, car-like or diff-drive, ..):
+// uniform branches, but each one ends a basic block, so the sqrt / divide chains of neighbouring terms cannot be scheduled into each
+// other's latency - and at one wave per SIMD that latency is all there is to fill. A translation unit compiled with
+// -DTEB_AMD_DEFAULTS_PROFILE (teb_opt_inst.hip does it for the scene kinds *_DEFAULTS) folds those flags to the values they have in a
+// default TebConfig: TEB_CFG(condition, value under the profile). The host launches such a kernel only when the handle's configuration
+// satisfies every folded condition (config_matches_defaults_profile, teb_amd.hip); anything else runs the generic instantiation. Same
+// operations in the same order on the taken paths: bit-identical bands (tests/test_gpu_config_profile.py).
+#ifdef TEB_AMD_DEFAULTS_PROFILE
+#define TEB_CFG(expr, dflt) (dflt)
+#else
+#define TEB_CFG(expr, dflt) (expr)
+#endif
+
 namespace tebamd {
 
 #ifndef TEB_AMD_THREADS

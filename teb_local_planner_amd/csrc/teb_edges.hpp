@@ -57,7 +57,7 @@ __device__ __forceinline__ void signed_velocity(const teb_amd_config_t& c, doubl
   double dist = eucl;
   const double angle_diff = normalize_theta(thb - tha);
   bool arc = false;
-  if (c.exact_arc_length && angle_diff != 0) {
+  if (TEB_CFG(c.exact_arc_length, false) && angle_diff != 0) {
     double radius = dist / (2 * sin(angle_diff / 2));
     dist = fabs(angle_diff * radius);
     arc = true;
@@ -535,7 +535,7 @@ __device__ __forceinline__ void edge_kinematics_carlike(const teb_amd_config_t& 
   }
   if (angle_diff != 0) {
     double rho, drho_dn, drho_dth2, dev;
-    if (c.exact_arc_length) {
+    if (TEB_CFG(c.exact_arc_length, false)) {
       double h = angle_diff / 2, sh = sin(h), ch = cos(h);
       rho = fabs(nn / (2 * sh));
       drho_dn = 1.0 / (2 * fabs(sh));
@@ -603,7 +603,7 @@ __device__ __forceinline__ void edge_obstacle(const teb_amd_config_t& c, const S
   double dist = footprint_distance(c, sc, oi, w.x0, w.y0, w.c0, w.s0, false, 0.0, JAC ? gr : nullptr);
   double d0;
   double e0 = pen_below(dist, c.min_obstacle_dist, c.penalty_epsilon, d0);
-  if (c.obstacle_cost_exponent != 1.0 && c.min_obstacle_dist > 0.0) {
+  if (TEB_CFG(c.obstacle_cost_exponent != 1.0 && c.min_obstacle_dist > 0.0, false)) {
     double lin = e0;
     e0 = c.min_obstacle_dist * pow(lin / c.min_obstacle_dist, c.obstacle_cost_exponent);
     if (JAC) {
@@ -629,7 +629,7 @@ template <bool JAC, class ACC>
 __device__ __forceinline__ void obstacle_rows_g(const teb_amd_config_t& c, double dist, const double* gr, double w_obst, bool inflated, ACC& A) {
   double d0;
   double e0 = pen_below(dist, c.min_obstacle_dist, c.penalty_epsilon, d0);
-  if (c.obstacle_cost_exponent != 1.0 && c.min_obstacle_dist > 0.0) {
+  if (TEB_CFG(c.obstacle_cost_exponent != 1.0 && c.min_obstacle_dist > 0.0, false)) {
     double lin = e0;
     e0 = c.min_obstacle_dist * pow(lin / c.min_obstacle_dist, c.obstacle_cost_exponent);
     if (JAC) {
@@ -699,7 +699,7 @@ __device__ __forceinline__ double pointlike_distance(const teb_amd_config_t& c, 
   const double vx_ = px - ox, vy_ = py - oy;
   const double dn = sqrt(vx_ * vx_ + vy_ * vy_);
   double dist = dn - orad;
-  if (c.footprint_type == TEB_AMD_FOOTPRINT_CIRCULAR) dist = dist - c.footprint_radius;
+  if (TEB_CFG(c.footprint_type == TEB_AMD_FOOTPRINT_CIRCULAR, false)) dist = dist - c.footprint_radius;
   if (GRAD) {
     if (dn > 0) { grad[0] = vx_ / dn; grad[1] = vy_ / dn; } else { grad[0] = 0; grad[1] = 0; }
   }
@@ -712,7 +712,7 @@ template <bool JAC, class ACC>
 __device__ __forceinline__ void obstacle_rows(const teb_amd_config_t& c, double dist, const double* gr, double w_obst, bool inflated, ACC& A) {
   double d0;
   double e0 = pen_below(dist, c.min_obstacle_dist, c.penalty_epsilon, d0);
-  if (c.obstacle_cost_exponent != 1.0 && c.min_obstacle_dist > 0.0) {
+  if (TEB_CFG(c.obstacle_cost_exponent != 1.0 && c.min_obstacle_dist > 0.0, false)) {
     double lin = e0;
     e0 = c.min_obstacle_dist * pow(lin / c.min_obstacle_dist, c.obstacle_cost_exponent);
     if (JAC) {

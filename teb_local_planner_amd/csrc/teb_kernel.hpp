@@ -394,7 +394,7 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
   if (i >= 1) {
    if constexpr (PART != 2) {
     TEB_IF_FAST(FAST) {
-      if (!c.legacy_obstacle_association) {
+      if (TEB_CFG(!c.legacy_obstacle_association, true)) {
         // The association lists live in HBM (pose-major, coalesced over the lanes); a lane walks its list in order and at one wave per
         // SIMD every dependent load is a full round trip (L2 for the entry, LDS for the obstacle, then the sqrt chain: ~ 1.1 k cycles per
         // edge, measured). Four entries are fetched together and their distances computed side by side (independent chains); the
@@ -442,7 +442,7 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
         }
       }
       EVP(MODE == 0 ? 0 : 3);
-      if (c.include_dynamic_obstacles && c.weight_obstacle != 0) {
+      if (TEB_CFG(c.include_dynamic_obstacles && c.weight_obstacle != 0, true)) {   // (profile: weight_obstacle != 0; without include_dynamic_obstacles the dynamic list is empty)
         const double ti = l.tdyn[i];
         const double far_d = dyn_far_distance(c);
         // far-field culling (dyn_near_mask above): the mask of the first 64 obstacles of the slice comes from the caller (dyn_near_cached,
@@ -526,7 +526,7 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
     }
    }   // PART != 2
    if constexpr (PART != 1)
-    if (first && t.via_en && c.weight_viapoint != 0) {
+    if (TEB_CFG(true, false) && first && t.via_en && c.weight_viapoint != 0) {   // (profile: no via-points)
       for (int v = 0; v < sc.nvia; ++v)
         if (t.via_pose[v] == i) {
           const double vx = sc.viax[v], vy = sc.viay[v];
@@ -538,15 +538,15 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
   if constexpr (PART == 1) return;
   if (!first) return;   // the other slices only share the dynamic-obstacle edges
   // ---- AddEdgesVelocity :720-769
-  if (c.max_vel_y == 0) {
-    if (!(c.weight_max_vel_x == 0 && c.weight_max_vel_theta == 0)) TEB_EDGE(M_SEG, CAT_OTHER, edge_velocity<J_>(c, W, ACC_));
+  if (TEB_CFG(c.max_vel_y == 0, true)) {
+    if (TEB_CFG(!(c.weight_max_vel_x == 0 && c.weight_max_vel_theta == 0), true)) TEB_EDGE(M_SEG, CAT_OTHER, edge_velocity<J_>(c, W, ACC_));
   } else {
     if (!(c.weight_max_vel_x == 0 && c.weight_max_vel_y == 0 && c.weight_max_vel_theta == 0))
       TEB_EDGE(M_SEG, CAT_OTHER, edge_velocity_holonomic<J_>(c, W, ACC_));
   }
   // ---- AddEdgesAcceleration :771-873
-  if (!(c.weight_acc_lim_x == 0 && c.weight_acc_lim_theta == 0)) {
-    const bool nonholo = (c.max_vel_y == 0 || c.acc_lim_y == 0);
+  if (TEB_CFG(!(c.weight_acc_lim_x == 0 && c.weight_acc_lim_theta == 0), true)) {
+    const bool nonholo = TEB_CFG((c.max_vel_y == 0 || c.acc_lim_y == 0), true);
     if (nonholo) {
       if (i == 0 && t.has_vs) TEB_EDGE(M_SEG, CAT_OTHER, (edge_acceleration_se<J_, true>(c, W, t.vs[0], t.vs[2], ACC_)));
       if (has2) TEB_EDGE(M_ALL, CAT_OTHER, edge_acceleration<J_>(c, W, ACC_));
@@ -558,12 +558,12 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
     }
   }
   // ---- AddEdgesTimeOptimal :877-893 (analytic in the reference), AddEdgesShortestPath :895-912
-  if (c.weight_optimaltime != 0) edge_time_optimal<MODE != 0>(c, w, A);
-  if (c.weight_shortest_path != 0 && seg_active) TEB_EDGE(M_POSE0 | M_POSE1, CAT_OTHER, edge_shortest_path<J_>(c, W, ACC_));
+  if (TEB_CFG(c.weight_optimaltime != 0, true)) edge_time_optimal<MODE != 0>(c, w, A);
+  if (TEB_CFG(c.weight_shortest_path != 0, false) && seg_active) TEB_EDGE(M_POSE0 | M_POSE1, CAT_OTHER, edge_shortest_path<J_>(c, W, ACC_));
   // ---- kinematics :355-358, 916-958 (diff-drive: analytic in the reference)
   if (seg_active) {
-    if (c.min_turning_radius == 0 || c.weight_kinematics_turning_radius == 0) {
-      if (!(c.weight_kinematics_nh == 0 && c.weight_kinematics_forward_drive == 0)) edge_kinematics_diffdrive<MODE != 0>(c, w, A);
+    if (TEB_CFG(c.min_turning_radius == 0 || c.weight_kinematics_turning_radius == 0, true)) {
+      if (TEB_CFG(!(c.weight_kinematics_nh == 0 && c.weight_kinematics_forward_drive == 0), true)) edge_kinematics_diffdrive<MODE != 0>(c, w, A);
     } else {
       if (!(c.weight_kinematics_nh == 0 && c.weight_kinematics_turning_radius == 0))
         TEB_EDGE(M_POSE0 | M_POSE1, CAT_OTHER, edge_kinematics_carlike<J_>(c, W, ACC_));
@@ -575,7 +575,7 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
     TEB_EDGE(M_POSE0 | M_POSE1, CAT_OTHER, edge_prefer_rotdir<J_>(c, W, dir, ACC_));
   }
   // ---- AddEdgesVelocityObstacleRatio :999-1021
-  if (c.weight_velocity_obstacle_ratio > 0 && !c.legacy_obstacle_association) {   // obstacles_per_vertex_ stays empty in legacy mode
+  if (TEB_CFG(c.weight_velocity_obstacle_ratio > 0, false) && !c.legacy_obstacle_association) {   // obstacles_per_vertex_ stays empty in legacy mode
     for (int k = 0; k < cnt; ++k) {
       const int p = FAST ? t.assoc[(size_t)k * t.stride + i] : ld_list(t.mcu.shared_lists, &t.assoc[(size_t)k * t.stride + i]);
       bool replayed = false;
@@ -1271,7 +1271,7 @@ __device__ __forceinline__ void cr_backward(const double* __restrict__ D, const 
 //                  fine levels as round trips to L2, coarse levels on a compact copy in LDS; no backup / restore of H since the
 //                  band is never touched.
 template <bool GLOBAL, bool HB_GLOBAL>
-__device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, const SceneDev& sc, int n, double lambda, double* gbuf, double* gH) {
+__device__ __forceinline__ void cr_solve_t_impl(const LdsPlan plan, const SceneDev& sc, int n, double lambda, double* gbuf, double* gH) {
   TEB_SOLVER_FMA
   extern __shared__ __attribute__((aligned(16))) double lds_base[];
   CRP_DECL
@@ -1414,6 +1414,20 @@ __device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, const SceneDev&
   CRP(5);
 }
 
+template <bool GLOBAL, bool HB_GLOBAL>
+__device__ TEB_SOLVE_LINKAGE void cr_solve_t(const LdsPlan plan, const SceneDev& sc, int n, double lambda, double* gbuf, double* gH) {
+  cr_solve_t_impl<GLOBAL, HB_GLOBAL>(plan, sc, n, lambda, gbuf, gH);
+}
+// the copy the solver helpers of a small batch call (plain calling convention: see cr_solve_hybrid_helper below)
+#ifdef TEB_AMD_INLINE_SOLVE
+#define TEB_HELPER_SOLVE_LINKAGE_T __forceinline__
+#else
+#define TEB_HELPER_SOLVE_LINKAGE_T __noinline__
+#endif
+__device__ TEB_HELPER_SOLVE_LINKAGE_T void cr_solve_blocks_helper(const LdsPlan plan, const SceneDev& sc, int n, double lambda) {
+  cr_solve_t_impl<false, false>(plan, sc, n, lambda, nullptr, nullptr);
+}
+
 // ---- damped solve (K6 v4, "hybrid"): for bands whose block layout does not fit the LDS (SOLVER_BAND) ------------------------------------
 // The normal matrix is linearised into the LDS band. ONCE per LM iteration the band is copied as it is into the band's HBM scratch
 // (cr_copy_band: coalesced, read-only from then on, lambda-free, L2-resident); the band region of the LDS is dead until the next
@@ -1459,7 +1473,22 @@ __device__ __forceinline__ void cr_copy_band(const Lds& l, int n, double* __rest
 }
 
 constexpr int kHybridRounds = 3;   // level-0 rounds of 32 eliminations: block rows <= 172 (343 poses) -> <= 86 odd rows
-__device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, double lambda, double* gbuf) {
+// Two out-of-line copies of the solve: the band's own (no callee-saved block, above) and the one the SOLVER HELPERS of a small batch
+// call. The helper's copy keeps the plain calling convention. Reason: small-batch kernels with BOTH call sites on the no-callee-saved
+// path failed on MI355X in two builds of this round (a profiling build and the band-layout small-batch kernel specialised on the
+// TebConfig defaults: out-of-bounds global writes or a hang as soon as the helpers solved; the same sources with either call on the
+// plain convention ran clean and bit-identical, as did every kernel with a single such call) while the register masks at both call
+// sites check out in the ISA - an interaction inside the backend that this code does not depend on any more. The helper's solve is off
+// the band's critical path, so its save / restore costs the band nothing.
+#ifdef TEB_AMD_INLINE_SOLVE
+#define TEB_HELPER_SOLVE_LINKAGE __forceinline__
+#else
+#define TEB_HELPER_SOLVE_LINKAGE __noinline__
+#endif
+template <int WHO> __device__ void cr_solve_hybrid_impl(const LdsPlan plan, int n, double lambda, double* gbuf);
+__device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, double lambda, double* gbuf) { cr_solve_hybrid_impl<0>(plan, n, lambda, gbuf); }
+__device__ TEB_HELPER_SOLVE_LINKAGE void cr_solve_hybrid_helper(const LdsPlan plan, int n, double lambda, double* gbuf) { cr_solve_hybrid_impl<1>(plan, n, lambda, gbuf); }
+template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const LdsPlan plan, int n, double lambda, double* gbuf) {
   TEB_SOLVER_FMA
   extern __shared__ __attribute__((aligned(16))) double lds_base[];
   CRP_DECL
@@ -2737,8 +2766,8 @@ __device__ inline void mcu_solver_helper(const SceneDev& sc, const BatchDev& bt,
       hmat_load<SOLVER_CR>(l, hsz, Nt, Hbk);
     }
     __syncthreads();
-    if constexpr (SOLVER == SOLVER_CR) cr_solve_t<false, false>(plan, sc, n, lambda, nullptr, nullptr);
-    else cr_solve_hybrid(plan, n, lambda, Hbk);
+    if constexpr (SOLVER == SOLVER_CR) cr_solve_blocks_helper(plan, sc, n, lambda);
+    else cr_solve_hybrid_helper(plan, n, lambda, Hbk);
     for (int r = tid; r < Nt; r += kThreads) st_agent_f64(out + r, l.dxv[r]);
     if (tid == 0) st_agent_f64(out + 4 * S + 8, l.ired[0] != 0 ? 1.0 : 0.0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2753,14 +2782,20 @@ __device__ inline void mcu_solver_helper(const SceneDev& sc, const BatchDev& bt,
 // for the other's code (placement, registers).
 // The _SMALL kinds are the same two for SMALL BATCHES (teb_multicu.hpp): launched with helper workgroups on the CUs the batch leaves idle -
 // K solver helpers per band (speculative LM trials) and, for generic scenes, D distance helpers. Closed-form Jacobians only.
-enum { SCENE_POINTS = 0, SCENE_GENERIC = 1, SCENE_POINTS_SMALL = 2, SCENE_GENERIC_SMALL = 3 };
+// *_DEFAULTS: the two point-like kinds compiled with the configuration flags folded to the TebConfig defaults (teb_device.hpp: TEB_CFG).
+enum { SCENE_POINTS = 0, SCENE_GENERIC = 1, SCENE_POINTS_SMALL = 2, SCENE_GENERIC_SMALL = 3, SCENE_POINTS_DEFAULTS = 4, SCENE_POINTS_SMALL_DEFAULTS = 5 };
 template <int SOLVER, int JMODE, int SCENE>
 __global__ void __launch_bounds__(kThreads)
 teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev bt, const OptArgs args,
                     const LdsPlan plan, const McuDev mc) {
   extern __shared__ __attribute__((aligned(16))) double lds_base[];
-  constexpr bool FAST = SCENE == SCENE_POINTS || SCENE == SCENE_POINTS_SMALL;
-  constexpr bool MCU = SCENE == SCENE_POINTS_SMALL || SCENE == SCENE_GENERIC_SMALL;   // small-batch instantiation: helper workgroups possible
+  constexpr bool FAST = SCENE == SCENE_POINTS || SCENE == SCENE_POINTS_SMALL || SCENE == SCENE_POINTS_DEFAULTS || SCENE == SCENE_POINTS_SMALL_DEFAULTS;
+  constexpr bool MCU = SCENE == SCENE_POINTS_SMALL || SCENE == SCENE_GENERIC_SMALL || SCENE == SCENE_POINTS_SMALL_DEFAULTS;   // small-batch instantiation: helper workgroups possible
+#ifdef TEB_AMD_DEFAULTS_PROFILE
+  static_assert(SCENE == SCENE_POINTS_DEFAULTS || SCENE == SCENE_POINTS_SMALL_DEFAULTS, "a unit compiled with the profile holds a *_DEFAULTS kind");
+#else
+  static_assert(SCENE != SCENE_POINTS_DEFAULTS && SCENE != SCENE_POINTS_SMALL_DEFAULTS, "*_DEFAULTS kinds need -DTEB_AMD_DEFAULTS_PROFILE");
+#endif
   static_assert(!MCU || JMODE == TEB_AMD_JACOBIAN_ANALYTIC, "the small-batch kinds exist for closed-form Jacobians");
   if constexpr (MCU) {
     if (mc.K + mc.D > 0 && (int)blockIdx.x >= bt.B) {   // workgroups B .. B (1 + K + D) - 1: helpers of band (x - B) / (K + D)
@@ -2873,7 +2908,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     const bool obst_edges = !(c.weight_obstacle == 0 || weight_multiplier == 0);
     if (obst_edges) {
       int ovf = 0;
-      if (c.legacy_obstacle_association)
+      if (TEB_CFG(c.legacy_obstacle_association, false))
         associate_legacy(c, sc, l, n, assoc_cnt, assoc, bt.assoc_cap, S, &ovf, bt.legacy_idx + (size_t)b * bt.assoc_cap);
       else if (mcu_on && (mc.debug_flags & 1)) {   // (diagnostic) this workgroup scans, the helpers of the DIST phases read the lists
         associate_range<FAST, true>(c, sc, l, n, 0, n, assoc_cnt, assoc, bt.assoc_cap, S, &ovf);
@@ -2906,7 +2941,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       for (; i < n - 1; ++i) { l.tdyn[i] = time; time += l.sdt[i]; }
     }
     LNP(10);
-    if (t.via_en && c.weight_viapoint != 0 && sc.nvia > 0 && n >= 3) {   // :675-718
+    if (TEB_CFG(true, false) && t.via_en && c.weight_viapoint != 0 && sc.nvia > 0 && n >= 3) {   // :675-718
       int start_pose_idx = 0;
       for (int v = 0; v < sc.nvia; ++v) {
         int index = -1;

@@ -239,6 +239,14 @@ class TebBatchSolver:
         _chk(lib().teb_amd_last_launch_info(self._h, C.byref(a), C.byref(k), C.byref(b)), "teb_amd_last_launch_info")
         return a.value, k.value, bool(b.value)
 
+    def last_config_profile(self):
+        """True if the last optimize() ran a kernel specialised on the TebConfig defaults (teb_amd_options_t::generic_config_path)"""
+        L = lib()
+        L.teb_amd_debug_last_config_profile.argtypes = [C.c_void_p, _abi.p_i32]
+        v = C.c_int32(0)
+        _chk(L.teb_amd_debug_last_config_profile(self._h, C.byref(v)), "teb_amd_debug_last_config_profile")
+        return bool(v.value)
+
     def capacity(self):
         a = C.c_int32(0)
         b = C.c_int32(0)

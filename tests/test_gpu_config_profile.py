@@ -1,0 +1,108 @@
+"""The kernel instantiations specialised on the TebConfig defaults (csrc/teb_device.hpp: TEB_CFG; teb_amd_options_t::generic_config_path):
+a configuration that takes the default paths runs them and gets the bands of the generic instantiation bit for bit; any configuration that
+leaves one of the folded paths must run the generic instantiation."""
+import copy
+
+import numpy as np
+import pytest
+
+from teb_local_planner_amd import _abi, planner, scenes
+from teb_local_planner_amd.config import RobotFootprintModel
+
+pytestmark = pytest.mark.gpu
+
+
+def run(cfg, obst, via, batch, **opt):
+    s = planner.make_solver(cfg, obst, via, batch, options=_abi.Options(**opt) if opt else None)
+    s.optimize(cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations, True, 100.0, 1.0, False)
+    res = s.results()
+    out = s.download(batch.copy())
+    prof = s.last_config_profile()
+    info = s.last_launch_info()
+    s.close()
+    return out, res, prof, info
+
+
+def same_bits(a, ra, b, rb):
+    np.testing.assert_array_equal(a.n, b.n)
+    for f in ("x", "y", "theta", "dt"):
+        np.testing.assert_array_equal(getattr(a, f), getattr(b, f))
+    for f in ("status", "lm_iterations", "lm_trials", "chi2", "cost"):
+        np.testing.assert_array_equal(getattr(ra, f), getattr(rb, f))
+
+
+@pytest.mark.parametrize("scene", ["c2", "c3", "c4_blocks", "c4_hybrid", "c4_band_hbm"])
+def test_default_configuration_runs_the_specialised_kernel_with_identical_bits(scene):
+    if scene == "c2":
+        cfg, obst, via, batch = scenes.scene_c2(stride=208)                       # one band, solver helpers (small-batch kind)
+    elif scene == "c3":
+        cfg, obst, via, batch = scenes.scene_c3(B=16, n=150, M=200, stride=208)
+    elif scene == "c4_blocks":
+        cfg, obst, via, batch = scenes.scene_c4(B=24, stride=208); cfg.trajectory.teb_autosize = False
+    elif scene == "c4_hybrid":
+        cfg, obst, via, batch = scenes.scene_c4(B=24, stride=288)
+    else:
+        cfg, obst, via, batch = scenes.scene_c4(B=8, n=300, stride=420)
+    a, ra, pa, ia = run(cfg, obst, via, batch)
+    b, rb, pb, ib = run(cfg, obst, via, batch, generic_config_path=True)
+    assert pa and not pb, (pa, pb)
+    assert ia == ib
+    same_bits(a, ra, b, rb)
+
+
+@pytest.mark.parametrize("layout", ["band", "blocks"])
+@pytest.mark.parametrize("B", [2, 24, 64])
+def test_small_batches_with_solver_helpers_in_both_kernels(layout, B):
+    """Small batches run with solver helper workgroups (speculative LM trials): specialised and generic kernel, with the helpers and
+    confined to one CU per band - four launches, one result. (The band-layout small-batch kernel of the specialised kind is the one that
+    exposed the call-convention interaction described at cr_solve_hybrid_helper.)"""
+    if layout == "band":
+        cfg, obst, via, batch = scenes.scene_c4(B=B, stride=288)
+    else:
+        cfg, obst, via, batch = scenes.scene_c4(B=B, stride=208); cfg.trajectory.teb_autosize = False
+    t = run(cfg, obst, via, batch)
+    g = run(cfg, obst, via, batch, generic_config_path=True)
+    t0 = run(cfg, obst, via, batch, speculative_trials=-1)
+    g0 = run(cfg, obst, via, batch, generic_config_path=True, speculative_trials=-1)
+    assert t[2] and t0[2] and not g[2] and not g0[2]
+    assert t[3][1] > 0 and g[3][1] > 0 and t0[3][1] == 0 and g0[3][1] == 0, (t[3], g[3], t0[3], g0[3])
+    for other in (g, t0, g0):
+        same_bits(t[0], t[1], other[0], other[1])
+
+
+def _with(cfg, **kw):
+    c = copy.deepcopy(cfg)
+    for k, v in kw.items():
+        grp, name = k.split("__")
+        setattr(getattr(c, grp), name, v)
+    return c
+
+
+def test_configurations_off_the_folded_paths_run_the_generic_kernel():
+    cfg0, obst, via, batch = scenes.scene_c3(B=4, n=60, M=40, stride=96)
+    variants = {
+        "holonomic": _with(cfg0, robot__max_vel_y=0.2, robot__acc_lim_y=0.3),
+        "no velocity edges": _with(cfg0, optim__weight_max_vel_x=0.0, optim__weight_max_vel_theta=0.0),
+        "no acceleration edges": _with(cfg0, optim__weight_acc_lim_x=0.0, optim__weight_acc_lim_theta=0.0),
+        "no time-optimal edges": _with(cfg0, optim__weight_optimaltime=0.0),
+        "shortest path": _with(cfg0, optim__weight_shortest_path=1.0),
+        "car-like": _with(cfg0, robot__min_turning_radius=0.8, optim__weight_kinematics_turning_radius=1.0),
+        "no kinematics edges": _with(cfg0, optim__weight_kinematics_nh=0.0, optim__weight_kinematics_forward_drive=0.0),
+        "velocity-obstacle ratio": _with(cfg0, optim__weight_velocity_obstacle_ratio=1.0),
+        "legacy association": _with(cfg0, obstacles__legacy_obstacle_association=True),
+        "no obstacle edges": _with(cfg0, optim__weight_obstacle=0.0),
+        "exact arc length": _with(cfg0, trajectory__exact_arc_length=True),
+        "cost exponent": _with(cfg0, optim__obstacle_cost_exponent=1.5),
+    }
+    for name, cfg in variants.items():
+        _, res, prof, _ = run(cfg, obst, via, batch)
+        assert not prof, name
+        assert (np.asarray(res.status) != _abi.TEB_NONFINITE).all(), name
+    c = copy.deepcopy(cfg0)
+    c.robot_model = RobotFootprintModel.circular(0.2)
+    assert not run(c, obst, via, batch)[2], "circular footprint"
+    assert not run(cfg0, obst, [(3.0, 0.2)], batch)[2], "via-points"
+    c = copy.deepcopy(cfg0)
+    c.jacobian_mode = 1   # TEB_AMD_JACOBIAN_G2O_NUMERIC: no specialised instantiation
+    assert not run(c, obst, via, batch)[2], "numeric Jacobians"
+    assert run(cfg0, obst, via, batch)[2], "the unchanged configuration is on the folded paths"
