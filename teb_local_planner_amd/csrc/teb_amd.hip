@@ -306,7 +306,10 @@ bool config_matches_defaults_profile(const teb_amd_handle* h) {
          c.weight_obstacle != 0 &&                                                   // (dynamic-obstacle edges: the list is empty without include_dynamic_obstacles)
          h->nvia == 0 &&                                                             // no via-points
          !c.exact_arc_length && !(c.obstacle_cost_exponent != 1.0 && c.min_obstacle_dist > 0.0) &&
-         c.footprint_type == TEB_AMD_FOOTPRINT_POINT;
+         c.footprint_type == TEB_AMD_FOOTPRINT_POINT &&
+         c.inflation_dist > c.min_obstacle_dist &&                                   // inflated obstacle edges (two rows)
+         !c.divergence_detection_enable && !h->band_ldlt &&                          // no second error evaluation per iteration; hybrid solve
+         h->static_radius_zero && !h->opt.no_near_cache;                             // radius-free static list; cached near masks
 }
 hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const BatchDev& bt, const OptArgs& a, int solver, const LdsPlan& plan,
                       const McuDev* mcu = nullptr) {
@@ -316,7 +319,7 @@ hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const Bat
   const bool small = mc->K + mc->D > 0;   // helper workgroups: the small-batch instantiation of the scene kind
   const void* k = nullptr;
   h->last_defaults_profile = 0;
-  if (sc.fast_points && config_matches_defaults_profile(h)) {   // (a build without the twins returns null: generic instantiation)
+  if (sc.fast_points && !a.debug_linearize && !a.band_ldlt && config_matches_defaults_profile(h)) {   // (a build without the twins returns null: generic instantiation)
     k = opt_kernel(solver, h->cfg.jacobian_mode, small ? SCENE_POINTS_SMALL_DEFAULTS : SCENE_POINTS_DEFAULTS);
     if (k) h->last_defaults_profile = 1;
   }

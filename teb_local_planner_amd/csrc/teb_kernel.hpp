@@ -2368,7 +2368,7 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
       }
 #else
 #ifndef TEB_AMD_ASSOC_PASS1_V1
-      if (sc.static_radius_zero) {
+      if (TEB_CFG(sc.static_radius_zero, true)) {
         // no radii in the static list (point obstacles): the threshold is one number, hoisted; the mask is built in its two 32-bit halves
         // (the bit of obstacle k is a scalar: a conditional move and an OR per obstacle). Same comparisons on the same values.
         const double thr = (far_d + 0.0) * (1.0 + 1e-12), thr2 = thr * thr;
@@ -2817,8 +2817,8 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   mm.ctl = (mm.H > 0 || mm.K > 0) ? mc.ctl + (size_t)b * kMcuCtlWords : nullptr;
   mm.pub = mm.H > 0 ? mc.pub + (size_t)b * kMcuPubArrays * S : nullptr;
   mm.spec = mm.K > 0 ? mc.spec + (size_t)b * (mc.K + 1) * mcu_spec_slot(S) : nullptr;
-  const bool mcu_on = MCU && mm.H > 0 && !args.debug_linearize && !c.legacy_obstacle_association;
-  const bool spec_on = MCU && mm.K > 0 && !args.debug_linearize && !(SOLVER == SOLVER_BAND && args.band_ldlt) && !(mc.debug_flags & 4);
+  const bool mcu_on = MCU && mm.H > 0 && !TEB_CFG(args.debug_linearize, false) && !c.legacy_obstacle_association;
+  const bool spec_on = MCU && mm.K > 0 && !TEB_CFG(args.debug_linearize, false) && !(SOLVER == SOLVER_BAND && TEB_CFG(args.band_ldlt, false)) && !(mc.debug_flags & 4);
   if constexpr (FAST) {   // stage the point-like obstacle table once: static list first, then the dynamic list
     const int tot = sc.n_static + sc.n_dyn;
     for (int k = tid; k < tot; k += kThreads) {
@@ -2857,7 +2857,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   t.has_vs = bt.has_vs[b]; t.has_vg = bt.has_vg[b]; t.rotdir = bt.rotdir[b]; t.via_en = bt.via_en[b];
 #pragma unroll
   for (int q = 0; q < 3; ++q) { t.vs[q] = bt.vs[3 * b + q]; t.vg[q] = bt.vg[3 * b + q]; }
-  t.inflated = c.inflation_dist > c.min_obstacle_dist;
+  t.inflated = TEB_CFG(c.inflation_dist > c.min_obstacle_dist, true);
   int* assoc_cnt = bt.assoc_cnt + so;
   int* assoc = bt.assoc + (size_t)b * bt.assoc_cap * S;
   int* via_pose = bt.via_pose + (size_t)b * bt.via_cap;
@@ -2870,10 +2870,10 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   int optimized = c.optimization_activate ? 0 : bt.optimized[b];   // optimized_ = false (src/optimal_planner.cpp:189), after the early return
   double chi2_final = 0, lambda = 0, cost = __longlong_as_double(0x7ff8000000000000LL);
   double last_cats[4] = {0, 0, 0, 0};
-  double weight_multiplier = args.debug_linearize ? args.debug_weight_multiplier : 1.0;
+  double weight_multiplier = TEB_CFG(args.debug_linearize, false) ? args.debug_weight_multiplier : 1.0;
   NearCache near_cache;   // near masks of the dynamic-obstacle edges, per lane (dyn_near_cached)
   near_cache.invalidate();
-  near_cache.off = args.no_near_cache != 0;
+  near_cache.off = TEB_CFG(args.no_near_cache != 0, false);
   const bool fast_mode = !c.include_dynamic_obstacles;
   bool done = false;
   bool trig_stale = true;   // the cos / sin cache (l.cs, l.sn) does not match the headings (uniform)
@@ -2886,7 +2886,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
 
   for (int outer = 0; outer < args.outer && !done; ++outer) {
     // ---- K1: autoResize
-    if (c.teb_autosize && !args.debug_linearize) {
+    if (c.teb_autosize && !TEB_CFG(args.debug_linearize, false)) {
       int ovf = 0;
       PROF_START();
       // edit script + new poses + split stack (autoresize_scratch_doubles: 5 S + 104 doubles) live in the LDS region of the normal matrix, which is rebuilt afterwards
@@ -2972,7 +2972,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
 
     near_cache.invalidate();   // the graph was rebuilt: new pose numbering, new time stamps
     // ---- optimize(): Levenberg-Marquardt
-    if (args.inner <= 0 && !args.debug_linearize) { status = TEB_AMD_TEB_FAILED; break; }   // optimize(0) returns 0
+    if (args.inner <= 0 && !TEB_CFG(args.debug_linearize, false)) { status = TEB_AMD_TEB_FAILED; break; }   // optimize(0) returns 0
     // multi-CU mode: the distance records of the freshly built graph for the first linearisation; the later ones find the records
     // of the error evaluation that accepted their state
     t.mcu.items = nullptr;
@@ -2993,7 +2993,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       trig_stale = false;
       PROF_END(2);
       double currentChi = ((cats[0] + cats[1]) + cats[2]) + cats[3];
-      if (args.debug_linearize) {
+      if (TEB_CFG(args.debug_linearize, false)) {
         if (b == 0) {
           const int Nt = 4 * n;
           for (int q = tid; q < Nt * kBand; q += kThreads) {   // always exported in band form
@@ -3022,7 +3022,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       }
       PROF_START();
       const int hsz = (SOLVER != SOLVER_CR) ? Nt * kBand : ((Nt + 7) >> 3) * 2 * kBlk;
-      const bool keep_copy = !(SOLVER != SOLVER_CR && !args.band_ldlt);   // the HBM-block reductions never touch the band
+      const bool keep_copy = !(SOLVER != SOLVER_CR && !TEB_CFG(args.band_ldlt, false));   // the HBM-block reductions never touch the band
       if constexpr (MCU) {
         if (spec_on) spec_wait_idle(mm, l.ired + 26);   // the solver helpers are done with the buffers of the previous iteration
       }
@@ -3034,7 +3034,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
           hmat_save<SOLVER>(l, hsz, Nt, Hbk);   // saved for rejected trials
         }
       }
-      if (SOLVER == SOLVER_BAND && !args.band_ldlt) cr_copy_band(l, n, Hbk, spec_now);   // hybrid solve: the band to HBM once per iteration
+      if (SOLVER == SOLVER_BAND && !TEB_CFG(args.band_ldlt, false)) cr_copy_band(l, n, Hbk, spec_now);   // hybrid solve: the band to HBM once per iteration
       if constexpr (MCU) {
         if (spec_now) spec_issue(mm, l.bv, Nt, n, S, lambda, ni);   // retries 1 .. K start on their CUs now
       }
@@ -3057,7 +3057,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
         }
         h_spent = true;
         if constexpr (SOLVER == SOLVER_BAND) {
-          if (args.band_ldlt) {
+          if (TEB_CFG(args.band_ldlt, false)) {
             if (tid < 64) {
               bool ok = banded_ldlt_solve_wave0(l, Nt, lambda);
               if (tid == 0) l.ired[0] = ok ? 1 : 0;
@@ -3153,7 +3153,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       ++iters;
       chi2_final = currentChi;
       if (qmax == 10 || rho == 0 || !isfinite(lambda)) lm_ok = false;   // Terminate
-      if (c.divergence_detection_enable) {   // setComputeBatchStatistics -> computeActiveErrors after each solve
+      if (TEB_CFG(c.divergence_detection_enable, false)) {   // setComputeBatchStatistics -> computeActiveErrors after each solve
         double fc[5];
         fc[4] = 0;
         if (MCU && t.mcu.items != nullptr) {
