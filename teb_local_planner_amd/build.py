@@ -28,7 +28,11 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-cont
 # alternating libraries, 11 launches each, +-0.3 %: headline launch 3.71 ms without the flag, 3.62 ms with it, 3.59 ms for round 2's
 # single kernel (which carried that code for every scene). What changes is the register allocation / placement of the hot loops, not
 # the work; no compiler flag tried (scheduler strategies, -O2, -Os) moves it. Kept because the headline is what is measured.
-UNIT_FLAGS = {"opt_0_0_0.o": ["-DTEB_AMD_POINTS_KEEP_GENERIC"]}
+# -DTEB_AMD_INLINE_SOLVE on the small-batch, blocks-in-LDS instantiation specialised on the TebConfig defaults (C2 / C3 / the planner
+# tick run it): the specialised kernels are small enough (~ 90 KB) for the solve to be inlined there without the spills that made it
+# 21 % slower in the generic kernel - C2 1.36 -> 1.31 ms, C3 1.57 -> 1.48 (same box, alternating); in the band layout and in the
+# full-batch kinds it still loses (headline 2.59 -> 3.08 ms), so those keep the call.
+UNIT_FLAGS = {"opt_0_0_0.o": ["-DTEB_AMD_POINTS_KEEP_GENERIC"], "opt_1_0_5.o": ["-DTEB_AMD_INLINE_SOLVE"]}
 
 VARIANTS = {
     "product": dict(lib=LIB, defines=[], jmodes=(0, 1)),
