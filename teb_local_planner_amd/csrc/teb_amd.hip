@@ -306,7 +306,7 @@ bool config_matches_defaults_profile(const teb_amd_handle* h) {
          c.weight_obstacle != 0 &&                                                   // (dynamic-obstacle edges: the list is empty without include_dynamic_obstacles)
          h->nvia == 0 &&                                                             // no via-points
          !c.exact_arc_length && !(c.obstacle_cost_exponent != 1.0 && c.min_obstacle_dist > 0.0) &&
-         c.footprint_type == TEB_AMD_FOOTPRINT_POINT &&
+                                                                                     // (point or circular footprint: fast_points above)
          c.inflation_dist > c.min_obstacle_dist &&                                   // inflated obstacle edges (two rows)
          !c.divergence_detection_enable && !h->band_ldlt &&                          // no second error evaluation per iteration; hybrid solve
          h->static_radius_zero && !h->opt.no_near_cache;                             // radius-free static list; cached near masks
