@@ -295,7 +295,7 @@ const void* opt_kernel(int solver, int jmode, int scene) {
 // takes the same paths in both instantiations.
 bool config_matches_defaults_profile(const teb_amd_handle* h) {
   const teb_amd_config_t& c = h->cfg;
-  return h->fast_points && c.jacobian_mode == TEB_AMD_JACOBIAN_ANALYTIC && !h->opt.generic_config_path &&
+  return h->fast_points && !h->opt.generic_config_path &&                             // (either Jacobian mode; the numeric one has no small-batch kind)
          c.max_vel_y == 0 &&                                                         // non-holonomic velocity and acceleration edges
          !(c.weight_max_vel_x == 0 && c.weight_max_vel_theta == 0) &&
          !(c.weight_acc_lim_x == 0 && c.weight_acc_lim_theta == 0) &&
@@ -320,7 +320,7 @@ hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const Bat
   const void* k = nullptr;
   h->last_defaults_profile = 0;
   if (sc.fast_points && !a.debug_linearize && !a.band_ldlt && config_matches_defaults_profile(h)) {   // (a build without the twins returns null: generic instantiation)
-    k = opt_kernel(solver, h->cfg.jacobian_mode, small ? SCENE_POINTS_SMALL_DEFAULTS : SCENE_POINTS_DEFAULTS);
+    k = opt_kernel(solver, h->cfg.jacobian_mode, (small && h->cfg.jacobian_mode == TEB_AMD_JACOBIAN_ANALYTIC) ? SCENE_POINTS_SMALL_DEFAULTS : SCENE_POINTS_DEFAULTS);
     if (k) h->last_defaults_profile = 1;
   }
   if (!k) k = opt_kernel(solver, h->cfg.jacobian_mode, sc.fast_points ? (small ? SCENE_POINTS_SMALL : SCENE_POINTS) : (small ? SCENE_GENERIC_SMALL : SCENE_GENERIC));

@@ -28,5 +28,9 @@
 #ifdef TEB_AMD_ANALYTIC_ONLY
 #define TEB_OPT_FOR_ALL(X) TEB_OPT_FOR_ANALYTIC(X)
 #else
+#if defined(TEB_AMD_SINGLE_TU) || defined(TEB_AMD_NO_DEFAULTS_TWINS)
 #define TEB_OPT_FOR_ALL(X) TEB_OPT_FOR_ANALYTIC(X) X(0, 1, 0) X(1, 1, 0) X(2, 1, 0) X(0, 1, 1) X(1, 1, 1) X(2, 1, 1)
+#else
+#define TEB_OPT_FOR_ALL(X) TEB_OPT_FOR_ANALYTIC(X) X(0, 1, 0) X(1, 1, 0) X(2, 1, 0) X(0, 1, 1) X(1, 1, 1) X(2, 1, 1) X(0, 1, 4) X(1, 1, 4) X(2, 1, 4)
+#endif
 #endif

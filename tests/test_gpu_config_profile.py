@@ -70,6 +70,18 @@ def test_small_batches_with_solver_helpers_in_both_kernels(layout, B):
         same_bits(t[0], t[1], other[0], other[1])
 
 
+@pytest.mark.parametrize("stride", [208, 288])
+def test_numeric_jacobian_mode_has_its_specialised_kernel_too(stride):
+    cfg, obst, via, batch = scenes.scene_c4(B=12, stride=stride)
+    cfg.jacobian_mode = 1   # TEB_AMD_JACOBIAN_G2O_NUMERIC
+    if stride == 208:
+        cfg.trajectory.teb_autosize = False
+    t = run(cfg, obst, via, batch)
+    g = run(cfg, obst, via, batch, generic_config_path=True)
+    assert t[2] and not g[2]
+    same_bits(t[0], t[1], g[0], g[1])
+
+
 def test_circular_footprint_is_inside_the_profile():
     cfg, obst, via, batch = scenes.scene_c3(B=8, n=100, M=120, stride=208)
     cfg.robot_model = RobotFootprintModel.circular(0.2)
@@ -108,7 +120,4 @@ def test_configurations_off_the_folded_paths_run_the_generic_kernel():
         assert not prof, name
         assert (np.asarray(res.status) != _abi.TEB_NONFINITE).all(), name
     assert not run(cfg0, obst, [(3.0, 0.2)], batch)[2], "via-points"
-    c = copy.deepcopy(cfg0)
-    c.jacobian_mode = 1   # TEB_AMD_JACOBIAN_G2O_NUMERIC: no specialised instantiation
-    assert not run(c, obst, via, batch)[2], "numeric Jacobians"
     assert run(cfg0, obst, via, batch)[2], "the unchanged configuration is on the folded paths"
