@@ -295,13 +295,16 @@ const void* opt_kernel(int solver, int jmode, int scene) {
 // takes the same paths in both instantiations.
 bool config_matches_defaults_profile(const teb_amd_handle* h) {
   const teb_amd_config_t& c = h->cfg;
-  return h->fast_points && !h->opt.generic_config_path &&                             // (either Jacobian mode; the numeric one has no small-batch kind)
+  // point-like scenes fold the kinematics (diff-drive) and the radius-free static list as well; generic-shape scenes keep diff-drive /
+  // car-like at run time and exist for closed-form Jacobians only
+  const bool scene_part = h->fast_points ? ((c.min_turning_radius == 0 || c.weight_kinematics_turning_radius == 0) &&
+                                            !(c.weight_kinematics_nh == 0 && c.weight_kinematics_forward_drive == 0) && h->static_radius_zero)
+                                         : c.jacobian_mode == TEB_AMD_JACOBIAN_ANALYTIC;
+  return scene_part && !h->opt.generic_config_path &&                                // (numeric Jacobians: the full-batch point-like kind only)
          c.max_vel_y == 0 &&                                                         // non-holonomic velocity and acceleration edges
          !(c.weight_max_vel_x == 0 && c.weight_max_vel_theta == 0) &&
          !(c.weight_acc_lim_x == 0 && c.weight_acc_lim_theta == 0) &&
          c.weight_optimaltime != 0 && c.weight_shortest_path == 0 &&
-         (c.min_turning_radius == 0 || c.weight_kinematics_turning_radius == 0) &&    // diff-drive kinematics
-         !(c.weight_kinematics_nh == 0 && c.weight_kinematics_forward_drive == 0) &&
          !(c.weight_velocity_obstacle_ratio > 0) && !c.legacy_obstacle_association &&
          c.weight_obstacle != 0 &&                                                   // (dynamic-obstacle edges: the list is empty without include_dynamic_obstacles)
          h->nvia == 0 &&                                                             // no via-points
@@ -309,7 +312,7 @@ bool config_matches_defaults_profile(const teb_amd_handle* h) {
                                                                                      // (point or circular footprint: fast_points above)
          c.inflation_dist > c.min_obstacle_dist &&                                   // inflated obstacle edges (two rows)
          !c.divergence_detection_enable && !h->band_ldlt &&                          // no second error evaluation per iteration; hybrid solve
-         h->static_radius_zero && !h->opt.no_near_cache;                             // radius-free static list; cached near masks
+         !h->opt.no_near_cache;                                                      // cached near masks
 }
 hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const BatchDev& bt, const OptArgs& a, int solver, const LdsPlan& plan,
                       const McuDev* mcu = nullptr) {
@@ -319,8 +322,9 @@ hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const Bat
   const bool small = mc->K + mc->D > 0;   // helper workgroups: the small-batch instantiation of the scene kind
   const void* k = nullptr;
   h->last_defaults_profile = 0;
-  if (sc.fast_points && !a.debug_linearize && !a.band_ldlt && config_matches_defaults_profile(h)) {   // (a build without the twins returns null: generic instantiation)
-    k = opt_kernel(solver, h->cfg.jacobian_mode, (small && h->cfg.jacobian_mode == TEB_AMD_JACOBIAN_ANALYTIC) ? SCENE_POINTS_SMALL_DEFAULTS : SCENE_POINTS_DEFAULTS);
+  if (!a.debug_linearize && !a.band_ldlt && config_matches_defaults_profile(h)) {   // (a build without the twins returns null: generic instantiation)
+    const bool sm = small && h->cfg.jacobian_mode == TEB_AMD_JACOBIAN_ANALYTIC;
+    k = opt_kernel(solver, h->cfg.jacobian_mode, sc.fast_points ? (sm ? SCENE_POINTS_SMALL_DEFAULTS : SCENE_POINTS_DEFAULTS) : (sm ? SCENE_GENERIC_SMALL_DEFAULTS : SCENE_GENERIC_DEFAULTS));
     if (k) h->last_defaults_profile = 1;
   }
   if (!k) k = opt_kernel(solver, h->cfg.jacobian_mode, sc.fast_points ? (small ? SCENE_POINTS_SMALL : SCENE_POINTS) : (small ? SCENE_GENERIC_SMALL : SCENE_GENERIC));
@@ -688,7 +692,7 @@ int teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max
   if (ok && hipEventCreate(&h->ev1) != hipSuccess) ok = false;
   for (int sv : {SOLVER_BAND, SOLVER_CR, SOLVER_BANDG})   // every layout may be launched (teb_amd_set_obstacles / per-launch choice)
     for (int jm : {TEB_AMD_JACOBIAN_ANALYTIC, TEB_AMD_JACOBIAN_G2O_NUMERIC})
-      for (int sk : {SCENE_POINTS, SCENE_GENERIC, SCENE_POINTS_SMALL, SCENE_GENERIC_SMALL, SCENE_POINTS_DEFAULTS, SCENE_POINTS_SMALL_DEFAULTS}) {
+      for (int sk : {SCENE_POINTS, SCENE_GENERIC, SCENE_POINTS_SMALL, SCENE_GENERIC_SMALL, SCENE_POINTS_DEFAULTS, SCENE_POINTS_SMALL_DEFAULTS, SCENE_GENERIC_DEFAULTS, SCENE_GENERIC_SMALL_DEFAULTS}) {
         const void* k = opt_kernel(sv, jm, sk);
         if (ok && k && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit) != hipSuccess) ok = false;
       }

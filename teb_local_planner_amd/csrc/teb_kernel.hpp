@@ -253,6 +253,11 @@ __device__ __forceinline__ double distance_lower_bound(const SceneDev& sc, int o
 // 2 = g2o central differences over the residual code (the two edges the reference linearises analytically -
 // EdgeKinematicsDiffDrive edge_kinematics.h:112-149, EdgeTimeOptimal edge_time_optimal.h:93-99 - stay analytic).
 // Inside CALL the window is W, the accumulator ACC_ and the Jacobian switch J_.
+#ifdef TEB_AMD_PROFILE_ANY_KINEMATICS
+#define TEB_KIN_CFG(expr, dflt) (expr)
+#else
+#define TEB_KIN_CFG(expr, dflt) TEB_CFG(expr, dflt)
+#endif
 #define TEB_EDGE(VMASK, CAT, ...)                                                                                   \
   do {                                                                                                                \
     if constexpr (MODE == 2) {                                                                                        \
@@ -562,8 +567,8 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
   if (TEB_CFG(c.weight_shortest_path != 0, false) && seg_active) TEB_EDGE(M_POSE0 | M_POSE1, CAT_OTHER, edge_shortest_path<J_>(c, W, ACC_));
   // ---- kinematics :355-358, 916-958 (diff-drive: analytic in the reference)
   if (seg_active) {
-    if (TEB_CFG(c.min_turning_radius == 0 || c.weight_kinematics_turning_radius == 0, true)) {
-      if (TEB_CFG(!(c.weight_kinematics_nh == 0 && c.weight_kinematics_forward_drive == 0), true)) edge_kinematics_diffdrive<MODE != 0>(c, w, A);
+    if (TEB_KIN_CFG(c.min_turning_radius == 0 || c.weight_kinematics_turning_radius == 0, true)) {
+      if (TEB_KIN_CFG(!(c.weight_kinematics_nh == 0 && c.weight_kinematics_forward_drive == 0), true)) edge_kinematics_diffdrive<MODE != 0>(c, w, A);
     } else {
       if (!(c.weight_kinematics_nh == 0 && c.weight_kinematics_turning_radius == 0))
         TEB_EDGE(M_POSE0 | M_POSE1, CAT_OTHER, edge_kinematics_carlike<J_>(c, W, ACC_));
@@ -2783,18 +2788,25 @@ __device__ inline void mcu_solver_helper(const SceneDev& sc, const BatchDev& bt,
 // The _SMALL kinds are the same two for SMALL BATCHES (teb_multicu.hpp): launched with helper workgroups on the CUs the batch leaves idle -
 // K solver helpers per band (speculative LM trials) and, for generic scenes, D distance helpers. Closed-form Jacobians only.
 // *_DEFAULTS: the two point-like kinds compiled with the configuration flags folded to the TebConfig defaults (teb_device.hpp: TEB_CFG).
-enum { SCENE_POINTS = 0, SCENE_GENERIC = 1, SCENE_POINTS_SMALL = 2, SCENE_GENERIC_SMALL = 3, SCENE_POINTS_DEFAULTS = 4, SCENE_POINTS_SMALL_DEFAULTS = 5 };
+// The generic-shape *_DEFAULTS kinds keep the kinematics flags at run time (-DTEB_AMD_PROFILE_ANY_KINEMATICS): polygon robots are car-like
+// as often as not (BASELINE C5).
+enum { SCENE_POINTS = 0, SCENE_GENERIC = 1, SCENE_POINTS_SMALL = 2, SCENE_GENERIC_SMALL = 3, SCENE_POINTS_DEFAULTS = 4, SCENE_POINTS_SMALL_DEFAULTS = 5,
+       SCENE_GENERIC_DEFAULTS = 6, SCENE_GENERIC_SMALL_DEFAULTS = 7 };
 template <int SOLVER, int JMODE, int SCENE>
 __global__ void __launch_bounds__(kThreads)
 teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev bt, const OptArgs args,
                     const LdsPlan plan, const McuDev mc) {
   extern __shared__ __attribute__((aligned(16))) double lds_base[];
   constexpr bool FAST = SCENE == SCENE_POINTS || SCENE == SCENE_POINTS_SMALL || SCENE == SCENE_POINTS_DEFAULTS || SCENE == SCENE_POINTS_SMALL_DEFAULTS;
-  constexpr bool MCU = SCENE == SCENE_POINTS_SMALL || SCENE == SCENE_GENERIC_SMALL || SCENE == SCENE_POINTS_SMALL_DEFAULTS;   // small-batch instantiation: helper workgroups possible
+  constexpr bool MCU = SCENE == SCENE_POINTS_SMALL || SCENE == SCENE_GENERIC_SMALL || SCENE == SCENE_POINTS_SMALL_DEFAULTS ||
+                       SCENE == SCENE_GENERIC_SMALL_DEFAULTS;   // small-batch instantiation: helper workgroups possible
 #ifdef TEB_AMD_DEFAULTS_PROFILE
-  static_assert(SCENE == SCENE_POINTS_DEFAULTS || SCENE == SCENE_POINTS_SMALL_DEFAULTS, "a unit compiled with the profile holds a *_DEFAULTS kind");
+  static_assert(SCENE >= SCENE_POINTS_DEFAULTS, "a unit compiled with the profile holds a *_DEFAULTS kind");
 #else
-  static_assert(SCENE != SCENE_POINTS_DEFAULTS && SCENE != SCENE_POINTS_SMALL_DEFAULTS, "*_DEFAULTS kinds need -DTEB_AMD_DEFAULTS_PROFILE");
+  static_assert(SCENE < SCENE_POINTS_DEFAULTS, "*_DEFAULTS kinds need -DTEB_AMD_DEFAULTS_PROFILE");
+#endif
+#ifdef TEB_AMD_PROFILE_ANY_KINEMATICS
+  static_assert(SCENE == SCENE_GENERIC_DEFAULTS || SCENE == SCENE_GENERIC_SMALL_DEFAULTS, "the generic-shape kinds of the profile keep the kinematics flags");
 #endif
   static_assert(!MCU || JMODE == TEB_AMD_JACOBIAN_ANALYTIC, "the small-batch kinds exist for closed-form Jacobians");
   if constexpr (MCU) {

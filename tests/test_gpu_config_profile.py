@@ -82,6 +82,23 @@ def test_numeric_jacobian_mode_has_its_specialised_kernel_too(stride):
     same_bits(t[0], t[1], g[0], g[1])
 
 
+@pytest.mark.parametrize("scene", ["c5_carlike_polygons", "mixed_polygon_diffdrive", "mixed_two_circles"])
+def test_generic_shape_scenes_have_specialised_kernels_for_either_kinematics(scene):
+    """polygon / line / two-circle robots and obstacles: the generic-shape kinds of the profile keep diff-drive / car-like at run time"""
+    if scene == "c5_carlike_polygons":
+        cfg, obst, via, batch = scenes.scene_c5(stride=320)           # 60 distance + 3 solver helpers
+    else:
+        cfg, obst, via, batch = scenes.scene_small_mixed(footprint="polygon" if "polygon" in scene else "two_circles", with_via=False)
+    t = run(cfg, obst, via, batch)
+    g = run(cfg, obst, via, batch, generic_config_path=True)
+    assert t[2] and not g[2]
+    assert t[3] == g[3]
+    same_bits(t[0], t[1], g[0], g[1])
+    t0 = run(cfg, obst, via, batch, multi_cu=-1, speculative_trials=-1)
+    assert t0[2] and t0[3][:2] == (0, 0)
+    same_bits(t[0], t[1], t0[0], t0[1])
+
+
 def test_circular_footprint_is_inside_the_profile():
     cfg, obst, via, batch = scenes.scene_c3(B=8, n=100, M=120, stride=208)
     cfg.robot_model = RobotFootprintModel.circular(0.2)
