@@ -102,7 +102,7 @@ def kernel_source_hash(root=None):
     d = os.path.join(root or ROOT, "teb_local_planner_amd", "csrc")
     # the translation unit of the optimise kernel (teb_opt_inst.hip and what it includes) + the flags build.py gives the headline unit;
     # the host side (teb_amd.hip) and the kernels of the rows either side of the path do not change the profiled binary
-    kernel_files = ("teb_device.hpp", "teb_edges.hpp", "teb_geometry.hpp", "teb_kernel.hpp", "teb_multicu.hpp", "teb_opt_inst.hip", "teb_opt_launch.hpp")
+    kernel_files = ("teb_autoresize_chain.hpp", "teb_device.hpp", "teb_edges.hpp", "teb_geometry.hpp", "teb_kernel.hpp", "teb_multicu.hpp", "teb_opt_inst.hip", "teb_opt_launch.hpp")
     try:
         from teb_local_planner_amd import build as _b
         h.update(repr(sorted(_b.UNIT_FLAGS.items())).encode() + repr(_b.HIPCC_FLAGS).encode())

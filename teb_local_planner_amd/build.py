@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libteb_amd.so")
 LIB_MFMA = os.path.join(HERE, "libteb_amd_mfma.so")
 HEADERS = ["teb_device.hpp", "teb_comm.hpp", "teb_feasibility.hpp", "teb_geometry.hpp", "teb_edges.hpp", "teb_kernel.hpp", "teb_strip.hpp",
-           "teb_hsig.hpp", "teb_graph.hpp", "teb_opt_launch.hpp", "teb_multicu.hpp",
+           "teb_hsig.hpp", "teb_graph.hpp", "teb_opt_launch.hpp", "teb_multicu.hpp", "teb_autoresize_chain.hpp",
            os.path.join("..", "..", "include", "teb_amd.h"), os.path.join("..", "..", "include", "teb_amd_debug.h")]
 
 # -ffp-contract=off: the parity contract is against a plain IEEE mul/add restatement of the reference;
@@ -59,7 +59,7 @@ def _units(variant):
 
 
 # what a kernel instantiation is made of (the host translation unit depends on everything)
-KERNEL_DEPS = ["teb_opt_inst.hip", "teb_device.hpp", "teb_geometry.hpp", "teb_edges.hpp", "teb_kernel.hpp", "teb_opt_launch.hpp", "teb_multicu.hpp",
+KERNEL_DEPS = ["teb_opt_inst.hip", "teb_device.hpp", "teb_geometry.hpp", "teb_edges.hpp", "teb_kernel.hpp", "teb_opt_launch.hpp", "teb_multicu.hpp", "teb_autoresize_chain.hpp",
                os.path.join("..", "..", "include", "teb_amd.h")]
 
 
