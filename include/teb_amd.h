@@ -260,10 +260,11 @@ typedef struct teb_amd_options {
                                   /* Jacobians, blocks-in-LDS or hybrid layout; as many of the three as the batch leaves CUs for:  */
                                   /* 3 solver workgroups per band up to 64 bands, 1 up to 128, none beyond), -1 = never,           */
                                   /* k = 1 .. 3: at most that many                                                                 */
-  int32_t generic_config_path;    /* 1: never launch the kernel instantiations specialised on the TebConfig defaults (point-like    */
-                                  /* scenes whose configuration takes the default paths - non-holonomic, diff-drive, no via-points, */
-                                  /* cost exponent 1, .. - run a kernel with those flags folded at compile time: same operations,   */
-                                  /* bit-identical bands, 5 - 8 % faster); cross-check switch                                       */
+  int32_t generic_config_path;    /* 1: never launch the kernel instantiations specialised on the TebConfig defaults. A configuration  */
+                                  /* that takes the paths of a default TebConfig (non-holonomic, no via-points, new association, cost */
+                                  /* exponent 1, no exact arc length, inflated obstacle edges, no batch statistics; point-like scenes: */
+                                  /* diff-drive, point obstacles) runs kernels compiled with those flags folded: same operations,     */
+                                  /* bit-identical bands, 10 - 25 % faster. Cross-check switch.                                        */
   int32_t reserved[5];            /* must be 0                                                                                  */
 } teb_amd_options_t;
 void teb_amd_options_default(teb_amd_options_t* opt);
