@@ -145,6 +145,33 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def noise_floor(RC, cfg, obst, via, batch, ref_pack, out_dev, B):
+    """The reference against a SECOND BUILD OF ITSELF (oracle/_ref/libteb_ref_alt.so: -O3, FMA contraction, builtin sin / cos) on the same
+    bands, and the device's per-band distance to the reference held against it: checker only."""
+    from oracle import ref_alt_py
+    if not os.path.exists(ref_alt_py.SO):
+        return {"error": "oracle/_ref/libteb_ref_alt.so is not built"}
+    alt = ref_alt_py.optimize_batch(cfg, obst, via, batch, threads=min(B, os.cpu_count() or 1), trace=True)
+    rr = RC.ref_vs_ref(alt[0], alt[1], alt[2], alt[4], ref_pack[0], ref_pack[1], ref_pack[2], ref_pack[4])
+    per_band = rr.pop("per_band")
+    rr["outside"] = rr["outside"][:8]; rr["pose_count_mismatch"] = rr["pose_count_mismatch"][:8]
+    rr["best_index_alt_build"] = int(RC.select_best_of_costs(alt[2]))
+    rr["builds"] = "libteb_ref.so (-O2 -ffp-contract=off, libm sin / cos) vs libteb_ref_alt.so (-O3 -ffp-contract=fast, builtin sin / cos), oracle/ref_shim/Makefile"
+    if out_dev is not None:
+        ratios, beyond = [], []
+        for b in range(B):
+            if per_band[b] is None or int(out_dev.n[b]) != int(ref_pack[0].n[b]):
+                continue
+            d = RC.state_error(out_dev.get_teb(b), ref_pack[0].get_teb(b))
+            ratios.append(d / max(per_band[b], RC.NOISE_FLOOR_ABS))
+            if d > max(RC.NOISE_FLOOR_ABS * RC.NOISE_FLOOR_K, RC.NOISE_FLOOR_K * per_band[b]):
+                beyond.append({"band": b, "device": d, "ref_vs_ref": per_band[b]})
+        if ratios:
+            rr["device_over_ref_vs_ref"] = {"p50": float(np.median(ratios)), "p99": float(np.percentile(ratios, 99)), "max": float(np.max(ratios)),
+                                            "k": RC.NOISE_FLOOR_K, "abs_floor": RC.NOISE_FLOOR_ABS, "bands_beyond_k": len(beyond), "beyond": beyond[:8]}
+    return rr
+
+
 def time_solver(torch, s, cfg, reps):
     """median kernel ms / wall ms per optimize over `reps` runs from the snapshot; returns (kernel_ms, wall_ms, results)."""
     ms, wall, res = [], [], None
@@ -173,7 +200,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=256, help="TEBs in the CPU-oracle sample")
     ap.add_argument("--parity-bands", type=int, default=16)
     ap.add_argument("--latency-reps", type=int, default=20)
-    ap.add_argument("--sustain-seconds", type=float, default=3.0, help="length of the sustained segment after the timed steps (N = 1 only; 0 = off)")
+    ap.add_argument("--sustain-seconds", type=float, default=12.0, help="length of the sustained segment after the timed steps (N = 1 only; 0 = off)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -476,6 +503,11 @@ def main():
                     s.set_iteration_log(False)
                     rep = RC.compare_with_reference_code(out_r, res_r, tr_r, ref_pack[0], ref_pack[1], ref_pack[2], ref_pack[4])
                     rep["outside"] = rep["outside"][:8]; rep["pose_count_mismatch"] = rep["pose_count_mismatch"][:8]
+                    # T4: selectBestTeb on the device's costs vs the arg-min of the reference code's own costs
+                    best_ref = RC.select_best_of_costs(ref_pack[2])
+                    rep["best_index"] = {"device": int(s.select_best(-1, -1)[0]), "reference_code": int(best_ref)}
+                    rep["best_index_equal"] = bool(rep["best_index"]["device"] == best_ref)
+                    rep["ref_vs_ref"] = noise_floor(RC, cfg, obst, via, batch, ref_pack, out_r, B)
                     rep.update({"mode": "analytic (closed-form Jacobians; the reference differentiates numerically)",
                                 "against": "oracle/_ref/libteb_ref.so: TebOptimalPlanner::optimizeTEB of the reference on every band, %.1f s on the host" % t_ref,
                                 "tolerance_T3": {"state": RC.T3_STATE, "chi2_rel": RC.T3_CHI2_REL},

@@ -250,7 +250,10 @@ typedef struct teb_amd_options {
                                   /* robot <-> obstacle distances of every (pose, obstacle) pair are computed by helper workgroups */
                                   /* on the idle CUs, the bands are bit-identical to the single-CU result): 0 = automatic (<= 16   */
                                   /* bands, closed-form Jacobians, new association, enough obstacles x poses), -1 = never,         */
-                                  /* n > 0 = at most n helper workgroups per band, whatever the size of the scene                  */
+                                  /* n > 0 = at most n helper workgroups per band, whatever the size of the scene. A launch with   */
+                                  /* distance helpers is synchronous and copies the strips first (it may have to be repeated); its */
+                                  /* record buffer is bounded (1 GiB: beyond that, or when it cannot be allocated, the launch runs  */
+                                  /* on one CU per band); misses are backed off, see teb_amd_multi_cu_backoff                       */
   int32_t multi_cu_timeout_us;    /* how long a band waits for its helper workgroups before it gives the launch up (it is then     */
                                   /* repeated on one CU per band); 0 = 2000 (2 ms: a phase takes some 10 us when the helpers have */
                                   /* CUs - they do unless other work occupies the device)                                          */
@@ -339,6 +342,12 @@ int  teb_amd_select_best(teb_amd_handle_t* h, int32_t last_best, int32_t initial
  * device busy with other work). */
 int  teb_amd_last_launch_info(teb_amd_handle_t* h, int32_t* distance_helpers_per_band, int32_t* solver_helpers_per_band,
                               int32_t* repeated_single_cu);
+/* Back-off of the distance helpers on a device that is not empty: after a launch whose helpers came late (it was repeated on one CU per
+ * band) the next *pause_length launches (4, doubling with every further miss up to 256) run on one CU per band without asking for
+ * helpers - no wait, no repeat -, then one launch probes again; a probe that succeeds clears the pause. *launches_paused = how many of
+ * them are still to come (0 = the next launch asks for helpers). A launch with distance helpers is synchronous (the per-band flags
+ * decide about the repeat) and is preceded by a device-to-device copy of the strips; a paused one is neither. */
+int  teb_amd_multi_cu_backoff(teb_amd_handle_t* h, int32_t* launches_paused, int32_t* pause_length);
 
 /* -- zero-copy access for callers that already live on the GPU (benchmarks, torch interop) ---------- */
 /*

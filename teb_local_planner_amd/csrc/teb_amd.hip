@@ -185,6 +185,11 @@ struct teb_amd_handle {
   int mcu_last_helpers = 0;   // distance helpers per band of the last launch (0: none), teb_amd_last_launch_info
   int mcu_last_solvers = 0;   // solver helpers per band of the last launch
   int mcu_last_repeated = 0;  // that launch timed out waiting for its helpers and was repeated on one CU per band
+  // back-off of the distance helpers: after a launch whose helpers came late (a device busy with other work) the next
+  // mcu_backoff_left launches run on one CU per band without asking; then one launch probes again. Every further miss doubles the pause
+  // (4, 8, .. 256 launches), a probe that succeeds clears it.
+  int mcu_backoff_left = 0;
+  int mcu_backoff_len = 0;
   unsigned* mcu_trace = nullptr;   // teb_amd_debug_mcu_watchdog: host-pinned breadcrumbs of the multi-CU launch, one word per workgroup
   int mcu_watchdog_ms = 0;
   int mcu_debug_flags = 0;
@@ -342,6 +347,7 @@ hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const Bat
 // of the layouts) means B (1 + K + D) <= number of CUs keeps every workgroup resident. Closed-form Jacobians (the small-batch
 // instantiations); the solver helpers need a layout whose normal matrix another workgroup can pick up (blocks in LDS with their HBM
 // backup, or the band copy of the hybrid solve), the distance helpers the new association.
+constexpr size_t kMcuItemsMaxBytes = (size_t)1 << 30;   // distance records of the multi-CU mode: beyond 1 GiB the launch stays on one CU per band
 void mcu_helpers_for(teb_amd_handle* h, const OptArgs& args, int eff_solver, int* K_out, int* D_out) {
   *K_out = 0; *D_out = 0;
   if (args.debug_linearize || h->cfg.jacobian_mode != TEB_AMD_JACOBIAN_ANALYTIC || h->B <= 0) return;
@@ -457,6 +463,18 @@ int launch(teb_amd_handle* h, const OptArgs& args) {
   // multi-CU mode: helper workgroups per band (0 = none); its buffers, and the control words zeroed on the stream before the launch
   int K = 0, D = 0;
   mcu_helpers_for(h, args, eff_solver, &K, &D);
+  if (D > 0 && h->mcu_backoff_left > 0) { D = 0; --h->mcu_backoff_left; }   // paused after a miss: one CU per band, no wait, no repeat
+  if (D > 0) {
+    // distance records [B][M][4][stride]: bounded (the association list of a pose is short, but its capacity is every obstacle), and a
+    // failed allocation is no error - the launch then runs on one CU per band
+    const size_t need_items = (size_t)h->B * h->M * 4 * h->stride;
+    if (need_items * sizeof(double) > kMcuItemsMaxBytes) D = 0;
+    else if (h->mcu_items_have < need_items) {
+      h->mcu_items.free(); h->mcu_items_have = 0;
+      if (h->mcu_items.alloc(need_items) != hipSuccess) { (void)hipGetLastError(); D = 0; }
+      else h->mcu_items_have = need_items;
+    }
+  }
   const int H = K + D;
   McuDev mcu;
   std::memset(&mcu, 0, sizeof mcu);
@@ -465,15 +483,12 @@ int launch(teb_amd_handle* h, const OptArgs& args) {
       HIPCHK(h->mcu_ctl.alloc((size_t)h->max_tebs * kMcuCtlWords)); HIPCHK(h->mcu_pub.alloc((size_t)h->max_tebs * kMcuPubArrays * h->stride));
       HIPCHK(h->mcu_spec.alloc((size_t)h->max_tebs * (kMcuMaxSpec + 1) * mcu_spec_slot(h->stride)));
     }
-    const size_t need_items = D > 0 ? (size_t)h->B * h->M * 4 * h->stride : 0;
-    if (h->mcu_items_have < need_items) {
-      h->mcu_items.free(); h->mcu_items_have = 0;
-      HIPCHK(h->mcu_items.alloc(need_items));
-      h->mcu_items_have = need_items;
-    }
     HIPCHK(hipMemsetAsync(h->mcu_ctl.p, 0, (size_t)h->B * kMcuCtlWords * sizeof(unsigned), h->stream));
-    mcu.K = K; mcu.D = D; mcu.ctl = h->mcu_ctl.p; mcu.pub = h->mcu_pub.p; mcu.items = h->mcu_items.p; mcu.item_cap = h->M; mcu.spec = h->mcu_spec.p;
+    mcu.K = K; mcu.D = D; mcu.ctl = h->mcu_ctl.p; mcu.pub = h->mcu_pub.p; mcu.items = D > 0 ? h->mcu_items.p : nullptr; mcu.item_cap = h->M; mcu.spec = h->mcu_spec.p;
     mcu.timeout_ticks = (long long)(h->opt.multi_cu_timeout_us > 0 ? h->opt.multi_cu_timeout_us : 2000) * 100LL;   // 100 MHz real-time counter
+    // a probe after a pause waits 250 us at most: helpers that have CUs answer a phase within ~ 10 us, and a device that is still busy
+    // should cost the tick as little as possible beyond its one-CU time
+    if (D > 0 && h->mcu_backoff_len > 0) mcu.timeout_ticks = std::min(mcu.timeout_ticks, 25000LL);
     mcu.trace = h->mcu_trace;
     mcu.debug_flags = h->mcu_debug_flags;
     if (h->mcu_trace) std::memset(h->mcu_trace, 0, 1024 * sizeof(unsigned));
@@ -515,12 +530,26 @@ int launch(teb_amd_handle* h, const OptArgs& args) {
     for (int v : ovf) { outgrown = outgrown || (v & 2); helpers_late = helpers_late || (v & 4); }
     h->nmax_known = 0;
     for (int v : nn) h->nmax_known = std::max(h->nmax_known, v);
+    if (D > 0) {
+      if (helpers_late) { h->mcu_backoff_len = std::min(256, std::max(4, 2 * h->mcu_backoff_len)); h->mcu_backoff_left = h->mcu_backoff_len; }
+      else { h->mcu_backoff_len = 0; h->mcu_backoff_left = 0; }
+    }
     if (outgrown || helpers_late) {
       // from the saved strips: in the handle's own layout when a band outgrew the optimistic one, and on one CU per band when the
       // helpers of the multi-CU mode did not show up in time (a busy device: nothing promises their residency)
       if (int crc = copy_strips(h, Strips{h->x.p, h->y.p, h->th.p, h->dt.p, h->n.p}, Strips{h->ob_x.p, h->ob_y.p, h->ob_th.p, h->ob_dt.p, h->ob_n.p}, h->B)) return crc;
-      if (outgrown || !optimistic) HIPCHK(launch_opt(h, h->B, sc, bt, args));   // ev0 stays where it was: the reported time includes the discarded first launch
-      else HIPCHK(launch_opt(h, h->B, sc, bt, args, eff_solver, eff_plan));
+      bool own_layout = outgrown || !optimistic;
+      if (!own_layout) {
+        // helpers late, no band outgrown so far: once more in the optimistic layout - whose capacity a band may outgrow in THIS run
+        // (the first one was cut short), so its flags are read as well
+        HIPCHK(launch_opt(h, h->B, sc, bt, args, eff_solver, eff_plan));
+        HIPCHK(hipMemcpyAsync(ovf.data(), h->assoc_ovf.p, h->B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (int v : ovf) own_layout = own_layout || (v & 2);
+        if (own_layout)
+          if (int crc = copy_strips(h, Strips{h->x.p, h->y.p, h->th.p, h->dt.p, h->n.p}, Strips{h->ob_x.p, h->ob_y.p, h->ob_th.p, h->ob_dt.p, h->ob_n.p}, h->B)) return crc;
+      }
+      if (own_layout) HIPCHK(launch_opt(h, h->B, sc, bt, args));   // ev0 stays where it was: the reported time includes the discarded launches
       h->mcu_last_repeated = helpers_late ? 1 : 0;
       h->nmax_known = -1;
     }
@@ -972,6 +1001,7 @@ int teb_amd_download_tebs(teb_amd_handle_t* h, teb_amd_teb_batch_t* bt) {
   if (!bt || !bt->n || !bt->x || !bt->y || !bt->theta || !bt->dt) return fail(TEB_AMD_ERR_INVALID_ARG, "bad TEB batch");
   if (bt->count < h->B) return fail(TEB_AMD_ERR_INVALID_ARG, "batch too small for the resident TEBs");
   const int B = h->B;
+  if (B == 0) return TEB_AMD_OK;   // an empty handle (before the first upload, after every band was dropped, a rank without candidates): nothing to copy
   {
     const int wc = bt->stride < h->stride ? bt->stride : h->stride;
     const size_t plane = (size_t)B * wc, count = (size_t)B + 4 * plane;
@@ -1068,6 +1098,7 @@ int teb_amd_get_results(teb_amd_handle_t* h, teb_amd_results_t* out) {
   if (rc) return rc;
   if (!out) return fail(TEB_AMD_ERR_INVALID_ARG, "null results");
   const int B = h->B;
+  if (B == 0) return TEB_AMD_OK;   // an empty handle has no results to copy (a grid of 0 workgroups would be a launch error)
   if (h->pack_host && 6 * (size_t)B <= kPackMaxDoubles) {   // six result columns in one gather + one copy
     hipLaunchKernelGGL(pack_results_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->pack_dev.p, B, h->status.p, h->iters.p, h->trials.p, h->chi2.p, h->cost.p,
                        h->lambda.p);
@@ -1162,32 +1193,41 @@ void teb_amd_comm_destroy(teb_amd_comm_t* c) {
   delete c;
 }
 
+// A collective like teb_amd_broadcast_band: whatever is wrong on THIS rank (bad handle, a handle on another device than the communicator's,
+// a failed launch) must not keep it out of the all-gather - the peers would wait for ever. Such a rank contributes the
+// unusable record (DBL_MAX, -1), which no other rank can pick, and returns its own error AFTER the collective; the peers get the best
+// band of the ranks that had one. Only a rank without a communicator cannot take part at all.
 int teb_amd_select_best_distributed(teb_amd_handle_t* h, teb_amd_comm_t* c, int32_t global_offset, int32_t last_best_global,
                                     int32_t initial_plan_global, int32_t* best_global, double* best_cost, int32_t* owner_rank) {
-  int rc = check_handle(h);
-  if (rc) return rc;
-  if (!c || !c->comm || !best_global) return fail(TEB_AMD_ERR_INVALID_ARG, "teb_amd_select_best_distributed: null communicator / output");
-  if (c->device != h->device) return fail(TEB_AMD_ERR_INVALID_ARG, "communicator and handle live on different devices");
-  const int have = h->B > 0;
-  if (have) {   // local arg-min with the multipliers applied where this rank owns the favoured candidates
-    int lb = last_best_global - global_offset, ip = initial_plan_global - global_offset;
-    if (last_best_global < 0 || lb < 0 || lb >= h->B) lb = -1;
-    if (initial_plan_global < 0 || ip < 0 || ip >= h->B) ip = -1;
-    hipLaunchKernelGGL(select_best_kernel, dim3(1), dim3(kThreads), 0, h->stream, h->cost.p, h->B, lb, ip,
-                       h->cfg.selection_cost_hysteresis, h->cfg.selection_prefer_initial_plan, h->sel_cost.p, h->sel_idx.p);
+  if (!c || !c->comm) return fail(TEB_AMD_ERR_INVALID_ARG, "teb_amd_select_best_distributed: null communicator");
+  int local = TEB_AMD_OK;
+  std::string why;
+  if (check_handle(h)) { local = TEB_AMD_ERR_INVALID_ARG; why = "bad handle"; }
+  else if (!best_global) { local = TEB_AMD_ERR_INVALID_ARG; why = "null output"; }
+  else if (c->device != h->device) { local = TEB_AMD_ERR_INVALID_ARG; why = "communicator and handle live on different devices"; }
+  (void)hipSetDevice(c->device);
+  hipStream_t stream = local == TEB_AMD_OK ? h->stream : nullptr;   // (a rank with an unusable handle takes part on the null stream)
+  if (local == TEB_AMD_OK) {
+    const int have = h->B > 0;
+    if (have) {   // local arg-min with the multipliers applied where this rank owns the favoured candidates
+      int lb = last_best_global - global_offset, ip = initial_plan_global - global_offset;
+      if (last_best_global < 0 || lb < 0 || lb >= h->B) lb = -1;
+      if (initial_plan_global < 0 || ip < 0 || ip >= h->B) ip = -1;
+      hipLaunchKernelGGL(select_best_kernel, dim3(1), dim3(kThreads), 0, stream, h->cost.p, h->B, lb, ip,
+                         h->cfg.selection_cost_hysteresis, h->cfg.selection_prefer_initial_plan, h->sel_cost.p, h->sel_idx.p);
+    }
+    hipLaunchKernelGGL(pack_record_kernel, dim3(1), dim3(64), 0, stream, h->sel_cost.p, h->sel_idx.p, global_offset, have, c->rec);
+    if (hipGetLastError() != hipSuccess) { local = TEB_AMD_ERR_HIP; why = "local selection kernels failed to launch"; }
   }
-  hipLaunchKernelGGL(pack_record_kernel, dim3(1), dim3(64), 0, h->stream, h->sel_cost.p, h->sel_idx.p, global_offset, have, c->rec);
-  // a launch error on THIS rank must not keep it out of the collective (the peers would wait for ever): an unusable record is sent instead
-  const bool local_ok = hipGetLastError() == hipSuccess;
-  if (!local_ok) {
+  if (local != TEB_AMD_OK) {
     const double none[2] = {1.7976931348623157e308, -1.0};
-    (void)hipMemcpyAsync(c->rec, none, sizeof(none), hipMemcpyHostToDevice, h->stream);
+    (void)hipMemcpyAsync(c->rec, none, sizeof(none), hipMemcpyHostToDevice, stream);
   }
-  NCCLCHK(rccl().AllGather(c->rec, c->all, 2, kRcclFloat64, c->comm, h->stream));
+  NCCLCHK(rccl().AllGather(c->rec, c->all, 2, kRcclFloat64, c->comm, stream));
   std::vector<double> all(2 * (size_t)c->world);
-  HIPCHK(hipMemcpyAsync(all.data(), c->all, all.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  if (!local_ok) return fail(TEB_AMD_ERR_HIP, "teb_amd_select_best_distributed: local selection kernels failed to launch");
+  HIPCHK(hipMemcpyAsync(all.data(), c->all, all.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  if (local != TEB_AMD_OK) return fail(local, "teb_amd_select_best_distributed: " + why + " (this rank sent an unusable record; its peers were not held up)");
   double bc; int bi, owner;
   world_argmin(all.data(), c->world, &bi, &bc, &owner);
   *best_global = bi;
@@ -2172,6 +2212,14 @@ int teb_amd_last_launch_info(teb_amd_handle_t* h, int32_t* distance_helpers_per_
   if (distance_helpers_per_band) *distance_helpers_per_band = h->mcu_last_helpers;
   if (solver_helpers_per_band) *solver_helpers_per_band = h->mcu_last_solvers;
   if (repeated_single_cu) *repeated_single_cu = h->mcu_last_repeated;
+  return TEB_AMD_OK;
+}
+
+int teb_amd_multi_cu_backoff(teb_amd_handle_t* h, int32_t* launches_paused, int32_t* pause_length) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (launches_paused) *launches_paused = h->mcu_backoff_left;
+  if (pause_length) *pause_length = h->mcu_backoff_len;
   return TEB_AMD_OK;
 }
 

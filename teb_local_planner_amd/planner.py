@@ -56,6 +56,8 @@ def lib():
         L.teb_amd_select_best.argtypes = [vp, C.c_int32, C.c_int32, _abi.p_i32, _abi.p_f64]
         if hasattr(L, "teb_amd_last_launch_info"):
             L.teb_amd_last_launch_info.argtypes = [vp, _abi.p_i32, _abi.p_i32, _abi.p_i32]
+        if hasattr(L, "teb_amd_multi_cu_backoff"):
+            L.teb_amd_multi_cu_backoff.argtypes = [vp, _abi.p_i32, _abi.p_i32]
         if hasattr(L, "teb_amd_set_iteration_log"):   # (absent from the older builds tools/ compares against through TEB_AMD_LIB)
             L.teb_amd_set_iteration_log.argtypes = [vp, C.c_int32]
             L.teb_amd_get_iteration_log.argtypes = [vp, C.c_int32, _abi.p_f64, C.c_int32, _abi.p_i32]
@@ -238,6 +240,12 @@ class TebBatchSolver:
         a = C.c_int32(0); k = C.c_int32(0); b = C.c_int32(0)
         _chk(lib().teb_amd_last_launch_info(self._h, C.byref(a), C.byref(k), C.byref(b)), "teb_amd_last_launch_info")
         return a.value, k.value, bool(b.value)
+
+    def multi_cu_backoff(self):
+        """(launches still paused, current pause length) of the distance helpers' back-off (teb_amd_multi_cu_backoff)"""
+        a = C.c_int32(0); k = C.c_int32(0)
+        _chk(lib().teb_amd_multi_cu_backoff(self._h, C.byref(a), C.byref(k)), "teb_amd_multi_cu_backoff")
+        return a.value, k.value
 
     def last_config_profile(self):
         """True if the last optimize() ran a kernel specialised on the TebConfig defaults (teb_amd_options_t::generic_config_path)"""

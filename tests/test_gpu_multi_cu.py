@@ -161,3 +161,35 @@ def test_helper_count_follows_the_room_the_batch_leaves():
         many, rm, info, _, _ = _run(cfg, obst, via, batch)
         assert info1 == (0, 0, False) and info == (0, want, False), (B, info)
         _assert_identical(many, rm, one, r1)
+
+
+def test_late_helpers_are_backed_off_and_probed_again():
+    """a launch whose distance helpers came late is repeated on one CU per band; the next 4 launches then run on one
+    CU per band without asking (no wait, no repeat), the 6th probes again, a second miss doubles the pause. Bands identical throughout."""
+    cfg, obst, via, batch = scenes.scene_small_mixed(footprint="polygon")
+    one, r1, _, _, _ = _run(cfg, obst, via, batch, multi_cu=-1, speculative_trials=-1)
+    s = planner.make_solver(cfg, obst, via, batch, options=_abi.Options(multi_cu=6, multi_cu_timeout_us=1))
+    s.snapshot()
+    seen = []
+    for tick in range(11):
+        s.restore()
+        s.optimize(cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations, True, cfg.hcp.selection_obst_cost_scale,
+                   cfg.hcp.selection_viapoint_cost_scale, cfg.hcp.selection_alternative_time_cost)
+        seen.append((s.last_launch_info(), s.multi_cu_backoff()))
+        _assert_identical(s.download(batch.copy()), s.results(), one, r1)
+    s.close()
+    assert seen[0] == ((6, 3, True), (4, 4)), seen          # miss -> pause of 4
+    for k in range(1, 5):
+        assert seen[k] == ((0, 3, False), (4 - k, 4)), seen  # paused: no distance helpers, no repeat
+    assert seen[5] == ((6, 3, True), (8, 8)), seen           # probe, missed again -> pause of 8
+    for k in range(6, 11):
+        assert seen[k][0] == (0, 3, False), seen
+
+
+def test_a_successful_probe_clears_the_pause():
+    cfg, obst, via, batch = scenes.scene_small_mixed(footprint="polygon")
+    s = planner.make_solver(cfg, obst, via, batch, options=_abi.Options(multi_cu=6))
+    s.snapshot()
+    s.optimize(cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations, True, 1.0, 1.0, False)
+    assert s.last_launch_info() == (6, 3, False) and s.multi_cu_backoff() == (0, 0)
+    s.close()

@@ -32,7 +32,7 @@ sys.path.insert(0, HERE)
 import sensitivity  # noqa: E402
 
 from teb_local_planner_amd import scenes, planner, _abi  # noqa: E402
-from oracle import ref_py, refcode_compare as RC  # noqa: E402
+from oracle import ref_py, ref_alt_py, refcode_compare as RC  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -63,6 +63,23 @@ def _reference(name):
     return _REF[name]
 
 
+_ALT = {}
+
+
+def _noise_floor(name):
+    """The reference against a second build of itself (oracle/_ref/libteb_ref_alt.so) on every band: per-band state distance
+    (None where the two builds end with different pose counts) and the alt build's selectBestTeb index."""
+    if name not in _ALT:
+        if not os.path.exists(ref_alt_py.SO):
+            pytest.skip("oracle/_ref/libteb_ref_alt.so is not built (oracle/ref_shim/Makefile)")
+        rout, rok, rcost, rtr = _reference(name)
+        cfg, obst, via, batch = CASES[name]()
+        aout, aok, acost, ait, atr = ref_alt_py.optimize_batch(cfg, obst, via, batch, threads=THREADS, trace=True)
+        rr = RC.ref_vs_ref(aout, aok, acost, atr, rout, rok, rcost, rtr)
+        _ALT[name] = (rr, RC.select_best_of_costs(acost))
+    return _ALT[name]
+
+
 @pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("name", list(CASES))
 def test_measured_configuration_matches_reference_code(oracle, name, mode):
@@ -81,6 +98,28 @@ def test_measured_configuration_matches_reference_code(oracle, name, mode):
         print("   pose count differs:", o)
     assert rep["success_equal"] == B, rep
     assert rep["pose_counts_equal"] >= int(np.floor(POSE_COUNT_FLOOR * B)), rep
+    # T4: selectBestTeb on the device's costs = the arg-min of the reference code's own costs (src/homotopy_class_planner.cpp:593-615)
+    best_ref = RC.select_best_of_costs(rcost)
+    best_dev = RC.select_best_of_costs(res.cost)
+    assert best_dev == best_ref, (name, mode, best_dev, best_ref)
+    # Independent yardstick: a SECOND BUILD of the reference's code (-O3, FMA contraction, builtin sin / cos). On every
+    # band the device may be at most NOISE_FLOOR_K x as far from the reference as that build is (absolute floor K x NOISE_FLOOR_ABS), and
+    # every band the device has beyond T3 must be one that the two reference builds disagree on by at least a tenth of the device's distance.
+    rr, best_alt = _noise_floor(name)
+    per_band = rr["per_band"]
+    worst = 0.0
+    for b in range(B):
+        if per_band[b] is None or int(out.n[b]) != int(rout.n[b]):
+            continue
+        d = RC.state_error(out.get_teb(b), rout.get_teb(b))
+        bound = max(RC.NOISE_FLOOR_K * RC.NOISE_FLOOR_ABS, RC.NOISE_FLOOR_K * per_band[b])
+        worst = max(worst, d / bound)
+        assert d <= bound, ("band %d: device %.3e from the reference, the reference's two builds %.3e apart" % (b, d, per_band[b]), name, mode)
+    for o in rep["outside"]:
+        b = o["band"]
+        assert per_band[b] is None or per_band[b] >= 0.1 * o["state_err"] or per_band[b] >= RC.T3_STATE, (o, per_band[b])
+    print("   reference vs its second build: state err %s, outside T3 %d (bands %s), best index %d; device / (K x that) worst %.2f" % (
+        rr["state_err"], rr["bands_outside_T3"], [o["band"] for o in rr["outside"]], best_alt, worst))
     inside = rep["pose_counts_equal"] - rep["bands_outside_T3"]
     assert inside >= int(np.floor(T3_FLOOR * rep["pose_counts_equal"])), rep
     # every band beyond T3 (or with another pose count) must be one on which the reference's own linearisation noise decides: the CPU
