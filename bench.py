@@ -145,7 +145,7 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def noise_floor(RC, cfg, obst, via, batch, ref_pack, out_dev, B):
+def noise_floor(RC, cfg, obst, via, batch, ref_pack, out_dev, B, numeric_mode=False):
     """The reference against a SECOND BUILD OF ITSELF (oracle/_ref/libteb_ref_alt.so: -O3, FMA contraction, builtin sin / cos) on the same
     bands, and the device's per-band distance to the reference held against it: checker only."""
     from oracle import ref_alt_py
@@ -164,7 +164,8 @@ def noise_floor(RC, cfg, obst, via, batch, ref_pack, out_dev, B):
                 continue
             d = RC.state_error(out_dev.get_teb(b), ref_pack[0].get_teb(b))
             ratios.append(d / max(per_band[b], RC.NOISE_FLOOR_ABS))
-            if d > max(RC.NOISE_FLOOR_ABS * RC.NOISE_FLOOR_K, RC.NOISE_FLOOR_K * per_band[b]):
+            # same method as the reference (central differences): K x its own noise on the band; closed forms: T3 or that, whichever is larger
+            if d > max(RC.NOISE_FLOOR_ABS * RC.NOISE_FLOOR_K if numeric_mode else RC.T3_STATE, RC.NOISE_FLOOR_K * per_band[b]):
                 beyond.append({"band": b, "device": d, "ref_vs_ref": per_band[b]})
         if ratios:
             rr["device_over_ref_vs_ref"] = {"p50": float(np.median(ratios)), "p99": float(np.percentile(ratios, 99)), "max": float(np.max(ratios)),
@@ -318,9 +319,11 @@ def main():
         dist.barrier()
     kernel_ms = []
     t0 = time.perf_counter()
+    clock_mhz = []
     for _ in range(args.steps):
         best = step()
         kernel_ms.append(s.last_kernel_ms())            # HIP events on the launch stream
+        clock_mhz.append(s.last_shader_clock_mhz())     # (step() has synchronised the stream: a 32-byte read)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -416,6 +419,10 @@ def main():
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,
                          "kernel": "teb_optimize_kernel", "kernel_ms": kms,
+                         "shader_clock_mhz": {"mean": float(np.mean(clock_mhz)), "min": float(np.min(clock_mhz)), "max": float(np.max(clock_mhz)),
+                                              "what": "cycle counter / 100 MHz real-time counter between entry and exit of the kernel's first workgroup, "
+                                                      "per timed step: boxes of the pool sustain 2.05 - 2.35 GHz under this load; kernel_ms x clock = cycles"},
+                         "kernel_mcycles": kms * float(np.mean(clock_mhz)) * 1e-3,
                          "alg_bytes_per_unit": abu, "alg_bytes_per_launch": alg_bytes_launch},
         }
         if sustained:
@@ -631,6 +638,9 @@ def main():
                     num_vs_ref = RC.compare_with_reference_code(out_n, res_n, tr_n, ref_pack[0], ref_pack[1], ref_pack[2], ref_pack[4])
                     num_vs_ref["outside"] = num_vs_ref["outside"][:8]; num_vs_ref["pose_count_mismatch"] = num_vs_ref["pose_count_mismatch"][:8]
                     num_vs_ref["mode"] = "g2o_numeric (the reference's own linearisation scheme)"
+                    num_vs_ref["best_index"] = {"device": int(s4n.select_best(-1, -1)[0]), "reference_code": int(RC.select_best_of_costs(ref_pack[2]))}
+                    num_vs_ref["best_index_equal"] = bool(num_vs_ref["best_index"]["device"] == num_vs_ref["best_index"]["reference_code"])
+                    num_vs_ref["ref_vs_ref"] = noise_floor(RC, c4n, o4n, v4n, b4n, ref_pack, out_n, B, numeric_mode=True)
             except Exception as e:   # noqa: BLE001
                 num_vs_ref = {"error": str(e)[:200]}
             s4n.close()
@@ -640,6 +650,23 @@ def main():
                             "scheme: 1 + 2 x #columns residual evaluations per edge",
                 "kernel_ms": kn, "ms_per_step": wn, "units_per_step": un, "value": un / (wn * 1e-3), "unit": "TEB.LM-iterations/s",
                 "tebs_ok": int((rn.status == 0).sum()), "vs_reference_code": num_vs_ref}
+            # the headline workload OFF the kernels specialised on the TebConfig defaults: the generic instantiation
+            # forced (teb_amd_options_t::generic_config_path), and one flag changed - three via-points on the candidates' corridor with
+            # weight_viapoint 1 -, which the profile of the defaults does not fold (last_config_profile says which kernel ran)
+            for nm, mk_opt, what in (("c4_generic_config_path", lambda: (scenes.scene_c4(B=B, n=n, stride=STRIDE), _abi.Options(generic_config_path=True)),
+                                      "the headline workload, generic kernel instantiation forced (no configuration folded at compile time)"),
+                                     ("c4_with_via_points", lambda: (scenes.scene_c4_via(B=B, n=n, stride=STRIDE), None),
+                                      "the headline workload + 3 via-points, weight_viapoint 1 (EdgeViaPoint, src/optimal_planner.cpp:675-718)")):
+                (cc, oo, vv, bb), opt = mk_opt()
+                sx = planner.make_solver(cc, oo, vv, bb, options=opt)
+                sx.snapshot()
+                kx, wx, rx = time_solver(torch, sx, cc, 5)
+                prof = bool(sx.last_config_profile())
+                sx.close()
+                ux = int(rx.lm_iterations.sum())
+                sec[nm] = {"workload": what, "kernel_ms": kx, "ms_per_step": wx, "units_per_step": ux, "value": ux / (wx * 1e-3),
+                           "unit": "TEB.LM-iterations/s", "tebs_ok": int((rx.status == 0).sum()), "kernel_specialised_on_the_configuration": prof,
+                           "vs_headline_kernel_ms": kx / float(np.mean(kernel_ms))}
             for nm, mk, what in (("c3_autosize_on", lambda: scenes.scene_c3(stride=208), "C3: 64 candidate TEBs x 150 poses, 200 point obstacles"),
                                  ("c2_autosize_on", lambda: scenes.scene_c2(stride=232), "C2: 1 TEB x 200 poses, 100 point obstacles"),
                                  ("c5_carlike_polygons", lambda: scenes.scene_c5(stride=343),

@@ -559,6 +559,10 @@ int  teb_amd_broadcast_band(teb_amd_handle_t* h, teb_amd_comm_t* comm, int32_t o
 /* Duration [ms] of the last optimize_batch call on the device, measured with HIP events on the launch stream: from before the
  * (first) kernel launch to after the last one, i.e. including a repeated launch when autoResize outgrew the optimistic layout. */
 int  teb_amd_last_kernel_ms(teb_amd_handle_t* h, float* ms);
+/* Shader clock [MHz] the last optimise kernel ran at: shader-cycle counter / 100 MHz real-time counter between entry and exit of its
+ * first workgroup. The boxes of a pool sustain different clocks under the same load; a measurement quotes it so that a slow box is not
+ * read as a regression. */
+int  teb_amd_last_shader_clock_mhz(teb_amd_handle_t* h, double* mhz);
 /* LDS bytes per workgroup and the largest pose count this build can optimise. */
 int  teb_amd_capacity(teb_amd_handle_t* h, int32_t* lds_bytes, int32_t* max_poses_supported);
 

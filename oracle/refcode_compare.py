@@ -87,6 +87,7 @@ def run_device_traced(planner, cfg, obst, via, batch, options=None):
     s.optimize(cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations, True, cfg.hcp.selection_obst_cost_scale,
                cfg.hcp.selection_viapoint_cost_scale, cfg.hcp.selection_alternative_time_cost)
     res = s.results()
+    res.best_index = int(s.select_best(-1, -1)[0])   # the device's selectBestTeb (select_best_kernel) on the resident costs
     out = s.download(batch.copy())
     traces = [s.iteration_log(b) for b in range(batch.count)]
     ms = s.last_kernel_ms()

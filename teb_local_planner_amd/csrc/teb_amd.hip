@@ -176,6 +176,7 @@ struct teb_amd_handle {
   DevBuf<int> n, has_vs, has_vg, rotdir, via_en, status, optimized, iters, trials, assoc_cnt, assoc, assoc_ovf, via_pose, legacy_idx;
   DevBuf<double> x, y, th, dt, vs, vg, chi2, cost, lambda, Hbackup, Hband, ob_x, ob_y, ob_th, ob_dt;   // ob_*: strips before an optimistic launch
   DevBuf<int> ob_n;
+  DevBuf<long long> clk;   // BatchDev::clk
   // multi-CU mode (teb_multicu.hpp): control words, published poses, distance records; sized on first use
   DevBuf<unsigned> mcu_ctl;
   DevBuf<double> pack_dev;          // packed messages of small batches (kPackMaxDoubles)
@@ -273,6 +274,7 @@ BatchDev batch_of(teb_amd_handle* h) {
   b.assoc_overflow = h->assoc_ovf.p; b.legacy_idx = h->legacy_idx.p;
   b.via_pose = h->via_pose.p; b.via_cap = h->max_via > 0 ? h->max_via : 1;
   b.Hbackup = h->Hbackup.p; b.hmat_stride = h->hmat_stride;
+  b.clk = h->clk.p;
   return b;
 }
 
@@ -707,6 +709,7 @@ int teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max
   A(h->vs.alloc(3 * (size_t)max_tebs)); A(h->vg.alloc(3 * (size_t)max_tebs));
   A(h->chi2.alloc(max_tebs)); A(h->cost.alloc(max_tebs)); A(h->lambda.alloc(max_tebs));
   A(h->Hbackup.alloc((size_t)max_tebs * h->hmat_stride));
+  A(h->clk.alloc(4));
   h->hband_stride = solver == SOLVER_BANDG ? (size_t)4 * max_poses * kBand : 0;
   A(h->Hband.alloc((size_t)max_tebs * h->hband_stride));
   A(h->snap_n.alloc(max_tebs)); A(h->snap_x.alloc(BS)); A(h->snap_y.alloc(BS)); A(h->snap_th.alloc(BS)); A(h->snap_dt.alloc(BS));
@@ -1220,19 +1223,20 @@ int teb_amd_select_best_distributed(teb_amd_handle_t* h, teb_amd_comm_t* c, int3
     if (hipGetLastError() != hipSuccess) { local = TEB_AMD_ERR_HIP; why = "local selection kernels failed to launch"; }
   }
   if (local != TEB_AMD_OK) {
-    const double none[2] = {1.7976931348623157e308, -1.0};
+    static const double none[2] = {1.7976931348623157e308, -1.0};   // (static: the copy is asynchronous)
     (void)hipMemcpyAsync(c->rec, none, sizeof(none), hipMemcpyHostToDevice, stream);
   }
   NCCLCHK(rccl().AllGather(c->rec, c->all, 2, kRcclFloat64, c->comm, stream));
   std::vector<double> all(2 * (size_t)c->world);
   HIPCHK(hipMemcpyAsync(all.data(), c->all, all.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
   HIPCHK(hipStreamSynchronize(stream));
-  if (local != TEB_AMD_OK) return fail(local, "teb_amd_select_best_distributed: " + why + " (this rank sent an unusable record; its peers were not held up)");
   double bc; int bi, owner;
   world_argmin(all.data(), c->world, &bi, &bc, &owner);
-  *best_global = bi;
+  // the peers' choice is reported even to the rank that failed (it has to follow them into teb_amd_broadcast_band, a collective too)
+  if (best_global) *best_global = bi;
   if (best_cost) *best_cost = bc;
   if (owner_rank) *owner_rank = owner;
+  if (local != TEB_AMD_OK) return fail(local, "teb_amd_select_best_distributed: " + why + " (this rank sent an unusable record; its peers were not held up)");
   return TEB_AMD_OK;
 }
 
@@ -2466,6 +2470,18 @@ int teb_amd_debug_mcu_watchdog(teb_amd_handle_t* h, int32_t milliseconds) {
 }
 
 // diagnostic of the multi-CU mode: 1 = the association stays with the band's own workgroup, 2 = the distances do (bisecting a difference)
+int teb_amd_last_shader_clock_mhz(teb_amd_handle_t* h, double* mhz) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!mhz || !h->timed) return fail(TEB_AMD_ERR_INVALID_ARG, "no kernel has been launched yet");
+  long long c[4];
+  HIPCHK(hipMemcpyAsync(c, h->clk.p, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const double ticks = (double)(c[3] - c[1]);   // 100 MHz real-time counter
+  *mhz = ticks > 0 ? (double)(c[2] - c[0]) / ticks * 100.0 : 0.0;
+  return TEB_AMD_OK;
+}
+
 int teb_amd_debug_last_config_profile(teb_amd_handle_t* h, int32_t* defaults_profile) {
   int rc = check_handle(h);
   if (rc) return rc;
@@ -2481,16 +2497,6 @@ int teb_amd_debug_mcu_flags(teb_amd_handle_t* h, int32_t flags) {
   return TEB_AMD_OK;
 }
 
-#ifdef TEB_MCU_VERIFY
-extern "C" int teb_amd_debug_mcu_verify(teb_amd_handle_t* h, double* out16) {
-  (void)h;
-  unsigned long long c[8]; double v[8];
-  HIPCHK(hipMemcpyFromSymbol(c, HIP_SYMBOL(tebamd::g_mcu_verify), sizeof c));
-  HIPCHK(hipMemcpyFromSymbol(v, HIP_SYMBOL(tebamd::g_mcu_verify_val), sizeof v));
-  for (int q = 0; q < 8; ++q) { out16[q] = (double)c[q]; out16[8 + q] = v[q]; }
-  return TEB_AMD_OK;
-}
-#endif
 
 int teb_amd_debug_assoc_overflow(teb_amd_handle_t* h, int32_t* flags) {
   int rc = check_handle(h);

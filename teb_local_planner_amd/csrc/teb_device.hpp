@@ -31,10 +31,7 @@
 
 namespace tebamd {
 
-#ifndef TEB_AMD_THREADS
-#define TEB_AMD_THREADS 256
-#endif
-constexpr int kThreads = TEB_AMD_THREADS;   // 4 wave64 per workgroup, one workgroup per candidate TEB
+constexpr int kThreads = 256;   // 4 wave64 per workgroup, one workgroup per candidate TEB (512 = two waves per SIMD: measured in round 2, 1100 - 1600 spill slots, 6.9 vs 4.8 ms)
 constexpr int kWaves = kThreads / 64;
 constexpr int kBand = 11;           // diagonal + scalar half-bandwidth 10
 constexpr int kMaxPoseIter = 2;     // poses handled per thread: n <= kThreads * kMaxPoseIter
@@ -106,6 +103,7 @@ struct BatchDev {
   int via_cap;
   double* Hbackup;  // [B][hmat_stride]
   size_t hmat_stride;
+  long long* clk;   // [4] workgroup 0: shader-clock counter and 100 MHz real-time counter at kernel entry, then at exit (teb_amd_last_shader_clock_mhz)
 };
 
 struct OptArgs {

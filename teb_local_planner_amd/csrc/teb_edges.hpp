@@ -114,7 +114,6 @@ struct Accum {
     // bit-level counterpart in the reference (g2o adds the edges in another order). The fusion is spelled out (fma(), not a contraction
     // pragma that leaves the choice to the optimiser): every instantiation that replays a row - single-CU, multi-CU, any layout - rounds
     // it the same way. -DTEB_AMD_NO_ROW_FMA: separate mul / add (C4 with 200 fixed poses + 5 %, C2 / C3 + 3 %, headline + 2 %).
-#ifndef TEB_AMD_NO_ROW_FMA
     chi[cat] = fma(e, w * e, chi[cat]);
     if (JAC) {
 #pragma unroll
@@ -129,22 +128,6 @@ struct Accum {
         }
       }
     }
-#else
-    chi[cat] += e * (w * e);
-    if (JAC) {
-#pragma unroll
-      for (int a = 0; a < 11; ++a) {
-        if (!((MASK >> a) & 1u)) continue;
-        double ra = r[a] * w;
-        g[a] += ra * e;
-#pragma unroll
-        for (int b = 0; b <= a; ++b) {
-          if (!((MASK >> b) & 1u)) continue;
-          H[a * (a + 1) / 2 + b] += ra * r[b];
-        }
-      }
-    }
-#endif
   }
 };
 

@@ -28,10 +28,6 @@ namespace tebamd {
 #define PROF_END(k)
 #endif
 
-#ifdef TEB_MCU_VERIFY
-__device__ unsigned long long g_mcu_verify[8];   // records checked | evaluate: dist differs, grad differs | linearise: dist differs, only grad differs
-__device__ double g_mcu_verify_val[8];
-#endif
 #ifdef TEB_PROFILE
 __device__ long long g_ev_prof[8];   // thread 1 (pose 1) of workgroup 0: evaluate {static, dynamic, chain}, linearise {static, dynamic, chain}, trig, scatter
 #define EVP_DECL long long evp_t0 = clock64(), evp_t1;
@@ -135,19 +131,7 @@ __device__ __forceinline__ double dpp_move(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
-// the value of lane SRC (0..7) of each aligned group of 8 lanes, for all 8 lanes of the group (ds_swizzle, bit-mask mode: lane id
-// & 0x18 | SRC within each half wave; no LDS memory is touched)
-template <int SRC>
-__device__ __forceinline__ double bcast8(double v) {
-  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), (SRC << 5) | 0x18);
-  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), (SRC << 5) | 0x18);
-  return __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ double wave_sum(double v) {
-#ifdef TEB_AMD_SHFL_REDUCE
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-#else
   {
     const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
     const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
@@ -162,7 +146,6 @@ __device__ __forceinline__ double wave_sum(double v) {
   v += dpp_move<0x104>(v);   // row_shl:4
   v += dpp_move<0x102>(v);   // row_shl:2
   v += dpp_move<0x101>(v);   // row_shl:1
-#endif
   return v;
 }
 template <int K>
@@ -295,20 +278,6 @@ __device__ __forceinline__ unsigned long long dyn_near_mask(const teb_amd_config
   const double far_d = dyn_far_distance(c) + margin;
   const double x = l.sx[i], y = l.sy[i], ti = l.tdyn[i];
   unsigned long long near = 0;
-#ifdef TEB_AMD_SCALAR_OBSTACLES   // (measured: headline +0.5 %, C4 with 200 fixed poses -1 %, C3 -0.3 %: off)
-  typedef const __attribute__((address_space(4))) double* kptr;   // wave-uniform index: scalar loads (see assoc_scan)
-  const kptr gx = (kptr)(unsigned long long)sc.lox, gy = (kptr)(unsigned long long)sc.loy, gr = (kptr)(unsigned long long)sc.lor,
-             gvx = (kptr)(unsigned long long)sc.lovx, gvy = (kptr)(unsigned long long)sc.lovy;
-#pragma unroll 4   // independent chains: at one wave per SIMD only instruction-level parallelism hides the fp64 latency
-  for (int k = kb; k < ke; ++k) {
-    const int p = sc.n_static + k;
-    // pos_ + t*centroid_velocity_ (obstacles.h:382-385)
-    const double ddx = x - (gx[p] + ti * gvx[p]), ddy = y - (gy[p] + ti * gvy[p]);
-    const double d2 = ddx * ddx + ddy * ddy;
-    const double thr = (far_d + gr[p]) * (1.0 + 1e-12) + (MODE == 2 ? 1e-6 : 0.0);
-    if (!(d2 >= thr * thr) || thr <= 0) near |= 1ull << (k - kb);   // non-finite distances count as near
-  }
-#else
 #pragma unroll 4   // independent chains: at one wave per SIMD only instruction-level parallelism hides the fp64 latency
   for (int k = kb; k < ke; ++k) {
     const int p = sc.n_static + k;
@@ -318,7 +287,6 @@ __device__ __forceinline__ unsigned long long dyn_near_mask(const teb_amd_config
     const double thr = (far_d + l.obr[p]) * (1.0 + 1e-12) + (MODE == 2 ? 1e-6 : 0.0);
     if (!(d2 >= thr * thr) || thr <= 0) near |= 1ull << (k - kb);   // non-finite distances count as near
   }
-#endif
   return near;
 }
 // the chunk of the dynamic-obstacle list of slice sl of nsl (multiples of 4)
@@ -333,11 +301,9 @@ __device__ __forceinline__ void dyn_chunk(const SceneDev& sc, int sl, int nsl, i
 // that is near at any position p with |p - r| <= m (triangle inequality), and a superset is all pass 2 needs: the edges it
 // evaluates beyond the true threshold contribute exact zeros, like in the full loop. So each lane keeps (mask, r) per pose it serves
 // (kMaxPoseIter of them, in registers) and recomputes only when its pose has left the disc - or when the graph was rebuilt (r = NaN).
-// m = TEB_NEAR_MARGIN_FACTOR x the culling distance: the wider the disc the rarer the recomputation and the more zero edges in pass 2
+// m = kNearMarginFactor x the culling distance: the wider the disc the rarer the recomputation and the more zero edges in pass 2
 // (headline kernel 4.21 ms without the cache; 4.04 / 3.99 / 3.96 / 3.99 ms at factor 0.5 / 1 / 2 / 3).
-#ifndef TEB_NEAR_MARGIN_FACTOR
-#define TEB_NEAR_MARGIN_FACTOR 1.5
-#endif
+constexpr double kNearMarginFactor = 1.5;   // margin of the cached near masks in units of the culling distance (1, 2, 3 measured: DESIGN.md section 3)
 struct NearCache {
   unsigned long long m0, m1;
   double rx0, ry0, rx1, ry1;
@@ -348,7 +314,7 @@ template <int MODE, bool FAST>
 __device__ __forceinline__ unsigned long long dyn_near_cached(const teb_amd_config_t& c, const SceneDev& sc, const Lds& l, int i, int sl, int nsl,
                                                               NearCache& nc, int pass) {
   if (!(FAST && i >= 1 && c.include_dynamic_obstacles && c.weight_obstacle != 0)) return 0;
-  const double m = nc.off ? 0.0 : TEB_NEAR_MARGIN_FACTOR * dyn_far_distance(c);
+  const double m = nc.off ? 0.0 : kNearMarginFactor * dyn_far_distance(c);
   const double x = l.sx[i], y = l.sy[i];
   const double rx = pass == 0 ? nc.rx0 : nc.rx1, ry = pass == 0 ? nc.ry0 : nc.ry1;
   unsigned long long mask = pass == 0 ? nc.m0 : nc.m1;
@@ -483,20 +449,6 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
             double gr[3] = {0, 0, 0};
             if (JAC) { gr[0] = ld_agent_f64(it + (size_t)(4 * k + 1) * t.stride); gr[1] = ld_agent_f64(it + (size_t)(4 * k + 2) * t.stride);
                        gr[2] = ld_agent_f64(it + (size_t)(4 * k + 3) * t.stride); }
-#ifdef TEB_MCU_VERIFY   // (diagnostic build) the record against the same quantity computed here
-            {
-              double g2[3] = {0, 0, 0};
-              const double d2 = footprint_distance(c, sc, sc.static_idx[ent & kAssocMask], w.x0, w.y0, w.c0, w.s0, false, 0.0, JAC ? g2 : nullptr);
-              const int bad = (d2 != dist ? 1 : 0) | (JAC && (g2[0] != gr[0] || g2[1] != gr[1] || g2[2] != gr[2]) ? 2 : 0);
-              atomicAdd(&g_mcu_verify[0], 1ull);
-              if (bad) {
-                if (atomicAdd(&g_mcu_verify[1 + (bad & 1 ? 0 : 1) + (JAC ? 2 : 0)], 1ull) == 0) {
-                  g_mcu_verify_val[0] = dist; g_mcu_verify_val[1] = d2; g_mcu_verify_val[2] = gr[0]; g_mcu_verify_val[3] = g2[0]; g_mcu_verify_val[4] = gr[2]; g_mcu_verify_val[5] = g2[2];
-                  g_mcu_verify_val[6] = (double)i; g_mcu_verify_val[7] = (double)k;
-                }
-              }
-            }
-#endif
 #pragma unroll 1
             for (int rep = (ent & kAssocTriple) ? 3 : 1; rep > 0; --rep) obstacle_rows_g<JAC>(c, dist, gr, t.w_obst, t.inflated, A);
           }
@@ -854,30 +806,19 @@ __device__ __forceinline__ double fast_rcp(double d) {
 // order); measured effect: 5 - 8 % on the C4 step, parity tests unchanged (poses <= 1e-8, identical LM trial counts).
 #define TEB_SOLVER_FMA _Pragma("clang fp contract(fast)")
 // scheduling fences inside the Schur-product loops of the cyclic reduction (they bound the number of LDS operands in flight)
-#ifndef TEB_CR_FENCE_EVERY
-#define TEB_CR_FENCE_EVERY 4   // rows of a Schur product between two fences
-#endif
-#ifdef TEB_AMD_NO_CR_FENCE
-#define TEB_CR_SCHED_BARRIER
-#else
+#define TEB_CR_FENCE_EVERY 4   // rows of a Schur product between two fences (1 fence per row, 2 and 8 rows, no fence: measured)
 #define TEB_CR_SCHED_BARRIER __builtin_amdgcn_sched_barrier(0);
-#endif
 // Pairs of consecutive doubles at 16-byte aligned addresses are fetched with one 16-byte access (LDS: ds_read_b128, 256 B/clk, where the
 // 8-byte aligned pair the compiler forms by itself is a ds_read2_b64 at 128 B/clk). Every 8x8 block starts on a 16-byte boundary (kBlk is
 // even, the regions start at even offsets of the 16-byte aligned LDS window / of the hipMalloc'ed scratch) and its rows are 64 bytes.
 template <int N>
 __device__ __forceinline__ void ld_row(const double* __restrict__ p, double* out) {   // out[0 .. N) = p[0 .. N), p 16-byte aligned
-#ifdef TEB_AMD_NO_B128
-#pragma unroll
-  for (int t = 0; t < N; ++t) out[t] = p[t];
-#else
 #pragma unroll
   for (int t = 0; t + 1 < N; t += 2) {
     const teb_v2d v = *reinterpret_cast<const teb_v2d*>(p + t);
     out[t] = v.x; out[t + 1] = v.y;
   }
   if (N & 1) out[N - 1] = p[N - 1];
-#endif
 }
 struct Ldl8 {   // in-place LDL^T of one 8x8 SPD block: a[r(r+1)/2 + c] holds l_rc (r > c) and 1/d_r on the diagonal
   double a[36];
@@ -959,9 +900,11 @@ __device__ long long g_crw_prof[32];   // per group width (8, 16, 32, 64 lanes):
 // of the three Schur products and, of that column, the rows q R .. q R + R - 1 (R = 8 / M); the factorisation of D_i and the three
 // triangular solves are repeated by the M lanes that share a column (they cost latency, not throughput, at the levels where M > 1: there
 // the machine is mostly idle). Every output element is summed in the same order for every M, so the result does not depend on M.
+// bD / bF: distance in doubles between consecutive block rows of the system in D, L / in f (kBlk / 8 for a contiguous system; the
+// interface rows of the partitioned solve are reduced where they lie, every q-th block row: q kBlk / 8 q).
 template <int M>
 __device__ __forceinline__ bool cr_forward_round(double* __restrict__ D, double* __restrict__ L, double* __restrict__ f, int Nb, int s,
-                                                 int e0, int E) {
+                                                 int e0, int E, int bD = kBlk, int bF = 8) {
   TEB_SOLVER_FMA
   constexpr int R = 8 / M;
   constexpr int kW = M == 1 ? 0 : M == 2 ? 1 : M == 4 ? 2 : 3;   // (profiling build) row of the per-width counters
@@ -977,16 +920,16 @@ __device__ __forceinline__ bool cr_forward_round(double* __restrict__ D, double*
   double s1 = 0, s2 = 0;
   CRR_DECL
   if (act) {
-    const double* Di = D + i * kBlk;
-    const double* Li = L + i * kBlk;
-    const double* Lp = L + (i + s) * kBlk;   // U_i^T, valid iff hasU
+    const double* Di = D + i * bD;
+    const double* Li = L + i * bD;
+    const double* Lp = L + (i + s) * bD;   // U_i^T, valid iff hasU
     Ldl8 F;
     F.load(Di);
     ok = F.factor();
     CRR(0);
     double cu[8];
     ld_row<8>((hasU ? Lp : Li) + c * 8, cu);   // row c of L_{i+s} (an address inside the blocks even without an upper neighbour)
-    ld_row<8>(f + i * 8, wf);
+    ld_row<8>(f + i * bF, wf);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       wL[k] = Li[k * 8 + c];
@@ -1026,31 +969,31 @@ __device__ __forceinline__ bool cr_forward_round(double* __restrict__ D, double*
   // L_{i+s}, f_i) belong to exactly one group, a group never straddles two waves (8 M <= 64), and the survivors' D / f are only written
   // (never read) in this level.
   if (act) {
-    double* Dm = D + (i - s) * kBlk;
-    double* Di = D + i * kBlk;
-    double* Li = L + i * kBlk;
+    double* Dm = D + (i - s) * bD;
+    double* Di = D + i * bD;
+    double* Li = L + i * bD;
 #pragma unroll
     for (int t = 0; t < R; ++t) Dm[(a0 + t) * 8 + c] -= o1[t];
     if (hasU) {
-      double* Lp = L + (i + s) * kBlk;
+      double* Lp = L + (i + s) * bD;
 #pragma unroll
       for (int t = 0; t < R; ++t) Lp[(a0 + t) * 8 + c] = o2[t];
     }
     if (q == 0) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) { Di[k * 8 + c] = wL[k]; Li[k * 8 + c] = wU[k]; }
-      f[(i - s) * 8 + c] -= s1;
-      f[i * 8 + c] = wf[c];
+      f[(i - s) * bF + c] -= s1;
+      f[i * bF + c] = wf[c];
     }
   }
   CRR(3);
   __syncthreads();
   CRR(4);
   if (hasU) {
-    double* Dp = D + (i + s) * kBlk;
+    double* Dp = D + (i + s) * bD;
 #pragma unroll
     for (int t = 0; t < R; ++t) Dp[(a0 + t) * 8 + c] -= o3[t];
-    if (q == 0) f[(i + s) * 8 + c] -= s2;
+    if (q == 0) f[(i + s) * bF + c] -= s2;
   }
   __syncthreads();
   CRR(5);
@@ -1062,18 +1005,15 @@ __device__ __forceinline__ bool cr_forward_round(double* __restrict__ D, double*
 // alone on a CU (tools/micro/cr_round_bench.hip): 5.1 k cycles per round with 8-lane groups, 3.9 k with 32, 3.3 k with 64; 16-lane groups
 // gain too little to pay for their code (-DTEB_CR_NARROW_ONLY: 8-lane groups everywhere).
 __device__ __forceinline__ bool cr_forward(double* __restrict__ D, double* __restrict__ L, double* __restrict__ f, int Nb, int s_lo,
-                                           int s_hi) {
+                                           int s_hi, int bD = kBlk, int bF = 8) {
   bool ok = true;
   for (int s = s_lo; s < s_hi; s <<= 1) {
     const int E = (Nb - 1 - s) / (2 * s) + 1;
     for (int e0 = 0; e0 < E; e0 += kThreads / 8) {
       const int left = E - e0;
-#ifndef TEB_CR_NARROW_ONLY
-      if (left <= kThreads / 64) ok = cr_forward_round<8>(D, L, f, Nb, s, e0, E) && ok;
-      else if (left <= kThreads / 32) ok = cr_forward_round<4>(D, L, f, Nb, s, e0, E) && ok;
-      else
-#endif
-        ok = cr_forward_round<1>(D, L, f, Nb, s, e0, E) && ok;
+      if (left <= kThreads / 64) ok = cr_forward_round<8>(D, L, f, Nb, s, e0, E, bD, bF) && ok;
+      else if (left <= kThreads / 32) ok = cr_forward_round<4>(D, L, f, Nb, s, e0, E, bD, bF) && ok;
+      else ok = cr_forward_round<1>(D, L, f, Nb, s, e0, E, bD, bF) && ok;
     }
   }
   return ok;
@@ -1091,7 +1031,7 @@ __device__ __forceinline__ bool cr_forward(double* __restrict__ D, double* __res
 // B(k = l >> 4, n = l & 15) and C(m = (l >> 4) + 4 r, n = l & 15), r = 0..3 (checked on the device by teb_amd_debug_mfma_selftest).
 typedef double v4d __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bool cr_forward_mfma(double* __restrict__ D, double* __restrict__ L, double* __restrict__ f, int Nb, int s_lo,
-                                                int s_hi) {
+                                                int s_hi, int bD = kBlk, int bF = 8) {
   TEB_SOLVER_FMA
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int grp = tid >> 3, c = tid & 7;
@@ -1111,7 +1051,7 @@ __device__ __forceinline__ bool cr_forward_mfma(double* __restrict__ D, double* 
       for (int q = 0; q < 8; ++q) {
         const int eq = e0 + 8 * wv + q, iq = s * (2 * eq + 1);
         const bool v = left ? (eq < E) : (eq < E && iq + s < Nb);
-        const double* src = left ? L + iq * kBlk + am : L + (iq + s) * kBlk + an * 8;   // L_i[k][m]  |  L_{i+s}[m - 8][k]
+        const double* src = left ? L + iq * bD + am : L + (iq + s) * bD + an * 8;   // L_i[k][m]  |  L_{i+s}[m - 8][k]
         const int st = left ? 8 : 1;
         A0[q] = v ? src[ak * st] : 0.0;
         A1[q] = v ? src[(ak + 4) * st] : 0.0;
@@ -1119,9 +1059,9 @@ __device__ __forceinline__ bool cr_forward_mfma(double* __restrict__ D, double* 
       double wL[8], wU[8], wf[8];
       double s1 = 0, s2 = 0;
       if (act) {
-        double* Di = D + i * kBlk;
-        double* Li = L + i * kBlk;
-        const double* Lp = L + (i + s) * kBlk;   // U_i^T, valid iff hasU
+        double* Di = D + i * bD;
+        double* Li = L + i * bD;
+        const double* Lp = L + (i + s) * bD;   // U_i^T, valid iff hasU
         Ldl8 F;
         F.load(Di);
         ok = F.factor() && ok;
@@ -1130,7 +1070,7 @@ __device__ __forceinline__ bool cr_forward_mfma(double* __restrict__ D, double* 
         for (int k = 0; k < 8; ++k) {
           cl[k] = wL[k] = Li[k * 8 + c];
           cu[k] = wU[k] = hasU ? Lp[c * 8 + k] : 0.0;
-          wf[k] = f[i * 8 + k];
+          wf[k] = f[i * bF + k];
         }
         F.solve3(wL, wU, wf);
 #pragma unroll
@@ -1146,7 +1086,7 @@ __device__ __forceinline__ bool cr_forward_mfma(double* __restrict__ D, double* 
         const int eq = e0 + 8 * wv + q, iq = s * (2 * eq + 1);
         C[q] = v4d{0.0, 0.0, 0.0, 0.0};
         if (eq < E) {
-          const double* W = (left ? D : L) + iq * kBlk + an;   // W_L | W_U, entry (k, n)
+          const double* W = (left ? D : L) + iq * bD + an;   // W_L | W_U, entry (k, n)
           const double b0 = W[ak * 8], b1 = W[(ak + 4) * 8];
           C[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[q], b0, C[q], 0, 0, 0);
           C[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[q], b1, C[q], 0, 0, 0);
@@ -1157,29 +1097,29 @@ __device__ __forceinline__ bool cr_forward_mfma(double* __restrict__ D, double* 
       for (int q = 0; q < 8; ++q) {
         const int eq = e0 + 8 * wv + q, iq = s * (2 * eq + 1);
         if (eq < E && left) {
-          double* Dm = D + (iq - s) * kBlk;
+          double* Dm = D + (iq - s) * bD;
           Dm[ak * 8 + am] -= C[q][0];
           Dm[(ak + 4) * 8 + am] -= C[q][1];
           if (iq + s < Nb) {
-            double* Lq = L + (iq + s) * kBlk;
+            double* Lq = L + (iq + s) * bD;
             Lq[ak * 8 + am] = -C[q][2];
             Lq[(ak + 4) * 8 + am] = -C[q][3];
           }
         }
       }
-      if (act) { f[(i - s) * 8 + c] -= s1; f[i * 8 + c] = wf[c]; }
+      if (act) { f[(i - s) * bF + c] -= s1; f[i * bF + c] = wf[c]; }
       __syncthreads();
       // phase 2: D_{i+s} -= C(8:16, 8:16)   (lanes n >= 8)
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int eq = e0 + 8 * wv + q, iq = s * (2 * eq + 1);
         if (eq < E && !left && iq + s < Nb) {
-          double* Dp = D + (iq + s) * kBlk;
+          double* Dp = D + (iq + s) * bD;
           Dp[ak * 8 + an] -= C[q][2];
           Dp[(ak + 4) * 8 + an] -= C[q][3];
         }
       }
-      if (hasU) f[(i + s) * 8 + c] -= s2;
+      if (hasU) f[(i + s) * bF + c] -= s2;
       __syncthreads();
     }
   }
@@ -1233,7 +1173,7 @@ __device__ __forceinline__ bool cr_top(const double* __restrict__ D, double* __r
 }
 // back substitution for the levels s_from, s_from / 2, .., s_to
 __device__ __forceinline__ void cr_backward(const double* __restrict__ D, const double* __restrict__ L, double* __restrict__ f, int Nb,
-                                            int s_from, int s_to) {
+                                            int s_from, int s_to, int bD = kBlk, int bF = 8) {
   TEB_SOLVER_FMA
   const int tid = threadIdx.x;
   for (int s = s_from; s >= s_to; s >>= 1) {
@@ -1241,20 +1181,20 @@ __device__ __forceinline__ void cr_backward(const double* __restrict__ D, const 
     for (int u = tid; u < E * 8; u += kThreads) {
       const int e = u >> 3, r = u & 7;
       const int i = s * (2 * e + 1);
-      double acc = f[i * 8 + r], acc2 = 0;
+      double acc = f[i * bF + r], acc2 = 0;
       double WL[8], xm[8];
-      ld_row<8>(D + i * kBlk + r * 8, WL);
-      ld_row<8>(f + (i - s) * 8, xm);
+      ld_row<8>(D + i * bD + r * 8, WL);
+      ld_row<8>(f + (i - s) * bF, xm);
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc -= WL[k] * xm[k];
       if (i + s < Nb) {
         double WU[8], xp[8];
-        ld_row<8>(L + i * kBlk + r * 8, WU);
-        ld_row<8>(f + (i + s) * 8, xp);
+        ld_row<8>(L + i * bD + r * 8, WU);
+        ld_row<8>(f + (i + s) * bF, xp);
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc2 -= WU[k] * xp[k];
       }
-      f[i * 8 + r] = acc + acc2;
+      f[i * bF + r] = acc + acc2;
     }
     __syncthreads();
   }
@@ -1265,8 +1205,6 @@ __device__ __forceinline__ void cr_backward(const double* __restrict__ D, const 
 // -DTEB_AMD_INLINE_SOLVE builds the inlined variant (4.1 GB per launch, 18 % slower: it spills inside the loops instead).
 #ifdef TEB_AMD_INLINE_SOLVE
 #define TEB_SOLVE_LINKAGE __forceinline__
-#elif defined(TEB_AMD_SOLVE_CSR)
-#define TEB_SOLVE_LINKAGE __noinline__
 #else
 #define TEB_SOLVE_LINKAGE __noinline__ __attribute__((not_tail_called))
 #endif
@@ -1458,7 +1396,6 @@ __device__ __forceinline__ void cr_copy_band(const Lds& l, int n, double* __rest
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
-#ifndef TEB_AMD_BAND_COPY_V1
     // rows [0, Nt): a linear copy, two doubles per access (the band starts on a 16-byte boundary in LDS and in the scratch, Nt * kBand is
     // even); the padding rows [Nt, 8 Nb) of an odd pose count become identity rows
     typedef double __attribute__((address_space(1))) gdouble_t;
@@ -1466,12 +1403,6 @@ __device__ __forceinline__ void cr_copy_band(const Lds& l, int n, double* __rest
     const int live = Nt * kBand;
     for (int q = 2 * tid; q < live; q += 2 * kThreads) *reinterpret_cast<gv2d_t*>((gdouble_t*)gband + q) = *reinterpret_cast<const teb_v2d*>(Hb + q);
     for (int q = live + tid; q < Nb * 8 * kBand; q += kThreads) gband[q] = ((q - live) % kBand) == 0 ? 1.0 : 0.0;
-#else
-    for (int q = tid; q < Nb * 8 * kBand; q += kThreads) {
-      const int r = q / kBand;
-      gband[q] = r < Nt ? Hb[q] : ((q - r * kBand) == 0 ? 1.0 : 0.0);
-    }
-#endif
   }
   __threadfence_block();
   __syncthreads();
@@ -1506,11 +1437,7 @@ template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const Ld
   // coupled by their original L blocks) and are reduced by its levels, which need no extra round for them (Nc = 80 instead of 72 rows at
   // 287 poses: 40 / 20 / 10 / 5 / 2 / 1 eliminations instead of 36 / 18 / 9 / 4 / 2 / 1, seven rounds either way) - as long as
   // the larger compact system fits the band region. Compact row j is block row 2 j for j <= E0 and block row j + E0 beyond.
-#ifndef TEB_AMD_HYBRID_THREE_ROUNDS
   const int E0 = (E > 2 * (kThreads / 8) && (size_t)(Nb - 2 * (kThreads / 8)) * (2 * kBlk + 8) <= (size_t)4 * plan.S * kBand) ? 2 * (kThreads / 8) : E;
-#else
-  const int E0 = E;
-#endif
   const int Nc = Nb - E0;   // (= the even rows alone, (Nb + 1) / 2, when every odd row is eliminated at level 0)
 #define TEB_HYB_ROW(j) ((j) <= E0 ? 2 * (j) : (j) + E0)
   // Hg: the band copy, entry (r, c), c <= r <= c + 10, at Hg[r * 11 + (r - c)]. In terms of 8x8 blocks:
@@ -1595,38 +1522,42 @@ template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const Ld
         const double fm = fc[e * 8 + c];
 #pragma unroll
         for (int aa = 0; aa < 8; ++aa) { o1[aa] = 0; o2[aa] = 0; o3[aa] = 0; }
-        // The operands of the products are already in the group: lane aa holds column aa of L_i (cl) and row aa of L_{i+1} (cu). They are
-        // broadcast inside the group (bcast8) instead of being gathered a second time from the band copy: 98 L2 loads per lane less.
-#ifdef TEB_AMD_LEVEL0_RELOAD
-#define TEB_L0_LI(k, aa) Hi[(k) * kBand + (8 + (k) - (aa))]
-#define TEB_L0_LP(aa, k) Hp[(aa) * kBand + (8 + (aa) - (k))]
-#else
-#define TEB_L0_LI(k, aa) bcast8<aa>(cl[k])
-#define TEB_L0_LP(aa, k) bcast8<aa>(cu[k])
-#endif
+        // The operands of the products are already in the group: lane aa holds column aa of L_i (cl) and row aa of L_{i+1} (cu). They reach
+        // the other lanes through LDS in 16-byte accesses: every lane writes its 8 values as one 64-byte row of a scratch block, "column aa
+        // of L_i" is then one contiguous read for all 8 lanes (a ds_swizzle moves 4 bytes per lane and instruction through the same pipe:
+        // 196 of them per round made level 0 the most expensive round of the solve). The scratch is the L block of compact row e + 1, which
+        // this group writes below (o2) and nobody reads before; the one elimination without an upper neighbour takes the L block of
+        // compact row 0, which is never used. Same products in the same order: bit-identical.
+        double* scr = Lc + (hasU ? e + 1 : 0) * kBlk;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          if (0 >= k - 2) o1[0] += TEB_L0_LI(k, 0) * wL[k];                               // (L_i^T W_L)[aa][c]
-          if (1 >= k - 2) o1[1] += TEB_L0_LI(k, 1) * wL[k];
-          if (2 >= k - 2) o1[2] += TEB_L0_LI(k, 2) * wL[k];
-          if (3 >= k - 2) o1[3] += TEB_L0_LI(k, 3) * wL[k];
-          if (4 >= k - 2) o1[4] += TEB_L0_LI(k, 4) * wL[k];
-          if (5 >= k - 2) o1[5] += TEB_L0_LI(k, 5) * wL[k];
-          o1[6] += TEB_L0_LI(k, 6) * wL[k];
-          o1[7] += TEB_L0_LI(k, 7) * wL[k];
-          s1 += cl[k] * wf[k];                                                             // (L_i^T P f_i)[c]
+        for (int k = 0; k < 8; k += 2) *reinterpret_cast<teb_v2d*>(scr + c * 8 + k) = teb_v2d{cl[k], cl[k + 1]};
+#pragma unroll
+        for (int aa = 0; aa < 8; ++aa) {
+          double lc[8];                                    // column aa of L_i
+          ld_row<8>(scr + aa * 8, lc);
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (aa >= k - 2) o1[aa] += lc[k] * wL[k];                                       // (L_i^T W_L)[aa][c]
+          if ((aa % TEB_CR_FENCE_EVERY) == TEB_CR_FENCE_EVERY - 1) { TEB_CR_SCHED_BARRIER }
         }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s1 += cl[k] * wf[k];                                    // (L_i^T P f_i)[c]
         if (hasU) {
-#define TEB_L0_ROW(aa)                                                                  \
-          _Pragma("unroll") for (int k = 0; k < 8; ++k) {                               \
-            if (k >= aa - 2) {                                                          \
-              const double lp = TEB_L0_LP(aa, k);                     /* L_{i+1}[aa][k] */ \
-              o2[aa] -= lp * wL[k];                                                     \
-              o3[aa] += lp * wU[k];                                                     \
-            }                                                                           \
+#pragma unroll
+          for (int k = 0; k < 8; k += 2) *reinterpret_cast<teb_v2d*>(scr + c * 8 + k) = teb_v2d{cu[k], cu[k + 1]};
+#pragma unroll
+          for (int aa = 0; aa < 8; ++aa) {
+            double lp[8];                                  // row aa of L_{i+1}
+            ld_row<8>(scr + aa * 8, lp);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              if (k >= aa - 2) {
+                o2[aa] -= lp[k] * wL[k];
+                o3[aa] += lp[k] * wU[k];
+              }
+            }
+            if ((aa % TEB_CR_FENCE_EVERY) == TEB_CR_FENCE_EVERY - 1) { TEB_CR_SCHED_BARRIER }
           }
-          TEB_L0_ROW(0) TEB_L0_ROW(1) TEB_L0_ROW(2) TEB_L0_ROW(3) TEB_L0_ROW(4) TEB_L0_ROW(5) TEB_L0_ROW(6) TEB_L0_ROW(7)
-#undef TEB_L0_ROW
 #pragma unroll
           for (int k = 0; k < 8; ++k) s2 += cu[k] * wf[k];                                  // (L_{i+1} P f_i)[c]
         }
@@ -1868,202 +1799,6 @@ __device__ __noinline__ void autoresize_script_lane0(double dt_ref_, double hyst
 }
 
 
-// ---- the same rule machine run by the 64 lanes of wave 0 with its arrays in REGISTERS ----------------------------------------------
-// autoresize_script_lane0 spends ~ 590 cycles per rule step, most of it on LDS round trips of a single lane (the next interval, the
-// emitted descriptors) and on exec-mask bookkeeping: values one lane loaded from LDS count as divergent. Here the time differences of
-// the band live in the registers of wave 0 (lane l holds intervals l, 64 + l, ..), element j is fetched with v_readlane (an SGPR
-// result: every decision is a scalar branch), emitted intervals / descriptors / new-pose records / run records are appended into register
-// chunks (a compare + conditional move per element) and written to the LDS scratch by all lanes at the end. Same rules, same order, same results
-// (tests/test_gpu_parity.py: autoResize tests; the bit fingerprints).
-__device__ __forceinline__ double rl_f64(double v, int lane) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
-}
-// element `lane` of a register "array" := val (val and lane uniform): one compare + conditional moves (this compiler has no writelane builtin)
-__device__ __forceinline__ double wl_f64(double old, double val, int lane) { return ((int)(threadIdx.x & 63) == lane) ? val : old; }
-__device__ __forceinline__ int wl_i32(int old, int val, int lane) { return ((int)(threadIdx.x & 63) == lane) ? val : old; }
-constexpr int kArChunks = 8;   // 64 intervals each: pose capacity 512
-template <typename T>
-__device__ __forceinline__ T ar_sel(const T (&v)[kArChunks], int c) {   // c uniform: a scalar jump, no dynamic register indexing
-  switch (c) { case 0: return v[0]; case 1: return v[1]; case 2: return v[2]; case 3: return v[3]; case 4: return v[4]; case 5: return v[5]; case 6: return v[6]; default: return v[7]; }
-}
-template <typename T>
-__device__ __forceinline__ void ar_put(T (&v)[kArChunks], int c, T x) {
-  switch (c) { case 0: v[0] = x; break; case 1: v[1] = x; break; case 2: v[2] = x; break; case 3: v[3] = x; break; case 4: v[4] = x; break; case 5: v[5] = x; break; case 6: v[6] = x; break; default: v[7] = x; break; }
-}
-// append-only register array: element k goes to lane k & 63 of chunk k >> 6; the chunk under construction is `cur`
-template <typename T> struct ArOut { T done[kArChunks]; T cur; int cchunk; };
-__device__ __forceinline__ void ar_push(ArOut<double>& o, int k, double val) {
-  const int c = k >> 6;
-  if (c != o.cchunk) { ar_put(o.done, o.cchunk, o.cur); o.cchunk = c; o.cur = ar_sel(o.done, c); }
-  o.cur = wl_f64(o.cur, val, k & 63);
-}
-__device__ __forceinline__ void ar_push(ArOut<int>& o, int k, int val) {
-  const int c = k >> 6;
-  if (c != o.cchunk) { ar_put(o.done, o.cchunk, o.cur); o.cchunk = c; o.cur = ar_sel(o.done, c); }
-  o.cur = wl_i32(o.cur, val, k & 63);
-}
-template <typename T> __device__ __forceinline__ void ar_init(ArOut<T>& o) {
-#pragma unroll
-  for (int c = 0; c < kArChunks; ++c) o.done[c] = T(0);
-  o.cur = T(0); o.cchunk = 0;
-}
-__device__ __noinline__ void autoresize_script_wave0(double dt_ref_, double hyst_, int max_samples_, int min_samples_, int off_state_,
-                                                       int off_scratch_, int n_in_, int stride_, int off_out_) {
-  extern __shared__ __attribute__((aligned(16))) double lds_base[];
-  const int lane = threadIdx.x & 63;
-  const double dt_ref = uni(dt_ref_), hyst = uni(hyst_);
-  const int max_samples = uni(max_samples_), min_samples = uni(min_samples_), off_state = uni(off_state_), off_scratch = uni(off_scratch_),
-            n_in = uni(n_in_), stride = uni(stride_);
-  int* res = reinterpret_cast<int*>(lds_base) + uni(off_out_);
-  int ovf = 0;
-  const double* in_dt = lds_base + off_state + 3 * stride;   // Lds: sx sy sth sdt ...
-  double* odt = lds_base + off_scratch;
-  int* out_desc = reinterpret_cast<int*>(odt + 4 * stride);
-  int* rec = out_desc + stride;
-  double* stk_dt = odt + 5 * stride;
-  int* stk_desc = reinterpret_cast<int*>(stk_dt + kSplitStack);
-  const unsigned long long* masks = reinterpret_cast<const unsigned long long*>(stk_dt + kSplitStack + kSplitStack / 2);
-  int* runs = reinterpret_cast<int*>(stk_dt + kSplitStack + kSplitStack / 2 + kActiveMasks);
-  const int Tin = n_in - 1;
-  // the band's time differences into registers
-  double vin[kArChunks];
-#pragma unroll
-  for (int c = 0; c < kArChunks; ++c) { const int idx = 64 * c + lane; vin[c] = idx < Tin ? in_dt[idx] : 0.0; }
-  int in_chunk = 0;
-  double in_cur = vin[0];
-  auto fetch = [&](int j) -> double {   // in_dt[j], j uniform
-    const int c = j >> 6;
-    if (c != in_chunk) { in_chunk = c; in_cur = ar_sel(vin, c); }
-    return rl_f64(in_cur, j & 63);
-  };
-  ArOut<double> o_dt; ArOut<int> o_desc, o_rec, o_runs;
-  ar_init(o_dt); ar_init(o_desc); ar_init(o_rec); ar_init(o_runs);
-  int T = Tin;           // sizeTimeDiffs()
-  int j = 1;             // next unread input interval
-  int sp = 0;            // stack size
-  int k = 0;             // emitted intervals
-  int nn = 0, md = 0;    // new poses, deepest split tree
-  int nruns = 0, tail_k = -1;
-  int mchunk = -1; unsigned long long mcur = 0;   // register copy of the marks of the current chunk
-  bool modified = false;
-  int cdesc = 0, cdepth = 0;
-  double cdt = Tin >= 1 ? fetch(0) : 0.0;
-  bool fresh = true;     // cur is the untouched input interval cdesc (nothing was added to it)
-  double pdt = (j < Tin) ? fetch(j) : 0.0;
-  bool ptouched = false; // an excess was pushed onto the prefetched interval
-  bool alive = Tin >= 1;
-  int top_desc = 0, top_depth = 0; double top_dt = 0;   // register copy of the stack top
-  while (alive) {
-    if (fresh && sp == 0) {
-      const int j0 = cdesc;
-      if ((j0 >> 6) != mchunk) {
-        mchunk = j0 >> 6;
-        unsigned long long mv = mchunk < kActiveMasks ? masks[mchunk] : ~0ull;
-        mcur = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mv >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)mv);
-      }
-      int a = j0;
-      if (!((mcur >> (j0 & 63)) & 1ull)) {
-        a = Tin;
-        unsigned long long m = mcur & (~0ull << (j0 & 63));
-        for (int cidx = mchunk; ; ) {
-          if (m) { a = (cidx << 6) + __ffsll((long long)m) - 1; break; }
-          ++cidx;
-          if (cidx >= kActiveMasks || (cidx << 6) >= Tin) break;
-          unsigned long long mv = masks[cidx];
-          m = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mv >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)mv);
-        }
-        if (a > Tin) a = Tin;
-      }
-      const int len = a - j0;
-      if (len >= 2) {
-        if (k + len > stride - 1) { ovf = 1; break; }
-        ar_push(o_runs, nruns, k | (j0 << 10) | (len << 20));
-        ++nruns;
-        k += len;
-        j = a + 1;
-        if (a < Tin) {
-          cdesc = a; cdepth = 0; cdt = fetch(a); fresh = true;
-          pdt = (j < Tin) ? fetch(j) : 0.0; ptouched = false;
-        } else { alive = false; break; }
-      }
-    }
-    const bool has_next = (sp > 0) || (j < Tin);
-    if (cdt > dt_ref + hyst && T < max_samples) {
-      if (cdt > 2 * dt_ref) {
-        const double newtime = 0.5 * cdt;
-        int edesc, edepth;
-        if (sp > 0) { edesc = top_desc; edepth = top_depth; }
-        else { edesc = (j < Tin) ? j : n_in - 1; edepth = 0; }
-        if (sp >= kSplitStack || nn >= stride) { ovf = 1; break; }
-        const int depth = 1 + (cdepth > edepth ? cdepth : edepth);
-        ar_push(o_rec, nn, cdesc | (edesc << 11) | (depth << 22));
-        md = depth > md ? depth : md;
-        if (sp > 0 && lane == 0) { stk_dt[sp - 1] = top_dt; stk_desc[sp - 1] = top_desc | (top_depth << 16); }   // spill the old top
-        top_desc = kNewPose + nn; top_depth = depth; top_dt = newtime;
-        ++nn; ++sp;
-        cdt = newtime; fresh = false;
-        ++T;
-        modified = true;
-        continue;   // i-- : re-check the left half
-      } else {
-        if (has_next) {
-          if (sp > 0) top_dt += cdt - dt_ref;
-          else { pdt += cdt - dt_ref; ptouched = true; }
-        }
-        cdt = dt_ref; fresh = false;
-      }
-    } else if (cdt < dt_ref - hyst && T > min_samples) {
-      if (has_next) {
-        if (sp > 0) {
-          cdt = top_dt + cdt; --sp;
-          if (sp > 0) { top_dt = uni(stk_dt[sp - 1]); const int e = uni(stk_desc[sp - 1]); top_desc = e & 0xffff; top_depth = e >> 16; }
-        } else {
-          cdt = pdt + cdt; ++j;
-          if (j < Tin) pdt = fetch(j);
-          ptouched = false;
-        }
-        fresh = false;
-        --T;
-        modified = true;
-        continue;
-      } else if (k > 0) {
-        tail_k = k - 1;
-        if (lane == 0) odt[stride - 1] = cdt;   // (slot never used by an emitted interval: k <= stride - 1 intervals)
-        --T;
-        modified = true;
-        alive = false;
-        break;
-      }
-    }
-    // emit cur, advance
-    if (k >= stride - 1) { ovf = 1; break; }
-    ar_push(o_desc, k, cdesc); ar_push(o_dt, k, cdt);
-    ++k;
-    if (sp > 0) {
-      cdesc = top_desc; cdepth = top_depth; cdt = top_dt; --sp; fresh = false;
-      if (sp > 0) { top_dt = uni(stk_dt[sp - 1]); const int e = uni(stk_desc[sp - 1]); top_desc = e & 0xffff; top_depth = e >> 16; }
-    } else if (j < Tin) {
-      cdesc = j; cdepth = 0; cdt = pdt; fresh = !ptouched; ++j;
-      if (j < Tin) pdt = fetch(j);
-      ptouched = false;
-    } else alive = false;
-  }
-  // the register chunks to the LDS scratch, all lanes (the slots of the run records are overwritten by their expansion afterwards)
-  ar_put(o_dt.done, o_dt.cchunk, o_dt.cur); ar_put(o_desc.done, o_desc.cchunk, o_desc.cur);
-  ar_put(o_rec.done, o_rec.cchunk, o_rec.cur); ar_put(o_runs.done, o_runs.cchunk, o_runs.cur);
-#pragma unroll
-  for (int c = 0; c < kArChunks; ++c) {
-    const int idx = 64 * c + lane;
-    if (idx < k) { odt[idx] = o_dt.done[c]; out_desc[idx] = o_desc.done[c]; }
-    if (idx < nn) rec[idx] = o_rec.done[c];
-    if (idx < nruns) runs[idx] = o_runs.done[c];
-  }
-  if (lane == 0) {
-    res[0] = k + 1; res[1] = modified ? 1 : 0; res[2] = ovf; res[3] = nn; res[4] = md; res[5] = nruns; res[6] = tail_k;
-    if (!ovf) out_desc[k] = n_in - 1;   // the goal pose
-  }
-}
-
 // ---- one sweep as chains that run side by side (teb_autoresize_chain.hpp) ---------------------------------------------------------------
 // All lanes: pass A (every input interval starts a chain), pointer doubling over next[] from interval 0, prefix sums over the members,
 // pass B (the members write the edit script). Results in ired[16 .. 22] like autoresize_script_lane0 (no run records). Returns 0 when
@@ -2219,7 +1954,6 @@ __device__ inline int autoresize(const teb_amd_config_t& c, const Lds& l, int n,
     }
     trig = __syncthreads_or(trig);
     if (!trig) break;
-#ifndef TEB_AMD_AUTORESIZE_SEQ
     // the sweep as parallel chains; the sequential machine below takes over when they decline (uniform decision)
     bool by_chains = false;
     if (T < kMaxPoseIter * kThreads) {
@@ -2228,11 +1962,7 @@ __device__ inline int autoresize(const teb_amd_config_t& c, const Lds& l, int n,
       by_chains = uni(autoresize_chains(c.dt_ref, c.dt_hysteresis, c.max_samples, c.min_samples, n, off_state, off_scratch, stride,
                                         (int)(l.red - lds_base))) != 0;
     }
-#else
-    const bool by_chains = false;
-#endif
     if (!by_chains) {
-#ifndef TEB_AMD_AUTORESIZE_WAVE0   // one lane, arrays in LDS (the register-resident variant of wave 0 measured slower: DESIGN.md section 3)
     if (tid == 0) {
 #ifdef TEB_PROFILE
       const long long sw_t0 = clock64();
@@ -2244,19 +1974,6 @@ __device__ inline int autoresize(const teb_amd_config_t& c, const Lds& l, int n,
 #endif
       __threadfence_block();
     } else if (tid >= 64) {
-#else
-    if (tid < 64) {
-#ifdef TEB_PROFILE
-      const long long sw_t0 = clock64();
-#endif
-      autoresize_script_wave0(c.dt_ref, c.dt_hysteresis, c.max_samples, c.min_samples, off_state, off_scratch, n, stride,
-                              (int)(reinterpret_cast<int*>(l.ired + 16) - reinterpret_cast<int*>(lds_base)));
-#ifdef TEB_PROFILE
-      if (tid == 0) { l.ired[12] += (int)(clock64() - sw_t0); l.ired[13] += 1; }
-#endif
-      __threadfence_block();
-    } else {
-#endif
       // meanwhile the other waves refresh cos / sin of the poses as they are now (the cache may date from a rejected LM trial);
       // wave 0 is excluded so that lane 0 is not held up by its own wave
       for (int i = tid - 64; i < n; i += kThreads - 64) { double sv, cv; sincos(l.sth[i], &sv, &cv); l.cs[i] = cv; l.sn[i] = sv; }
@@ -2359,20 +2076,6 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
     for (; k0 < k_hi; k0 += 64) {
       const int ke = k0 + 64 < k_hi ? k0 + 64 : k_hi;
       unsigned long long near = 0;
-#ifdef TEB_AMD_SCALAR_OBSTACLES   // (measured: headline +0.5 %, C4 with 200 fixed poses -1 %, C3 -0.3 %: off)
-      // the obstacle index is wave-uniform: x, y, radius come through the scalar cache (constant address space: s_load), not through the
-      // LDS pipe the four waves share; same values as the LDS cache (teb_amd.hip fills both from the same table), same operations
-      typedef const __attribute__((address_space(4))) double* kptr;
-      const kptr gx = (kptr)(unsigned long long)sc.lox, gy = (kptr)(unsigned long long)sc.loy, gr = (kptr)(unsigned long long)sc.lor;
-#pragma unroll 8
-      for (int k = k0; k < ke; ++k) {
-        const double ddx = x - gx[k], ddy = y - gy[k];
-        const double d2 = ddx * ddx + ddy * ddy;
-        const double thr = (far_d + gr[k]) * (1.0 + 1e-12);
-        if (!(d2 > thr * thr) || thr <= 0) near |= 1ull << (k - k0);   // non-finite distances count as near
-      }
-#else
-#ifndef TEB_AMD_ASSOC_PASS1_V1
       if (TEB_CFG(sc.static_radius_zero, true)) {
         // no radii in the static list (point obstacles): the threshold is one number, hoisted; the mask is built in its two 32-bit halves
         // (the bit of obstacle k is a scalar: a conditional move and an OR per obstacle). Same comparisons on the same values.
@@ -2395,7 +2098,6 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
         near = ((unsigned long long)hi << 32) | lo;
         if (all) near = ke - k0 >= 64 ? ~0ull : ((1ull << (ke - k0)) - 1ull);
       } else
-#endif
       {
 #pragma unroll 4
       for (int k = k0; k < ke; ++k) {
@@ -2405,7 +2107,6 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
         if (!(d2 > thr * thr) || thr <= 0) near |= 1ull << (k - k0);   // non-finite distances count as near
       }
       }
-#endif
       while (near) {
         const int k = k0 + __ffsll((long long)near) - 1;
         near &= near - 1;
@@ -2437,7 +2138,6 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
         const int k = k0 + __ffsll((long long)near) - 1;
         near &= near - 1;
         const int oi = sc.static_idx[k];
-#ifndef TEB_AMD_NO_GENERIC_ASSOC_PRUNE
         // The same bound decides most candidates without their exact distance: one that is certainly not force-included (bound >= force)
         // and certainly not closer than the nearest obstacle found so far on its side (bound >= that minimum; the scan keeps the FIRST
         // minimum, so an equal distance would not replace it either) leaves the scan's state untouched. Bit-identical, C5 14.1 -> 12.9 ms
@@ -2451,7 +2151,6 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
         if (lb >= force && lb >= (on_left ? r.left_min : r.right_min)) continue;
 #ifdef TEB_PROFILE
         atomicAdd(&g_assoc_stats[1], 1ull);
-#endif
 #endif
         const double dist = footprint_distance(c, sc, oi, x, y, ox_, oy_, false, 0.0, nullptr);
         visit(k, dist, sc.cx[oi], sc.cy[oi]);
@@ -2822,6 +2521,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     }
   }
   const int b = blockIdx.x, tid = threadIdx.x, S = bt.stride;
+  if (b == 0 && tid == 0) { bt.clk[0] = clock64(); bt.clk[1] = wall_clock64(); }   // shader clock of this launch (a slow box is not a regression)
   const Lds l = carve(lds_base, plan, SOLVER == SOLVER_BANDG ? args.Hband + (size_t)b * args.hband_stride : nullptr, SOLVER == SOLVER_BANDG);
   McuMaster mm;
   mm.H = (MCU && !FAST) ? mc.D : 0; mm.K = (MCU && SOLVER != SOLVER_BANDG) ? mc.K : 0;
@@ -3156,12 +2856,10 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
         PROF_END(6);
         qmax++;
       } while (rho < 0 && qmax < 10);
-#ifndef TEB_AMD_NO_ITER_LOG   // (A/B switch: what the opt-in log costs the launches that leave it off)
       if (args.iter_log && tid == 0 && iters < args.iter_log_cap) {   // "iteration= i chi2= .. lambda= .. levenbergIter= .." of g2o's verbose mode
         double* row = args.iter_log + ((size_t)b * args.iter_log_cap + iters) * 4;
         row[0] = currentChi; row[1] = lambda; row[2] = (double)qmax; row[3] = (double)n;
       }
-#endif
       ++iters;
       chi2_final = currentChi;
       if (qmax == 10 || rho == 0 || !isfinite(lambda)) lm_ok = false;   // Terminate
@@ -3215,6 +2913,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   }
 #endif
   if (tid == 0) {
+    if (b == 0) { bt.clk[2] = clock64(); bt.clk[3] = wall_clock64(); }
     if (nonfinite) status = TEB_AMD_TEB_NONFINITE;
     bt.n[b] = n;
     bt.status[b] = status; bt.iters[b] = iters; bt.trials[b] = trials; bt.optimized[b] = optimized;

@@ -631,6 +631,19 @@ int TebAmdBatch::selectBestTebDistributed(int last_best_global, int initial_plan
   return best;
 }
 
+// The same collective entered by a rank whose tick failed locally (exploration, signatures, upload, optimise): it contributes the
+// unusable record - no peer can pick it, no peer waits for it - and learns the peers' choice so that it can follow them into
+// broadcastBand. Returns the peers' best global index (-1: nobody has a candidate).
+int TebAmdBatch::selectBestTebDistributedAsFailedRank(int* owner_rank)
+{
+  int32_t best = -1, owner = -1;
+  double bc = 0;
+  if (!comm_) { error_ = "selectBestTebDistributedAsFailedRank: no communicator (setCommunicator)"; return -1; }
+  (void)teb_amd_select_best_distributed(NULL, comm_, global_offset_, -1, -1, &best, &bc, &owner);   // returns this rank's error by design
+  if (owner_rank) *owner_rank = owner;
+  return best;
+}
+
 bool TebAmdBatch::broadcastBand(int owner_rank, int local_index, TimedElasticBand& teb)
 {
   if (!h_ || !comm_) { error_ = "broadcastBand: no communicator (setCommunicator)"; return false; }

@@ -116,6 +116,7 @@ public:
    * owner in *owner_rank. Same arithmetic as selectBestTeb: the rank that owns last_best / initial_plan applies the multipliers.
    */
   int selectBestTebDistributed(int last_best_global, int initial_plan_global, double* best_cost = NULL, int* owner_rank = NULL);
+  int selectBestTebDistributedAsFailedRank(int* owner_rank = NULL);   // a rank whose tick failed still enters the collective (unusable record)
   /** The winner's band from its owner to every rank (collective): `teb` is rebuilt from it on every rank. */
   bool broadcastBand(int owner_rank, int local_index, TimedElasticBand& teb);
 

@@ -56,10 +56,17 @@ bool HomotopyClassPlannerAmd::plan(const PoseSE2& start, const PoseSE2& goal, co
   std::function<bool()> drop;
   if (cfg_->hcp.selection_dropping_probability != 0.0)
     drop = [this]() { return random_() <= cfg_->hcp.selection_dropping_probability * random_.max(); };
+  // In the sharded mode plan() is a collective: a rank on which a step fails must not return before the selection exchange, or its peers
+  // wait in the all-gather for ever. It records the failure, skips the rest of its own work, enters the exchange with the
+  // unusable record, follows the peers through the winner broadcast and returns false afterwards.
+  bool local_ok = true;
   if (!batch_->exploreEquivalenceClassesAndInitTebs(*cfg_, obstacles_, via_points_, cand, best_index, start, goal,
                                                     cfg_->obstacles.min_obstacle_dist, start_vel, free_goal_vel, initial_plan_, &initial_index,
                                                     &drop))
-    return false;
+  {
+    if (!batch_->sharded()) return false;
+    local_ok = false; cand.clear(); initial_index = -1; best_index = -1;
+  }
   tebs_.clear();
   for (const TebOptimalPlannerAmdPtr& p : cand) tebs_.push_back(p);
   initial_plan_teb_ = initial_index >= 0 ? tebs_[initial_index] : TebOptimalPlannerPtr();
@@ -69,8 +76,12 @@ bool HomotopyClassPlannerAmd::plan(const PoseSE2& start, const PoseSE2& goal, co
   equivalence_classes_.clear();
   if (!tebs_.empty())
   {
-    if (!batch_->signatures(*cfg_, values, width)) return false;
-    for (std::size_t b = 0; b < tebs_.size(); ++b)
+    if (!batch_->signatures(*cfg_, values, width))
+    {
+      if (!batch_->sharded()) return false;
+      local_ok = false;
+    }
+    for (std::size_t b = 0; local_ok && b < tebs_.size(); ++b)
     {
       if (cfg_->obstacles.include_dynamic_obstacles)
       {
@@ -85,8 +96,8 @@ bool HomotopyClassPlannerAmd::plan(const PoseSE2& start, const PoseSE2& goal, co
         equivalence_classes_.push_back(std::make_pair(EquivalenceClassPtr(H), false));
       }
     }
-    if (best_index >= 0) best_teb_eq_class_ = equivalence_classes_[best_index].first;
-    if (initial_index >= 0 && initial_plan_) initial_plan_eq_class_ = equivalence_classes_[initial_index].first;
+    if (local_ok && best_index >= 0) best_teb_eq_class_ = equivalence_classes_[best_index].first;
+    if (local_ok && initial_index >= 0 && initial_plan_) initial_plan_eq_class_ = equivalence_classes_[initial_index].first;
   }
   // update via-points if activated: done on the device-side flags and mirrored onto the candidates by the call above (:286-315)
 
@@ -97,7 +108,7 @@ bool HomotopyClassPlannerAmd::plan(const PoseSE2& start, const PoseSE2& goal, co
     return true;
   }
   // ---- optimizeAllTEBs (:466-493): one launch ------------------------------------------------------------------------------------------
-  if (!tebs_.empty())
+  if (local_ok && !tebs_.empty())
   {
     std::vector<TebOptimalPlannerAmd*> raw;
     for (const TebOptimalPlannerAmdPtr& p : cand) raw.push_back(p.get());
@@ -113,10 +124,11 @@ bool HomotopyClassPlannerAmd::plan(const PoseSE2& start, const PoseSE2& goal, co
     if (best_owner_ == rank_ && best_teb_)
       for (std::size_t i = 0; i < tebs_.size(); ++i) if (tebs_[i] == best_teb_) last_global = off + (int)i;
     int owner = -1;
-    const int sel = batch_->selectBestTebDistributed(last_global, initial_global, NULL, &owner);
+    const int sel = local_ok ? batch_->selectBestTebDistributed(last_global, initial_global, NULL, &owner)
+                             : batch_->selectBestTebDistributedAsFailedRank(&owner);
     TebOptimalPlannerPtr previous = best_teb_;
-    if (sel < 0) { best_teb_.reset(); best_global_ = -1; best_owner_ = -1; initial_plan_ = nullptr; return true; }
-    if (owner == rank_)
+    if (sel < 0) { best_teb_.reset(); best_global_ = -1; best_owner_ = -1; initial_plan_ = nullptr; return local_ok; }
+    if (owner == rank_ && local_ok)
       best_teb_ = tebs_[sel - off];
     else
     {
@@ -129,7 +141,7 @@ bool HomotopyClassPlannerAmd::plan(const PoseSE2& start, const PoseSE2& goal, co
     (void)previous;   // the switching_blocking_period rule needs one clock for all ranks: it stays with the caller in the sharded mode
     best_global_ = sel; best_owner_ = owner;
     initial_plan_ = nullptr;
-    return true;
+    return local_ok;
   }
   {
     int last_best = -1;

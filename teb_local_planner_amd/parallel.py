@@ -36,6 +36,11 @@ def local_best(costs, offset=0, last_best=-1, initial_plan=-1, hysteresis=1.0, p
     return best_c, best_i
 
 
+# what a rank contributes when its local selection failed (bad handle, device mismatch, failed launch): it still enters the collective -
+# its peers must not wait for ever - with a record no rank can pick (teb_amd_select_best_distributed does the same inside libteb_amd.so)
+UNUSABLE_RECORD = (float(np.finfo(np.float64).max), -1)
+
+
 def pick_global(records):
     """records: iterable of (cost, global_index). Lowest cost wins, ties -> lowest index; -1 entries ignored."""
     best_c, best_i = np.finfo(np.float64).max, -1

@@ -235,6 +235,14 @@ class TebBatchSolver:
         _chk(lib().teb_amd_last_kernel_ms(self._h, C.byref(ms)), "teb_amd_last_kernel_ms")
         return ms.value
 
+    def last_shader_clock_mhz(self):
+        """shader clock of the last optimise kernel (cycle counter / real-time counter of its first workgroup)"""
+        L = lib()
+        L.teb_amd_last_shader_clock_mhz.argtypes = [C.c_void_p, _abi.p_f64]
+        v = C.c_double(0)
+        _chk(L.teb_amd_last_shader_clock_mhz(self._h, C.byref(v)), "teb_amd_last_shader_clock_mhz")
+        return v.value
+
     def last_launch_info(self):
         """(distance helpers per band of the last optimize(), solver helpers per band, repeated on one CU per band after a timeout)"""
         a = C.c_int32(0); k = C.c_int32(0); b = C.c_int32(0)

@@ -109,6 +109,17 @@ def scene_c4(B=256, n=200, M_static=450, M_dyn=50, seed=1004, stride=None, lengt
     return cfg, obst, via, batch
 
 
+def scene_c4_via(B=256, n=200, seed=1004, stride=None, length=20.0):
+    """The C4 batch with one configuration flag off the TebConfig defaults: via-points (EdgeViaPoint, src/optimal_planner.cpp:675-718) -
+    three of them along the corridor, weight_viapoint = 1, enabled on every candidate. Used by bench.py (secondary.c4_with_via_points)
+    and the configuration-profile tests: the kernels specialised on the defaults do not fold this flag."""
+    cfg, obst, via, batch = scene_c4(B=B, n=n, seed=seed, stride=stride, length=length)
+    cfg.optim.weight_viapoint = 1.0
+    via = [(0.25 * length, 0.3), (0.5 * length, -0.2), (0.75 * length, 0.25)]
+    batch.via_points_enabled[:] = 1
+    return cfg, obst, via, batch
+
+
 def scene_c5(n=300, M=300, seed=1005, stride=None, length=30.0):
     cfg = TebConfig()
     cfg.robot.min_turning_radius = 1.0

@@ -45,6 +45,16 @@ def _worker(rank, world, port, case, q):
             c, i = parallel.local_best(res.cost, offset=lo)
             gc, gi = parallel.select_best_distributed(c, i)
             q.put((rank, gc, gi, res.cost.tolist(), lo))
+        elif case == "one_rank_unusable":
+            # gloo-side mirror of teb_amd_select_best_distributed's error path (csrc/teb_amd.hip): the rank on which something went wrong
+            # (bad handle, device mismatch, failed launch) still ENTERS the all-gather with the unusable record (DBL_MAX, -1) and reports
+            # its error afterwards; its peers pick among the other ranks' candidates and nobody waits for ever
+            costs = np.array([5.0, 1.0, 9.0, 3.0, 7.0, 4.0])
+            lo, hi = parallel.shard_range(len(costs), rank, world)
+            failed = (rank == 1)                       # rank 1 owns the overall minimum (index 1 or 2 .. depending on world) and fails
+            c, i = parallel.UNUSABLE_RECORD if failed else parallel.local_best(costs[lo:hi], offset=lo)
+            gc, gi = parallel.select_best_distributed(c, i)
+            q.put((rank, gc, gi, failed, lo, hi))
         else:
             res = []
             for cs in case:
@@ -117,3 +127,14 @@ def test_two_ranks_optimise_shards_and_agree():
         for k, c in enumerate(costs):
             allc[lo + k] = c
     np.testing.assert_array_equal(np.array([allc[k] for k in range(6)]), res.cost)   # sharding does not change results
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_a_failing_rank_sends_the_unusable_record_and_nobody_hangs(world):
+    outs = _run(world, "one_rank_unusable")
+    costs = np.array([5.0, 1.0, 9.0, 3.0, 7.0, 4.0])
+    lo1, hi1 = parallel.shard_range(len(costs), 1, world)
+    masked = costs.copy(); masked[lo1:hi1] = np.inf      # the failing rank's candidates take no part
+    want = int(np.argmin(masked))
+    for rank, gc, gi, failed, lo, hi in outs:
+        assert gi == want and gc == costs[want], (rank, gc, gi, want)

@@ -47,6 +47,28 @@ def test_c_abi_exchange_on_a_world_of_one(oracle):
     s.close()
 
 
+def test_a_rank_with_a_bad_handle_still_enters_the_all_gather():
+    """whatever is wrong on ONE rank - a null handle, no output pointer - it contributes the unusable record
+    (DBL_MAX, -1) to the all-gather and returns its error afterwards; it never leaves its peers waiting. On a world of one the proof is
+    that the call returns an error AND the communicator is still usable (a collective that had been skipped by one of two ranks would
+    have hung; here the collective demonstrably ran: the next call on the same communicator gives the right answer)."""
+    import ctypes as C
+    cfg, obst, via, batch = scenes.scene_c3(B=8, n=60, M=40, stride=128)
+    s = planner.make_solver(cfg, obst, via, batch)
+    s.optimize(5, 4, True, 100.0, 1.0, False)
+    comm = parallel.RcclComm(parallel.RcclComm.unique_id(), 0, 1, 0)
+    L = planner.lib()
+    best = C.c_int32(-7); cost = C.c_double(0); owner = C.c_int32(-7)
+    rc = L.teb_amd_select_best_distributed(None, comm._c, 0, -1, -1, C.byref(best), C.byref(cost), C.byref(owner))
+    assert rc != 0 and b"unusable record" in L.teb_amd_last_error()
+    rc = L.teb_amd_select_best_distributed(s._h, comm._c, 0, -1, -1, None, None, None)
+    assert rc != 0 and b"unusable record" in L.teb_amd_last_error()
+    g, c, o = s.select_best_distributed(comm, 10)
+    assert g >= 10 and (g - 10, c) == s.select_best(-1, -1) and o == 0
+    comm.close()
+    s.close()
+
+
 def _bench(*extra, timeout=600):
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):

@@ -193,3 +193,53 @@ def test_a_successful_probe_clears_the_pause():
     s.optimize(cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations, True, 1.0, 1.0, False)
     assert s.last_launch_info() == (6, 3, False) and s.multi_cu_backoff() == (0, 0)
     s.close()
+
+
+def test_ticks_on_a_busy_device_fall_back_to_one_cu_per_band_without_paying_for_it_every_tick():
+    """C5 ticks while another stream keeps the device busy (a queue of large fp32 GEMMs on all CUs). Whatever the
+    scheduler does with the helper workgroups - arrive in time or not -, every tick must give the one-CU bands bit for bit, and once a miss
+    has started the back-off the paused ticks neither wait nor repeat: each costs at most the one-CU tick under the same load + 10 %."""
+    import time
+    import torch
+    cfg, obst, via, batch = scenes.scene_c5(stride=320)
+    one, r1, _, _, _ = _run(cfg, obst, via, batch, multi_cu=-1, speculative_trials=-1)
+    a = torch.randn(8192, 8192, device="cuda"); b = torch.randn(8192, 8192, device="cuda")
+    side = torch.cuda.Stream()
+
+    def load(k):
+        with torch.cuda.stream(side):
+            for _ in range(k):
+                torch.mm(a, b)
+
+    def ticks(s, count):
+        wall, info = [], []
+        for _ in range(count):
+            load(6)                                   # ~ 6 x 10 ms of GEMM queued beside every tick
+            s.restore()
+            t0 = time.perf_counter()
+            s.optimize(cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations, True, cfg.hcp.selection_obst_cost_scale,
+                       cfg.hcp.selection_viapoint_cost_scale, cfg.hcp.selection_alternative_time_cost)
+            s.synchronize()
+            wall.append(time.perf_counter() - t0)
+            info.append((s.last_launch_info(), s.multi_cu_backoff()))
+            _assert_identical(s.download(batch.copy()), s.results(), one, r1)
+        return wall, info
+
+    s1 = planner.make_solver(cfg, obst, via, batch, options=_abi.Options(multi_cu=-1, speculative_trials=-1))
+    s1.snapshot()
+    w1, _ = ticks(s1, 6)
+    s1.close()
+    sm = planner.make_solver(cfg, obst, via, batch)
+    sm.snapshot()
+    wm, im = ticks(sm, 12)
+    sm.close()
+    torch.cuda.synchronize()
+    one_cu = float(np.median(w1))
+    paused = [w for w, (li, bo) in zip(wm, im) if li[0] == 0]          # ticks inside a pause: no distance helpers asked for
+    missed = [w for w, (li, bo) in zip(wm, im) if li[2]]
+    print("busy device: one CU per band %.2f ms; multi-CU ticks %s ms; %d missed, %d paused" % (
+        1e3 * one_cu, ["%.2f" % (1e3 * w) for w in wm], len(missed), len(paused)))
+    for w in paused:
+        assert w <= 1.10 * one_cu + 1e-3, (w, one_cu)
+    if missed:
+        assert paused, "a miss must start a pause"

@@ -100,11 +100,16 @@ def test_measured_configuration_matches_reference_code(oracle, name, mode):
     assert rep["pose_counts_equal"] >= int(np.floor(POSE_COUNT_FLOOR * B)), rep
     # T4: selectBestTeb on the device's costs = the arg-min of the reference code's own costs (src/homotopy_class_planner.cpp:593-615)
     best_ref = RC.select_best_of_costs(rcost)
-    best_dev = RC.select_best_of_costs(res.cost)
+    best_dev = res.best_index   # select_best_kernel on the device-resident costs
+    assert best_dev == RC.select_best_of_costs(res.cost)
     assert best_dev == best_ref, (name, mode, best_dev, best_ref)
-    # Independent yardstick: a SECOND BUILD of the reference's code (-O3, FMA contraction, builtin sin / cos). On every
-    # band the device may be at most NOISE_FLOOR_K x as far from the reference as that build is (absolute floor K x NOISE_FLOOR_ABS), and
-    # every band the device has beyond T3 must be one that the two reference builds disagree on by at least a tenth of the device's distance.
+    # Independent yardstick: a SECOND BUILD of the reference's code (-O3, FMA contraction, builtin sin / cos). In the
+    # reference's own linearisation scheme (g2o_numeric: same method, only rounding differs) the device may be on EVERY band at most
+    # NOISE_FLOOR_K x as far from the reference as that build is (absolute floor K x NOISE_FLOOR_ABS). With closed-form Jacobians the
+    # method itself differs from the reference's delta = 1e-9 central differences (whose truncation + cancellation error is not compiler
+    # noise: C5 sits 6e-4 from the reference in this mode and 2e-7 in the numeric one), so there the bound is T3 or K x the reference's
+    # own noise on that band, whichever is larger. In both modes every band the device has beyond T3 must be one that the two reference
+    # builds disagree on by at least a tenth of the device's distance.
     rr, best_alt = _noise_floor(name)
     per_band = rr["per_band"]
     worst = 0.0
@@ -112,7 +117,7 @@ def test_measured_configuration_matches_reference_code(oracle, name, mode):
         if per_band[b] is None or int(out.n[b]) != int(rout.n[b]):
             continue
         d = RC.state_error(out.get_teb(b), rout.get_teb(b))
-        bound = max(RC.NOISE_FLOOR_K * RC.NOISE_FLOOR_ABS, RC.NOISE_FLOOR_K * per_band[b])
+        bound = max(RC.NOISE_FLOOR_K * RC.NOISE_FLOOR_ABS if mode == "g2o_numeric" else RC.T3_STATE, RC.NOISE_FLOOR_K * per_band[b])
         worst = max(worst, d / bound)
         assert d <= bound, ("band %d: device %.3e from the reference, the reference's two builds %.3e apart" % (b, d, per_band[b]), name, mode)
     for o in rep["outside"]:

@@ -38,7 +38,7 @@ for name in which:
         print("   vs reference code:", json.dumps({k: v for k, v in rep.items() if k not in ("outside", "pose_count_mismatch")}))
         for o in rep["outside"][:8]: print("      outside T3:", o)
         for o in rep["pose_count_mismatch"][:8]: print("      pose count:", o)
-        best_dev = RC.select_best_of_costs(res.cost)
+        best_dev = res.best_index
         print("   T4 selectBestTeb: device %d, reference code %d, alt build %d" % (best_dev, best_ref, RC.select_best_of_costs(acost)))
         dd = [(RC.state_error(out.get_teb(b), rout.get_teb(b)), rr_band[b], b) for b in range(batch.count) if out.n[b] == rout.n[b] and rr_band[b] is not None]
         ratio = np.array([a / max(r, 1e-9) for a, r, b in dd])
