@@ -661,11 +661,11 @@ def main():
                 sx = planner.make_solver(cc, oo, vv, bb, options=opt)
                 sx.snapshot()
                 kx, wx, rx = time_solver(torch, sx, cc, 5)
-                prof = bool(sx.last_config_profile())
+                prof = int(sx.last_config_profile())
                 sx.close()
                 ux = int(rx.lm_iterations.sum())
                 sec[nm] = {"workload": what, "kernel_ms": kx, "ms_per_step": wx, "units_per_step": ux, "value": ux / (wx * 1e-3),
-                           "unit": "TEB.LM-iterations/s", "tebs_ok": int((rx.status == 0).sum()), "kernel_specialised_on_the_configuration": prof,
+                           "unit": "TEB.LM-iterations/s", "tebs_ok": int((rx.status == 0).sum()), "kernel_specialised_on_the_configuration": {0: "no (generic instantiation)", 1: "yes (defaults profile)", 2: "yes (wide kinds: via-points / holonomic at run time)"}[prof],
                            "vs_headline_kernel_ms": kx / float(np.mean(kernel_ms))}
             for nm, mk, what in (("c3_autosize_on", lambda: scenes.scene_c3(stride=208), "C3: 64 candidate TEBs x 150 poses, 200 point obstacles"),
                                  ("c2_autosize_on", lambda: scenes.scene_c2(stride=232), "C2: 1 TEB x 200 poses, 100 point obstacles"),

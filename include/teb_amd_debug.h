@@ -65,8 +65,9 @@ int teb_amd_debug_mcu_watchdog(teb_amd_handle_t* h, int32_t milliseconds);
  * (to bisect a difference between the two modes). */
 int teb_amd_debug_mcu_flags(teb_amd_handle_t* h, int32_t flags);
 
-/* 1 if the last optimise launch ran a kernel instantiation specialised on the TebConfig defaults (teb_amd_options_t::generic_config_path),
- * 0 if it ran the generic one. */
+/* Which kernel instantiation the last optimise launch ran: 1 = specialised on the TebConfig defaults (every flag of the profile table of
+ * csrc/teb_device.hpp folded at compile time), 2 = the same folds except the via-points and the holonomic choice of the velocity /
+ * acceleration edges (point-like scenes), 0 = the generic one (teb_amd_options_t::generic_config_path forces it). */
 int teb_amd_debug_last_config_profile(teb_amd_handle_t* h, int32_t* defaults_profile);
 
 /* per-TEB flags of the last launch: bit0 association list overflow, bit1 autoResize capacity overflow */

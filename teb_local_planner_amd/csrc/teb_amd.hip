@@ -297,29 +297,24 @@ const void* opt_kernel(int solver, int jmode, int scene) {
 #undef TEB_OPT_PICK
   return nullptr;   // (a -DTEB_AMD_ANALYTIC_ONLY build asked for the numeric mode)
 }
-// The *_DEFAULTS instantiations fold these flags at compile time (teb_device.hpp: TEB_CFG; the conditions below are exactly the folded
-// ones, in the order they appear in teb_kernel.hpp / teb_edges.hpp): a configuration that satisfies them all - a default TebConfig does -
-// takes the same paths in both instantiations.
-bool config_matches_defaults_profile(const teb_amd_handle* h) {
+// Which specialised instantiation may run this launch: 1 = the *_DEFAULTS kinds (every flag of the profile table folded), 2 = the *_WIDE
+// kinds (point-like scenes: every fold but the via-points and the holonomic choice), 0 = none (generic instantiation). GENERATED from the
+// table of teb_device.hpp (TEB_PF_ALL): a flag is folded in the kernel exactly when its TEB_PF_HOST_<ID> condition is required here, so a
+// fold cannot exist without its host-side check (tests/test_config_profile_sites.py). `c`, `args`, `sc` are the names the table's
+// expressions use - the very objects the kernel is launched with.
+int profile_matches(const teb_amd_handle* h, const OptArgs& args, const SceneDev& sc) {
+  if (h->opt.generic_config_path) return 0;
   const teb_amd_config_t& c = h->cfg;
-  // point-like scenes fold the kinematics (diff-drive) and the radius-free static list as well; generic-shape scenes keep diff-drive /
-  // car-like at run time and exist for closed-form Jacobians only
-  const bool scene_part = h->fast_points ? ((c.min_turning_radius == 0 || c.weight_kinematics_turning_radius == 0) &&
-                                            !(c.weight_kinematics_nh == 0 && c.weight_kinematics_forward_drive == 0) && h->static_radius_zero)
-                                         : c.jacobian_mode == TEB_AMD_JACOBIAN_ANALYTIC;
-  return scene_part && !h->opt.generic_config_path &&                                // (numeric Jacobians: the full-batch point-like kind only)
-         c.max_vel_y == 0 &&                                                         // non-holonomic velocity and acceleration edges
-         !(c.weight_max_vel_x == 0 && c.weight_max_vel_theta == 0) &&
-         !(c.weight_acc_lim_x == 0 && c.weight_acc_lim_theta == 0) &&
-         c.weight_optimaltime != 0 && c.weight_shortest_path == 0 &&
-         !(c.weight_velocity_obstacle_ratio > 0) && !c.legacy_obstacle_association &&
-         c.weight_obstacle != 0 &&                                                   // (dynamic-obstacle edges: the list is empty without include_dynamic_obstacles)
-         h->nvia == 0 &&                                                             // no via-points
-         !c.exact_arc_length && !(c.obstacle_cost_exponent != 1.0 && c.min_obstacle_dist > 0.0) &&
-                                                                                     // (point or circular footprint: fast_points above)
-         c.inflation_dist > c.min_obstacle_dist &&                                   // inflated obstacle edges (two rows)
-         !c.divergence_detection_enable && !h->band_ldlt &&                          // no second error evaluation per iteration; hybrid solve
-         !h->opt.no_near_cache;                                                      // cached near masks
+  const bool points = sc.fast_points != 0;   // (generic-shape kinds keep the TEB_PF_KIN_* flags at run time)
+  bool narrow = true, wide = true;
+#define TEB_PF_CHECK(ID)                                                        \
+  if ((points || !TEB_PF_KIN_##ID) && !(TEB_PF_HOST_##ID)) {                    \
+    narrow = false;                                                             \
+    if (!TEB_PF_WIDE_##ID) wide = false;                                        \
+  }
+  TEB_PF_ALL(TEB_PF_CHECK)
+#undef TEB_PF_CHECK
+  return narrow ? 1 : (wide && points ? 2 : 0);
 }
 hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const BatchDev& bt, const OptArgs& a, int solver, const LdsPlan& plan,
                       const McuDev* mcu = nullptr) {
@@ -329,10 +324,12 @@ hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const Bat
   const bool small = mc->K + mc->D > 0;   // helper workgroups: the small-batch instantiation of the scene kind
   const void* k = nullptr;
   h->last_defaults_profile = 0;
-  if (!a.debug_linearize && !a.band_ldlt && config_matches_defaults_profile(h)) {   // (a build without the twins returns null: generic instantiation)
+  const int pf = profile_matches(h, a, sc);   // (a build without the twins, or a mode they do not exist for, returns null: generic instantiation)
+  if (pf != 0) {
     const bool sm = small && h->cfg.jacobian_mode == TEB_AMD_JACOBIAN_ANALYTIC;
-    k = opt_kernel(solver, h->cfg.jacobian_mode, sc.fast_points ? (sm ? SCENE_POINTS_SMALL_DEFAULTS : SCENE_POINTS_DEFAULTS) : (sm ? SCENE_GENERIC_SMALL_DEFAULTS : SCENE_GENERIC_DEFAULTS));
-    if (k) h->last_defaults_profile = 1;
+    if (pf == 1) k = opt_kernel(solver, h->cfg.jacobian_mode, sc.fast_points ? (sm ? SCENE_POINTS_SMALL_DEFAULTS : SCENE_POINTS_DEFAULTS) : (sm ? SCENE_GENERIC_SMALL_DEFAULTS : SCENE_GENERIC_DEFAULTS));
+    else k = opt_kernel(solver, h->cfg.jacobian_mode, sm ? SCENE_POINTS_SMALL_WIDE : SCENE_POINTS_WIDE);
+    if (k) h->last_defaults_profile = pf;
   }
   if (!k) k = opt_kernel(solver, h->cfg.jacobian_mode, sc.fast_points ? (small ? SCENE_POINTS_SMALL : SCENE_POINTS) : (small ? SCENE_GENERIC_SMALL : SCENE_GENERIC));
   if (!k) return hipErrorInvalidDeviceFunction;

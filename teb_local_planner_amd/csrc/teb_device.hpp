@@ -19,14 +19,140 @@
 // Every cost term sits behind run-time flags of teb_amd_config_t (holonomic or not, which weights are zero, car-like or diff-drive, ..):
 // uniform branches, but each one ends a basic block, so the sqrt / divide chains of neighbouring terms cannot be scheduled into each
 // other's latency - and at one wave per SIMD that latency is all there is to fill. A translation unit compiled with
-// -DTEB_AMD_DEFAULTS_PROFILE (teb_opt_inst.hip does it for the scene kinds *_DEFAULTS) folds those flags to the values they have in a
-// default TebConfig: TEB_CFG(condition, value under the profile). The host launches such a kernel only when the handle's configuration
-// satisfies every folded condition (config_matches_defaults_profile, teb_amd.hip); anything else runs the generic instantiation. Same
-// operations in the same order on the taken paths: bit-identical bands (tests/test_gpu_config_profile.py).
-#ifdef TEB_AMD_DEFAULTS_PROFILE
-#define TEB_CFG(expr, dflt) (dflt)
+// -DTEB_AMD_DEFAULTS_PROFILE (teb_opt_inst.hip does it for the scene kinds *_DEFAULTS and *_WIDE) folds those flags to the values they
+// have in a default TebConfig. Same operations in the same order on the taken paths: bit-identical bands
+// (tests/test_gpu_config_profile.py).
+//
+// ONE TABLE says what is folded (round 4; before, the host kept a hand-written mirror of the TEB_CFG sites). Per flag ID:
+//   TEB_PF_EXPR_<ID>   the run-time condition, over `c` (teb_amd_config_t), `args` (OptArgs), `sc` (SceneDev) - whichever the site has
+//   TEB_PF_DFLT_<ID>   its value under the profile (what the device code is folded to)
+//   TEB_PF_HOST_<ID>   when the fold is VALID, evaluated on the host with the same three names in scope (normally EXPR == DFLT)
+//   TEB_PF_WIDE_<ID>   1: the flag stays a run-time flag in the *_WIDE kinds (-DTEB_AMD_PROFILE_WIDE): via-points and holonomic robots
+//                      run kernels that keep every other fold
+//   TEB_PF_KIN_<ID>    1: folded in the point-like kinds only (the generic-shape kinds keep diff-drive / car-like at run time,
+//                      -DTEB_AMD_PROFILE_ANY_KINEMATICS)
+// A device site writes TEB_CFGI(ID); the host's profile_matches() (teb_amd.hip) is generated from TEB_PF_ALL over the same entries.
+#define TEB_PF_ALL(X)                                                                                                              \
+  X(EXACT_ARC) X(COST_EXPONENT) X(NEW_ASSOCIATION) X(DYNAMIC_EDGES) X(VIA_POINTS) X(NONHOLONOMIC_VELOCITY) X(VELOCITY_EDGES)      \
+  X(ACCELERATION_EDGES) X(NONHOLONOMIC_ACCELERATION) X(TIME_OPTIMAL) X(SHORTEST_PATH) X(VELOCITY_OBSTACLE_RATIO) X(RADIUS_FREE)   \
+  X(DEBUG_LINEARIZE) X(BAND_LDLT) X(INFLATED) X(NO_NEAR_CACHE) X(DIVERGENCE_DETECTION) X(KIN_DIFF_DRIVE) X(KIN_EDGES)
+#define TEB_PF_EXPR_EXACT_ARC (c.exact_arc_length)
+#define TEB_PF_DFLT_EXACT_ARC false
+#define TEB_PF_EXPR_COST_EXPONENT (c.obstacle_cost_exponent != 1.0 && c.min_obstacle_dist > 0.0)
+#define TEB_PF_DFLT_COST_EXPONENT false
+#define TEB_PF_EXPR_NEW_ASSOCIATION (!c.legacy_obstacle_association)
+#define TEB_PF_DFLT_NEW_ASSOCIATION true
+#define TEB_PF_EXPR_DYNAMIC_EDGES (c.include_dynamic_obstacles && c.weight_obstacle != 0)
+#define TEB_PF_DFLT_DYNAMIC_EDGES true
+#define TEB_PF_HOST_DYNAMIC_EDGES (c.weight_obstacle != 0)   /* without include_dynamic_obstacles the dynamic list is empty: the folded loop runs over nothing */
+#define TEB_PF_EXPR_VIA_POINTS (sc.nvia > 0 && c.weight_viapoint != 0)
+#define TEB_PF_DFLT_VIA_POINTS false
+#define TEB_PF_WIDE_VIA_POINTS 1
+#define TEB_PF_EXPR_NONHOLONOMIC_VELOCITY (c.max_vel_y == 0)
+#define TEB_PF_DFLT_NONHOLONOMIC_VELOCITY true
+#define TEB_PF_WIDE_NONHOLONOMIC_VELOCITY 1
+#define TEB_PF_EXPR_VELOCITY_EDGES (!(c.weight_max_vel_x == 0 && c.weight_max_vel_theta == 0))
+#define TEB_PF_DFLT_VELOCITY_EDGES true
+#define TEB_PF_EXPR_ACCELERATION_EDGES (!(c.weight_acc_lim_x == 0 && c.weight_acc_lim_theta == 0))
+#define TEB_PF_DFLT_ACCELERATION_EDGES true
+#define TEB_PF_EXPR_NONHOLONOMIC_ACCELERATION (c.max_vel_y == 0 || c.acc_lim_y == 0)
+#define TEB_PF_DFLT_NONHOLONOMIC_ACCELERATION true
+#define TEB_PF_WIDE_NONHOLONOMIC_ACCELERATION 1
+#define TEB_PF_EXPR_TIME_OPTIMAL (c.weight_optimaltime != 0)
+#define TEB_PF_DFLT_TIME_OPTIMAL true
+#define TEB_PF_EXPR_SHORTEST_PATH (c.weight_shortest_path != 0)
+#define TEB_PF_DFLT_SHORTEST_PATH false
+#define TEB_PF_EXPR_VELOCITY_OBSTACLE_RATIO (c.weight_velocity_obstacle_ratio > 0)
+#define TEB_PF_DFLT_VELOCITY_OBSTACLE_RATIO false
+#define TEB_PF_EXPR_RADIUS_FREE (sc.static_radius_zero != 0)
+#define TEB_PF_DFLT_RADIUS_FREE true
+#define TEB_PF_KIN_RADIUS_FREE 1   /* (a property of point-like scenes) */
+#define TEB_PF_EXPR_DEBUG_LINEARIZE (args.debug_linearize != 0)
+#define TEB_PF_DFLT_DEBUG_LINEARIZE false
+#define TEB_PF_EXPR_BAND_LDLT (args.band_ldlt != 0)
+#define TEB_PF_DFLT_BAND_LDLT false
+#define TEB_PF_EXPR_INFLATED (c.inflation_dist > c.min_obstacle_dist)
+#define TEB_PF_DFLT_INFLATED true
+#define TEB_PF_EXPR_NO_NEAR_CACHE (args.no_near_cache != 0)
+#define TEB_PF_DFLT_NO_NEAR_CACHE false
+#define TEB_PF_EXPR_DIVERGENCE_DETECTION (c.divergence_detection_enable)
+#define TEB_PF_DFLT_DIVERGENCE_DETECTION false
+#define TEB_PF_EXPR_KIN_DIFF_DRIVE (c.min_turning_radius == 0 || c.weight_kinematics_turning_radius == 0)
+#define TEB_PF_DFLT_KIN_DIFF_DRIVE true
+#define TEB_PF_KIN_KIN_DIFF_DRIVE 1
+#define TEB_PF_EXPR_KIN_EDGES (!(c.weight_kinematics_nh == 0 && c.weight_kinematics_forward_drive == 0))
+#define TEB_PF_DFLT_KIN_EDGES true
+#define TEB_PF_KIN_KIN_EDGES 1
+// defaults of the optional columns
+#ifndef TEB_PF_HOST_EXACT_ARC
+#define TEB_PF_HOST_EXACT_ARC (TEB_PF_EXPR_EXACT_ARC == TEB_PF_DFLT_EXACT_ARC)
+#endif
+#define TEB_PF_HOST_COST_EXPONENT (TEB_PF_EXPR_COST_EXPONENT == TEB_PF_DFLT_COST_EXPONENT)
+#define TEB_PF_HOST_NEW_ASSOCIATION (TEB_PF_EXPR_NEW_ASSOCIATION == TEB_PF_DFLT_NEW_ASSOCIATION)
+#define TEB_PF_HOST_VIA_POINTS (TEB_PF_EXPR_VIA_POINTS == TEB_PF_DFLT_VIA_POINTS)
+#define TEB_PF_HOST_NONHOLONOMIC_VELOCITY (TEB_PF_EXPR_NONHOLONOMIC_VELOCITY == TEB_PF_DFLT_NONHOLONOMIC_VELOCITY)
+#define TEB_PF_HOST_VELOCITY_EDGES (TEB_PF_EXPR_VELOCITY_EDGES == TEB_PF_DFLT_VELOCITY_EDGES)
+#define TEB_PF_HOST_ACCELERATION_EDGES (TEB_PF_EXPR_ACCELERATION_EDGES == TEB_PF_DFLT_ACCELERATION_EDGES)
+#define TEB_PF_HOST_NONHOLONOMIC_ACCELERATION (TEB_PF_EXPR_NONHOLONOMIC_ACCELERATION == TEB_PF_DFLT_NONHOLONOMIC_ACCELERATION)
+#define TEB_PF_HOST_TIME_OPTIMAL (TEB_PF_EXPR_TIME_OPTIMAL == TEB_PF_DFLT_TIME_OPTIMAL)
+#define TEB_PF_HOST_SHORTEST_PATH (TEB_PF_EXPR_SHORTEST_PATH == TEB_PF_DFLT_SHORTEST_PATH)
+#define TEB_PF_HOST_VELOCITY_OBSTACLE_RATIO (TEB_PF_EXPR_VELOCITY_OBSTACLE_RATIO == TEB_PF_DFLT_VELOCITY_OBSTACLE_RATIO)
+#define TEB_PF_HOST_RADIUS_FREE (TEB_PF_EXPR_RADIUS_FREE == TEB_PF_DFLT_RADIUS_FREE)
+#define TEB_PF_HOST_DEBUG_LINEARIZE (TEB_PF_EXPR_DEBUG_LINEARIZE == TEB_PF_DFLT_DEBUG_LINEARIZE)
+#define TEB_PF_HOST_BAND_LDLT (TEB_PF_EXPR_BAND_LDLT == TEB_PF_DFLT_BAND_LDLT)
+#define TEB_PF_HOST_INFLATED (TEB_PF_EXPR_INFLATED == TEB_PF_DFLT_INFLATED)
+#define TEB_PF_HOST_NO_NEAR_CACHE (TEB_PF_EXPR_NO_NEAR_CACHE == TEB_PF_DFLT_NO_NEAR_CACHE)
+#define TEB_PF_HOST_DIVERGENCE_DETECTION (TEB_PF_EXPR_DIVERGENCE_DETECTION == TEB_PF_DFLT_DIVERGENCE_DETECTION)
+#define TEB_PF_HOST_KIN_DIFF_DRIVE (TEB_PF_EXPR_KIN_DIFF_DRIVE == TEB_PF_DFLT_KIN_DIFF_DRIVE)
+#define TEB_PF_HOST_KIN_EDGES (TEB_PF_EXPR_KIN_EDGES == TEB_PF_DFLT_KIN_EDGES)
+#define TEB_PF_WIDE_EXACT_ARC 0
+#define TEB_PF_WIDE_COST_EXPONENT 0
+#define TEB_PF_WIDE_NEW_ASSOCIATION 0
+#define TEB_PF_WIDE_DYNAMIC_EDGES 0
+#define TEB_PF_WIDE_VELOCITY_EDGES 0
+#define TEB_PF_WIDE_ACCELERATION_EDGES 0
+#define TEB_PF_WIDE_TIME_OPTIMAL 0
+#define TEB_PF_WIDE_SHORTEST_PATH 0
+#define TEB_PF_WIDE_VELOCITY_OBSTACLE_RATIO 0
+#define TEB_PF_WIDE_RADIUS_FREE 0
+#define TEB_PF_WIDE_DEBUG_LINEARIZE 0
+#define TEB_PF_WIDE_BAND_LDLT 0
+#define TEB_PF_WIDE_INFLATED 0
+#define TEB_PF_WIDE_NO_NEAR_CACHE 0
+#define TEB_PF_WIDE_DIVERGENCE_DETECTION 0
+#define TEB_PF_WIDE_KIN_DIFF_DRIVE 0
+#define TEB_PF_WIDE_KIN_EDGES 0
+#define TEB_PF_KIN_EXACT_ARC 0
+#define TEB_PF_KIN_COST_EXPONENT 0
+#define TEB_PF_KIN_NEW_ASSOCIATION 0
+#define TEB_PF_KIN_DYNAMIC_EDGES 0
+#define TEB_PF_KIN_VIA_POINTS 0
+#define TEB_PF_KIN_NONHOLONOMIC_VELOCITY 0
+#define TEB_PF_KIN_VELOCITY_EDGES 0
+#define TEB_PF_KIN_ACCELERATION_EDGES 0
+#define TEB_PF_KIN_NONHOLONOMIC_ACCELERATION 0
+#define TEB_PF_KIN_TIME_OPTIMAL 0
+#define TEB_PF_KIN_SHORTEST_PATH 0
+#define TEB_PF_KIN_VELOCITY_OBSTACLE_RATIO 0
+#define TEB_PF_KIN_DEBUG_LINEARIZE 0
+#define TEB_PF_KIN_BAND_LDLT 0
+#define TEB_PF_KIN_INFLATED 0
+#define TEB_PF_KIN_NO_NEAR_CACHE 0
+#define TEB_PF_KIN_DIVERGENCE_DETECTION 0
+
+// what a device site sees
+#if defined(TEB_AMD_DEFAULTS_PROFILE)
+#if defined(TEB_AMD_PROFILE_WIDE) && defined(TEB_AMD_PROFILE_ANY_KINEMATICS)
+#define TEB_CFGI(ID) ((TEB_PF_WIDE_##ID || TEB_PF_KIN_##ID) ? (TEB_PF_EXPR_##ID) : (TEB_PF_DFLT_##ID))
+#elif defined(TEB_AMD_PROFILE_WIDE)
+#define TEB_CFGI(ID) (TEB_PF_WIDE_##ID ? (TEB_PF_EXPR_##ID) : (TEB_PF_DFLT_##ID))
+#elif defined(TEB_AMD_PROFILE_ANY_KINEMATICS)
+#define TEB_CFGI(ID) (TEB_PF_KIN_##ID ? (TEB_PF_EXPR_##ID) : (TEB_PF_DFLT_##ID))
 #else
-#define TEB_CFG(expr, dflt) (expr)
+#define TEB_CFGI(ID) (TEB_PF_DFLT_##ID)
+#endif
+#else
+#define TEB_CFGI(ID) (TEB_PF_EXPR_##ID)
 #endif
 
 namespace tebamd {

@@ -57,7 +57,7 @@ __device__ __forceinline__ void signed_velocity(const teb_amd_config_t& c, doubl
   double dist = eucl;
   const double angle_diff = normalize_theta(thb - tha);
   bool arc = false;
-  if (TEB_CFG(c.exact_arc_length, false) && angle_diff != 0) {
+  if (TEB_CFGI(EXACT_ARC) && angle_diff != 0) {
     double radius = dist / (2 * sin(angle_diff / 2));
     dist = fabs(angle_diff * radius);
     arc = true;
@@ -518,7 +518,7 @@ __device__ __forceinline__ void edge_kinematics_carlike(const teb_amd_config_t& 
   }
   if (angle_diff != 0) {
     double rho, drho_dn, drho_dth2, dev;
-    if (TEB_CFG(c.exact_arc_length, false)) {
+    if (TEB_CFGI(EXACT_ARC)) {
       double h = angle_diff / 2, sh = sin(h), ch = cos(h);
       rho = fabs(nn / (2 * sh));
       drho_dn = 1.0 / (2 * fabs(sh));
@@ -586,7 +586,7 @@ __device__ __forceinline__ void edge_obstacle(const teb_amd_config_t& c, const S
   double dist = footprint_distance(c, sc, oi, w.x0, w.y0, w.c0, w.s0, false, 0.0, JAC ? gr : nullptr);
   double d0;
   double e0 = pen_below(dist, c.min_obstacle_dist, c.penalty_epsilon, d0);
-  if (TEB_CFG(c.obstacle_cost_exponent != 1.0 && c.min_obstacle_dist > 0.0, false)) {
+  if (TEB_CFGI(COST_EXPONENT)) {
     double lin = e0;
     e0 = c.min_obstacle_dist * pow(lin / c.min_obstacle_dist, c.obstacle_cost_exponent);
     if (JAC) {
@@ -612,7 +612,7 @@ template <bool JAC, class ACC>
 __device__ __forceinline__ void obstacle_rows_g(const teb_amd_config_t& c, double dist, const double* gr, double w_obst, bool inflated, ACC& A) {
   double d0;
   double e0 = pen_below(dist, c.min_obstacle_dist, c.penalty_epsilon, d0);
-  if (TEB_CFG(c.obstacle_cost_exponent != 1.0 && c.min_obstacle_dist > 0.0, false)) {
+  if (TEB_CFGI(COST_EXPONENT)) {
     double lin = e0;
     e0 = c.min_obstacle_dist * pow(lin / c.min_obstacle_dist, c.obstacle_cost_exponent);
     if (JAC) {
@@ -701,7 +701,7 @@ template <bool JAC, class ACC>
 __device__ __forceinline__ void obstacle_rows(const teb_amd_config_t& c, double dist, const double* gr, double w_obst, bool inflated, ACC& A) {
   double d0;
   double e0 = pen_below(dist, c.min_obstacle_dist, c.penalty_epsilon, d0);
-  if (TEB_CFG(c.obstacle_cost_exponent != 1.0 && c.min_obstacle_dist > 0.0, false)) {
+  if (TEB_CFGI(COST_EXPONENT)) {
     double lin = e0;
     e0 = c.min_obstacle_dist * pow(lin / c.min_obstacle_dist, c.obstacle_cost_exponent);
     if (JAC) {

@@ -236,11 +236,6 @@ __device__ __forceinline__ double distance_lower_bound(const SceneDev& sc, int o
 // 2 = g2o central differences over the residual code (the two edges the reference linearises analytically -
 // EdgeKinematicsDiffDrive edge_kinematics.h:112-149, EdgeTimeOptimal edge_time_optimal.h:93-99 - stay analytic).
 // Inside CALL the window is W, the accumulator ACC_ and the Jacobian switch J_.
-#ifdef TEB_AMD_PROFILE_ANY_KINEMATICS
-#define TEB_KIN_CFG(expr, dflt) (expr)
-#else
-#define TEB_KIN_CFG(expr, dflt) TEB_CFG(expr, dflt)
-#endif
 #define TEB_EDGE(VMASK, CAT, ...)                                                                                   \
   do {                                                                                                                \
     if constexpr (MODE == 2) {                                                                                        \
@@ -365,7 +360,7 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
   if (i >= 1) {
    if constexpr (PART != 2) {
     TEB_IF_FAST(FAST) {
-      if (TEB_CFG(!c.legacy_obstacle_association, true)) {
+      if (TEB_CFGI(NEW_ASSOCIATION)) {
         // The association lists live in HBM (pose-major, coalesced over the lanes); a lane walks its list in order and at one wave per
         // SIMD every dependent load is a full round trip (L2 for the entry, LDS for the obstacle, then the sqrt chain: ~ 1.1 k cycles per
         // edge, measured). Four entries are fetched together and their distances computed side by side (independent chains); the
@@ -413,7 +408,7 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
         }
       }
       EVP(MODE == 0 ? 0 : 3);
-      if (TEB_CFG(c.include_dynamic_obstacles && c.weight_obstacle != 0, true)) {   // (profile: weight_obstacle != 0; without include_dynamic_obstacles the dynamic list is empty)
+      if (TEB_CFGI(DYNAMIC_EDGES)) {   // (profile: weight_obstacle != 0; without include_dynamic_obstacles the dynamic list is empty)
         const double ti = l.tdyn[i];
         const double far_d = dyn_far_distance(c);
         // far-field culling (dyn_near_mask above): the mask of the first 64 obstacles of the slice comes from the caller (dyn_near_cached,
@@ -483,7 +478,7 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
     }
    }   // PART != 2
    if constexpr (PART != 1)
-    if (TEB_CFG(true, false) && first && t.via_en && c.weight_viapoint != 0) {   // (profile: no via-points)
+    if (TEB_CFGI(VIA_POINTS) && first && t.via_en) {   // (profile: no via-points)
       for (int v = 0; v < sc.nvia; ++v)
         if (t.via_pose[v] == i) {
           const double vx = sc.viax[v], vy = sc.viay[v];
@@ -495,15 +490,15 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
   if constexpr (PART == 1) return;
   if (!first) return;   // the other slices only share the dynamic-obstacle edges
   // ---- AddEdgesVelocity :720-769
-  if (TEB_CFG(c.max_vel_y == 0, true)) {
-    if (TEB_CFG(!(c.weight_max_vel_x == 0 && c.weight_max_vel_theta == 0), true)) TEB_EDGE(M_SEG, CAT_OTHER, edge_velocity<J_>(c, W, ACC_));
+  if (TEB_CFGI(NONHOLONOMIC_VELOCITY)) {
+    if (TEB_CFGI(VELOCITY_EDGES)) TEB_EDGE(M_SEG, CAT_OTHER, edge_velocity<J_>(c, W, ACC_));
   } else {
     if (!(c.weight_max_vel_x == 0 && c.weight_max_vel_y == 0 && c.weight_max_vel_theta == 0))
       TEB_EDGE(M_SEG, CAT_OTHER, edge_velocity_holonomic<J_>(c, W, ACC_));
   }
   // ---- AddEdgesAcceleration :771-873
-  if (TEB_CFG(!(c.weight_acc_lim_x == 0 && c.weight_acc_lim_theta == 0), true)) {
-    const bool nonholo = TEB_CFG((c.max_vel_y == 0 || c.acc_lim_y == 0), true);
+  if (TEB_CFGI(ACCELERATION_EDGES)) {
+    const bool nonholo = TEB_CFGI(NONHOLONOMIC_ACCELERATION);
     if (nonholo) {
       if (i == 0 && t.has_vs) TEB_EDGE(M_SEG, CAT_OTHER, (edge_acceleration_se<J_, true>(c, W, t.vs[0], t.vs[2], ACC_)));
       if (has2) TEB_EDGE(M_ALL, CAT_OTHER, edge_acceleration<J_>(c, W, ACC_));
@@ -515,12 +510,12 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
     }
   }
   // ---- AddEdgesTimeOptimal :877-893 (analytic in the reference), AddEdgesShortestPath :895-912
-  if (TEB_CFG(c.weight_optimaltime != 0, true)) edge_time_optimal<MODE != 0>(c, w, A);
-  if (TEB_CFG(c.weight_shortest_path != 0, false) && seg_active) TEB_EDGE(M_POSE0 | M_POSE1, CAT_OTHER, edge_shortest_path<J_>(c, W, ACC_));
+  if (TEB_CFGI(TIME_OPTIMAL)) edge_time_optimal<MODE != 0>(c, w, A);
+  if (TEB_CFGI(SHORTEST_PATH) && seg_active) TEB_EDGE(M_POSE0 | M_POSE1, CAT_OTHER, edge_shortest_path<J_>(c, W, ACC_));
   // ---- kinematics :355-358, 916-958 (diff-drive: analytic in the reference)
   if (seg_active) {
-    if (TEB_KIN_CFG(c.min_turning_radius == 0 || c.weight_kinematics_turning_radius == 0, true)) {
-      if (TEB_KIN_CFG(!(c.weight_kinematics_nh == 0 && c.weight_kinematics_forward_drive == 0), true)) edge_kinematics_diffdrive<MODE != 0>(c, w, A);
+    if (TEB_CFGI(KIN_DIFF_DRIVE)) {
+      if (TEB_CFGI(KIN_EDGES)) edge_kinematics_diffdrive<MODE != 0>(c, w, A);
     } else {
       if (!(c.weight_kinematics_nh == 0 && c.weight_kinematics_turning_radius == 0))
         TEB_EDGE(M_POSE0 | M_POSE1, CAT_OTHER, edge_kinematics_carlike<J_>(c, W, ACC_));
@@ -532,7 +527,7 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
     TEB_EDGE(M_POSE0 | M_POSE1, CAT_OTHER, edge_prefer_rotdir<J_>(c, W, dir, ACC_));
   }
   // ---- AddEdgesVelocityObstacleRatio :999-1021
-  if (TEB_CFG(c.weight_velocity_obstacle_ratio > 0, false) && !c.legacy_obstacle_association) {   // obstacles_per_vertex_ stays empty in legacy mode
+  if (TEB_CFGI(VELOCITY_OBSTACLE_RATIO) && !c.legacy_obstacle_association) {   // obstacles_per_vertex_ stays empty in legacy mode
     for (int k = 0; k < cnt; ++k) {
       const int p = FAST ? t.assoc[(size_t)k * t.stride + i] : ld_list(t.mcu.shared_lists, &t.assoc[(size_t)k * t.stride + i]);
       bool replayed = false;
@@ -2076,7 +2071,7 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
     for (; k0 < k_hi; k0 += 64) {
       const int ke = k0 + 64 < k_hi ? k0 + 64 : k_hi;
       unsigned long long near = 0;
-      if (TEB_CFG(sc.static_radius_zero, true)) {
+      if (TEB_CFGI(RADIUS_FREE)) {
         // no radii in the static list (point obstacles): the threshold is one number, hoisted; the mask is built in its two 32-bit halves
         // (the bit of obstacle k is a scalar: a conditional move and an OR per obstacle). Same comparisons on the same values.
         const double thr = (far_d + 0.0) * (1.0 + 1e-12), thr2 = thr * thr;
@@ -2489,16 +2484,20 @@ __device__ inline void mcu_solver_helper(const SceneDev& sc, const BatchDev& bt,
 // *_DEFAULTS: the two point-like kinds compiled with the configuration flags folded to the TebConfig defaults (teb_device.hpp: TEB_CFG).
 // The generic-shape *_DEFAULTS kinds keep the kinematics flags at run time (-DTEB_AMD_PROFILE_ANY_KINEMATICS): polygon robots are car-like
 // as often as not (BASELINE C5).
+// *_WIDE (round 4): the two point-like kinds once more with every fold of the profile EXCEPT the via-points and the holonomic /
+// non-holonomic choice of the velocity and acceleration edges (teb_device.hpp: TEB_PF_WIDE_*), for configurations that differ from the
+// defaults in nothing else - a goal-directed planner with via-points, an omnidirectional base (-DTEB_AMD_PROFILE_WIDE).
 enum { SCENE_POINTS = 0, SCENE_GENERIC = 1, SCENE_POINTS_SMALL = 2, SCENE_GENERIC_SMALL = 3, SCENE_POINTS_DEFAULTS = 4, SCENE_POINTS_SMALL_DEFAULTS = 5,
-       SCENE_GENERIC_DEFAULTS = 6, SCENE_GENERIC_SMALL_DEFAULTS = 7 };
+       SCENE_GENERIC_DEFAULTS = 6, SCENE_GENERIC_SMALL_DEFAULTS = 7, SCENE_POINTS_WIDE = 8, SCENE_POINTS_SMALL_WIDE = 9 };
 template <int SOLVER, int JMODE, int SCENE>
 __global__ void __launch_bounds__(kThreads)
 teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev bt, const OptArgs args,
                     const LdsPlan plan, const McuDev mc) {
   extern __shared__ __attribute__((aligned(16))) double lds_base[];
-  constexpr bool FAST = SCENE == SCENE_POINTS || SCENE == SCENE_POINTS_SMALL || SCENE == SCENE_POINTS_DEFAULTS || SCENE == SCENE_POINTS_SMALL_DEFAULTS;
+  constexpr bool FAST = SCENE == SCENE_POINTS || SCENE == SCENE_POINTS_SMALL || SCENE == SCENE_POINTS_DEFAULTS || SCENE == SCENE_POINTS_SMALL_DEFAULTS ||
+                        SCENE == SCENE_POINTS_WIDE || SCENE == SCENE_POINTS_SMALL_WIDE;
   constexpr bool MCU = SCENE == SCENE_POINTS_SMALL || SCENE == SCENE_GENERIC_SMALL || SCENE == SCENE_POINTS_SMALL_DEFAULTS ||
-                       SCENE == SCENE_GENERIC_SMALL_DEFAULTS;   // small-batch instantiation: helper workgroups possible
+                       SCENE == SCENE_GENERIC_SMALL_DEFAULTS || SCENE == SCENE_POINTS_SMALL_WIDE;   // small-batch instantiation: helper workgroups possible
 #ifdef TEB_AMD_DEFAULTS_PROFILE
   static_assert(SCENE >= SCENE_POINTS_DEFAULTS, "a unit compiled with the profile holds a *_DEFAULTS kind");
 #else
@@ -2506,6 +2505,11 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
 #endif
 #ifdef TEB_AMD_PROFILE_ANY_KINEMATICS
   static_assert(SCENE == SCENE_GENERIC_DEFAULTS || SCENE == SCENE_GENERIC_SMALL_DEFAULTS, "the generic-shape kinds of the profile keep the kinematics flags");
+#endif
+#ifdef TEB_AMD_PROFILE_WIDE
+  static_assert(SCENE == SCENE_POINTS_WIDE || SCENE == SCENE_POINTS_SMALL_WIDE, "-DTEB_AMD_PROFILE_WIDE builds the *_WIDE kinds");
+#else
+  static_assert(SCENE != SCENE_POINTS_WIDE && SCENE != SCENE_POINTS_SMALL_WIDE, "*_WIDE kinds need -DTEB_AMD_PROFILE_WIDE");
 #endif
   static_assert(!MCU || JMODE == TEB_AMD_JACOBIAN_ANALYTIC, "the small-batch kinds exist for closed-form Jacobians");
   if constexpr (MCU) {
@@ -2529,8 +2533,8 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   mm.ctl = (mm.H > 0 || mm.K > 0) ? mc.ctl + (size_t)b * kMcuCtlWords : nullptr;
   mm.pub = mm.H > 0 ? mc.pub + (size_t)b * kMcuPubArrays * S : nullptr;
   mm.spec = mm.K > 0 ? mc.spec + (size_t)b * (mc.K + 1) * mcu_spec_slot(S) : nullptr;
-  const bool mcu_on = MCU && mm.H > 0 && !TEB_CFG(args.debug_linearize, false) && !c.legacy_obstacle_association;
-  const bool spec_on = MCU && mm.K > 0 && !TEB_CFG(args.debug_linearize, false) && !(SOLVER == SOLVER_BAND && TEB_CFG(args.band_ldlt, false)) && !(mc.debug_flags & 4);
+  const bool mcu_on = MCU && mm.H > 0 && !TEB_CFGI(DEBUG_LINEARIZE) && !c.legacy_obstacle_association;
+  const bool spec_on = MCU && mm.K > 0 && !TEB_CFGI(DEBUG_LINEARIZE) && !(SOLVER == SOLVER_BAND && TEB_CFGI(BAND_LDLT)) && !(mc.debug_flags & 4);
   if constexpr (FAST) {   // stage the point-like obstacle table once: static list first, then the dynamic list
     const int tot = sc.n_static + sc.n_dyn;
     for (int k = tid; k < tot; k += kThreads) {
@@ -2569,7 +2573,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   t.has_vs = bt.has_vs[b]; t.has_vg = bt.has_vg[b]; t.rotdir = bt.rotdir[b]; t.via_en = bt.via_en[b];
 #pragma unroll
   for (int q = 0; q < 3; ++q) { t.vs[q] = bt.vs[3 * b + q]; t.vg[q] = bt.vg[3 * b + q]; }
-  t.inflated = TEB_CFG(c.inflation_dist > c.min_obstacle_dist, true);
+  t.inflated = TEB_CFGI(INFLATED);
   int* assoc_cnt = bt.assoc_cnt + so;
   int* assoc = bt.assoc + (size_t)b * bt.assoc_cap * S;
   int* via_pose = bt.via_pose + (size_t)b * bt.via_cap;
@@ -2582,10 +2586,10 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   int optimized = c.optimization_activate ? 0 : bt.optimized[b];   // optimized_ = false (src/optimal_planner.cpp:189), after the early return
   double chi2_final = 0, lambda = 0, cost = __longlong_as_double(0x7ff8000000000000LL);
   double last_cats[4] = {0, 0, 0, 0};
-  double weight_multiplier = TEB_CFG(args.debug_linearize, false) ? args.debug_weight_multiplier : 1.0;
+  double weight_multiplier = TEB_CFGI(DEBUG_LINEARIZE) ? args.debug_weight_multiplier : 1.0;
   NearCache near_cache;   // near masks of the dynamic-obstacle edges, per lane (dyn_near_cached)
   near_cache.invalidate();
-  near_cache.off = TEB_CFG(args.no_near_cache != 0, false);
+  near_cache.off = TEB_CFGI(NO_NEAR_CACHE);
   const bool fast_mode = !c.include_dynamic_obstacles;
   bool done = false;
   bool trig_stale = true;   // the cos / sin cache (l.cs, l.sn) does not match the headings (uniform)
@@ -2598,7 +2602,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
 
   for (int outer = 0; outer < args.outer && !done; ++outer) {
     // ---- K1: autoResize
-    if (c.teb_autosize && !TEB_CFG(args.debug_linearize, false)) {
+    if (c.teb_autosize && !TEB_CFGI(DEBUG_LINEARIZE)) {
       int ovf = 0;
       PROF_START();
       // edit script + new poses + split stack (autoresize_scratch_doubles: 5 S + 104 doubles) live in the LDS region of the normal matrix, which is rebuilt afterwards
@@ -2620,7 +2624,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     const bool obst_edges = !(c.weight_obstacle == 0 || weight_multiplier == 0);
     if (obst_edges) {
       int ovf = 0;
-      if (TEB_CFG(c.legacy_obstacle_association, false))
+      if (!TEB_CFGI(NEW_ASSOCIATION))
         associate_legacy(c, sc, l, n, assoc_cnt, assoc, bt.assoc_cap, S, &ovf, bt.legacy_idx + (size_t)b * bt.assoc_cap);
       else if (mcu_on && (mc.debug_flags & 1)) {   // (diagnostic) this workgroup scans, the helpers of the DIST phases read the lists
         associate_range<FAST, true>(c, sc, l, n, 0, n, assoc_cnt, assoc, bt.assoc_cap, S, &ovf);
@@ -2653,7 +2657,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       for (; i < n - 1; ++i) { l.tdyn[i] = time; time += l.sdt[i]; }
     }
     LNP(10);
-    if (TEB_CFG(true, false) && t.via_en && c.weight_viapoint != 0 && sc.nvia > 0 && n >= 3) {   // :675-718
+    if (TEB_CFGI(VIA_POINTS) && t.via_en && n >= 3) {   // :675-718
       int start_pose_idx = 0;
       for (int v = 0; v < sc.nvia; ++v) {
         int index = -1;
@@ -2684,7 +2688,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
 
     near_cache.invalidate();   // the graph was rebuilt: new pose numbering, new time stamps
     // ---- optimize(): Levenberg-Marquardt
-    if (args.inner <= 0 && !TEB_CFG(args.debug_linearize, false)) { status = TEB_AMD_TEB_FAILED; break; }   // optimize(0) returns 0
+    if (args.inner <= 0 && !TEB_CFGI(DEBUG_LINEARIZE)) { status = TEB_AMD_TEB_FAILED; break; }   // optimize(0) returns 0
     // multi-CU mode: the distance records of the freshly built graph for the first linearisation; the later ones find the records
     // of the error evaluation that accepted their state
     t.mcu.items = nullptr;
@@ -2705,7 +2709,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       trig_stale = false;
       PROF_END(2);
       double currentChi = ((cats[0] + cats[1]) + cats[2]) + cats[3];
-      if (TEB_CFG(args.debug_linearize, false)) {
+      if (TEB_CFGI(DEBUG_LINEARIZE)) {
         if (b == 0) {
           const int Nt = 4 * n;
           for (int q = tid; q < Nt * kBand; q += kThreads) {   // always exported in band form
@@ -2734,7 +2738,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       }
       PROF_START();
       const int hsz = (SOLVER != SOLVER_CR) ? Nt * kBand : ((Nt + 7) >> 3) * 2 * kBlk;
-      const bool keep_copy = !(SOLVER != SOLVER_CR && !TEB_CFG(args.band_ldlt, false));   // the HBM-block reductions never touch the band
+      const bool keep_copy = !(SOLVER != SOLVER_CR && !TEB_CFGI(BAND_LDLT));   // the HBM-block reductions never touch the band
       if constexpr (MCU) {
         if (spec_on) spec_wait_idle(mm, l.ired + 26);   // the solver helpers are done with the buffers of the previous iteration
       }
@@ -2746,7 +2750,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
           hmat_save<SOLVER>(l, hsz, Nt, Hbk);   // saved for rejected trials
         }
       }
-      if (SOLVER == SOLVER_BAND && !TEB_CFG(args.band_ldlt, false)) cr_copy_band(l, n, Hbk, spec_now);   // hybrid solve: the band to HBM once per iteration
+      if (SOLVER == SOLVER_BAND && !TEB_CFGI(BAND_LDLT)) cr_copy_band(l, n, Hbk, spec_now);   // hybrid solve: the band to HBM once per iteration
       if constexpr (MCU) {
         if (spec_now) spec_issue(mm, l.bv, Nt, n, S, lambda, ni);   // retries 1 .. K start on their CUs now
       }
@@ -2769,7 +2773,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
         }
         h_spent = true;
         if constexpr (SOLVER == SOLVER_BAND) {
-          if (TEB_CFG(args.band_ldlt, false)) {
+          if (TEB_CFGI(BAND_LDLT)) {
             if (tid < 64) {
               bool ok = banded_ldlt_solve_wave0(l, Nt, lambda);
               if (tid == 0) l.ired[0] = ok ? 1 : 0;
@@ -2863,7 +2867,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       ++iters;
       chi2_final = currentChi;
       if (qmax == 10 || rho == 0 || !isfinite(lambda)) lm_ok = false;   // Terminate
-      if (TEB_CFG(c.divergence_detection_enable, false)) {   // setComputeBatchStatistics -> computeActiveErrors after each solve
+      if (TEB_CFGI(DIVERGENCE_DETECTION)) {   // setComputeBatchStatistics -> computeActiveErrors after each solve
         double fc[5];
         fc[4] = 0;
         if (MCU && t.mcu.items != nullptr) {

@@ -256,12 +256,13 @@ class TebBatchSolver:
         return a.value, k.value
 
     def last_config_profile(self):
-        """True if the last optimize() ran a kernel specialised on the TebConfig defaults (teb_amd_options_t::generic_config_path)"""
+        """Which kernel the last optimize() ran: 1 = specialised on the TebConfig defaults, 2 = the same folds except via-points and the
+        holonomic choice (*_WIDE kinds), 0 = the generic instantiation (teb_amd_options_t::generic_config_path forces it)"""
         L = lib()
         L.teb_amd_debug_last_config_profile.argtypes = [C.c_void_p, _abi.p_i32]
         v = C.c_int32(0)
         _chk(L.teb_amd_debug_last_config_profile(self._h, C.byref(v)), "teb_amd_debug_last_config_profile")
-        return bool(v.value)
+        return int(v.value)
 
     def capacity(self):
         a = C.c_int32(0)

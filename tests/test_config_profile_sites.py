@@ -1,6 +1,8 @@
-"""Host logic of the kernels specialised on the TebConfig defaults: every configuration field a device source folds with TEB_CFG /
-TEB_KIN_CFG (csrc/teb_device.hpp) must be checked by config_matches_defaults_profile / launch_opt in csrc/teb_amd.hip before such a kernel
-is launched - a fold without its host-side condition would silently compute a different cost function."""
+"""Host logic of the kernels specialised on the configuration (csrc/teb_device.hpp: the profile table TEB_PF_*). A device source folds a
+flag by writing TEB_CFGI(ID); the host's profile_matches() (csrc/teb_amd.hip) is generated from TEB_PF_ALL over the same table. What can
+still go wrong is checked here, without a GPU: an id used at a device site but missing from TEB_PF_ALL (its host-side condition would
+never be evaluated - a fold without its check silently computes another cost function), a table entry without its columns, and a
+hand-written fold that bypasses the table."""
 import os
 import re
 
@@ -8,44 +10,37 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "..", "teb_local_planner_amd", "csrc")
 
 
-def _macro_args(text, name):
-    """first arguments of every NAME( .. , .. ) invocation (balanced parentheses)"""
-    out = []
-    for m in re.finditer(r"\b%s\(" % name, text):
-        depth, i, start = 1, m.end(), m.end()
-        first_end = None
-        while depth:
-            ch = text[i]
-            if ch == "(":
-                depth += 1
-            elif ch == ")":
-                depth -= 1
-            elif ch == "," and depth == 1 and first_end is None:
-                first_end = i
-            i += 1
-        out.append(text[start:first_end])
-    return out
+def _read(f):
+    return open(os.path.join(CSRC, f)).read()
 
 
-def test_every_folded_flag_has_its_host_side_condition():
-    folded = set()
+def test_every_folded_flag_is_in_the_table_the_host_check_is_generated_from():
+    dev = _read("teb_device.hpp")
+    listed = re.findall(r"X\((\w+)\)", dev[dev.index("#define TEB_PF_ALL(X)"):dev.index("#define TEB_PF_EXPR_EXACT_ARC")])
+    assert len(listed) >= 20 and len(set(listed)) == len(listed), listed
+    used = set()
     sites = 0
-    for f in ("teb_kernel.hpp", "teb_edges.hpp"):
-        text = open(os.path.join(CSRC, f)).read()
-        text = re.sub(r"#define TEB_(KIN_)?CFG\(.*", "", text)
-        for name in ("TEB_CFG", "TEB_KIN_CFG"):
-            for arg in _macro_args(text, name):
-                sites += 1
-                folded.update(re.findall(r"\b(?:c|args|sc)\.(\w+)", arg))
-    assert sites >= 20, sites
-    host = open(os.path.join(CSRC, "teb_amd.hip")).read()
-    body = host[host.index("bool config_matches_defaults_profile"):host.index("if (!k) k = opt_kernel")]
-    checked = set(re.findall(r"\bc\.(\w+)", body)) | set(re.findall(r"\bh->(?:opt\.)?(\w+)", body)) | set(re.findall(r"\ba\.(\w+)", body))
-    # the kinematics flags are folded in the point-like kinds only, and checked for them only (scene_part); fields that appear under
-    # another name on the host: the via-points (nvia), the near-mask switch (opt.no_near_cache), the footprint (fast_points)
-    alias = {"include_dynamic_obstacles": "weight_obstacle",   # without include_dynamic_obstacles the dynamic list is empty: only weight_obstacle decides
-             "acc_lim_y": "max_vel_y"}                       # max_vel_y == 0 alone makes the acceleration edges non-holonomic
-    missing = sorted(f for f in folded if alias.get(f, f) not in checked)
-    assert not missing, "folded on the device but not checked on the host: %s" % missing
-    for must in ("nvia", "generic_config_path", "fast_points", "static_radius_zero", "band_ldlt", "debug_linearize", "no_near_cache"):
-        assert must in checked, must
+    for f in ("teb_kernel.hpp", "teb_edges.hpp", "teb_geometry.hpp", "teb_multicu.hpp", "teb_autoresize_chain.hpp"):
+        ids = re.findall(r"\bTEB_CFGI\((\w+)\)", _read(f))
+        sites += len(ids)
+        used.update(ids)
+    assert sites >= 25, sites
+    assert used <= set(listed), "folded at a device site but absent from TEB_PF_ALL: %s" % sorted(used - set(listed))
+    assert set(listed) <= used, "in the table but folded nowhere: %s" % sorted(set(listed) - used)
+    for ident in listed:   # every column of every entry
+        for col in ("EXPR", "DFLT", "HOST", "WIDE", "KIN"):
+            assert re.search(r"#define TEB_PF_%s_%s\b" % (col, ident), dev), (col, ident)
+
+
+def test_the_host_check_is_the_generated_one_and_nothing_folds_by_hand():
+    host = _read("teb_amd.hip")
+    body = host[host.index("int profile_matches("):host.index("hipError_t launch_opt(")]
+    assert "TEB_PF_ALL(TEB_PF_CHECK)" in body and "TEB_PF_HOST_##ID" in body and "TEB_PF_WIDE_##ID" in body and "TEB_PF_KIN_##ID" in body
+    assert "generic_config_path" in body
+    assert "config_matches_defaults_profile" not in host          # the hand-kept mirror of rounds 3 is gone
+    for f in ("teb_kernel.hpp", "teb_edges.hpp"):                  # no fold outside the table
+        text = _read(f)
+        assert not re.search(r"\bTEB_(KIN_)?CFG\(", text), f
+    # the only other use of the build flag: the branch-free footprint radius (no configuration flag is folded there)
+    edges = _read("teb_edges.hpp")
+    assert edges.count("TEB_AMD_DEFAULTS_PROFILE") == 1 and "footprint_radius : 0.0" in edges

@@ -119,7 +119,6 @@ def _with(cfg, **kw):
 def test_configurations_off_the_folded_paths_run_the_generic_kernel():
     cfg0, obst, via, batch = scenes.scene_c3(B=4, n=60, M=40, stride=96)
     variants = {
-        "holonomic": _with(cfg0, robot__max_vel_y=0.2, robot__acc_lim_y=0.3),
         "no velocity edges": _with(cfg0, optim__weight_max_vel_x=0.0, optim__weight_max_vel_theta=0.0),
         "no acceleration edges": _with(cfg0, optim__weight_acc_lim_x=0.0, optim__weight_acc_lim_theta=0.0),
         "no time-optimal edges": _with(cfg0, optim__weight_optimaltime=0.0),
@@ -136,5 +135,40 @@ def test_configurations_off_the_folded_paths_run_the_generic_kernel():
         _, res, prof, _ = run(cfg, obst, via, batch)
         assert not prof, name
         assert (np.asarray(res.status) != _abi.TEB_NONFINITE).all(), name
-    assert not run(cfg0, obst, [(3.0, 0.2)], batch)[2], "via-points"
-    assert run(cfg0, obst, via, batch)[2], "the unchanged configuration is on the folded paths"
+    assert run(cfg0, obst, via, batch)[2] == 1, "the unchanged configuration is on the folded paths"
+
+
+@pytest.mark.parametrize("layout", ["blocks", "hybrid"])
+@pytest.mark.parametrize("what", ["via_points", "holonomic", "holonomic_with_via_points", "holonomic_velocity_only"])
+def test_via_points_and_holonomic_robots_run_the_wide_kinds_with_identical_bits(what, layout):
+    """Round 4: configurations that differ from the defaults only in via-points and / or a holonomic base run the
+    *_WIDE kinds (every other fold of the profile kept, teb_device.hpp: TEB_PF_WIDE_*), full batch and small batch with solver helpers,
+    and get the generic kernel's bands bit for bit."""
+    for B in (3, 24):
+        if layout == "hybrid":
+            cfg, obst, via, batch = scenes.scene_c4(B=B, stride=288)
+        else:
+            cfg, obst, via, batch = scenes.scene_c4(B=B, stride=208); cfg.trajectory.teb_autosize = False
+        if "holonomic" in what:
+            cfg.robot.max_vel_y = 0.2; cfg.robot.max_vel_trans = 0.5
+            cfg.robot.acc_lim_y = 0.0 if what == "holonomic_velocity_only" else 0.3   # acc_lim_y == 0: holonomic velocity, non-holonomic acceleration edges
+            cfg.optim.weight_max_vel_y = 2.0; cfg.optim.weight_acc_lim_y = 1.0
+        if "via" in what:
+            cfg.optim.weight_viapoint = 1.0
+            via = [(5.0, 0.3), (10.0, -0.2), (15.0, 0.25)]
+            batch.via_points_enabled[:] = 1
+            batch.via_points_enabled[0] = 0      # per-band switch stays a run-time flag
+        t = run(cfg, obst, via, batch)
+        g = run(cfg, obst, via, batch, generic_config_path=True)
+        assert t[2] == 2 and g[2] == 0, (what, layout, B, t[2], g[2])
+        assert t[3] == g[3]
+        same_bits(t[0], t[1], g[0], g[1])
+
+
+def test_wide_kinds_do_not_take_what_they_fold():
+    cfg0, obst, via, batch = scenes.scene_c3(B=4, n=60, M=40, stride=96)
+    cfg = _with(cfg0, robot__max_vel_y=0.2, robot__acc_lim_y=0.3, optim__weight_shortest_path=1.0)   # holonomic AND a flag the wide kinds fold
+    assert run(cfg, obst, via, batch)[2] == 0
+    cfg = _with(cfg0, robot__max_vel_y=0.2, robot__acc_lim_y=0.3)
+    cfg.jacobian_mode = 1                                                                          # the wide kinds exist for closed forms only
+    assert run(cfg, obst, via, batch)[2] == 0

@@ -129,6 +129,14 @@ def main():
         lines.append(json.dumps(summary["calibration"]))
     open(os.path.join(DST, "rocprof_%s_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
     json.dump(summary, open(os.path.join(DST, "rocprof_%s_summary.json" % tag), "w"), indent=1)
+    # the phase split and the per-band times of the SAME sources (-DTEB_PROFILE build run by tools/profile.sh), stamped with the hash this
+    # script computes itself - one profile per round, nothing stamped by hand
+    for src_name, dst_name, what in (("phases.txt", "phases_%s.txt" % tag, "tools/prof_phases.py c4on c3 c2 c5 (workgroup 0, clock64 section counters)"),
+                                     ("band_times.txt", "band_times_%s.txt" % tag, "tools/band_times.py c4on (which bands the launch waits for)")):
+        p = os.path.join(SRC, src_name)
+        if os.path.exists(p):
+            open(os.path.join(DST, dst_name), "w").write("# %s\n# source_hash %s (device + host sources of the library, bench.kernel_source_hash)\n%s" % (
+                what, summary["source_hash"], open(p).read()))
     for name in ("bench_trace.json", "bench_fetch.json", "bench_write.json"):
         p = os.path.join(SRC, name)
         if os.path.exists(p):

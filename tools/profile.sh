@@ -24,6 +24,11 @@ fi
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/cal_fetch -o calf -- python $ROOT/tools/calib_stream.py > /dev/null 2> $OUT/calf.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/cal_write -o calw -- python $ROOT/tools/calib_stream.py > /dev/null 2> $OUT/calw.log
 cd $ROOT
+# phase split of the same binary's sources (-DTEB_PROFILE build, tools/build_prof.sh) and which bands the launch waits for
+if [ -f $ROOT/tools/libteb_amd_prof.so ]; then
+  TEB_AMD_LIB=$ROOT/tools/libteb_amd_prof.so python $ROOT/tools/prof_phases.py c4on c3 c2 c5 > $OUT/phases.txt 2>&1
+  TEB_AMD_LIB=$ROOT/tools/libteb_amd_prof.so python $ROOT/tools/band_times.py c4on > $OUT/band_times.txt 2>&1
+fi
 python - <<PY
 import sqlite3, json, os
 out = "$OUT"
