@@ -669,7 +669,7 @@ def main():
                            "vs_headline_kernel_ms": kx / float(np.mean(kernel_ms))}
             for nm, mk, what in (("c3_autosize_on", lambda: scenes.scene_c3(stride=208), "C3: 64 candidate TEBs x 150 poses, 200 point obstacles"),
                                  ("c2_autosize_on", lambda: scenes.scene_c2(stride=232), "C2: 1 TEB x 200 poses, 100 point obstacles"),
-                                 ("c5_carlike_polygons", lambda: scenes.scene_c5(stride=343),
+                                 ("c5_carlike_polygons", lambda: scenes.scene_c5(stride=336),
                                   "C5: 1 TEB x 300 poses, car-like, polygon footprint vs 300 polygon obstacles")):
                 cc, oo, vv, bb = mk()
                 sx = planner.make_solver(cc, oo, vv, bb)
@@ -758,7 +758,7 @@ def main():
             # ---- CPU p50 latency of one plan()-equivalent optimizeTEB beside the GPU latencies above: one thread for the
             #      single-band configurations C2 / C5 (g2o-numeric oracle and the reference's own code), thread per TEB for the C4 batch
             pl = {}
-            for nm, mk in (("c2", lambda: scenes.scene_c2(stride=232)), ("c5", lambda: scenes.scene_c5(stride=343))):
+            for nm, mk in (("c2", lambda: scenes.scene_c2(stride=232)), ("c5", lambda: scenes.scene_c5(stride=336))):
                 cc, oo, vv, bb = mk()
                 cc.jacobian_mode = _abi.JACOBIAN_G2O_NUMERIC
                 reps = 7 if nm == "c2" else 3

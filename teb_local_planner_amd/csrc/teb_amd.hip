@@ -435,9 +435,9 @@ int launch(teb_amd_handle* h, const OptArgs& args) {
   if (h->B <= 0) return fail(TEB_AMD_ERR_INVALID_ARG, "no TEBs uploaded");
   SceneDev sc = scene_of(h);
   BatchDev bt = batch_of(h);
-  // The layout of the normal matrix follows the pose capacity of the handle (blocks in LDS <= 238 poses, band in LDS <= 343, band in
+  // The layout of the normal matrix follows the pose capacity of the handle (blocks in LDS <= 238 poses, band in LDS <= 337, band in
   // HBM beyond), the faster layouts only hold shorter bands. A handle created for long bands that currently holds short ones is
-  // launched in the fastest layout that leaves the bands 12.5 % room to grow (autoResize); should a band outgrow it all the same, the
+  // launched in the fastest layout that leaves the bands 10 % room to grow (autoResize); should a band outgrow it all the same, the
   // launch is repeated from the saved strips in the handle's own layout. Results do not depend on the layout (same arithmetic up to
   // the order of the block reduction). TEB_AMD_FIXED_LAYOUT=1 switches this off.
   int eff_solver = h->solver;
@@ -452,10 +452,10 @@ int launch(teb_amd_handle* h, const OptArgs& args) {
       nmax = 0;
       for (int v : n) nmax = std::max(nmax, v);
     }
-    const int need = nmax + nmax / 8 + 4;   // 12.5 % room to grow; a band that needs more triggers the repeat below
+    const int need = nmax + nmax / 10 + 4;   // 10 % room to grow; a band that needs more triggers the repeat below
     const int ob = h->fast_points ? h->M : 0;
     const int s_cr = max_capacity_of(h, SOLVER_CR, std::min(h->stride, 238));
-    const int s_band = h->solver == SOLVER_BANDG ? max_capacity_of(h, SOLVER_BAND, std::min(h->stride, 343)) : 0;
+    const int s_band = h->solver == SOLVER_BANDG ? max_capacity_of(h, SOLVER_BAND, std::min(h->stride, 337)) : 0;
     if (s_cr > 0 && need <= s_cr) { eff_solver = SOLVER_CR; eff_plan = make_lds_plan(s_cr, SOLVER_CR, ob); optimistic = true; }
     else if (s_band > 0 && need <= s_band) { eff_solver = SOLVER_BAND; eff_plan = make_lds_plan(s_band, SOLVER_BAND, ob); optimistic = true; }
   }
@@ -639,7 +639,7 @@ int teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max
   // Normal matrix as 8x8 blocks in LDS (SOLVER_CR: cyclic reduction in place, fastest) when that fits TOGETHER with the LDS cache
   // of a full obstacle table of max_obstacles point-like entries; otherwise as a band in LDS (SOLVER_BAND: 44 instead of 70
   // doubles per pose) with the hybrid cyclic reduction (level 0 from a band-form copy in HBM) - within 2 % of the block layout
-  // per step, keeps the obstacle cache and holds bands up to 343 poses.
+  // per step, keeps the obstacle cache and holds bands up to 337 poses.
   int solver = SOLVER_CR;
   // the kernel also owns a little static LDS (__syncthreads_or scratch): keep 1 KiB of head-room
   const size_t lds_limit = (size_t)prop.sharedMemPerBlock - 1024;
@@ -653,7 +653,7 @@ int teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max
     if (lds_bytes_for(max_poses, SOLVER_CR) > lds_limit) return fail(TEB_AMD_ERR_CAPACITY, "TEB_AMD_LAYOUT_BLOCKS_LDS: max_poses too large for the block layout");
     solver = SOLVER_CR;
   }
-  // bands too long for the LDS band (> 343 poses; the reference's max_samples default is 500): the band form of the normal matrix
+  // bands too long for the LDS band (> 337 poses; the reference's max_samples default is 500): the band form of the normal matrix
   // moves to HBM (SOLVER_BANDG: 44 doubles per pose, L2-resident), everything else stays as it is
   if (solver == SOLVER_BAND && lds_bytes_for(max_poses, SOLVER_BAND) > lds_limit) solver = SOLVER_BANDG;
   const size_t lds = lds_bytes_for(max_poses, solver);
@@ -707,7 +707,7 @@ int teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max
   A(h->chi2.alloc(max_tebs)); A(h->cost.alloc(max_tebs)); A(h->lambda.alloc(max_tebs));
   A(h->Hbackup.alloc((size_t)max_tebs * h->hmat_stride));
   A(h->clk.alloc(4));
-  h->hband_stride = solver == SOLVER_BANDG ? (size_t)4 * max_poses * kBand : 0;
+  h->hband_stride = solver == SOLVER_BANDG ? (size_t)hbo(4 * max_poses) + 2 : 0;
   A(h->Hband.alloc((size_t)max_tebs * h->hband_stride));
   A(h->snap_n.alloc(max_tebs)); A(h->snap_x.alloc(BS)); A(h->snap_y.alloc(BS)); A(h->snap_th.alloc(BS)); A(h->snap_dt.alloc(BS));
   A(h->dbg_H.alloc((size_t)4 * max_poses * kBand)); A(h->dbg_b.alloc((size_t)4 * max_poses)); A(h->dbg_chi2.alloc(4));
@@ -805,13 +805,13 @@ int commit_obstacles(teb_amd_handle* h) {
   for (int i = 0; i < M && pointlike; ++i) pointlike = (o.type[i] == TEB_AMD_OBST_POINT || o.type[i] == TEB_AMD_OBST_CIRCULAR);
   if (h->opt.generic_distance_path) pointlike = false;
   // a point-like scene whose obstacle cache does not fit beside the LDS band: the band moves to HBM and the cache stays (measured,
-  // 64 bands x 343 poses x 500 obstacles: 9.0 instead of 11.8 ms per step)
+  // 64 bands x 337 poses x 500 obstacles: 9.0 instead of 11.8 ms per step)
   h->solver = h->solver_created;
   if (pointlike && M > 0 && h->solver == SOLVER_BAND && h->opt.layout == TEB_AMD_LAYOUT_AUTO &&
       (size_t)make_lds_plan(h->stride, SOLVER_BAND, M).total_bytes > h->lds_limit &&
       (size_t)make_lds_plan(h->stride, SOLVER_BANDG, M).total_bytes <= h->lds_limit) {
     if (h->hband_stride == 0) {
-      h->hband_stride = (size_t)4 * h->stride * kBand;
+      h->hband_stride = (size_t)hbo(4 * h->stride) + 2;
       h->Hband.free();
       HIPCHK(h->Hband.alloc((size_t)h->max_tebs * h->hband_stride));
     }

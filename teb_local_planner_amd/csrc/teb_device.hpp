@@ -160,6 +160,11 @@ namespace tebamd {
 constexpr int kThreads = 256;   // 4 wave64 per workgroup, one workgroup per candidate TEB (512 = two waves per SIMD: measured in round 2, 1100 - 1600 spill slots, 6.9 vs 4.8 ms)
 constexpr int kWaves = kThreads / 64;
 constexpr int kBand = 11;           // diagonal + scalar half-bandwidth 10
+// Where band row r (a scalar row: entries (r, r - d), d = 0 .. 10) starts in a band buffer: 11 doubles per row plus ONE padding double per
+// pose (4 rows). Lane i of the linearisation owns the rows of pose i; with rows of 11 the lanes of a wave were 44 doubles = 88 banks apart,
+// i.e. on 8 distinct bank positions (8-way conflicts in every read-modify-write of the scatter, a quarter of all LDS cycles of the kernel);
+// 45 doubles apart they spread over 32. One layout for every band buffer (LDS band, its HBM copy, the HBM band of long bands).
+__host__ __device__ constexpr int hbo(int r) { return r * kBand + (r >> 2); }
 constexpr int kMaxPoseIter = 2;     // poses handled per thread: n <= kThreads * kMaxPoseIter
 
 // LDS layout of one workgroup, computed on the host (offsets in doubles from the dynamic-LDS base).

@@ -76,7 +76,7 @@ __host__ __device__ inline int nb_for(int S) { return (4 * S + 7) / 8; }
 __host__ __device__ inline size_t hmat_doubles(int S, int solver) {  // (LDS-resident part)
   if (solver == SOLVER_BANDG) return (size_t)6 * S + 256;   // only the scratch of autoResize (edit script + new poses + split stack + runs)
   if (solver == SOLVER_CR) return (size_t)nb_for(S) * (2 * kBlk + 8);
-  const size_t band = (size_t)4 * S * kBand, compact = (size_t)((nb_for(S) + 1) / 2) * (2 * kBlk + 8);   // hybrid solve: even block rows in LDS
+  const size_t band = (size_t)hbo(4 * S), compact = (size_t)((nb_for(S) + 1) / 2) * (2 * kBlk + 8);   // hybrid solve: even block rows in LDS
   return band > compact ? band : compact;
 }
 // per-band HBM scratch of the solves: SOLVER_CR keeps a copy of H there; SOLVER_BAND / BANDG the 8x8 blocks (D, L, f) the reduction
@@ -578,7 +578,7 @@ __device__ __forceinline__ void scatter(const Accum& A, const Lds& l, int i, int
       if (fb) continue;
       const double v = A.H[a * (a + 1) / 2 + b];
       if (SOLVER != SOLVER_CR) {
-        l.Hb[ra * kBand + (a - b)] += v;
+        l.Hb[hbo(ra) + (a - b)] += v;
       } else {
         const int jr = ra >> 3, jc = rb >> 3;   // window spans at most two consecutive block rows
         if (jr == jc) l.Db[jr * kBlk + (ra & 7) * 8 + (rb & 7)] += v;
@@ -616,7 +616,7 @@ __device__ __forceinline__ void hmat_load(const Lds& l, int hsz, int Nt, const d
 // address of the diagonal entry of variable r
 template <int SOLVER>
 __device__ __forceinline__ double* diag_ptr(const Lds& l, int r) {
-  return SOLVER != SOLVER_CR ? &l.Hb[r * kBand] : &l.Db[(r >> 3) * kBlk + (r & 7) * 9];
+  return SOLVER != SOLVER_CR ? &l.Hb[hbo(r)] : &l.Db[(r >> 3) * kBlk + (r & 7) * 9];
 }
 
 // per-pose cos/sin cache: every cost term that needs the heading reads these instead of re-evaluating libm
@@ -629,7 +629,7 @@ template <int SOLVER, int JMODE, bool FAST>
 __device__ inline void linearize(const teb_amd_config_t& c, const SceneDev& sc, const TebCtx& t, const Lds& l, NearCache& nc,
                                  double* cats /*4, out on all threads*/, bool trig_is_current = false) {
   const int n = t.n, Nt = 4 * n, tid = threadIdx.x;
-  const int hsz = (SOLVER != SOLVER_CR) ? Nt * kBand : ((Nt + 7) >> 3) * 2 * kBlk;
+  const int hsz = (SOLVER != SOLVER_CR) ? hbo(Nt) : ((Nt + 7) >> 3) * 2 * kBlk;
   LNP_DECL
   for (int q = tid; q < hsz; q += kThreads) *hmat_ptr<SOLVER>(l, q, Nt) = 0;
   for (int q = tid; q < Nt + 8; q += kThreads) l.bv[q] = 0;
@@ -747,31 +747,31 @@ __device__ inline bool banded_ldlt_solve_wave0(const Lds& l, int Nt, double lamb
   __builtin_amdgcn_wave_barrier();
   bool ok = true;
   for (int k = 0; k < Nt; ++k) {
-    const double d = H[k * kBand] + lambda;
+    const double d = H[hbo(k)] + lambda;
     if (!(d > 0)) { ok = false; break; }
     const double inv = 1.0 / d;
     const double xk = x[k];
     if (k + wi < Nt) {
-      const double ci = H[(k + wi) * kBand + wi];
+      const double ci = H[hbo(k + wi) + wi];
       if (wj > 0) {
-        const double cj = H[(k + wj) * kBand + wj];
-        H[(k + wi) * kBand + (wi - wj)] -= (ci * inv) * cj;
+        const double cj = H[hbo(k + wj) + wj];
+        H[hbo(k + wi) + (wi - wj)] -= (ci * inv) * cj;
       } else {
         x[k + wi] -= (ci * inv) * xk;
       }
     }
-    if (lane == 0 && k + 10 < Nt) x[k + 10] -= (H[(k + 10) * kBand + 10] * inv) * xk;
+    if (lane == 0 && k + 10 < Nt) x[k + 10] -= (H[hbo(k + 10) + 10] * inv) * xk;
     __builtin_amdgcn_wave_barrier();
-    if (lane < 10 && k + lane + 1 < Nt) H[(k + lane + 1) * kBand + lane + 1] *= inv;   // L(k+i, k)
-    if (lane == 0) H[k * kBand] = d;
+    if (lane < 10 && k + lane + 1 < Nt) H[hbo(k + lane + 1) + lane + 1] *= inv;   // L(k+i, k)
+    if (lane == 0) H[hbo(k)] = d;
     __builtin_amdgcn_wave_barrier();
   }
   if (!ok) return false;
-  for (int r = lane; r < Nt; r += 64) x[r] = x[r] / H[r * kBand];
+  for (int r = lane; r < Nt; r += 64) x[r] = x[r] / H[hbo(r)];
   __builtin_amdgcn_wave_barrier();
   for (int k = Nt - 1; k > 0; --k) {
     const double xk = x[k];
-    if (lane < 10 && k - lane - 1 >= 0) x[k - lane - 1] -= H[k * kBand + lane + 1] * xk;
+    if (lane < 10 && k - lane - 1 >= 0) x[k - lane - 1] -= H[hbo(k) + lane + 1] * xk;
     __builtin_amdgcn_wave_barrier();
   }
   return true;
@@ -1227,13 +1227,13 @@ __device__ __forceinline__ void cr_solve_t_impl(const LdsPlan plan, const SceneD
       double v = 0;
       if (w < 64) {            // D_j[a][bcol]
         const int cc = 8 * j + bcol;
-        if (r < Nt && cc < Nt) v = (cc <= r) ? Hb[r * kBand + (r - cc)] : Hb[cc * kBand + (cc - r)];
+        if (r < Nt && cc < Nt) v = (cc <= r) ? Hb[hbo(r) + (r - cc)] : Hb[hbo(cc) + (cc - r)];
         else if (r == cc) v = 1.0;
         if (r == cc) v += lambda;
         D[j * kBlk + a * 8 + bcol] = v;
       } else {                 // L_j[a][bcol] = H[8j+a][8(j-1)+bcol]
         const int d = 8 + a - bcol;
-        if (j >= 1 && r < Nt && d < kBand) v = Hb[r * kBand + d];
+        if (j >= 1 && r < Nt && d < kBand) v = Hb[hbo(r) + d];
         L[j * kBlk + a * 8 + bcol] = v;
       }
     }
@@ -1384,20 +1384,24 @@ __device__ __forceinline__ void cr_copy_band(const Lds& l, int n, double* __rest
   const int tid = threadIdx.x;
   const int Nt = 4 * n, Nb = (Nt + 7) >> 3;
   const double* Hb = l.Hb;
+  const int live = hbo(Nt);   // rows [0, Nt) incl. their padding doubles: copied as they stand
   if (shared) {   // (8-byte write-through stores; 16-byte ones through inline asm measured 7 - 10 % slower end to end on C2 / C3 / C5)
-    for (int q = tid; q < Nb * 8 * kBand; q += kThreads) {
-      const int r = q / kBand;
-      st_agent_f64(gband + q, r < Nt ? Hb[q] : ((q - r * kBand) == 0 ? 1.0 : 0.0));
+    for (int q = tid; q < live; q += kThreads) st_agent_f64(gband + q, Hb[q]);
+    for (int q = tid; q < (Nb * 8 - Nt) * kBand; q += kThreads) {   // the padding rows [Nt, 8 Nb) of an odd pose count become identity rows
+      const int r = Nt + q / kBand, d = q - (r - Nt) * kBand;
+      st_agent_f64(gband + hbo(r) + d, d == 0 ? 1.0 : 0.0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
-    // rows [0, Nt): a linear copy, two doubles per access (the band starts on a 16-byte boundary in LDS and in the scratch, Nt * kBand is
-    // even); the padding rows [Nt, 8 Nb) of an odd pose count become identity rows
+    // a linear copy, two doubles per access (the band starts on a 16-byte boundary in LDS and in the scratch)
     typedef double __attribute__((address_space(1))) gdouble_t;
     typedef teb_v2d __attribute__((address_space(1))) gv2d_t;
-    const int live = Nt * kBand;
-    for (int q = 2 * tid; q < live; q += 2 * kThreads) *reinterpret_cast<gv2d_t*>((gdouble_t*)gband + q) = *reinterpret_cast<const teb_v2d*>(Hb + q);
-    for (int q = live + tid; q < Nb * 8 * kBand; q += kThreads) gband[q] = ((q - live) % kBand) == 0 ? 1.0 : 0.0;
+    for (int q = 2 * tid; q + 1 < live; q += 2 * kThreads) *reinterpret_cast<gv2d_t*>((gdouble_t*)gband + q) = *reinterpret_cast<const teb_v2d*>(Hb + q);
+    if ((live & 1) && tid == 0) gband[live - 1] = Hb[live - 1];
+    for (int q = tid; q < (Nb * 8 - Nt) * kBand; q += kThreads) {
+      const int r = Nt + q / kBand, d = q - (r - Nt) * kBand;
+      gband[hbo(r) + d] = d == 0 ? 1.0 : 0.0;
+    }
   }
   __threadfence_block();
   __syncthreads();
@@ -1432,7 +1436,7 @@ template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const Ld
   // coupled by their original L blocks) and are reduced by its levels, which need no extra round for them (Nc = 80 instead of 72 rows at
   // 287 poses: 40 / 20 / 10 / 5 / 2 / 1 eliminations instead of 36 / 18 / 9 / 4 / 2 / 1, seven rounds either way) - as long as
   // the larger compact system fits the band region. Compact row j is block row 2 j for j <= E0 and block row j + E0 beyond.
-  const int E0 = (E > 2 * (kThreads / 8) && (size_t)(Nb - 2 * (kThreads / 8)) * (2 * kBlk + 8) <= (size_t)4 * plan.S * kBand) ? 2 * (kThreads / 8) : E;
+  const int E0 = (E > 2 * (kThreads / 8) && (size_t)(Nb - 2 * (kThreads / 8)) * (2 * kBlk + 8) <= (size_t)hbo(4 * plan.S)) ? 2 * (kThreads / 8) : E;
   const int Nc = Nb - E0;   // (= the even rows alone, (Nb + 1) / 2, when every odd row is eliminated at level 0)
 #define TEB_HYB_ROW(j) ((j) <= E0 ? 2 * (j) : (j) + E0)
   // Hg: the band copy, entry (r, c), c <= r <= c + 10, at Hg[r * 11 + (r - c)]. In terms of 8x8 blocks:
@@ -1454,7 +1458,7 @@ template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const Ld
       const int q = q0 + u * kThreads;
       const int j = q >> 6, a8 = (q >> 3) & 7, b8 = q & 7;
       const int hi = a8 > b8 ? a8 : b8, lo = a8 > b8 ? b8 : a8;
-      v[u] = q < Nc * 64 ? Hg[(size_t)(8 * TEB_HYB_ROW(j) + hi) * kBand + (hi - lo)] : 0.0;
+      v[u] = q < Nc * 64 ? Hg[hbo(8 * TEB_HYB_ROW(j) + hi) + (hi - lo)] : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < kInitBatch; ++u) {
@@ -1472,7 +1476,7 @@ template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const Ld
   // the couplings of the rows that skip level 0 (compact rows E0 + 1 ..): their original L blocks
   for (int q = (E0 + 1) * 64 + tid; q < Nc * 64; q += kThreads) {
     const int j = q >> 6, a8 = (q >> 3) & 7, b8 = q & 7;
-    Lc[j * kBlk + (q & 63)] = b8 >= a8 - 2 ? Hg[(size_t)(8 * (j + E0) + a8) * kBand + (8 + a8 - b8)] : 0.0;
+    Lc[j * kBlk + (q & 63)] = b8 >= a8 - 2 ? Hg[hbo(8 * (j + E0) + a8) + (8 + a8 - b8)] : 0.0;
   }
   if (tid == 0) l.ired[0] = 1;
   __syncthreads();
@@ -1493,20 +1497,20 @@ template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const Ld
     double s1 = 0, s2 = 0;
     if (rr * (kThreads / 8) < E0) {   // (uniform) this round has eliminations at all
       if (act) {
-        gdouble_t* Hi = Hg + (size_t)(8 * i) * kBand;         // band rows of block row i
-        gdouble_t* Hp = Hg + (size_t)(8 * (i + 1)) * kBand;   // ... of block row i + 1 (valid iff hasU)
+        gdouble_t* Hi = Hg + hbo(8 * i);         // band rows of block row i (8 i is a multiple of 4: row r of the block starts at Hi + hbo(r))
+        gdouble_t* Hp = Hg + hbo(8 * (i + 1));   // ... of block row i + 1 (valid iff hasU)
         Ldl8 F;
 #pragma unroll
         for (int r = 0; r < 8; ++r)
 #pragma unroll
-          for (int cc = 0; cc <= r; ++cc) F.a[Ldl8::idx(r, cc)] = Hi[r * kBand + (r - cc)];
+          for (int cc = 0; cc <= r; ++cc) F.a[Ldl8::idx(r, cc)] = Hi[hbo(r) + (r - cc)];
 #pragma unroll
         for (int k = 0; k < 8; ++k) F.a[Ldl8::idx(k, k)] += lambda;
         double cl[8], cu[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          cl[k] = wL[k] = (c >= k - 2) ? Hi[k * kBand + (8 + k - c)] : 0.0;                 // L_i[k][c]
-          cu[k] = wU[k] = (hasU && k >= c - 2) ? Hp[c * kBand + (8 + c - k)] : 0.0;         // U_i[k][c] = L_{i+1}[c][k]
+          cl[k] = wL[k] = (c >= k - 2) ? Hi[hbo(k) + (8 + k - c)] : 0.0;                 // L_i[k][c]
+          cu[k] = wU[k] = (hasU && k >= c - 2) ? Hp[hbo(c) + (8 + c - k)] : 0.0;         // U_i[k][c] = L_{i+1}[c][k]
           wf[k] = (8 * i + k < Nt) ? l.bv[8 * i + k] : 0.0;
         }
         ok = F.factor() && ok;
@@ -2716,7 +2720,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
             const int r = q / kBand, d = q % kBand, cc = r - d;
             double v = 0;
             if (cc >= 0) {
-              if (SOLVER != SOLVER_CR) v = l.Hb[q];
+              if (SOLVER != SOLVER_CR) v = l.Hb[hbo(r) + d];
               else if ((r >> 3) == (cc >> 3)) v = l.Db[(r >> 3) * kBlk + (r & 7) * 8 + (cc & 7)];
               else if ((r >> 3) == (cc >> 3) + 1) v = l.Lb[(r >> 3) * kBlk + (r & 7) * 8 + (cc & 7)];
             }
@@ -2737,7 +2741,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
         ni = 2;
       }
       PROF_START();
-      const int hsz = (SOLVER != SOLVER_CR) ? Nt * kBand : ((Nt + 7) >> 3) * 2 * kBlk;
+      const int hsz = (SOLVER != SOLVER_CR) ? hbo(Nt) : ((Nt + 7) >> 3) * 2 * kBlk;
       const bool keep_copy = !(SOLVER != SOLVER_CR && !TEB_CFGI(BAND_LDLT));   // the HBM-block reductions never touch the band
       if constexpr (MCU) {
         if (spec_on) spec_wait_idle(mm, l.ired + 26);   // the solver helpers are done with the buffers of the previous iteration

@@ -14,7 +14,7 @@ CASES = [("C1 test_optim_node, 1 x 50 poses, 3 point obstacles", lambda: scenes.
          ("C2 1 x 200 poses, 100 point obstacles", lambda: scenes.scene_c2(stride=232)),
          ("C3 64 x 150 poses, 200 obstacles", lambda: scenes.scene_c3(stride=208)),
          ("C4 256 x 200 poses, 500 obstacles (50 dynamic), teb_autosize off", lambda: _c4()),
-         ("C5 1 x 300 poses, polygon footprint vs 300 polygon obstacles, car-like", lambda: scenes.scene_c5(stride=343))]
+         ("C5 1 x 300 poses, polygon footprint vs 300 polygon obstacles, car-like", lambda: scenes.scene_c5(stride=336))]
 def _c4():
     cfg, obst, via, batch = scenes.scene_c4(stride=208)
     cfg.trajectory.teb_autosize = False
