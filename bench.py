@@ -437,7 +437,7 @@ def main():
                 tr_per_it = float(res.lm_trials.sum()) / max(1.0, float(res.lm_iterations.sum()))
                 lm = latency_model(probe, int(round(float(n_after.max()))), tr_per_it, e_assoc / max(1.0, n_eff), 0.3)
                 # the launch ends with its slowest band: its LM iterations x the model against the kernel's cycles at the clock the probe ran at
-                clock_hz = 2.06e9     # shader clock with all 256 CUs busy (clock64 ticks per second of kernel time)
+                clock_hz = 1e6 * float(np.mean(clock_mhz)) if clock_mhz and np.mean(clock_mhz) > 0 else 2.06e9   # measured on the timed steps (roofline.shader_clock_mhz)
                 its = int(res.lm_iterations.max())
                 model_ms = 1e3 * its * lm["cycles_per_lm_iteration"] / clock_hz
                 lm.update({"lm_iterations_of_a_band": its, "model_ms_per_launch": model_ms, "kernel_ms": kms, "achieved_over_model": kms / model_ms,

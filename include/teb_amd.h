@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TEB_AMD_ABI_VERSION 2
+#define TEB_AMD_ABI_VERSION 3
 
 /* ---- status codes (library calls) ------------------------------------------------------------- */
 enum {
@@ -57,7 +57,7 @@ enum {
   TEB_AMD_FOOTPRINT_LINE = 3,        /* LineRobotFootprint       :439-635 */
   TEB_AMD_FOOTPRINT_POLYGON = 4      /* PolygonRobotFootprint    :644-770 */
 };
-#define TEB_AMD_MAX_FOOTPRINT_VERTICES 16
+#define TEB_AMD_MAX_FOOTPRINT_VERTICES 64   /* (16 until ABI 2; the reference's PolygonRobotFootprint has no limit, robot_footprint_model.h:664-683) */
 
 /* ---- obstacle types: include/teb_local_planner/obstacles.h:67-1111 ------------------------------ */
 enum {

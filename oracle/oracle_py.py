@@ -18,9 +18,11 @@ COST_REFERENCE, COST_FRESH = 0, 1
 
 def build(force=False):
     so = os.path.join(_HERE, "libteb_oracle.so")
-    src = os.path.join(_HERE, "teb_oracle.cpp")
-    if force or not os.path.exists(so) or (
-            os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+    # every file the Makefile's rule depends on: a header that changes the layout of teb_amd_config_t (include/teb_amd.h) must rebuild the
+    # oracle too, or it reads the caller's structs at the old offsets (found in round 4: TEB_AMD_MAX_FOOTPRINT_VERTICES 16 -> 64)
+    deps = [os.path.join(_HERE, f) for f in ("teb_oracle.cpp", "teb_oracle.h", "grid_costmap.h")] + [os.path.join(_HERE, "..", "include", "teb_amd.h")]
+    stale = not os.path.exists(so) or any(os.path.exists(d) and os.path.getmtime(d) > os.path.getmtime(so) for d in deps)
+    if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "libteb_oracle.so"])
     return so
 

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-MAX_FOOTPRINT_VERTICES = 16
+MAX_FOOTPRINT_VERTICES = 64
 
 # status codes
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED = range(6)

@@ -285,7 +285,7 @@ int validate_config(const teb_amd_config_t* c) {
     return fail(TEB_AMD_ERR_INVALID_ARG, "line footprint needs exactly 2 vertices");
   if (c->footprint_type == TEB_AMD_FOOTPRINT_POLYGON &&
       (c->footprint_n_vertices < 1 || c->footprint_n_vertices > TEB_AMD_MAX_FOOTPRINT_VERTICES))
-    return fail(TEB_AMD_ERR_INVALID_ARG, "polygon footprint needs 1..16 vertices");
+    return fail(TEB_AMD_ERR_INVALID_ARG, "polygon footprint needs 1..64 vertices");
   if (c->jacobian_mode != TEB_AMD_JACOBIAN_ANALYTIC && c->jacobian_mode != TEB_AMD_JACOBIAN_G2O_NUMERIC)
     return fail(TEB_AMD_ERR_INVALID_ARG, "jacobian_mode must be TEB_AMD_JACOBIAN_ANALYTIC or TEB_AMD_JACOBIAN_G2O_NUMERIC");
   return TEB_AMD_OK;

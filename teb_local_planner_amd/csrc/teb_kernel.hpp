@@ -209,6 +209,7 @@ struct TebCtx {
   const int* assoc;       // + b*cap*stride
   const int* via_pose;    // + b*via_cap
   int stride;
+  int assoc_cap;          // rows of the association list (= obstacle capacity)
   McuView mcu;            // multi-CU mode (generic scenes): delivered distance records / lists written by other workgroups
 };
 
@@ -355,6 +356,16 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
   // ---- unary edges of pose i (AddEdgesObstacles :444-548, AddEdgesDynamicObstacles :646-673, AddEdgesViaPoints :675-718)
   // association entries are POSITIONS in the static list (sc.static_idx / the LDS obstacle cache)
   // the static edges of the pose are dealt round-robin to its slices (k = sl, sl + nsl, ..)
+  int pre[4] = {0, 0, 0, 0};   // first batch of list entries of the point-like fast path, fetched beside the count (rows sl, sl + nsl, ..: < capacity)
+  if constexpr (FAST && MODE != 2) {
+    if (i >= 1 && TEB_CFGI(NEW_ASSOCIATION)) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kq = sl + u * nsl;
+        pre[u] = kq < t.assoc_cap ? t.assoc[(size_t)kq * t.stride + i] : 0;
+      }
+    }
+  }
   const int cnt = FAST ? t.assoc_cnt[i] : ld_list(t.mcu.shared_lists, t.assoc_cnt + i);
   EVP_DECL
   if (i >= 1) {
@@ -380,7 +391,10 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
             for (int u = 0; u < kStaticBatch; ++u) {
               const int kq = k0 + u * nsl;
               valid[u] = kq < cnt;
-              pp[u] = valid[u] ? t.assoc[(size_t)kq * t.stride + i] : 0;
+              // the first batch does not wait for the count: rows 0 .. of the list exist whatever it is (capacity = every obstacle), so
+              // its loads are issued together with the load of cnt - one L2 round trip instead of two in front of every edge loop
+              if (k0 == sl) pp[u] = pre[u];
+              else pp[u] = valid[u] ? t.assoc[(size_t)kq * t.stride + i] : 0;
             }
             double dist[kStaticBatch], g0[kStaticBatch], g1[kStaticBatch];
 #pragma unroll
@@ -631,8 +645,18 @@ __device__ inline void linearize(const teb_amd_config_t& c, const SceneDev& sc, 
   const int n = t.n, Nt = 4 * n, tid = threadIdx.x;
   const int hsz = (SOLVER != SOLVER_CR) ? hbo(Nt) : ((Nt + 7) >> 3) * 2 * kBlk;
   LNP_DECL
-  for (int q = tid; q < hsz; q += kThreads) *hmat_ptr<SOLVER>(l, q, Nt) = 0;
-  for (int q = tid; q < Nt + 8; q += kThreads) l.bv[q] = 0;
+  // 16 bytes per store (the band, both block regions and b start on 16-byte boundaries; what a pair writes beyond an odd end is padding or
+  // the next, not yet live row)
+  if constexpr (SOLVER != SOLVER_CR) {
+    for (int q = 2 * tid; q < hsz; q += 2 * kThreads) *reinterpret_cast<teb_v2d*>(l.Hb + q) = teb_v2d{0.0, 0.0};
+  } else {
+    const int half = ((Nt + 7) >> 3) * kBlk;   // (even)
+    for (int q = 2 * tid; q < half; q += 2 * kThreads) {
+      *reinterpret_cast<teb_v2d*>(l.Db + q) = teb_v2d{0.0, 0.0};
+      *reinterpret_cast<teb_v2d*>(l.Lb + q) = teb_v2d{0.0, 0.0};
+    }
+  }
+  for (int q = 2 * tid; q < Nt + 8; q += 2 * kThreads) *reinterpret_cast<teb_v2d*>(l.bv + q) = teb_v2d{0.0, 0.0};
   LNP(0);
   if (!trig_is_current) refresh_trig(l, n);   // (the LM loop keeps the cos / sin cache current itself: see the update step)
   __syncthreads();
@@ -2459,6 +2483,9 @@ __device__ inline void mcu_solver_helper(const SceneDev& sc, const BatchDev& bt,
     const int n = l.ired[25];
     __syncthreads();
     if (cmd == kMcuSpecExit || n < 2 || n > plan.S) return;
+    // every wave acquires before its plain loads of the band's buffers (H backup / band copy, right-hand side): the memory model asks each
+    // reader for it, not only the lane that polled
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     epoch = cmd;
     mcu_trace(mc.trace, epoch, 0x61);
     const int Nt = 4 * n;
@@ -2581,7 +2608,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   int* assoc_cnt = bt.assoc_cnt + so;
   int* assoc = bt.assoc + (size_t)b * bt.assoc_cap * S;
   int* via_pose = bt.via_pose + (size_t)b * bt.via_cap;
-  t.assoc_cnt = assoc_cnt; t.assoc = assoc; t.via_pose = via_pose;
+  t.assoc_cnt = assoc_cnt; t.assoc = assoc; t.via_pose = via_pose; t.assoc_cap = bt.assoc_cap;
   t.mcu.items = nullptr; t.mcu.shared_lists = false;
   const double* mcu_items = mcu_on ? mc.items + (size_t)b * mc.item_cap * 4 * S : nullptr;
   double* Hbk = bt.Hbackup + (size_t)b * bt.hmat_stride;

@@ -29,7 +29,7 @@ def test_exports_every_declared_symbol(header):
 
 def test_struct_sizes_match_ctypes_mirror():
     L = planner.lib()
-    assert L.teb_amd_abi_version() == 2
+    assert L.teb_amd_abi_version() == 3
     o = _abi.Options(layout="band")
     assert o.struct_size == C.sizeof(_abi.Options) == L.teb_amd_sizeof_options()
     d = _abi.Options(layout=3, fixed_layout=True)

@@ -721,3 +721,28 @@ def test_cached_near_masks_do_not_change_one_bit(jmode):
     for u, v in ((a.x, b.x), (a.y, b.y), (a.theta, b.theta), (a.dt, b.dt), (ra.cost, rb.cost), (ra.chi2, rb.chi2)):
         assert np.array_equal(u, v, equal_nan=True)
     assert ra.lm_iterations.sum() >= batch.count and (ra.lm_trials >= ra.lm_iterations).all()   # the batch did iterate
+
+
+def test_polygon_footprint_with_more_than_16_vertices(oracle):
+    """Round 4: polygon footprints up to 64 vertices in the optimiser (the reference's PolygonRobotFootprint has no limit,
+    robot_footprint_model.h:664-683; ABI 2 took 16). A 40-gon: distances and gradients against the oracle, then the full optimizeTEB."""
+    from teb_local_planner_amd.config import RobotFootprintModel
+    cfg, obst, via, batch = scenes.scene_small_mixed(footprint="polygon")
+    verts = [(0.05 + 0.32 * np.cos(2 * np.pi * k / 40), 0.22 * np.sin(2 * np.pi * k / 40)) for k in range(40)]
+    cfg.robot_model = RobotFootprintModel.polygon(verts)
+    s = planner.make_solver(cfg, obst, via, batch)
+    rng = np.random.default_rng(12)
+    nq = 200
+    oi = rng.integers(0, len(obst), nq); x = rng.uniform(0, 6, nq); y = rng.uniform(-2, 2, nq); th = rng.uniform(-3.1, 3.1, nq)
+    d, g = s.debug_distance(oi, x, y, th, None)
+    for q in range(nq):
+        do, go = oracle.distance(cfg, obst, int(oi[q]), x[q], y[q], th[q], None)
+        assert abs(d[q] - do) <= 1e-14 * max(1.0, abs(do))
+        assert np.abs(g[q] - go).max() <= 1e-12
+    s.close()
+    out, res, best = run_gpu(cfg, obst, via, batch)
+    ref, rres = oracle.optimize_batch(cfg, obst, via, batch)
+    assert_full_parity(out, res, ref, rres, pos_tol=1e-7, rtol=1e-7)
+    with pytest.raises(ValueError):
+        cfg.robot_model = RobotFootprintModel.polygon([(np.cos(k), np.sin(k)) for k in range(65)])
+        cfg.to_c()
