@@ -319,15 +319,14 @@ def main():
         dist.barrier()
     kernel_ms = []
     t0 = time.perf_counter()
-    clock_mhz = []
     for _ in range(args.steps):
         best = step()
         kernel_ms.append(s.last_kernel_ms())            # HIP events on the launch stream
-        clock_mhz.append(s.last_shader_clock_mhz())     # (step() has synchronised the stream: a 32-byte read)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    clock_mhz = [s.last_shader_clock_mhz()]             # of the last timed step (read outside the timed region: a copy + a synchronisation)
     res = s.results()
     # a sustained segment of the SAME step (>= 3 s): long enough for an external sampler (rocm-smi) to see the device busy; its
     # per-step time has to agree with the K timed steps above
@@ -339,6 +338,7 @@ def main():
             for _ in range(50):
                 step()
             ks += 50
+            clock_mhz.append(s.last_shader_clock_mhz())  # one sample per 50 steps of the sustained segment (same step, same load)
         torch.cuda.synchronize()
         tsus = time.perf_counter() - ts0
         sustained = {"seconds": tsus, "steps": ks, "ms_per_step": 1e3 * tsus / ks}
@@ -421,7 +421,7 @@ def main():
                          "kernel": "teb_optimize_kernel", "kernel_ms": kms,
                          "shader_clock_mhz": {"mean": float(np.mean(clock_mhz)), "min": float(np.min(clock_mhz)), "max": float(np.max(clock_mhz)),
                                               "what": "cycle counter / 100 MHz real-time counter between entry and exit of the kernel's first workgroup, "
-                                                      "per timed step: boxes of the pool sustain 2.05 - 2.35 GHz under this load; kernel_ms x clock = cycles"},
+                                                      "last timed step + one sample per 50 steps of the sustained segment: boxes of the pool sustain 2.05 - 2.4 GHz under this load; kernel_ms x clock = cycles"},
                          "kernel_mcycles": kms * float(np.mean(clock_mhz)) * 1e-3,
                          "alg_bytes_per_unit": abu, "alg_bytes_per_launch": alg_bytes_launch},
         }
@@ -656,7 +656,10 @@ def main():
             for nm, mk_opt, what in (("c4_generic_config_path", lambda: (scenes.scene_c4(B=B, n=n, stride=STRIDE), _abi.Options(generic_config_path=True)),
                                       "the headline workload, generic kernel instantiation forced (no configuration folded at compile time)"),
                                      ("c4_with_via_points", lambda: (scenes.scene_c4_via(B=B, n=n, stride=STRIDE), None),
-                                      "the headline workload + 3 via-points, weight_viapoint 1 (EdgeViaPoint, src/optimal_planner.cpp:675-718)")):
+                                      "the headline workload + 3 via-points, weight_viapoint 1 (EdgeViaPoint, src/optimal_planner.cpp:675-718)"),
+                                     ("c4_with_shortest_path_edges", lambda: (scenes.scene_c4_flag(B=B, n=n, stride=STRIDE), None),
+                                      "the headline workload with weight_shortest_path 1 (EdgeShortestPath, src/optimal_planner.cpp:895-912): a cost-term flag "
+                                      "neither the defaults nor the wide kinds take")):
                 (cc, oo, vv, bb), opt = mk_opt()
                 sx = planner.make_solver(cc, oo, vv, bb, options=opt)
                 sx.snapshot()
@@ -665,7 +668,7 @@ def main():
                 sx.close()
                 ux = int(rx.lm_iterations.sum())
                 sec[nm] = {"workload": what, "kernel_ms": kx, "ms_per_step": wx, "units_per_step": ux, "value": ux / (wx * 1e-3),
-                           "unit": "TEB.LM-iterations/s", "tebs_ok": int((rx.status == 0).sum()), "kernel_specialised_on_the_configuration": {0: "no (generic instantiation)", 1: "yes (defaults profile)", 2: "yes (wide kinds: via-points / holonomic at run time)"}[prof],
+                           "unit": "TEB.LM-iterations/s", "tebs_ok": int((rx.status == 0).sum()), "kernel_specialised_on_the_configuration": {0: "no (generic instantiation)", 1: "yes (defaults profile)", 2: "yes (wide kinds: via-points / holonomic at run time)", 3: "partly (light kinds: cost-term flags at run time)"}[prof],
                            "vs_headline_kernel_ms": kx / float(np.mean(kernel_ms))}
             for nm, mk, what in (("c3_autosize_on", lambda: scenes.scene_c3(stride=208), "C3: 64 candidate TEBs x 150 poses, 200 point obstacles"),
                                  ("c2_autosize_on", lambda: scenes.scene_c2(stride=232), "C2: 1 TEB x 200 poses, 100 point obstacles"),

@@ -52,8 +52,9 @@ def _units(variant):
             # closed-form Jacobians: + the small-batch scene kinds (helper workgroups) and, unless the variant opts out, the point-like
             # kinds specialised on the TebConfig defaults (4, 5: teb_device.hpp, TEB_CFG)
             twins = "-DTEB_AMD_NO_DEFAULTS_TWINS" not in v["defines"]
-            # (8, 9: the point-like kinds with every fold but the via-points and the holonomic choice, TEB_PF_WIDE_* in teb_device.hpp)
-            for sk in (((0, 1, 2, 3, 4, 5, 6, 7, 8, 9) if twins else (0, 1, 2, 3)) if jm == 0 else ((0, 1, 4) if twins else (0, 1))):
+            # (8, 9: the point-like kinds with every fold but the via-points and the holonomic choice, TEB_PF_WIDE_* in teb_device.hpp;
+            #  10, 11: every cost-term flag at run time, TEB_PF_LIGHT_*)
+            for sk in (((0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11) if twins else (0, 1, 2, 3)) if jm == 0 else ((0, 1, 4) if twins else (0, 1))):
                 units.append(("opt_%d_%d_%d.o" % (sv, jm, sk), "teb_opt_inst.hip",
                               ["-DTEB_INST_SOLVER=%d" % sv, "-DTEB_INST_JMODE=%d" % jm, "-DTEB_INST_SCENE=%d" % sk]))
     return units

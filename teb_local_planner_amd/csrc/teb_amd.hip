@@ -298,7 +298,8 @@ const void* opt_kernel(int solver, int jmode, int scene) {
   return nullptr;   // (a -DTEB_AMD_ANALYTIC_ONLY build asked for the numeric mode)
 }
 // Which specialised instantiation may run this launch: 1 = the *_DEFAULTS kinds (every flag of the profile table folded), 2 = the *_WIDE
-// kinds (point-like scenes: every fold but the via-points and the holonomic choice), 0 = none (generic instantiation). GENERATED from the
+// kinds (point-like scenes: every fold but the via-points and the holonomic choice), 3 = the *_LIGHT kinds (point-like scenes: every
+// cost-term flag at run time, only the never-reached bulk folded), 0 = none (generic instantiation). GENERATED from the
 // table of teb_device.hpp (TEB_PF_ALL): a flag is folded in the kernel exactly when its TEB_PF_HOST_<ID> condition is required here, so a
 // fold cannot exist without its host-side check (tests/test_config_profile_sites.py). `c`, `args`, `sc` are the names the table's
 // expressions use - the very objects the kernel is launched with.
@@ -306,15 +307,16 @@ int profile_matches(const teb_amd_handle* h, const OptArgs& args, const SceneDev
   if (h->opt.generic_config_path) return 0;
   const teb_amd_config_t& c = h->cfg;
   const bool points = sc.fast_points != 0;   // (generic-shape kinds keep the TEB_PF_KIN_* flags at run time)
-  bool narrow = true, wide = true;
+  bool narrow = true, wide = true, light = true;
 #define TEB_PF_CHECK(ID)                                                        \
   if ((points || !TEB_PF_KIN_##ID) && !(TEB_PF_HOST_##ID)) {                    \
     narrow = false;                                                             \
     if (!TEB_PF_WIDE_##ID) wide = false;                                        \
+    if (!TEB_PF_LIGHT_##ID) light = false;                                      \
   }
   TEB_PF_ALL(TEB_PF_CHECK)
 #undef TEB_PF_CHECK
-  return narrow ? 1 : (wide && points ? 2 : 0);
+  return narrow ? 1 : (wide && points ? 2 : (light && points ? 3 : 0));
 }
 hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const BatchDev& bt, const OptArgs& a, int solver, const LdsPlan& plan,
                       const McuDev* mcu = nullptr) {
@@ -328,7 +330,8 @@ hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const Bat
   if (pf != 0) {
     const bool sm = small && h->cfg.jacobian_mode == TEB_AMD_JACOBIAN_ANALYTIC;
     if (pf == 1) k = opt_kernel(solver, h->cfg.jacobian_mode, sc.fast_points ? (sm ? SCENE_POINTS_SMALL_DEFAULTS : SCENE_POINTS_DEFAULTS) : (sm ? SCENE_GENERIC_SMALL_DEFAULTS : SCENE_GENERIC_DEFAULTS));
-    else k = opt_kernel(solver, h->cfg.jacobian_mode, sm ? SCENE_POINTS_SMALL_WIDE : SCENE_POINTS_WIDE);
+    else if (pf == 2) k = opt_kernel(solver, h->cfg.jacobian_mode, sm ? SCENE_POINTS_SMALL_WIDE : SCENE_POINTS_WIDE);
+    else k = opt_kernel(solver, h->cfg.jacobian_mode, sm ? SCENE_POINTS_SMALL_LIGHT : SCENE_POINTS_LIGHT);
     if (k) h->last_defaults_profile = pf;
   }
   if (!k) k = opt_kernel(solver, h->cfg.jacobian_mode, sc.fast_points ? (small ? SCENE_POINTS_SMALL : SCENE_POINTS) : (small ? SCENE_GENERIC_SMALL : SCENE_GENERIC));

@@ -19,7 +19,7 @@
 // Every cost term sits behind run-time flags of teb_amd_config_t (holonomic or not, which weights are zero, car-like or diff-drive, ..):
 // uniform branches, but each one ends a basic block, so the sqrt / divide chains of neighbouring terms cannot be scheduled into each
 // other's latency - and at one wave per SIMD that latency is all there is to fill. A translation unit compiled with
-// -DTEB_AMD_DEFAULTS_PROFILE (teb_opt_inst.hip does it for the scene kinds *_DEFAULTS and *_WIDE) folds those flags to the values they
+// -DTEB_AMD_DEFAULTS_PROFILE (teb_opt_inst.hip does it for the scene kinds *_DEFAULTS, *_WIDE and *_LIGHT) folds those flags to the values they
 // have in a default TebConfig. Same operations in the same order on the taken paths: bit-identical bands
 // (tests/test_gpu_config_profile.py).
 //
@@ -29,6 +29,9 @@
 //   TEB_PF_HOST_<ID>   when the fold is VALID, evaluated on the host with the same three names in scope (normally EXPR == DFLT)
 //   TEB_PF_WIDE_<ID>   1: the flag stays a run-time flag in the *_WIDE kinds (-DTEB_AMD_PROFILE_WIDE): via-points and holonomic robots
 //                      run kernels that keep every other fold
+//   TEB_PF_LIGHT_<ID>  1: the flag stays a run-time flag in the *_LIGHT kinds (-DTEB_AMD_PROFILE_LIGHT): every cost-term flag does; what
+//                      those kinds fold is the bulk a planner configuration never reaches (legacy association, debug export, the
+//                      sequential LDL^T, the uncached near masks, the second error evaluation of the divergence detection)
 //   TEB_PF_KIN_<ID>    1: folded in the point-like kinds only (the generic-shape kinds keep diff-drive / car-like at run time,
 //                      -DTEB_AMD_PROFILE_ANY_KINEMATICS)
 // A device site writes TEB_CFGI(ID); the host's profile_matches() (teb_amd.hip) is generated from TEB_PF_ALL over the same entries.
@@ -140,9 +143,32 @@
 #define TEB_PF_KIN_NO_NEAR_CACHE 0
 #define TEB_PF_KIN_DIVERGENCE_DETECTION 0
 
+#define TEB_PF_LIGHT_EXACT_ARC 1
+#define TEB_PF_LIGHT_COST_EXPONENT 1
+#define TEB_PF_LIGHT_NEW_ASSOCIATION 0
+#define TEB_PF_LIGHT_DYNAMIC_EDGES 1
+#define TEB_PF_LIGHT_VIA_POINTS 1
+#define TEB_PF_LIGHT_NONHOLONOMIC_VELOCITY 1
+#define TEB_PF_LIGHT_VELOCITY_EDGES 1
+#define TEB_PF_LIGHT_ACCELERATION_EDGES 1
+#define TEB_PF_LIGHT_NONHOLONOMIC_ACCELERATION 1
+#define TEB_PF_LIGHT_TIME_OPTIMAL 1
+#define TEB_PF_LIGHT_SHORTEST_PATH 1
+#define TEB_PF_LIGHT_VELOCITY_OBSTACLE_RATIO 1
+#define TEB_PF_LIGHT_RADIUS_FREE 1
+#define TEB_PF_LIGHT_DEBUG_LINEARIZE 0
+#define TEB_PF_LIGHT_BAND_LDLT 0
+#define TEB_PF_LIGHT_INFLATED 1
+#define TEB_PF_LIGHT_NO_NEAR_CACHE 0
+#define TEB_PF_LIGHT_DIVERGENCE_DETECTION 0
+#define TEB_PF_LIGHT_KIN_DIFF_DRIVE 1
+#define TEB_PF_LIGHT_KIN_EDGES 1
+
 // what a device site sees
 #if defined(TEB_AMD_DEFAULTS_PROFILE)
-#if defined(TEB_AMD_PROFILE_WIDE) && defined(TEB_AMD_PROFILE_ANY_KINEMATICS)
+#if defined(TEB_AMD_PROFILE_LIGHT)
+#define TEB_CFGI(ID) (TEB_PF_LIGHT_##ID ? (TEB_PF_EXPR_##ID) : (TEB_PF_DFLT_##ID))
+#elif defined(TEB_AMD_PROFILE_WIDE) && defined(TEB_AMD_PROFILE_ANY_KINEMATICS)
 #define TEB_CFGI(ID) ((TEB_PF_WIDE_##ID || TEB_PF_KIN_##ID) ? (TEB_PF_EXPR_##ID) : (TEB_PF_DFLT_##ID))
 #elif defined(TEB_AMD_PROFILE_WIDE)
 #define TEB_CFGI(ID) (TEB_PF_WIDE_##ID ? (TEB_PF_EXPR_##ID) : (TEB_PF_DFLT_##ID))

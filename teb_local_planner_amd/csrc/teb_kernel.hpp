@@ -2519,16 +2519,17 @@ __device__ inline void mcu_solver_helper(const SceneDev& sc, const BatchDev& bt,
 // non-holonomic choice of the velocity and acceleration edges (teb_device.hpp: TEB_PF_WIDE_*), for configurations that differ from the
 // defaults in nothing else - a goal-directed planner with via-points, an omnidirectional base (-DTEB_AMD_PROFILE_WIDE).
 enum { SCENE_POINTS = 0, SCENE_GENERIC = 1, SCENE_POINTS_SMALL = 2, SCENE_GENERIC_SMALL = 3, SCENE_POINTS_DEFAULTS = 4, SCENE_POINTS_SMALL_DEFAULTS = 5,
-       SCENE_GENERIC_DEFAULTS = 6, SCENE_GENERIC_SMALL_DEFAULTS = 7, SCENE_POINTS_WIDE = 8, SCENE_POINTS_SMALL_WIDE = 9 };
+       SCENE_GENERIC_DEFAULTS = 6, SCENE_GENERIC_SMALL_DEFAULTS = 7, SCENE_POINTS_WIDE = 8, SCENE_POINTS_SMALL_WIDE = 9,
+       SCENE_POINTS_LIGHT = 10, SCENE_POINTS_SMALL_LIGHT = 11 };   // *_LIGHT: every cost-term flag at run time, only the never-reached bulk folded (TEB_PF_LIGHT_*)
 template <int SOLVER, int JMODE, int SCENE>
 __global__ void __launch_bounds__(kThreads)
 teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev bt, const OptArgs args,
                     const LdsPlan plan, const McuDev mc) {
   extern __shared__ __attribute__((aligned(16))) double lds_base[];
   constexpr bool FAST = SCENE == SCENE_POINTS || SCENE == SCENE_POINTS_SMALL || SCENE == SCENE_POINTS_DEFAULTS || SCENE == SCENE_POINTS_SMALL_DEFAULTS ||
-                        SCENE == SCENE_POINTS_WIDE || SCENE == SCENE_POINTS_SMALL_WIDE;
+                        SCENE == SCENE_POINTS_WIDE || SCENE == SCENE_POINTS_SMALL_WIDE || SCENE == SCENE_POINTS_LIGHT || SCENE == SCENE_POINTS_SMALL_LIGHT;
   constexpr bool MCU = SCENE == SCENE_POINTS_SMALL || SCENE == SCENE_GENERIC_SMALL || SCENE == SCENE_POINTS_SMALL_DEFAULTS ||
-                       SCENE == SCENE_GENERIC_SMALL_DEFAULTS || SCENE == SCENE_POINTS_SMALL_WIDE;   // small-batch instantiation: helper workgroups possible
+                       SCENE == SCENE_GENERIC_SMALL_DEFAULTS || SCENE == SCENE_POINTS_SMALL_WIDE || SCENE == SCENE_POINTS_SMALL_LIGHT;   // small-batch instantiation: helper workgroups possible
 #ifdef TEB_AMD_DEFAULTS_PROFILE
   static_assert(SCENE >= SCENE_POINTS_DEFAULTS, "a unit compiled with the profile holds a *_DEFAULTS kind");
 #else
@@ -2541,6 +2542,11 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   static_assert(SCENE == SCENE_POINTS_WIDE || SCENE == SCENE_POINTS_SMALL_WIDE, "-DTEB_AMD_PROFILE_WIDE builds the *_WIDE kinds");
 #else
   static_assert(SCENE != SCENE_POINTS_WIDE && SCENE != SCENE_POINTS_SMALL_WIDE, "*_WIDE kinds need -DTEB_AMD_PROFILE_WIDE");
+#endif
+#ifdef TEB_AMD_PROFILE_LIGHT
+  static_assert(SCENE == SCENE_POINTS_LIGHT || SCENE == SCENE_POINTS_SMALL_LIGHT, "-DTEB_AMD_PROFILE_LIGHT builds the *_LIGHT kinds");
+#else
+  static_assert(SCENE != SCENE_POINTS_LIGHT && SCENE != SCENE_POINTS_SMALL_LIGHT, "*_LIGHT kinds need -DTEB_AMD_PROFILE_LIGHT");
 #endif
   static_assert(!MCU || JMODE == TEB_AMD_JACOBIAN_ANALYTIC, "the small-batch kinds exist for closed-form Jacobians");
   if constexpr (MCU) {

@@ -257,7 +257,7 @@ class TebBatchSolver:
 
     def last_config_profile(self):
         """Which kernel the last optimize() ran: 1 = specialised on the TebConfig defaults, 2 = the same folds except via-points and the
-        holonomic choice (*_WIDE kinds), 0 = the generic instantiation (teb_amd_options_t::generic_config_path forces it)"""
+        holonomic choice (*_WIDE kinds), 3 = every cost-term flag at run time (*_LIGHT kinds), 0 = the generic instantiation (teb_amd_options_t::generic_config_path forces it)"""
         L = lib()
         L.teb_amd_debug_last_config_profile.argtypes = [C.c_void_p, _abi.p_i32]
         v = C.c_int32(0)

@@ -120,6 +120,14 @@ def scene_c4_via(B=256, n=200, seed=1004, stride=None, length=20.0):
     return cfg, obst, via, batch
 
 
+def scene_c4_flag(B=256, n=200, seed=1004, stride=None, length=20.0):
+    """The C4 batch with a cost-term flag off the TebConfig defaults that only the *_LIGHT kinds (and the generic kernel) take:
+    weight_shortest_path = 1 (EdgeShortestPath)."""
+    cfg, obst, via, batch = scene_c4(B=B, n=n, seed=seed, stride=stride, length=length)
+    cfg.optim.weight_shortest_path = 1.0
+    return cfg, obst, via, batch
+
+
 def scene_c5(n=300, M=300, seed=1005, stride=None, length=30.0):
     cfg = TebConfig()
     cfg.robot.min_turning_radius = 1.0

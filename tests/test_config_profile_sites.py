@@ -28,14 +28,14 @@ def test_every_folded_flag_is_in_the_table_the_host_check_is_generated_from():
     assert used <= set(listed), "folded at a device site but absent from TEB_PF_ALL: %s" % sorted(used - set(listed))
     assert set(listed) <= used, "in the table but folded nowhere: %s" % sorted(set(listed) - used)
     for ident in listed:   # every column of every entry
-        for col in ("EXPR", "DFLT", "HOST", "WIDE", "KIN"):
+        for col in ("EXPR", "DFLT", "HOST", "WIDE", "LIGHT", "KIN"):
             assert re.search(r"#define TEB_PF_%s_%s\b" % (col, ident), dev), (col, ident)
 
 
 def test_the_host_check_is_the_generated_one_and_nothing_folds_by_hand():
     host = _read("teb_amd.hip")
     body = host[host.index("int profile_matches("):host.index("hipError_t launch_opt(")]
-    assert "TEB_PF_ALL(TEB_PF_CHECK)" in body and "TEB_PF_HOST_##ID" in body and "TEB_PF_WIDE_##ID" in body and "TEB_PF_KIN_##ID" in body
+    assert "TEB_PF_ALL(TEB_PF_CHECK)" in body and "TEB_PF_HOST_##ID" in body and "TEB_PF_WIDE_##ID" in body and "TEB_PF_LIGHT_##ID" in body and "TEB_PF_KIN_##ID" in body
     assert "generic_config_path" in body
     assert "config_matches_defaults_profile" not in host          # the hand-kept mirror of rounds 3 is gone
     for f in ("teb_kernel.hpp", "teb_edges.hpp"):                  # no fold outside the table

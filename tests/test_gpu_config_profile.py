@@ -116,9 +116,12 @@ def _with(cfg, **kw):
     return c
 
 
-def test_configurations_off_the_folded_paths_run_the_generic_kernel():
+def test_configurations_off_the_default_cost_terms_run_the_light_kinds_with_identical_bits():
+    """Round 4: a configuration that leaves the defaults in a cost-term flag runs the *_LIGHT kinds (every cost-term flag at run time, only
+    the never-reached bulk folded: legacy association, debug export, sequential LDL^T, uncached near masks, divergence detection) and gets
+    the generic kernel's bands bit for bit; what those kinds fold still sends a configuration to the generic kernel."""
     cfg0, obst, via, batch = scenes.scene_c3(B=4, n=60, M=40, stride=96)
-    variants = {
+    light = {
         "no velocity edges": _with(cfg0, optim__weight_max_vel_x=0.0, optim__weight_max_vel_theta=0.0),
         "no acceleration edges": _with(cfg0, optim__weight_acc_lim_x=0.0, optim__weight_acc_lim_theta=0.0),
         "no time-optimal edges": _with(cfg0, optim__weight_optimaltime=0.0),
@@ -126,15 +129,26 @@ def test_configurations_off_the_folded_paths_run_the_generic_kernel():
         "car-like": _with(cfg0, robot__min_turning_radius=0.8, optim__weight_kinematics_turning_radius=1.0),
         "no kinematics edges": _with(cfg0, optim__weight_kinematics_nh=0.0, optim__weight_kinematics_forward_drive=0.0),
         "velocity-obstacle ratio": _with(cfg0, optim__weight_velocity_obstacle_ratio=1.0),
-        "legacy association": _with(cfg0, obstacles__legacy_obstacle_association=True),
         "no obstacle edges": _with(cfg0, optim__weight_obstacle=0.0),
         "exact arc length": _with(cfg0, trajectory__exact_arc_length=True),
         "cost exponent": _with(cfg0, optim__obstacle_cost_exponent=1.5),
+        "holonomic with shortest path": _with(cfg0, robot__max_vel_y=0.2, robot__acc_lim_y=0.3, robot__max_vel_trans=0.5, optim__weight_shortest_path=1.0),
     }
-    for name, cfg in variants.items():
+    for name, cfg in light.items():
+        t = run(cfg, obst, via, batch)
+        g = run(cfg, obst, via, batch, generic_config_path=True)
+        assert t[2] == 3 and g[2] == 0, (name, t[2], g[2])
+        assert (np.asarray(t[1].status) != _abi.TEB_NONFINITE).all(), name
+        same_bits(t[0], t[1], g[0], g[1])
+    generic = {
+        "legacy association": _with(cfg0, obstacles__legacy_obstacle_association=True),
+        "divergence detection": _with(cfg0, recovery__divergence_detection_enable=True),
+    }
+    for name, cfg in generic.items():
         _, res, prof, _ = run(cfg, obst, via, batch)
-        assert not prof, name
+        assert prof == 0, name
         assert (np.asarray(res.status) != _abi.TEB_NONFINITE).all(), name
+    assert run(cfg0, obst, via, batch, no_near_cache=True)[2] == 0
     assert run(cfg0, obst, via, batch)[2] == 1, "the unchanged configuration is on the folded paths"
 
 
@@ -168,7 +182,7 @@ def test_via_points_and_holonomic_robots_run_the_wide_kinds_with_identical_bits(
 def test_wide_kinds_do_not_take_what_they_fold():
     cfg0, obst, via, batch = scenes.scene_c3(B=4, n=60, M=40, stride=96)
     cfg = _with(cfg0, robot__max_vel_y=0.2, robot__acc_lim_y=0.3, optim__weight_shortest_path=1.0)   # holonomic AND a flag the wide kinds fold
-    assert run(cfg, obst, via, batch)[2] == 0
+    assert run(cfg, obst, via, batch)[2] == 3                                                      # (the light kinds take it)
     cfg = _with(cfg0, robot__max_vel_y=0.2, robot__acc_lim_y=0.3)
     cfg.jacobian_mode = 1                                                                          # the wide kinds exist for closed forms only
     assert run(cfg, obst, via, batch)[2] == 0

@@ -8,7 +8,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/${PROF_DIR:-prof}
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-parity-check --latency-reps 0"
+CMD="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-parity-check --latency-reps 0 --sustain-seconds 0"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/bench_trace.json 2> $OUT/trace.log
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o fetch -- $CMD > $OUT/bench_fetch.json 2> $OUT/fetch.log
@@ -26,7 +26,10 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/cal_write -o calw -- python $R
 cd $ROOT
 # phase split of the same binary's sources (-DTEB_PROFILE build, tools/build_prof.sh) and which bands the launch waits for
 if [ -f $ROOT/tools/libteb_amd_prof.so ]; then
-  TEB_AMD_LIB=$ROOT/tools/libteb_amd_prof.so python $ROOT/tools/prof_phases.py c4on c3 c2 c5 > $OUT/phases.txt 2>&1
+  : > $OUT/phases.txt
+  for cfgname in c4on c3 c2 c5; do   # (one process per configuration)
+    TEB_AMD_LIB=$ROOT/tools/libteb_amd_prof.so python $ROOT/tools/prof_phases.py $cfgname >> $OUT/phases.txt 2>&1
+  done
   TEB_AMD_LIB=$ROOT/tools/libteb_amd_prof.so python $ROOT/tools/band_times.py c4on > $OUT/band_times.txt 2>&1
 fi
 python - <<PY
