@@ -23,3 +23,10 @@ def available():
 optimize_batch = _m.optimize_batch
 optimize_teb = _m.optimize_teb
 lib = _m.lib
+
+
+# a third wrapper instance: the strict flags, another compiler (oracle/_ref/libteb_ref_clang.so; present where the image has clang)
+_spec_c = importlib.util.spec_from_file_location("oracle._ref_clang_impl", _strict.__file__)
+clang = importlib.util.module_from_spec(_spec_c)
+_spec_c.loader.exec_module(clang)
+clang.SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libteb_ref_clang.so")
