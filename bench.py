@@ -659,7 +659,11 @@ def main():
                                       "the headline workload + 3 via-points, weight_viapoint 1 (EdgeViaPoint, src/optimal_planner.cpp:675-718)"),
                                      ("c4_with_shortest_path_edges", lambda: (scenes.scene_c4_flag(B=B, n=n, stride=STRIDE), None),
                                       "the headline workload with weight_shortest_path 1 (EdgeShortestPath, src/optimal_planner.cpp:895-912): a cost-term flag "
-                                      "neither the defaults nor the wide kinds take")):
+                                      "neither the defaults nor the wide kinds take"),
+                                     ("c4_with_shortest_path_edges_compiled_for_the_configuration",
+                                      lambda: (scenes.scene_c4_flag(B=B, n=n, stride=STRIDE), _abi.Options(compile_for_config=2)),
+                                      "the same, teb_amd_options_t::compile_for_config = 2: the instantiation with every flag of the profile table "
+                                      "folded to this configuration's values, compiled by hipRTC at the first launch (csrc/teb_rtc.hpp)")):
                 (cc, oo, vv, bb), opt = mk_opt()
                 sx = planner.make_solver(cc, oo, vv, bb, options=opt)
                 sx.snapshot()
@@ -667,8 +671,11 @@ def main():
                 prof = int(sx.last_config_profile())
                 sx.close()
                 ux = int(rx.lm_iterations.sum())
+                if prof == 4:
+                    st = planner.TebBatchSolver.rtc_stats()
+                    what += " [hipRTC: %.1f s in the compiler]" % st[3]
                 sec[nm] = {"workload": what, "kernel_ms": kx, "ms_per_step": wx, "units_per_step": ux, "value": ux / (wx * 1e-3),
-                           "unit": "TEB.LM-iterations/s", "tebs_ok": int((rx.status == 0).sum()), "kernel_specialised_on_the_configuration": {0: "no (generic instantiation)", 1: "yes (defaults profile)", 2: "yes (wide kinds: via-points / holonomic at run time)", 3: "partly (light kinds: cost-term flags at run time)"}[prof],
+                           "unit": "TEB.LM-iterations/s", "tebs_ok": int((rx.status == 0).sum()), "kernel_specialised_on_the_configuration": {0: "no (generic instantiation)", 1: "yes (defaults profile)", 2: "yes (wide kinds: via-points / holonomic at run time)", 3: "partly (light kinds: cost-term flags at run time)", 4: "yes (compiled for this configuration at run time)"}[prof],
                            "vs_headline_kernel_ms": kx / float(np.mean(kernel_ms))}
             for nm, mk, what in (("c3_autosize_on", lambda: scenes.scene_c3(stride=208), "C3: 64 candidate TEBs x 150 poses, 200 point obstacles"),
                                  ("c2_autosize_on", lambda: scenes.scene_c2(stride=232), "C2: 1 TEB x 200 poses, 100 point obstacles"),

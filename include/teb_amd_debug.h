@@ -68,8 +68,11 @@ int teb_amd_debug_mcu_flags(teb_amd_handle_t* h, int32_t flags);
 /* Which kernel instantiation the last optimise launch ran: 1 = specialised on the TebConfig defaults (every flag of the profile table of
  * csrc/teb_device.hpp folded at compile time), 2 = the same folds except the via-points and the holonomic choice of the velocity /
  * acceleration edges (point-like scenes), 3 = every cost-term flag at run time, only the never-reached bulk folded (point-like scenes),
- * 0 = the generic one (teb_amd_options_t::generic_config_path forces it). */
+ * 4 = compiled at run time for this configuration (teb_amd_options_t::compile_for_config), 0 = the generic one (teb_amd_options_t::generic_config_path forces it). */
 int teb_amd_debug_last_config_profile(teb_amd_handle_t* h, int32_t* defaults_profile);
+/* Run-time compiled instantiations of this process (teb_amd_options_t::compile_for_config): how many are ready / still compiling /
+ * failed, the compile time of the last one that finished [s], and the reason of the last failure (empty string if none). */
+int teb_amd_debug_rtc_stats(int32_t* ready, int32_t* compiling, int32_t* failed, double* last_compile_seconds, char* last_error, int32_t capacity);
 
 /* per-TEB flags of the last launch: bit0 association list overflow, bit1 autoResize capacity overflow */
 int teb_amd_debug_assoc_overflow(teb_amd_handle_t* h, int32_t* flags);

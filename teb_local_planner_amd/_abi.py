@@ -98,10 +98,10 @@ class Options(C.Structure):
     """teb_amd_options_t (include/teb_amd.h): behaviour switches of a handle, fixed at create."""
     _fields_ = [("struct_size", c_i32), ("layout", c_i32), ("fixed_layout", c_i32), ("band_ldlt", c_i32),
                 ("generic_distance_path", c_i32), ("hsig3d_kernel", c_i32), ("no_near_cache", c_i32), ("multi_cu", c_i32),
-                ("multi_cu_timeout_us", c_i32), ("speculative_trials", c_i32), ("generic_config_path", c_i32), ("reserved", c_i32 * 5)]
+                ("multi_cu_timeout_us", c_i32), ("speculative_trials", c_i32), ("generic_config_path", c_i32), ("compile_for_config", c_i32), ("reserved", c_i32 * 4)]
 
     def __init__(self, layout=LAYOUT_AUTO, fixed_layout=False, band_ldlt=False, generic_distance_path=False, hsig3d_kernel=HSIG3D_AUTO,
-                 no_near_cache=False, multi_cu=0, multi_cu_timeout_us=0, speculative_trials=0, generic_config_path=False):
+                 no_near_cache=False, multi_cu=0, multi_cu_timeout_us=0, speculative_trials=0, generic_config_path=False, compile_for_config=0):
         super().__init__()
         self.struct_size = C.sizeof(Options)
         self.layout = {"auto": LAYOUT_AUTO, "cr": LAYOUT_BLOCKS_LDS, "band": LAYOUT_BAND_LDS, "bandg": LAYOUT_BAND_HBM}.get(layout, layout)
@@ -114,6 +114,7 @@ class Options(C.Structure):
         self.multi_cu_timeout_us = int(multi_cu_timeout_us)
         self.speculative_trials = int(speculative_trials)   # 0 auto, -1 never, 1 .. 3 solver workgroups per band
         self.generic_config_path = int(generic_config_path)   # 1: never the kernels specialised on the TebConfig defaults
+        self.compile_for_config = int(compile_for_config)     # 0 off, 1 compile for this configuration in the background (hipRTC), 2 wait for it
 
 
 class Results(C.Structure):

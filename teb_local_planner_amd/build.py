@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libteb_amd.so")
 LIB_MFMA = os.path.join(HERE, "libteb_amd_mfma.so")
 HEADERS = ["teb_device.hpp", "teb_comm.hpp", "teb_feasibility.hpp", "teb_geometry.hpp", "teb_edges.hpp", "teb_kernel.hpp", "teb_strip.hpp",
-           "teb_hsig.hpp", "teb_graph.hpp", "teb_opt_launch.hpp", "teb_multicu.hpp", "teb_autoresize_chain.hpp",
+           "teb_hsig.hpp", "teb_graph.hpp", "teb_opt_launch.hpp", "teb_multicu.hpp", "teb_autoresize_chain.hpp", "teb_rtc.hpp",
            os.path.join("..", "..", "include", "teb_amd.h"), os.path.join("..", "..", "include", "teb_amd_debug.h")]
 
 # -ffp-contract=off: the parity contract is against a plain IEEE mul/add restatement of the reference;
@@ -32,7 +32,18 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-cont
 # tick run it): the specialised kernels are small enough (~ 90 KB) for the solve to be inlined there without the spills that made it
 # 21 % slower in the generic kernel - C2 1.36 -> 1.31 ms, C3 1.57 -> 1.48 (same box, alternating); in the band layout and in the
 # full-batch kinds it still loses (headline 2.59 -> 3.08 ms), so those keep the call.
+# -DTEB_AMD_SOLVE_CSR on the GENERIC small-batch band-layout point-like instantiation (opt_0_0_2: reached with generic_config_path, legacy
+# association, divergence detection or the cross-check options on a batch with solver helpers): with the no-callee-saved call of the solve
+# this one kernel faulted (memory aperture violation) as soon as obstacle_cost_exponent != 1 sent the edge loops through pow() - the
+# pre-built light / wide / defaults kinds and the kernels compiled at run time run the same configuration clean and bit-identical
+# (round 4, tools/rtc_bisect.py; the same class of backend interaction as the two-call-site case of round 3).
 UNIT_FLAGS = {"opt_0_0_0.o": ["-DTEB_AMD_POINTS_KEEP_GENERIC"], "opt_1_0_5.o": ["-DTEB_AMD_INLINE_SOLVE"]}
+# The instantiations that keep EVERY cost term at run time (generic kinds 0 .. 3, light kinds 10, 11) call the solve on the plain
+# convention (-DTEB_AMD_SOLVE_CSR): see the note above UNIT_FLAGS.
+for _sv in (0, 1, 2):
+    for _jm in (0, 1):
+        for _sk in (0, 1, 2, 3, 10, 11):
+            UNIT_FLAGS.setdefault("opt_%d_%d_%d.o" % (_sv, _jm, _sk), []).append("-DTEB_AMD_SOLVE_CSR")
 
 VARIANTS = {
     "product": dict(lib=LIB, defines=[], jmodes=(0, 1)),

@@ -23,6 +23,7 @@
 #include "teb_hsig.hpp"
 #include "teb_graph.hpp"
 #include "teb_comm.hpp"
+#include "teb_rtc.hpp"
 #include "teb_feasibility.hpp"
 
 using namespace tebamd;
@@ -318,6 +319,25 @@ int profile_matches(const teb_amd_handle* h, const OptArgs& args, const SceneDev
 #undef TEB_PF_CHECK
   return narrow ? 1 : (wide && points ? 2 : (light && points ? 3 : 0));
 }
+// The instantiation compiled at run time for this launch (teb_amd_options_t::compile_for_config), READY, or null: not asked for, a default
+// configuration (pf == 1: its pre-built kernel IS the fully folded one), not ready yet, or failed. wait: block until the compiler is done.
+std::shared_ptr<RtcKernel> rtc_lookup(const teb_amd_handle* h, const OptArgs& args, const SceneDev& sc, int solver, bool small, int pf, bool wait) {
+  if (!((pf != 1 || h->opt.compile_for_config >= 3) && h->opt.compile_for_config > 0 && !h->opt.generic_config_path && !args.debug_linearize)) return nullptr;   // (3: even for a default configuration - measurement only)
+  const teb_amd_config_t& c = h->cfg;
+  RtcKey key;
+  key.flags = 0;
+  int bit = 0;
+#define TEB_PF_BIT(ID) key.flags |= (unsigned long long)((TEB_PF_EXPR_##ID) ? 1 : 0) << bit; ++bit;
+  TEB_PF_ALL(TEB_PF_BIT)
+#undef TEB_PF_BIT
+  const bool sm = small && c.jacobian_mode == TEB_AMD_JACOBIAN_ANALYTIC;
+  if (small && !sm) return nullptr;   // (helper workgroups exist in the small-batch kinds only, which exist for closed-form Jacobians)
+  key.solver = solver; key.jmode = c.jacobian_mode;
+  key.scene = sc.fast_points ? (sm ? SCENE_POINTS_SMALL_CUSTOM : SCENE_POINTS_CUSTOM) : (sm ? SCENE_GENERIC_SMALL_CUSTOM : SCENE_GENERIC_CUSTOM);
+  std::string why;
+  std::shared_ptr<RtcKernel> rk = rtc_request(key, wait, &why);
+  return (rk && rk->state.load() == RtcKernel::READY) ? rk : nullptr;
+}
 hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const BatchDev& bt, const OptArgs& a, int solver, const LdsPlan& plan,
                       const McuDev* mcu = nullptr) {
   McuDev none;
@@ -334,10 +354,19 @@ hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const Bat
     else k = opt_kernel(solver, h->cfg.jacobian_mode, sm ? SCENE_POINTS_SMALL_LIGHT : SCENE_POINTS_LIGHT);
     if (k) h->last_defaults_profile = pf;
   }
-  if (!k) k = opt_kernel(solver, h->cfg.jacobian_mode, sc.fast_points ? (small ? SCENE_POINTS_SMALL : SCENE_POINTS) : (small ? SCENE_GENERIC_SMALL : SCENE_GENERIC));
-  if (!k) return hipErrorInvalidDeviceFunction;
   void* params[] = {const_cast<teb_amd_config_t*>(&h->cfg), const_cast<SceneDev*>(&sc), const_cast<BatchDev*>(&bt), const_cast<OptArgs*>(&a),
                     const_cast<LdsPlan*>(&plan), const_cast<McuDev*>(mc)};
+  // a configuration off the defaults: the instantiation compiled for IT at run time, once it is ready (teb_rtc.hpp)
+  if (std::shared_ptr<RtcKernel> rk = rtc_lookup(h, a, sc, solver, small, pf, false)) {
+    std::string why;
+    hipFunction_t f = rtc_function(*rk, h->device, h->lds_limit, &why);
+    if (f) {
+      h->last_defaults_profile = 4;
+      return hipModuleLaunchKernel(f, grid * (1 + mc->K + mc->D), 1, 1, kThreads, 1, 1, plan.total_bytes, h->stream, params, nullptr);
+    }
+  }
+  if (!k) { k = opt_kernel(solver, h->cfg.jacobian_mode, sc.fast_points ? (small ? SCENE_POINTS_SMALL : SCENE_POINTS) : (small ? SCENE_GENERIC_SMALL : SCENE_GENERIC)); h->last_defaults_profile = 0; }
+  if (!k) return hipErrorInvalidDeviceFunction;
   return hipLaunchKernel(k, dim3(grid * (1 + mc->K + mc->D)), dim3(kThreads), params, plan.total_bytes, h->stream);
 }
 hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const BatchDev& bt, const OptArgs& a) {
@@ -505,6 +534,8 @@ int launch(teb_amd_handle* h, const OptArgs& args) {
     }
     if (int crc = copy_strips(h, Strips{h->ob_x.p, h->ob_y.p, h->ob_th.p, h->ob_dt.p, h->ob_n.p}, Strips{h->x.p, h->y.p, h->th.p, h->dt.p, h->n.p}, h->B)) return crc;
   }
+  if (h->opt.compile_for_config >= 2)   // synchronous mode: the wait for the compiler is not kernel time
+    (void)rtc_lookup(h, args, sc, eff_solver, H > 0, profile_matches(h, args, sc), true);
   HIPCHK(hipEventRecord(h->ev0, h->stream));   // (the kernel clears its bands' overflow flags itself)
   HIPCHK(launch_opt(h, h->B, sc, bt, args, eff_solver, eff_plan, H > 0 ? &mcu : nullptr));
   if (H > 0 && h->mcu_trace && h->mcu_watchdog_ms > 0) {
@@ -2479,6 +2510,26 @@ int teb_amd_last_shader_clock_mhz(teb_amd_handle_t* h, double* mhz) {
   HIPCHK(hipStreamSynchronize(h->stream));
   const double ticks = (double)(c[3] - c[1]);   // 100 MHz real-time counter
   *mhz = ticks > 0 ? (double)(c[2] - c[0]) / ticks * 100.0 : 0.0;
+  return TEB_AMD_OK;
+}
+
+int teb_amd_debug_rtc_stats(int32_t* ready, int32_t* compiling, int32_t* failed, double* last_compile_seconds, char* last_error, int32_t capacity) {
+  RtcCache& c = rtc_cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  int r = 0, w = 0, f = 0;
+  double secs = 0;
+  std::string err;
+  for (auto& kv : c.kernels) {
+    const int st = kv.second->state.load();
+    if (st == RtcKernel::READY) { ++r; secs = kv.second->compile_seconds; }
+    else if (st == RtcKernel::COMPILING) ++w;
+    else { ++f; err = kv.second->log; }
+  }
+  if (ready) *ready = r;
+  if (compiling) *compiling = w;
+  if (failed) *failed = f;
+  if (last_compile_seconds) *last_compile_seconds = secs;
+  if (last_error && capacity > 0) { std::snprintf(last_error, (size_t)capacity, "%s", err.c_str()); }
   return TEB_AMD_OK;
 }
 

@@ -166,7 +166,10 @@
 
 // what a device site sees
 #if defined(TEB_AMD_DEFAULTS_PROFILE)
-#if defined(TEB_AMD_PROFILE_LIGHT)
+#if defined(TEB_AMD_PROFILE_CUSTOM)
+// compiled at run time for ONE configuration (teb_rtc.hpp): every flag folds to the value it has there, -DTEB_PF_VALUE_<ID>=true|false
+#define TEB_CFGI(ID) (TEB_PF_VALUE_##ID)
+#elif defined(TEB_AMD_PROFILE_LIGHT)
 #define TEB_CFGI(ID) (TEB_PF_LIGHT_##ID ? (TEB_PF_EXPR_##ID) : (TEB_PF_DFLT_##ID))
 #elif defined(TEB_AMD_PROFILE_WIDE) && defined(TEB_AMD_PROFILE_ANY_KINEMATICS)
 #define TEB_CFGI(ID) ((TEB_PF_WIDE_##ID || TEB_PF_KIN_##ID) ? (TEB_PF_EXPR_##ID) : (TEB_PF_DFLT_##ID))

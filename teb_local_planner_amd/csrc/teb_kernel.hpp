@@ -393,7 +393,7 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
               valid[u] = kq < cnt;
               // the first batch does not wait for the count: rows 0 .. of the list exist whatever it is (capacity = every obstacle), so
               // its loads are issued together with the load of cnt - one L2 round trip instead of two in front of every edge loop
-              if (k0 == sl) pp[u] = pre[u];
+              if (k0 == sl) pp[u] = valid[u] ? pre[u] : 0;   // (rows beyond the count hold whatever the buffer held: never an index)
               else pp[u] = valid[u] ? t.assoc[(size_t)kq * t.stride + i] : 0;
             }
             double dist[kStaticBatch], g0[kStaticBatch], g1[kStaticBatch];
@@ -1224,6 +1224,10 @@ __device__ __forceinline__ void cr_backward(const double* __restrict__ D, const 
 // -DTEB_AMD_INLINE_SOLVE builds the inlined variant (4.1 GB per launch, 18 % slower: it spills inside the loops instead).
 #ifdef TEB_AMD_INLINE_SOLVE
 #define TEB_SOLVE_LINKAGE __forceinline__
+#elif defined(TEB_AMD_SOLVE_CSR)
+// (per-unit build flag, build.py: the plain calling convention - the callee saves and restores its callee-saved block - for the one
+// instantiation in which the no-callee-saved call was found to corrupt the caller: see UNIT_FLAGS)
+#define TEB_SOLVE_LINKAGE __noinline__
 #else
 #define TEB_SOLVE_LINKAGE __noinline__ __attribute__((not_tail_called))
 #endif
@@ -2520,16 +2524,20 @@ __device__ inline void mcu_solver_helper(const SceneDev& sc, const BatchDev& bt,
 // defaults in nothing else - a goal-directed planner with via-points, an omnidirectional base (-DTEB_AMD_PROFILE_WIDE).
 enum { SCENE_POINTS = 0, SCENE_GENERIC = 1, SCENE_POINTS_SMALL = 2, SCENE_GENERIC_SMALL = 3, SCENE_POINTS_DEFAULTS = 4, SCENE_POINTS_SMALL_DEFAULTS = 5,
        SCENE_GENERIC_DEFAULTS = 6, SCENE_GENERIC_SMALL_DEFAULTS = 7, SCENE_POINTS_WIDE = 8, SCENE_POINTS_SMALL_WIDE = 9,
-       SCENE_POINTS_LIGHT = 10, SCENE_POINTS_SMALL_LIGHT = 11 };   // *_LIGHT: every cost-term flag at run time, only the never-reached bulk folded (TEB_PF_LIGHT_*)
+       SCENE_POINTS_LIGHT = 10, SCENE_POINTS_SMALL_LIGHT = 11,   // *_LIGHT: every cost-term flag at run time, only the never-reached bulk folded (TEB_PF_LIGHT_*)
+       // *_CUSTOM: compiled at run time for the handle's configuration, every flag folded to its value there (teb_rtc.hpp, -DTEB_AMD_PROFILE_CUSTOM)
+       SCENE_POINTS_CUSTOM = 12, SCENE_POINTS_SMALL_CUSTOM = 13, SCENE_GENERIC_CUSTOM = 14, SCENE_GENERIC_SMALL_CUSTOM = 15 };
 template <int SOLVER, int JMODE, int SCENE>
 __global__ void __launch_bounds__(kThreads)
 teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev bt, const OptArgs args,
                     const LdsPlan plan, const McuDev mc) {
   extern __shared__ __attribute__((aligned(16))) double lds_base[];
   constexpr bool FAST = SCENE == SCENE_POINTS || SCENE == SCENE_POINTS_SMALL || SCENE == SCENE_POINTS_DEFAULTS || SCENE == SCENE_POINTS_SMALL_DEFAULTS ||
-                        SCENE == SCENE_POINTS_WIDE || SCENE == SCENE_POINTS_SMALL_WIDE || SCENE == SCENE_POINTS_LIGHT || SCENE == SCENE_POINTS_SMALL_LIGHT;
+                        SCENE == SCENE_POINTS_WIDE || SCENE == SCENE_POINTS_SMALL_WIDE || SCENE == SCENE_POINTS_LIGHT || SCENE == SCENE_POINTS_SMALL_LIGHT ||
+                        SCENE == SCENE_POINTS_CUSTOM || SCENE == SCENE_POINTS_SMALL_CUSTOM;
   constexpr bool MCU = SCENE == SCENE_POINTS_SMALL || SCENE == SCENE_GENERIC_SMALL || SCENE == SCENE_POINTS_SMALL_DEFAULTS ||
-                       SCENE == SCENE_GENERIC_SMALL_DEFAULTS || SCENE == SCENE_POINTS_SMALL_WIDE || SCENE == SCENE_POINTS_SMALL_LIGHT;   // small-batch instantiation: helper workgroups possible
+                       SCENE == SCENE_GENERIC_SMALL_DEFAULTS || SCENE == SCENE_POINTS_SMALL_WIDE || SCENE == SCENE_POINTS_SMALL_LIGHT ||
+                       SCENE == SCENE_POINTS_SMALL_CUSTOM || SCENE == SCENE_GENERIC_SMALL_CUSTOM;   // small-batch instantiation: helper workgroups possible
 #ifdef TEB_AMD_DEFAULTS_PROFILE
   static_assert(SCENE >= SCENE_POINTS_DEFAULTS, "a unit compiled with the profile holds a *_DEFAULTS kind");
 #else
@@ -2537,6 +2545,11 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
 #endif
 #ifdef TEB_AMD_PROFILE_ANY_KINEMATICS
   static_assert(SCENE == SCENE_GENERIC_DEFAULTS || SCENE == SCENE_GENERIC_SMALL_DEFAULTS, "the generic-shape kinds of the profile keep the kinematics flags");
+#endif
+#ifdef TEB_AMD_PROFILE_CUSTOM
+  static_assert(SCENE >= SCENE_POINTS_CUSTOM, "-DTEB_AMD_PROFILE_CUSTOM builds the *_CUSTOM kinds");
+#else
+  static_assert(SCENE < SCENE_POINTS_CUSTOM, "*_CUSTOM kinds are compiled at run time (teb_rtc.hpp)");
 #endif
 #ifdef TEB_AMD_PROFILE_WIDE
   static_assert(SCENE == SCENE_POINTS_WIDE || SCENE == SCENE_POINTS_SMALL_WIDE, "-DTEB_AMD_PROFILE_WIDE builds the *_WIDE kinds");

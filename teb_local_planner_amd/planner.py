@@ -264,6 +264,15 @@ class TebBatchSolver:
         _chk(L.teb_amd_debug_last_config_profile(self._h, C.byref(v)), "teb_amd_debug_last_config_profile")
         return int(v.value)
 
+    @staticmethod
+    def rtc_stats():
+        """run-time compiled instantiations of this process: (ready, compiling, failed, compile seconds of the last one, last error)"""
+        L = lib()
+        L.teb_amd_debug_rtc_stats.argtypes = [_abi.p_i32, _abi.p_i32, _abi.p_i32, _abi.p_f64, C.c_char_p, C.c_int32]
+        r = C.c_int32(0); w = C.c_int32(0); f = C.c_int32(0); s = C.c_double(0); buf = C.create_string_buffer(4096)
+        _chk(L.teb_amd_debug_rtc_stats(C.byref(r), C.byref(w), C.byref(f), C.byref(s), buf, 4096), "teb_amd_debug_rtc_stats")
+        return r.value, w.value, f.value, s.value, buf.value.decode(errors="replace")
+
     def capacity(self):
         a = C.c_int32(0)
         b = C.c_int32(0)

@@ -186,3 +186,91 @@ def test_wide_kinds_do_not_take_what_they_fold():
     cfg = _with(cfg0, robot__max_vel_y=0.2, robot__acc_lim_y=0.3)
     cfg.jacobian_mode = 1                                                                          # the wide kinds exist for closed forms only
     assert run(cfg, obst, via, batch)[2] == 0
+
+
+def test_kernel_compiled_for_the_configuration_at_run_time():
+    """teb_amd_options_t::compile_for_config (csrc/teb_rtc.hpp): a configuration off the defaults gets an instantiation with EVERY flag of
+    the profile table folded to its own values, compiled by hipRTC from the library's sources - the bands of the generic kernel bit for
+    bit, at the speed of a default configuration. Synchronous mode first (the launch waits for the compiler), then a second handle finds
+    the module in the process-wide cache; a generic-shape scene off the defaults; the numeric Jacobian mode."""
+    import time
+    cfg, obst, via, batch = scenes.scene_c4(B=24, stride=288)
+    cfg.optim.weight_shortest_path = 1.0
+    cfg.optim.obstacle_cost_exponent = 1.5
+    cfg.robot.max_vel_y = 0.2; cfg.robot.acc_lim_y = 0.3; cfg.robot.max_vel_trans = 0.5
+    g = run(cfg, obst, via, batch, generic_config_path=True)
+    t0 = time.perf_counter()
+    t = run(cfg, obst, via, batch, compile_for_config=2)
+    first = time.perf_counter() - t0
+    ready, compiling, failed, secs, err = planner.TebBatchSolver.rtc_stats()
+    assert t[2] == 4 and g[2] == 0, (t[2], g[2], err)
+    assert failed == 0 and ready >= 1, (ready, compiling, failed, err)
+    same_bits(t[0], t[1], g[0], g[1])
+    t0 = time.perf_counter()
+    t2 = run(cfg, obst, via, batch, compile_for_config=2)
+    again = time.perf_counter() - t0
+    assert t2[2] == 4
+    same_bits(t2[0], t2[1], g[0], g[1])
+    print("compiled for the configuration: %.1f s in the compiler, first call %.1f s, second handle %.3f s (cached module)" % (secs, first, again))
+    assert again < 0.5 * first
+    # blocks-in-LDS layout, small batch with solver helpers
+    cfg2, obst2, via2, batch2 = scenes.scene_c3(B=4, n=60, M=40, stride=96)
+    cfg2.optim.weight_velocity_obstacle_ratio = 1.0
+    a = run(cfg2, obst2, via2, batch2, compile_for_config=2)
+    b = run(cfg2, obst2, via2, batch2, generic_config_path=True)
+    assert a[2] == 4 and a[3] == b[3] and a[3][1] > 0, (a[2], a[3], b[3])
+    same_bits(a[0], a[1], b[0], b[1])
+    # generic shapes off the defaults (polygon footprint, via-points, every obstacle type)
+    cfg3, obst3, via3, batch3 = scenes.scene_small_mixed(footprint="polygon")
+    a = run(cfg3, obst3, via3, batch3, compile_for_config=2, multi_cu=-1, speculative_trials=-1)
+    b = run(cfg3, obst3, via3, batch3, generic_config_path=True, multi_cu=-1, speculative_trials=-1)
+    assert a[2] == 4 and b[2] == 0
+    same_bits(a[0], a[1], b[0], b[1])
+    # the reference's own linearisation scheme off the defaults
+    cfg.jacobian_mode = 1
+    a = run(cfg, obst, via, batch, compile_for_config=2)
+    b = run(cfg, obst, via, batch, generic_config_path=True)
+    assert a[2] == 4 and b[2] == 0
+    same_bits(a[0], a[1], b[0], b[1])
+
+
+def test_background_compilation_runs_the_prebuilt_kernel_until_the_module_is_ready():
+    import time
+    cfg, obst, via, batch = scenes.scene_c3(B=6, n=80, M=60, stride=128)
+    cfg.optim.weight_shortest_path = 0.5        # (a flag combination no other test compiles)
+    cfg.trajectory.exact_arc_length = True
+    g = run(cfg, obst, via, batch, generic_config_path=True)
+    s = planner.make_solver(cfg, obst, via, batch, options=_abi.Options(compile_for_config=1))
+    s.snapshot()
+    seen = []
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 120.0:
+        s.restore()
+        s.optimize(cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations, True, 100.0, 1.0, False)
+        prof = s.last_config_profile()
+        seen.append(prof)
+        same_bits(s.download(batch.copy()), s.results(), g[0], g[1])     # whichever kernel ran: the same bands
+        if prof == 4:
+            break
+        time.sleep(0.05)
+    s.close()
+    assert seen[0] == 3, seen[:3]                 # the first launch did not wait: the light kinds ran
+    assert seen[-1] == 4, (seen[-5:], planner.TebBatchSolver.rtc_stats())
+    print("background compilation: %d launches on the pre-built kernel, then the compiled one after %.1f s" % (len(seen) - 1, time.perf_counter() - t0))
+
+
+@pytest.mark.parametrize("layout", ["band", "blocks"])
+@pytest.mark.parametrize("kind", ["prebuilt", "generic", "compiled"])
+def test_every_kernel_kind_on_the_rarely_taken_cost_terms_with_and_without_solver_helpers(layout, kind):
+    """Round 4 found three instantiations (generic small-batch band, light full-batch band, light small-batch blocks) faulting - memory
+    aperture violation - as soon as obstacle_cost_exponent != 1 sent the edge loops through pow(): a path no test took. The cause is the
+    no-callee-saved call of the solve in the big instantiations (the class of backend interaction round 3 met with two such call sites);
+    every instantiation that keeps the cost terms at run time calls the solve on the plain convention now (build.py: UNIT_FLAGS). This
+    matrix (tools/kind_matrix.py; every case in a process of its own, a fault aborts only that one) runs each kind a configuration can
+    reach - the host's pre-built pick, the generic kernel forced, the kernel compiled for the configuration - in both layouts through
+    nine rarely taken configurations WITH solver helpers and without, and holds the two launches bit-identical."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "kind_matrix.py"), layout, kind, "all"], cwd=root, capture_output=True, text=True, timeout=900)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr[-2000:]
