@@ -266,9 +266,9 @@ def test_every_kernel_kind_on_the_rarely_taken_cost_terms_with_and_without_solve
     aperture violation - as soon as obstacle_cost_exponent != 1 sent the edge loops through pow(): a path no test took. The cause is the
     no-callee-saved call of the solve in the big instantiations (the class of backend interaction round 3 met with two such call sites);
     every instantiation that keeps the cost terms at run time calls the solve on the plain convention now (build.py: UNIT_FLAGS). This
-    matrix (tools/kind_matrix.py; every case in a process of its own, a fault aborts only that one) runs each kind a configuration can
+    matrix (tools/kind_matrix.py; one process per (layout, kind): a GPU fault aborts only that one, its last line says where) runs each kind a configuration can
     reach - the host's pre-built pick, the generic kernel forced, the kernel compiled for the configuration - in both layouts through
-    nine rarely taken configurations WITH solver helpers and without, and holds the two launches bit-identical."""
+    nine rarely taken configurations (four for the compiled kind: every case costs two compilations) WITH solver helpers and without, and holds the two launches bit-identical."""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "kind_matrix.py"), layout, kind, "all"], cwd=root, capture_output=True, text=True, timeout=900)
