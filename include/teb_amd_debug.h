@@ -73,6 +73,11 @@ int teb_amd_debug_last_config_profile(teb_amd_handle_t* h, int32_t* defaults_pro
 /* Run-time compiled instantiations of this process (teb_amd_options_t::compile_for_config): how many are ready / still compiling /
  * failed, the compile time of the last one that finished [s], and the reason of the last failure (empty string if none). */
 int teb_amd_debug_rtc_stats(int32_t* ready, int32_t* compiling, int32_t* failed, double* last_compile_seconds, char* last_error, int32_t capacity);
+/* Compiles (and waits for) the run-time instantiation for the given flag values - bit i = value of flag i of TEB_PF_ALL
+ * (csrc/teb_device.hpp) -, layout (0 band in LDS, 1 blocks in LDS, 2 band in HBM), Jacobian mode and scene kind (12 .. 15: the *_CUSTOM
+ * kinds). Needs no GPU: hipRTC cross-compiles for gfx950, so the CPU test stage covers the run-time compilation path. Returns
+ * TEB_AMD_OK iff the code object was produced; *code_bytes = its size. */
+int teb_amd_debug_rtc_compile(uint64_t flag_values, int32_t solver, int32_t jacobian_mode, int32_t scene_kind, int64_t* code_bytes);
 
 /* per-TEB flags of the last launch: bit0 association list overflow, bit1 autoResize capacity overflow */
 int teb_amd_debug_assoc_overflow(teb_amd_handle_t* h, int32_t* flags);

@@ -2513,6 +2513,19 @@ int teb_amd_last_shader_clock_mhz(teb_amd_handle_t* h, double* mhz) {
   return TEB_AMD_OK;
 }
 
+int teb_amd_debug_rtc_compile(uint64_t flag_values, int32_t solver, int32_t jacobian_mode, int32_t scene_kind, int64_t* code_bytes) {
+  if (solver < 0 || solver > 2 || jacobian_mode < 0 || jacobian_mode > 1 || scene_kind < SCENE_POINTS_CUSTOM || scene_kind > SCENE_GENERIC_SMALL_CUSTOM)
+    return fail(TEB_AMD_ERR_INVALID_ARG, "teb_amd_debug_rtc_compile: layout 0 .. 2, Jacobian mode 0 / 1, scene kind 12 .. 15");
+  RtcKey key;
+  key.flags = flag_values; key.solver = solver; key.jmode = jacobian_mode; key.scene = scene_kind;
+  std::string why;
+  std::shared_ptr<RtcKernel> rk = rtc_request(key, true, &why);
+  if (!rk) return fail(TEB_AMD_ERR_UNSUPPORTED, "run-time compilation unavailable: " + why);
+  if (rk->state.load() != RtcKernel::READY) return fail(TEB_AMD_ERR_HIP, rk->log.substr(0, 1500));
+  if (code_bytes) *code_bytes = (int64_t)rk->code.size();
+  return TEB_AMD_OK;
+}
+
 int teb_amd_debug_rtc_stats(int32_t* ready, int32_t* compiling, int32_t* failed, double* last_compile_seconds, char* last_error, int32_t capacity) {
   RtcCache& c = rtc_cache();
   std::lock_guard<std::mutex> lock(c.mu);
