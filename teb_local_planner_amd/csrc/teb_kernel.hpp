@@ -2475,7 +2475,12 @@ __device__ inline void mcu_solver_helper(const SceneDev& sc, const BatchDev& bt,
       for (;;) {
         cmd = ld_agent_u32(ctl + MCU_SCMD);
         if (cmd > epoch) break;
-        if (ld_agent_u32(ctl + MCU_SABORT) != 0 || realtime_ticks() - t0 > 4 * mc.timeout_ticks + 100000) { cmd = kMcuSpecExit; break; }
+        // patience: the band's own (multi_cu_timeout_us, 2 ms by default and at least that - the probe launches after a back-off shorten the
+        // band's side only: an LM iteration of the largest bands is a tenth of it, the association before the first command a fifth). A band
+        // that has given its helpers up says so (MCU_SABORT, spec_take / spec_wait_idle) and one that has finished sends the exit command;
+        // the bound is for a band whose workgroup is not running at all - a helper that leaves early only costs its band the one
+        // short wait of spec_take, never a bit of the result (was 4 x timeout + 1 ms)
+        if (ld_agent_u32(ctl + MCU_SABORT) != 0 || realtime_ticks() - t0 > (mc.timeout_ticks > 200000 ? mc.timeout_ticks : 200000)) { cmd = kMcuSpecExit; break; }
         __builtin_amdgcn_s_sleep(2);
       }
       l.ired[24] = (int)cmd;
