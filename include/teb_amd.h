@@ -268,13 +268,17 @@ typedef struct teb_amd_options {
                                   /* exponent 1, no exact arc length, inflated obstacle edges, no batch statistics; point-like scenes: */
                                   /* diff-drive, point obstacles) runs kernels compiled with those flags folded: same operations,     */
                                   /* bit-identical bands, 10 - 25 % faster. Cross-check switch.                                        */
-  int32_t compile_for_config;     /* a kernel compiled FOR the handle's configuration at run time (hipRTC, ~ 5 s per instantiation,   */
-                                  /* cached per process): a configuration off the TebConfig defaults then runs a kernel with every    */
-                                  /* flag of the profile table folded to ITS values - as fast as a default one, bit-identical bands. */
-                                  /* 0 = off, 1 = compile in the background at the first launch that needs it (the launches run the  */
-                                  /* best pre-built kernel until the module is ready), 2 = that launch waits for the compiler.       */
-                                  /* Needs libhiprtc and the kernel sources (csrc/ next to the library, or $TEB_AMD_CSRC); where     */
-                                  /* either is missing, or the compilation fails, the pre-built kernels run - it is never an error.   */
+  int32_t compile_for_config;     /* a kernel compiled FOR the handle's configuration at run time (hipRTC, 2 - 5 s per instantiation, */
+                                  /* cached per process and on disk): a configuration off the TebConfig defaults then runs a kernel  */
+                                  /* with every flag of the profile table folded to ITS values - as fast as a default one,           */
+                                  /* bit-identical bands. 0 = off, 1 = compile in the background at the first launch that needs it    */
+                                  /* (the launches run the best pre-built kernel until the module is ready), 2 = that launch waits   */
+                                  /* for the compiler. Needs libhiprtc and the ROCm headers ($ROCM_PATH, default /opt/rocm); the       */
+                                  /* kernel sources are inside the library ($TEB_AMD_CSRC = a csrc directory to compile instead).     */
+                                  /* Code objects are kept in $TEB_AMD_RTC_CACHE (default $XDG_CACHE_HOME/teb_amd or ~/.cache/teb_amd; */
+                                  /* "off" = no disk cache), keyed by sources, flag values, instantiation and compiler version: the   */
+                                  /* next process loads them in milliseconds. Where something is missing, or the compilation fails,   */
+                                  /* the pre-built kernels run - it is never an error.                                                 */
   int32_t reserved[4];            /* must be 0                                                                                  */
 } teb_amd_options_t;
 void teb_amd_options_default(teb_amd_options_t* opt);

@@ -78,6 +78,11 @@ int teb_amd_debug_rtc_stats(int32_t* ready, int32_t* compiling, int32_t* failed,
  * kinds). Needs no GPU: hipRTC cross-compiles for gfx950, so the CPU test stage covers the run-time compilation path. Returns
  * TEB_AMD_OK iff the code object was produced; *code_bytes = its size. */
 int teb_amd_debug_rtc_compile(uint64_t flag_values, int32_t solver, int32_t jacobian_mode, int32_t scene_kind, int64_t* code_bytes);
+/* Where the run-time compiler of this process takes its sources and keeps its code objects: *embedded = 1 iff it compiles the copy of the
+ * kernel sources inside the library (0: a csrc directory), *disk_hits / *disk_writes = code objects loaded from / written to the disk
+ * cache so far, cache_dir = its directory (empty string: disabled). Valid after the first request (teb_amd_debug_rtc_compile or a launch
+ * with compile_for_config). */
+int teb_amd_debug_rtc_cache(int32_t* embedded, int32_t* disk_hits, int32_t* disk_writes, char* cache_dir, int32_t capacity);
 
 /* per-TEB flags of the last launch: bit0 association list overflow, bit1 autoResize capacity overflow */
 int teb_amd_debug_assoc_overflow(teb_amd_handle_t* h, int32_t* flags);

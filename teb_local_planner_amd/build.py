@@ -99,6 +99,38 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+# what the optimise kernel's translation unit includes: embedded into the library for teb_amd_options_t::compile_for_config, so that a
+# deployed libteb_amd.so compiles the instantiation of a configuration without the source tree beside it
+RTC_SOURCES = ["teb_kernel.hpp", "teb_edges.hpp", "teb_geometry.hpp", "teb_device.hpp", "teb_multicu.hpp", "teb_autoresize_chain.hpp",
+               os.path.join("..", "..", "include", "teb_amd.h")]
+
+
+def write_rtc_sources(bdir):
+    """<bdir>/teb_rtc_embedded.inc: the kernel sources as string literals (name, text) + their hash, included by csrc/teb_rtc.hpp under
+    -DTEB_AMD_RTC_EMBEDDED. teb_device.hpp's include of the C-ABI header is rewritten to the flat name the in-memory header gets."""
+    parts, names = [], []
+    h = hashlib.sha256()
+    for f in RTC_SOURCES:
+        text = open(os.path.join(CSRC, f), "r").read()
+        text = text.replace('#include "../../include/teb_amd.h"', '#include "teb_amd.h"')
+        assert ')TEBSRC"' not in text
+        h.update(text.encode())
+        names.append(os.path.basename(f))
+        # (string literals are split: one literal per 8 KB keeps every compiler's limit far away; adjacent literals concatenate)
+        chunks = [text[k:k + 8192] for k in range(0, len(text), 8192)]
+        parts.append("\n".join('R"TEBSRC(%s)TEBSRC"' % c for c in chunks))
+    out = os.path.join(bdir, "teb_rtc_embedded.inc")
+    body = ("// generated by build.py (write_rtc_sources): do not edit\n"
+            "static const int kRtcEmbeddedCount = %d;\n" % len(names)
+            + "static const char* const kRtcEmbeddedNames[] = {%s};\n" % ", ".join('"%s"' % n for n in names)
+            + "static const char* const kRtcEmbeddedSources[] = {\n%s\n};\n" % ",\n".join(parts)
+            + 'static const char kRtcEmbeddedHash[] = "%s";\n' % h.hexdigest()[:16])
+    if not os.path.exists(out) or open(out).read() != body:
+        with open(out, "w") as fh:
+            fh.write(body)
+    return out
+
+
 def build(force=False, verbose=False, variant="product", jobs=None, extra_defines=(), out=None, unit_flags=None):
     """Compile the variant if its sources are newer than the library. Returns the library path.
     unit_flags: {object name: [extra compiler flags]} for single translation units (compiler-flag experiments of tools/)."""
@@ -115,12 +147,16 @@ def build(force=False, verbose=False, variant="product", jobs=None, extra_define
     jobs = jobs or int(os.environ.get("TEB_AMD_BUILD_JOBS", "0")) or min(os.cpu_count() or 1, 8)
     newest_all, newest_kernel = _newest_source(), _newest_source(KERNEL_DEPS)
 
+    embedded = write_rtc_sources(bdir)
+
     def compile_unit(u):
         obj, src, defs = u
         o = os.path.join(bdir, obj)
         newest = newest_kernel if src == "teb_opt_inst.hip" else newest_all
         if not force and os.path.exists(o) and os.path.getmtime(o) >= newest:
             return o
+        if src == "teb_amd.hip":   # the host side carries the kernel sources for the run-time compiler (teb_rtc.hpp)
+            defs = defs + ["-DTEB_AMD_RTC_EMBEDDED", "-I" + os.path.dirname(embedded)]
         cmd = [hipcc] + HIPCC_FLAGS + v["defines"] + list(extra_defines) + defs + list(unit_flags.get(obj, [])) + ["-c", os.path.join(CSRC, src), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)

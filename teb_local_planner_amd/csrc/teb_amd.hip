@@ -2526,6 +2526,16 @@ int teb_amd_debug_rtc_compile(uint64_t flag_values, int32_t solver, int32_t jaco
   return TEB_AMD_OK;
 }
 
+int teb_amd_debug_rtc_cache(int32_t* embedded, int32_t* disk_hits, int32_t* disk_writes, char* cache_dir, int32_t capacity) {
+  RtcCache& c = rtc_cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  if (embedded) *embedded = c.embedded ? 1 : 0;
+  if (disk_hits) *disk_hits = c.disk_hits.load();
+  if (disk_writes) *disk_writes = c.disk_writes.load();
+  if (cache_dir && capacity > 0) std::snprintf(cache_dir, (size_t)capacity, "%s", c.disk_dir.c_str());
+  return TEB_AMD_OK;
+}
+
 int teb_amd_debug_rtc_stats(int32_t* ready, int32_t* compiling, int32_t* failed, double* last_compile_seconds, char* last_error, int32_t capacity) {
   RtcCache& c = rtc_cache();
   std::lock_guard<std::mutex> lock(c.mu);

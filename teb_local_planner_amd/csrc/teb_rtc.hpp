@@ -10,16 +10,22 @@
 // takes ~ 5 s to compile (the offline build spends most of its minute per unit elsewhere); asynchronously the launches run the best
 // pre-built kernel until the module is ready.
 //
-// libhiprtc is loaded with dlopen on first use (users who leave the option off neither link nor load it); the kernel sources are read
-// from the csrc directory next to libteb_amd.so (the in-tree layout), hip/hip_runtime.h from the ROCm installation.
+// libhiprtc is loaded with dlopen on first use (users who leave the option off neither link nor load it). The kernel sources travel INSIDE
+// the library (build.py embeds them as string literals, -DTEB_AMD_RTC_EMBEDDED: a deployed libteb_amd.so needs no source tree beside it;
+// $TEB_AMD_CSRC, or a build without the embedded copy, reads them from a csrc directory instead), hip/hip_runtime.h comes from the ROCm
+// installation. Compiled code objects are kept on disk across processes ($TEB_AMD_RTC_CACHE, default ~/.cache/teb_amd; "off" disables):
+// keyed by the sources' hash, the flag values, the instantiation and the compiler's version, written atomically, checked on load.
 #pragma once
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -40,6 +46,7 @@ struct RtcApi {
   int (*GetLoweredName)(program_t, const char*, const char**) = nullptr;
   int (*GetCodeSize)(program_t, size_t*) = nullptr;
   int (*GetCode)(program_t, char*) = nullptr;
+  int (*Version)(int*, int*) = nullptr;
   std::string error;
   std::mutex mu;
   bool ready = false, failed = false;
@@ -62,6 +69,7 @@ struct RtcApi {
     GetLoweredName = reinterpret_cast<decltype(GetLoweredName)>(sym("hiprtcGetLoweredName"));
     GetCodeSize = reinterpret_cast<decltype(GetCodeSize)>(sym("hiprtcGetCodeSize"));
     GetCode = reinterpret_cast<decltype(GetCode)>(sym("hiprtcGetCode"));
+    Version = reinterpret_cast<decltype(Version)>(dlsym(l, "hiprtcVersion"));   // (optional: part of the disk-cache key)
     if (!ok) { failed = true; return false; }
     ready = true;
     return true;
@@ -76,6 +84,7 @@ struct RtcKernel {
   std::vector<char> code;        // the code object (kept: a module is loaded per device context on first use)
   std::string lowered, log;
   double compile_seconds = 0;
+  bool from_disk = false;        // the code object came from the disk cache of an earlier process
   std::mutex mu;                 // guards the per-device modules
   std::map<int, hipFunction_t> fn;   // device ordinal -> function
 };
@@ -91,33 +100,76 @@ struct RtcKey {
   }
 };
 
+#ifdef TEB_AMD_RTC_EMBEDDED
+#include "teb_rtc_embedded.inc"
+#endif
+
+inline unsigned long long rtc_fnv(const void* data, size_t n, unsigned long long h = 1469598103934665603ull) {
+  const unsigned char* p = static_cast<const unsigned char*>(data);
+  for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+  return h;
+}
+
 struct RtcCache {
   std::mutex mu;
   std::map<RtcKey, std::shared_ptr<RtcKernel>> kernels;
-  std::string csrc_dir, rocm_include;
+  std::string csrc_dir, rocm_include, disk_dir;
+  unsigned long long source_hash = 0;
+  bool embedded = false;        // the sources compiled are the copy inside the library
   bool located = false;
-  // the sources of the kernel: <directory of libteb_amd.so>/csrc (or $TEB_AMD_CSRC); hip headers: $ROCM_PATH/include or /opt/rocm/include
+  std::atomic<int> disk_hits{0}, disk_writes{0};
+  // the sources of the kernel: the embedded copy, or <$TEB_AMD_CSRC | directory of libteb_amd.so + /csrc>; hip headers: $ROCM_PATH/include
+  // or /opt/rocm/include; the disk cache: $TEB_AMD_RTC_CACHE | $XDG_CACHE_HOME/teb_amd | $HOME/.cache/teb_amd ("off" / "0" / no home: none)
   bool locate(std::string* why) {
     if (located) return true;
     const char* env = getenv("TEB_AMD_CSRC");
-    if (env && *env) csrc_dir = env;
-    else {
-      Dl_info info;
-      if (!dladdr(reinterpret_cast<const void*>(&rtc_api), &info) || !info.dli_fname) { *why = "cannot locate libteb_amd.so"; return false; }
-      std::string p = info.dli_fname;
-      const size_t k = p.find_last_of('/');
-      csrc_dir = (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/csrc";
+#ifdef TEB_AMD_RTC_EMBEDDED
+    embedded = !(env && *env);
+#endif
+    if (embedded) {
+#ifdef TEB_AMD_RTC_EMBEDDED
+      source_hash = rtc_fnv(kRtcEmbeddedHash, sizeof kRtcEmbeddedHash);
+#endif
+    } else {
+      if (env && *env) csrc_dir = env;
+      else {
+        Dl_info info;
+        if (!dladdr(reinterpret_cast<const void*>(&rtc_api), &info) || !info.dli_fname) { *why = "cannot locate libteb_amd.so"; return false; }
+        std::string p = info.dli_fname;
+        const size_t k = p.find_last_of('/');
+        csrc_dir = (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/csrc";
+      }
+      // (every file the translation unit includes goes into the key of the disk cache)
+      const char* files[] = {"teb_kernel.hpp", "teb_edges.hpp", "teb_geometry.hpp", "teb_device.hpp", "teb_multicu.hpp", "teb_autoresize_chain.hpp",
+                             "../../include/teb_amd.h"};
+      unsigned long long h = 1469598103934665603ull;
+      for (const char* name : files) {
+        FILE* f = fopen((csrc_dir + "/" + name).c_str(), "rb");
+        if (!f) { *why = "kernel sources not found at " + csrc_dir + " (" + name + "; set TEB_AMD_CSRC)"; return false; }
+        char buf[65536];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof buf, f)) > 0) h = rtc_fnv(buf, n, h);
+        fclose(f);
+      }
+      source_hash = h;
     }
-    FILE* f = fopen((csrc_dir + "/teb_kernel.hpp").c_str(), "r");
-    if (!f) { *why = "kernel sources not found at " + csrc_dir + " (set TEB_AMD_CSRC)"; return false; }
-    fclose(f);
     const char* rp = getenv("ROCM_PATH");
     rocm_include = std::string(rp && *rp ? rp : "/opt/rocm") + "/include";
+    const char* dc = getenv("TEB_AMD_RTC_CACHE");
+    if (dc && *dc) { if (std::string(dc) != "off" && std::string(dc) != "0") disk_dir = dc; }
+    else {
+      const char* xdg = getenv("XDG_CACHE_HOME");
+      const char* home = getenv("HOME");
+      if (xdg && *xdg) disk_dir = std::string(xdg) + "/teb_amd";
+      else if (home && *home) disk_dir = std::string(home) + "/.cache/teb_amd";
+    }
     located = true;
     return true;
   }
 };
 inline RtcCache& rtc_cache() { static RtcCache c; return c; }
+inline std::atomic<int>& rtc_cache_disk_hits() { return rtc_cache().disk_hits; }
+inline std::atomic<int>& rtc_cache_disk_writes() { return rtc_cache().disk_writes; }
 
 // names of the table's flags in TEB_PF_ALL order (-DTEB_PF_VALUE_<name>=0|1)
 inline const std::vector<std::string>& rtc_flag_names() {
@@ -129,21 +181,102 @@ inline const std::vector<std::string>& rtc_flag_names() {
   return names;
 }
 
-inline void rtc_compile(const RtcKey key, std::shared_ptr<RtcKernel> k, const std::string csrc_dir, const std::string rocm_include) {
+// what a compilation needs from the cache object (copied: the compiler thread outlives no lock)
+struct RtcEnv {
+  std::string csrc_dir, rocm_include, disk_dir;
+  unsigned long long source_hash = 0;
+  bool embedded = false;
+};
+
+// ---- the disk cache: <dir>/<key>.co = "TEBRTC01" | key | lowered-name length | code length | lowered name | code | FNV-1a of the code
+inline std::string rtc_disk_path(const RtcEnv& env, unsigned long long key) {
+  char name[64];
+  snprintf(name, sizeof name, "/%016llx.co", key);
+  return env.disk_dir + name;
+}
+inline bool rtc_disk_load(const RtcEnv& env, unsigned long long key, RtcKernel& k) {
+  if (env.disk_dir.empty()) return false;
+  FILE* f = fopen(rtc_disk_path(env, key).c_str(), "rb");
+  if (!f) return false;
+  bool ok = false;
+  char magic[8];
+  unsigned long long fkey = 0, clen = 0, sum = 0;
+  unsigned int llen = 0;
+  if (fread(magic, 1, 8, f) == 8 && memcmp(magic, "TEBRTC01", 8) == 0 && fread(&fkey, 8, 1, f) == 1 && fkey == key && fread(&llen, 4, 1, f) == 1 &&
+      fread(&clen, 8, 1, f) == 1 && llen > 0 && llen < 4096 && clen > 0 && clen < (1ull << 30)) {
+    std::string lowered(llen, '\0');
+    std::vector<char> code((size_t)clen);
+    if (fread(&lowered[0], 1, llen, f) == llen && fread(code.data(), 1, (size_t)clen, f) == (size_t)clen && fread(&sum, 8, 1, f) == 1 &&
+        sum == rtc_fnv(code.data(), code.size())) {
+      k.lowered = lowered;
+      k.code.swap(code);
+      ok = true;
+    }
+  }
+  fclose(f);
+  return ok;
+}
+inline bool rtc_disk_store(const RtcEnv& env, unsigned long long key, const RtcKernel& k) {
+  if (env.disk_dir.empty()) return false;
+  // (parents one level up are expected to exist: ~/.cache or the directory the user named; a failure just means no cache)
+  const size_t slash = env.disk_dir.find_last_of('/');
+  if (slash != std::string::npos && slash > 0) (void)mkdir(env.disk_dir.substr(0, slash).c_str(), 0700);
+  (void)mkdir(env.disk_dir.c_str(), 0700);
+  const std::string path = rtc_disk_path(env, key);
+  char tmp[64];
+  snprintf(tmp, sizeof tmp, ".tmp.%ld", (long)getpid());
+  const std::string tpath = path + tmp;
+  FILE* f = fopen(tpath.c_str(), "wb");
+  if (!f) return false;
+  const unsigned int llen = (unsigned int)k.lowered.size();
+  const unsigned long long clen = k.code.size(), sum = rtc_fnv(k.code.data(), k.code.size());
+  bool ok = fwrite("TEBRTC01", 1, 8, f) == 8 && fwrite(&key, 8, 1, f) == 1 && fwrite(&llen, 4, 1, f) == 1 && fwrite(&clen, 8, 1, f) == 1 &&
+            fwrite(k.lowered.data(), 1, llen, f) == llen && fwrite(k.code.data(), 1, (size_t)clen, f) == (size_t)clen && fwrite(&sum, 8, 1, f) == 1;
+  ok = (fclose(f) == 0) && ok;
+  if (ok) ok = rename(tpath.c_str(), path.c_str()) == 0;   // atomic: a reader sees the old file, no file, or the whole new one
+  if (!ok) (void)unlink(tpath.c_str());
+  return ok;
+}
+
+inline void rtc_compile(const RtcKey key, std::shared_ptr<RtcKernel> k, const RtcEnv env) {
   RtcApi& api = rtc_api();
   const auto t0 = std::chrono::steady_clock::now();
   auto fail = [&](const std::string& why) { k->log = why; k->state.store(RtcKernel::FAILED); };
   const std::string src = "#include \"teb_kernel.hpp\"\n";
-  RtcApi::program_t prog = nullptr;
-  if (api.CreateProgram(&prog, src.c_str(), "teb_amd_rtc.hip", 0, nullptr, nullptr) != 0) return fail("hiprtcCreateProgram failed");
   char name[128];
   snprintf(name, sizeof name, "tebamd::teb_optimize_kernel<%d, %d, %d>", key.solver, key.jmode, key.scene);
-  api.AddNameExpression(prog, name);
-  std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I" + csrc_dir, "-I" + rocm_include,
+  std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                                    "-DM_PI=3.14159265358979323846", "-DHUGE_VAL=__builtin_huge_val()",   // (hipRTC's built-in headers lack the two math.h macros)
                                    "-DTEB_AMD_DEFAULTS_PROFILE=1", "-DTEB_AMD_PROFILE_CUSTOM=1"};
   const std::vector<std::string>& names = rtc_flag_names();
   for (size_t i = 0; i < names.size(); ++i) opts.push_back("-DTEB_PF_VALUE_" + names[i] + "=" + (((key.flags >> i) & 1ull) ? "true" : "false"));
+  // the key of the disk cache: sources, options (flag values, target), instantiation, compiler version
+  unsigned long long dkey = rtc_fnv(&env.source_hash, sizeof env.source_hash);
+  for (const std::string& o : opts) dkey = rtc_fnv(o.data(), o.size() + 1, dkey);
+  dkey = rtc_fnv(name, strlen(name) + 1, dkey);
+  int vmaj = 0, vmin = 0;
+  if (api.Version) (void)api.Version(&vmaj, &vmin);
+  dkey = rtc_fnv(&vmaj, sizeof vmaj, dkey);
+  dkey = rtc_fnv(&vmin, sizeof vmin, dkey);
+  if (rtc_disk_load(env, dkey, *k)) {
+    k->from_disk = true;
+    ++rtc_cache_disk_hits();
+    k->compile_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    k->state.store(RtcKernel::READY);
+    return;
+  }
+  if (!env.embedded) opts.push_back("-I" + env.csrc_dir);
+  opts.push_back("-I" + env.rocm_include);
+  RtcApi::program_t prog = nullptr;
+  int nh = 0;
+  const char* const* hsrc = nullptr;
+  const char* const* hname = nullptr;
+#ifdef TEB_AMD_RTC_EMBEDDED
+  if (env.embedded) { nh = kRtcEmbeddedCount; hsrc = kRtcEmbeddedSources; hname = kRtcEmbeddedNames; }
+#endif
+  if (api.CreateProgram(&prog, src.c_str(), "teb_amd_rtc.hip", nh, const_cast<const char**>(hsrc), const_cast<const char**>(hname)) != 0)
+    return fail("hiprtcCreateProgram failed");
+  api.AddNameExpression(prog, name);
   std::vector<const char*> copts;
   for (const std::string& o : opts) copts.push_back(o.c_str());
   const int rc = api.CompileProgram(prog, (int)copts.size(), copts.data());
@@ -160,6 +293,7 @@ inline void rtc_compile(const RtcKey key, std::shared_ptr<RtcKernel> k, const st
   k->code.resize(cs);
   if (cs == 0 || api.GetCode(prog, k->code.data()) != 0) { api.DestroyProgram(&prog); return fail("hiprtcGetCode failed"); }
   api.DestroyProgram(&prog);
+  if (rtc_disk_store(env, dkey, *k)) ++rtc_cache_disk_writes();
   k->compile_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   k->log = log;
   k->state.store(RtcKernel::READY);
@@ -178,7 +312,9 @@ inline std::shared_ptr<RtcKernel> rtc_request(const RtcKey& key, bool wait, std:
     else {
       k = std::make_shared<RtcKernel>();
       c.kernels[key] = k;
-      std::thread(rtc_compile, key, k, c.csrc_dir, c.rocm_include).detach();
+      RtcEnv env;
+      env.csrc_dir = c.csrc_dir; env.rocm_include = c.rocm_include; env.disk_dir = c.disk_dir; env.source_hash = c.source_hash; env.embedded = c.embedded;
+      std::thread(rtc_compile, key, k, env).detach();
     }
   }
   if (wait)

@@ -259,6 +259,49 @@ def test_background_compilation_runs_the_prebuilt_kernel_until_the_module_is_rea
     print("background compilation: %d launches on the pre-built kernel, then the compiled one after %.1f s" % (len(seen) - 1, time.perf_counter() - t0))
 
 
+_DISK_CHILD = r"""
+import ctypes as C, hashlib, json, sys, time
+sys.path.insert(0, %r)
+from teb_local_planner_amd import scenes, planner, _abi
+cfg, obst, via, batch = scenes.scene_c3(B=6, n=80, M=60, stride=128)
+cfg.optim.weight_shortest_path = 0.25
+cfg.optim.obstacle_cost_exponent = 1.25
+t0 = time.perf_counter()
+s = planner.make_solver(cfg, obst, via, batch, options=_abi.Options(compile_for_config=2))
+s.optimize(cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations, True, 100.0, 1.0, False)
+out = s.download(batch.copy()); res = s.results()
+dt = time.perf_counter() - t0
+h = hashlib.sha256()
+for a in (out.n, out.x, out.y, out.theta, out.dt, res.chi2, res.cost, res.lm_trials): h.update(a.tobytes())
+L = planner.lib()
+L.teb_amd_debug_rtc_cache.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_char_p, C.c_int32]
+e = C.c_int32(-1); hits = C.c_int32(-1); w = C.c_int32(-1); buf = C.create_string_buffer(1024)
+L.teb_amd_debug_rtc_cache(C.byref(e), C.byref(hits), C.byref(w), buf, 1024)
+print(json.dumps(dict(profile=s.last_config_profile(), bits=h.hexdigest(), seconds=dt, embedded=e.value, hits=hits.value, writes=w.value)))
+"""
+
+
+def test_a_second_process_runs_the_code_object_the_first_one_left_on_disk(tmp_path):
+    """The disk cache of the run-time compiler (csrc/teb_rtc.hpp) on the GPU: the first process compiles (from the sources embedded in the
+    library) and stores, the second loads the stored code object as a module and runs it - same kernel kind, same bits, no compiler."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(planner.__file__)))
+    env = dict(os.environ, TEB_AMD_RTC_CACHE=str(tmp_path / "cache"), AMD_COMGR_CACHE="0")
+    runs = []
+    for _ in range(2):
+        p = subprocess.run([sys.executable, "-c", _DISK_CHILD % root], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        runs.append(json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]))
+    a, b = runs
+    assert a["profile"] == 4 and b["profile"] == 4, runs
+    assert a["embedded"] == 1 and (a["hits"], a["writes"]) == (0, 1) and (b["hits"], b["writes"]) == (1, 0), runs
+    assert a["bits"] == b["bits"], runs
+    print("compiled in the first process %.1f s (whole call), loaded from disk in the second %.1f s" % (a["seconds"], b["seconds"]))
+
+
 @pytest.mark.parametrize("layout", ["band", "blocks"])
 @pytest.mark.parametrize("kind", ["prebuilt", "generic", "compiled"])
 def test_every_kernel_kind_on_the_rarely_taken_cost_terms_with_and_without_solver_helpers(layout, kind):
