@@ -494,6 +494,14 @@ int  teb_amd_get_velocity_command(teb_amd_handle_t* h, int32_t b, int32_t look_a
 int  teb_amd_get_velocity_profile(teb_amd_handle_t* h, int32_t b, double* out, int32_t capacity_rows, int32_t* rows);
 int  teb_amd_get_full_trajectory(teb_amd_handle_t* h, int32_t b, double* out, int32_t capacity_rows, int32_t* rows);
 int  teb_amd_has_diverged(teb_amd_handle_t* h, int32_t b, int32_t* diverged);
+/*
+ * What optimizer_->batchStatistics() of every resident band would hold after the last teb_amd_optimize_batch (hasDiverged reads
+ * .back().chi2, src/optimal_planner.cpp:1029-1038): available [count] = the vector is not empty (divergence_detection_enable was set
+ * for that call, :331, and optimize() ran), back_chi2 [count] = .back().chi2. g2o sizes the vector to the REQUESTED inner iteration
+ * count and fills one entry per executed iteration, so a band whose last optimize() call stopped early has back_chi2 = 0 and does not
+ * count as diverged; teb_amd_has_diverged applies the same rule. A binding keeps the pair per planner object.
+ */
+int  teb_amd_get_batch_statistics(teb_amd_handle_t* h, int32_t* available, double* back_chi2);
 
 /*
  * f4 (arithmetic part) — TebOptimalPlanner::isTrajectoryFeasible (src/optimal_planner.cpp:1250-1308; declared optimal_planner.h:500,
@@ -543,7 +551,7 @@ int  teb_amd_filter_equivalence_classes(teb_amd_handle_t* h, double threshold, i
  *   all ranks: teb_amd_comm_create(id, rank, world, device, &comm)
  *   per plan:  teb_amd_optimize_batch(h, ...)         each rank on its own candidates
  *              teb_amd_select_best_distributed(...)    one ncclAllGather of 16 bytes per rank; same answer on every rank
- *              teb_amd_broadcast_band(...)             optional: the winner's strip (8 + 32 * capacity bytes) from its owner to all
+ *              teb_amd_broadcast_band(...)             optional: the winner's strip (24 + 32 * capacity bytes) from its owner to all
  */
 #define TEB_AMD_COMM_ID_BYTES 128
 typedef struct teb_amd_comm teb_amd_comm_t;
@@ -566,6 +574,12 @@ int  teb_amd_select_best_distributed(teb_amd_handle_t* h, teb_amd_comm_t* comm, 
  */
 int  teb_amd_broadcast_band(teb_amd_handle_t* h, teb_amd_comm_t* comm, int32_t owner_rank, int32_t local_index, int32_t capacity,
                             int32_t* n, double* x, double* y, double* theta, double* dt);
+/*
+ * The winner's batch statistics travel with its strip (24 bytes more): what teb_amd_get_batch_statistics returns for the band on its
+ * owner, as received by the last teb_amd_broadcast_band on this communicator. A rank that mirrors the winner answers hasDiverged
+ * (src/optimal_planner.cpp:1023-1039; the plugin asks after every plan(), src/teb_local_planner_ros.cpp:374) like the owner does.
+ */
+int  teb_amd_comm_last_band_statistics(const teb_amd_comm_t* comm, int32_t* available, double* back_chi2);
 
 /* Duration [ms] of the last optimize_batch call on the device, measured with HIP events on the launch stream: from before the
  * (first) kernel launch to after the last one, i.e. including a repeated launch when autoResize outgrew the optimistic layout. */

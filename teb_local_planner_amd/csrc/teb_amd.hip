@@ -163,6 +163,7 @@ struct teb_amd_handle {
   int static_radius_zero = 0;   // every obstacle of the static list enters the LDS cache with radius 0 (no circular obstacle among them)
   int last_defaults_profile = 0;   // the last optimise launch ran a *_DEFAULTS instantiation (teb_amd_debug_last_config_profile)
   teb_amd_options_t opt;   // behaviour switches fixed at create (ABI 2; never the process environment)
+  int last_inner = 0;      // iterations_innerloop of the last teb_amd_optimize_batch (hasDiverged: size of g2o's batch statistics)
   int snap_nmax = -1;      // nmax_known at the time of teb_amd_snapshot_state
   int snap_B = -1;         // B at that time (the bound covers those bands only)
   int nmax_known = -1;     // upper bound of the resident pose counts as far as the host knows it, -1 = unknown (device-side producers ran)
@@ -174,7 +175,7 @@ struct teb_amd_handle {
   DevBuf<double> o_ax, o_ay, o_bx, o_by, o_rad, o_vx, o_vy, o_cx, o_cy, o_brad, o_pvx, o_pvy, viax, viay;
   DevBuf<double> o_list;   // [5][max_obst]: x, y, radius, vx, vy in the order of the LDS obstacle cache (SceneDev::lox ..)
   // batch
-  DevBuf<int> n, has_vs, has_vg, rotdir, via_en, status, optimized, iters, trials, assoc_cnt, assoc, assoc_ovf, via_pose, legacy_idx;
+  DevBuf<int> n, has_vs, has_vg, rotdir, via_en, status, optimized, iters, last_iters, trials, assoc_cnt, assoc, assoc_ovf, via_pose, legacy_idx;
   DevBuf<double> x, y, th, dt, vs, vg, chi2, cost, lambda, Hbackup, Hband, ob_x, ob_y, ob_th, ob_dt;   // ob_*: strips before an optimistic launch
   DevBuf<int> ob_n;
   DevBuf<long long> clk;   // BatchDev::clk
@@ -269,7 +270,7 @@ BatchDev batch_of(teb_amd_handle* h) {
   b.n = h->n.p; b.x = h->x.p; b.y = h->y.p; b.th = h->th.p; b.dt = h->dt.p;
   b.has_vs = h->has_vs.p; b.vs = h->vs.p; b.has_vg = h->has_vg.p; b.vg = h->vg.p;
   b.rotdir = h->rotdir.p; b.via_en = h->via_en.p;
-  b.status = h->status.p; b.optimized = h->optimized.p; b.iters = h->iters.p; b.trials = h->trials.p;
+  b.status = h->status.p; b.optimized = h->optimized.p; b.iters = h->iters.p; b.last_iters = h->last_iters.p; b.trials = h->trials.p;
   b.chi2 = h->chi2.p; b.cost = h->cost.p; b.lambda = h->lambda.p;
   b.assoc_cnt = h->assoc_cnt.p; b.assoc = h->assoc.p; b.assoc_cap = h->max_obst > 0 ? h->max_obst : 1;
   b.assoc_overflow = h->assoc_ovf.p; b.legacy_idx = h->legacy_idx.p;
@@ -733,7 +734,7 @@ int teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max
   A(h->o_pvx.alloc(max_obstacle_vertices)); A(h->o_pvy.alloc(max_obstacle_vertices));
   A(h->viax.alloc(max_via_points)); A(h->viay.alloc(max_via_points));
   A(h->n.alloc(max_tebs)); A(h->has_vs.alloc(max_tebs)); A(h->has_vg.alloc(max_tebs)); A(h->rotdir.alloc(max_tebs));
-  A(h->via_en.alloc(max_tebs)); A(h->status.alloc(max_tebs)); A(h->optimized.alloc(max_tebs)); A(h->iters.alloc(max_tebs)); A(h->trials.alloc(max_tebs));
+  A(h->via_en.alloc(max_tebs)); A(h->status.alloc(max_tebs)); A(h->optimized.alloc(max_tebs)); A(h->iters.alloc(max_tebs)); A(h->last_iters.alloc(max_tebs)); A(h->trials.alloc(max_tebs));
   A(h->assoc_cnt.alloc(BS)); A(h->assoc.alloc(BS * Mo)); A(h->assoc_ovf.alloc(max_tebs)); A(h->legacy_idx.alloc((size_t)max_tebs * Mo));
   A(h->via_pose.alloc((size_t)max_tebs * (max_via_points > 0 ? max_via_points : 1)));
   A(h->x.alloc(BS)); A(h->y.alloc(BS)); A(h->th.alloc(BS)); A(h->dt.alloc(BS));
@@ -762,6 +763,7 @@ int teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max
   if (ok && hipMemset(h->cost.p, 0, sizeof(double) * max_tebs) != hipSuccess) ok = false;
   if (ok && hipMemset(h->chi2.p, 0, sizeof(double) * max_tebs) != hipSuccess) ok = false;
   if (ok && hipMemset(h->iters.p, 0, sizeof(int) * max_tebs) != hipSuccess) ok = false;   // hasDiverged: "no statistics yet"
+  if (ok && hipMemset(h->last_iters.p, 0, sizeof(int) * max_tebs) != hipSuccess) ok = false;
   if (ok && hipMemset(h->status.p, 0, sizeof(int) * max_tebs) != hipSuccess) ok = false;
   if (ok && hipMemset(h->optimized.p, 0, sizeof(int) * max_tebs) != hipSuccess) ok = false;
   if (!ok) { teb_amd_destroy(h); return fail(TEB_AMD_ERR_HIP, "device allocation / kernel attribute setup failed"); }
@@ -774,7 +776,7 @@ void teb_amd_destroy(teb_amd_handle_t* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   DevBuf<int>* ib[] = {&h->o_type, &h->o_dyn, &h->o_voff, &h->o_static, &h->o_dynidx, &h->n, &h->has_vs, &h->has_vg, &h->rotdir,
-                       &h->via_en, &h->status, &h->optimized, &h->iters, &h->trials, &h->assoc_cnt, &h->assoc, &h->assoc_ovf, &h->via_pose, &h->legacy_idx,
+                       &h->via_en, &h->status, &h->optimized, &h->iters, &h->last_iters, &h->trials, &h->assoc_cnt, &h->assoc, &h->assoc_ovf, &h->via_pose, &h->legacy_idx,
                        &h->snap_n, &h->sel_idx, &h->err_flag, &h->hs_pex};
   for (auto* q : ib) q->free();
   DevBuf<double>* db[] = {&h->o_ax, &h->o_ay, &h->o_bx, &h->o_by, &h->o_rad, &h->o_vx, &h->o_vy, &h->o_cx, &h->o_cy, &h->o_brad, &h->o_pvx,
@@ -1085,6 +1087,7 @@ int teb_amd_optimize_batch(teb_amd_handle_t* h, int32_t inner, int32_t outer, in
 #ifdef TEB_PROFILE
   a.dbg_H = h->dbg_H.p;
 #endif
+  h->last_inner = inner;
   return launch(h, a);
 }
 
@@ -1286,7 +1289,7 @@ int teb_amd_broadcast_band(teb_amd_handle_t* h, teb_amd_comm_t* c, int32_t owner
   else if (c->rank == owner_rank && (local_index < 0 || local_index >= h->B)) { local = TEB_AMD_ERR_INVALID_ARG; why = "local_index out of range on the owner"; }
   (void)hipSetDevice(c->device);
   hipStream_t stream = h ? h->stream : nullptr;   // (a rank with a bad handle still takes part, on the null stream)
-  const size_t count = capacity >= 2 ? 1 + 4 * (size_t)capacity : 0;
+  const size_t count = capacity >= 2 ? 3 + 4 * (size_t)capacity : 0;   // n, four strips, the band's statistics
   if (local == TEB_AMD_OK && c->msg_cap < count) {
     if (c->msg) (void)hipFree(c->msg);
     c->msg = nullptr; c->msg_cap = 0;
@@ -1311,7 +1314,8 @@ int teb_amd_broadcast_band(teb_amd_handle_t* h, teb_amd_comm_t* c, int32_t owner
   // round 2: the strip itself
   if (c->rank == owner_rank)
     hipLaunchKernelGGL(pack_band_kernel, dim3((capacity + 255) / 256), dim3(256), 0, stream, h->n.p, h->x.p, h->y.p, h->th.p, h->dt.p,
-                       local_index, h->stride, capacity, c->msg);
+                       local_index, h->stride, capacity, c->msg, h->chi2.p, h->iters.p, h->last_iters.p, h->cfg.divergence_detection_enable != 0,
+                       h->last_inner);
   const bool packed = hipGetLastError() == hipSuccess;   // (a failed pack still enters the broadcast; what arrives is then rejected below)
   NCCLCHK(rccl().Broadcast(c->msg, c->msg, count, kRcclFloat64, owner_rank, c->comm, stream));
   std::vector<double> host(count);
@@ -1325,6 +1329,14 @@ int teb_amd_broadcast_band(teb_amd_handle_t* h, teb_amd_comm_t* c, int32_t owner
   std::memcpy(y, host.data() + 1 + capacity, capacity * sizeof(double));
   std::memcpy(theta, host.data() + 1 + 2 * (size_t)capacity, capacity * sizeof(double));
   std::memcpy(dt, host.data() + 1 + 3 * (size_t)capacity, capacity * sizeof(double));
+  c->band_stats_available = host[1 + 4 * (size_t)capacity] != 0.0;
+  c->band_stats_back_chi2 = host[2 + 4 * (size_t)capacity];
+  return TEB_AMD_OK;
+}
+
+int teb_amd_comm_last_band_statistics(const teb_amd_comm_t* c, int32_t* available, double* back_chi2) {
+  if (!c || !available || !back_chi2) return fail(TEB_AMD_ERR_INVALID_ARG, "teb_amd_comm_last_band_statistics: null argument");
+  *available = c->band_stats_available; *back_chi2 = c->band_stats_back_chi2;
   return TEB_AMD_OK;
 }
 
@@ -1547,18 +1559,51 @@ int teb_amd_get_full_trajectory(teb_amd_handle_t* h, int32_t b, double* out, int
   return TEB_AMD_OK;
 }
 
+// TebOptimalPlanner::hasDiverged (src/optimal_planner.cpp:1023-1039) reads optimizer_->batchStatistics().back().chi2. g2o sizes that
+// vector to the REQUESTED iteration count of the last optimize() call and fills one entry per executed iteration: when the LM loop of
+// that call terminated early the last entry is still zero-initialised and the planner does not report a divergence whatever chi2 was
+// reached. The kernel returns the number of iterations of the band's last optimize() call beside the chi2 after its last iteration.
+static bool diverged_rule(const teb_amd_config_t& c, int last_inner, int iters, int last_iters, double chi2) {
+  if (!c.divergence_detection_enable) return false;                          // :1026-1027
+  if (iters <= 0 || last_inner <= 0) return false;                           // no statistics yet, :1031-1033
+  const double back = last_iters == last_inner ? chi2 : 0.0;                 // .back() of a vector resized to `iterations`
+  return back > c.divergence_detection_max_chi_squared;                      // :1038
+}
+
 int teb_amd_has_diverged(teb_amd_handle_t* h, int32_t b, int32_t* diverged) {
   int rc = check_handle(h);
   if (rc) return rc;
   if (b < 0 || b >= h->B || !diverged) return fail(TEB_AMD_ERR_INVALID_ARG, "TEB index out of range");
   *diverged = 0;
-  if (!h->cfg.divergence_detection_enable) return TEB_AMD_OK;            // :1026-1027
-  double chi2 = 0; int iters = 0;
+  if (!h->cfg.divergence_detection_enable) return TEB_AMD_OK;
+  double chi2 = 0; int iters = 0, last = 0;
   HIPCHK(hipMemcpyAsync(&chi2, h->chi2.p + b, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(&iters, h->iters.p + b, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(&last, h->last_iters.p + b, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  if (iters <= 0) return TEB_AMD_OK;                                      // no statistics yet, :1031-1033
-  *diverged = chi2 > h->cfg.divergence_detection_max_chi_squared;
+  *diverged = diverged_rule(h->cfg, h->last_inner, iters, last, chi2);
+  return TEB_AMD_OK;
+}
+
+// What optimizer_->batchStatistics() of every resident band would hold after the last teb_amd_optimize_batch: available [count] =
+// the vector is not empty (statistics were switched on for that call, src/optimal_planner.cpp:331, and optimize() ran), back_chi2
+// [count] = .back().chi2 (zero when the band's last optimize() call stopped before its last requested iteration). A binding keeps
+// the pair per planner object and applies hasDiverged's rule to the configuration it holds at that time.
+int teb_amd_get_batch_statistics(teb_amd_handle_t* h, int32_t* available, double* back_chi2) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!available || !back_chi2) return fail(TEB_AMD_ERR_INVALID_ARG, "null argument");
+  const int B = h->B;
+  if (B <= 0) return TEB_AMD_OK;
+  std::vector<double> chi2(B); std::vector<int> iters(B), last(B);
+  HIPCHK(hipMemcpyAsync(chi2.data(), h->chi2.p, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(iters.data(), h->iters.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(last.data(), h->last_iters.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int b = 0; b < B; ++b) {
+    available[b] = h->cfg.divergence_detection_enable && iters[b] > 0 && h->last_inner > 0;
+    back_chi2[b] = (available[b] && last[b] == h->last_inner) ? chi2[b] : 0.0;
+  }
   return TEB_AMD_OK;
 }
 
@@ -2086,7 +2131,7 @@ int teb_amd_compact_bands(teb_amd_handle_t* h, const int32_t* keep, int32_t best
     bool ok = true;
     auto A = [&](hipError_t e) { if (e != hipSuccess) ok = false; };
     A(h->tmp_x.alloc(BS)); A(h->tmp_y.alloc(BS)); A(h->tmp_th.alloc(BS)); A(h->tmp_dt.alloc(BS)); A(h->tmp_n.alloc(h->max_tebs));
-    A(h->tmp_vs.alloc(3 * (size_t)h->max_tebs)); A(h->tmp_vg.alloc(3 * (size_t)h->max_tebs)); A(h->tmp_i.alloc(8 * (size_t)h->max_tebs));
+    A(h->tmp_vs.alloc(3 * (size_t)h->max_tebs)); A(h->tmp_vg.alloc(3 * (size_t)h->max_tebs)); A(h->tmp_i.alloc(9 * (size_t)h->max_tebs));
     A(h->tmp_chi2.alloc(h->max_tebs)); A(h->tmp_cost.alloc(h->max_tebs)); A(h->tmp_lambda.alloc(h->max_tebs));
     if (!h->cand_ready && ensure_candidate_buffers(h) != TEB_AMD_OK) ok = false;
     if (!ok) return fail(TEB_AMD_ERR_HIP, "compaction scratch allocation failed");
@@ -2108,7 +2153,7 @@ int teb_amd_compact_bands(teb_amd_handle_t* h, const int32_t* keep, int32_t best
     tmp.has_vs = h->tmp_i.p; tmp.has_vg = h->tmp_i.p + h->max_tebs; tmp.rotdir = h->tmp_i.p + 2 * (size_t)h->max_tebs;
     tmp.via_en = h->tmp_i.p + 3 * (size_t)h->max_tebs; tmp.status = h->tmp_i.p + 4 * (size_t)h->max_tebs;
     tmp.iters = h->tmp_i.p + 5 * (size_t)h->max_tebs; tmp.trials = h->tmp_i.p + 6 * (size_t)h->max_tebs;
-    tmp.optimized = h->tmp_i.p + 7 * (size_t)h->max_tebs;
+    tmp.optimized = h->tmp_i.p + 7 * (size_t)h->max_tebs; tmp.last_iters = h->tmp_i.p + 8 * (size_t)h->max_tebs;
     tmp.vs = h->tmp_vs.p; tmp.vg = h->tmp_vg.p; tmp.chi2 = h->tmp_chi2.p; tmp.cost = h->tmp_cost.p; tmp.lambda = h->tmp_lambda.p;
     std::vector<int> ident(K);
     for (int k = 0; k < K; ++k) ident[k] = k;
@@ -2298,7 +2343,7 @@ int teb_amd_debug_linearize(teb_amd_handle_t* h, int32_t b, double weight_multip
   bt.B = 1;
   bt.n += b; bt.x += so; bt.y += so; bt.th += so; bt.dt += so;
   bt.has_vs += b; bt.vs += 3 * b; bt.has_vg += b; bt.vg += 3 * b; bt.rotdir += b; bt.via_en += b;
-  bt.status += b; bt.iters += b; bt.trials += b; bt.chi2 += b; bt.cost += b; bt.lambda += b;
+  bt.status += b; bt.iters += b; bt.last_iters += b; bt.trials += b; bt.chi2 += b; bt.cost += b; bt.lambda += b;
   bt.assoc_cnt += so; bt.assoc += (size_t)b * bt.assoc_cap * h->stride; bt.assoc_overflow += b;
   bt.via_pose += (size_t)b * bt.via_cap; bt.Hbackup += (size_t)b * h->hmat_stride;
   // results of TEB b must not be clobbered by the debug run: save and restore them

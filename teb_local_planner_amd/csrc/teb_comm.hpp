@@ -78,11 +78,17 @@ __global__ void pack_record_kernel(const double* sel_cost, const int* sel_idx, i
     rec[1] = i >= 0 ? (double)(offset + i) : -1.0;
   }
 }
-// winner's strip -> one contiguous message [n | x | y | theta | dt], each strip `cap` doubles
+// winner's strip -> one contiguous message [n | x | y | theta | dt | statistics], each strip `cap` doubles; statistics = (available,
+// back_chi2) of teb_amd_get_batch_statistics: what hasDiverged reads travels with the band, so a mirror of the winner answers like its owner
 __global__ void pack_band_kernel(const int* n, const double* x, const double* y, const double* th, const double* dt, int b, int stride, int cap,
-                                 double* msg) {
+                                 double* msg, const double* chi2, const int* iters, const int* last_iters, int stats_on, int last_inner) {
   const int nb = n[b];
-  if (blockIdx.x == 0 && threadIdx.x == 0) msg[0] = (double)nb;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    msg[0] = (double)nb;
+    const bool avail = stats_on && iters[b] > 0 && last_inner > 0;
+    msg[1 + 4 * (size_t)cap] = avail ? 1.0 : 0.0;
+    msg[2 + 4 * (size_t)cap] = (avail && last_iters[b] == last_inner) ? chi2[b] : 0.0;
+  }
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x) {
     const bool in = i < nb && i < stride;
     const size_t o = (size_t)b * stride + i;
@@ -99,4 +105,6 @@ struct teb_amd_comm {
   double* all = nullptr;       // [2 * world]
   double* msg = nullptr;       // broadcast message, msg_cap doubles
   size_t msg_cap = 0;
+  int band_stats_available = 0;   // statistics that came with the last broadcast band (teb_amd_comm_last_band_statistics)
+  double band_stats_back_chi2 = 0;
 };

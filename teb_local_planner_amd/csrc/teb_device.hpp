@@ -249,6 +249,8 @@ struct BatchDev {
   int* status;
   int* optimized;   // TebOptimalPlanner::optimized_ (optimal_planner.h:691): an outer iteration of the last optimizeTEB call completed
   int* iters;
+  int* last_iters;  // LM iterations of the LAST optimize() call of the band: g2o sizes batchStatistics() to the requested count and fills one
+                    // entry per executed iteration, so .back() (src/optimal_planner.cpp:1036) holds a chi2 only when this equals `inner`
   int* trials;
   double* chi2;
   double* cost;

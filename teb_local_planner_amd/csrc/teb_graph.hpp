@@ -165,7 +165,7 @@ __global__ void move_bands_kernel(BatchDev src, BatchDev dst, const int* map, in
       const_cast<int*>(dst.has_vs)[d] = src.has_vs[s]; const_cast<int*>(dst.has_vg)[d] = src.has_vg[s];
       const_cast<int*>(dst.rotdir)[d] = src.rotdir[s]; const_cast<int*>(dst.via_en)[d] = src.via_en[s];
       for (int k = 0; k < 3; ++k) { const_cast<double*>(dst.vs)[3 * d + k] = src.vs[3 * s + k]; const_cast<double*>(dst.vg)[3 * d + k] = src.vg[3 * s + k]; }
-      dst.status[d] = src.status[s]; dst.iters[d] = src.iters[s]; dst.trials[d] = src.trials[s]; dst.optimized[d] = src.optimized[s];
+      dst.status[d] = src.status[s]; dst.iters[d] = src.iters[s]; dst.last_iters[d] = src.last_iters[s]; dst.trials[d] = src.trials[s]; dst.optimized[d] = src.optimized[s];
       dst.chi2[d] = src.chi2[s]; dst.cost[d] = src.cost[s]; dst.lambda[d] = src.lambda[s];
     }
   }

@@ -2606,7 +2606,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   if (n > plan.S || n > S || n < 0) {
     if (tid == 0) {
       bt.assoc_overflow[b] = 2;
-      bt.status[b] = TEB_AMD_TEB_FAILED; bt.iters[b] = 0; bt.trials[b] = 0;
+      bt.status[b] = TEB_AMD_TEB_FAILED; bt.iters[b] = 0; bt.last_iters[b] = 0; bt.trials[b] = 0;
       bt.chi2[b] = 0; bt.cost[b] = __longlong_as_double(0x7ff8000000000000LL); bt.lambda[b] = 0;
     }
     if (MCU && mm.H + mm.K > 0) mcu_exit(mm);   // the helpers of this band must not wait for a master that has left
@@ -2637,7 +2637,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   const double* mcu_items = mcu_on ? mc.items + (size_t)b * mc.item_cap * 4 * S : nullptr;
   double* Hbk = bt.Hbackup + (size_t)b * bt.hmat_stride;
 
-  int status = TEB_AMD_TEB_OK, iters = 0, trials = 0;
+  int status = TEB_AMD_TEB_OK, iters = 0, last_iters = 0, trials = 0;
   int optimized = c.optimization_activate ? 0 : bt.optimized[b];   // optimized_ = false (src/optimal_planner.cpp:189), after the early return
   double chi2_final = 0, lambda = 0, cost = __longlong_as_double(0x7ff8000000000000LL);
   double last_cats[4] = {0, 0, 0, 0};
@@ -2755,6 +2755,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     }
     double ni = 2;
     bool lm_ok = true;
+    last_iters = 0;   // SparseOptimizer::optimize clears the batch statistics
     for (int it = 0; it < args.inner && lm_ok; ++it) {
       double cats[4];
       PROF_START();
@@ -2920,6 +2921,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
         row[0] = currentChi; row[1] = lambda; row[2] = (double)qmax; row[3] = (double)n;
       }
       ++iters;
+      ++last_iters;
       chi2_final = currentChi;
       if (qmax == 10 || rho == 0 || !isfinite(lambda)) lm_ok = false;   // Terminate
       if (TEB_CFGI(DIVERGENCE_DETECTION)) {   // setComputeBatchStatistics -> computeActiveErrors after each solve
@@ -2975,7 +2977,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
     if (b == 0) { bt.clk[2] = clock64(); bt.clk[3] = wall_clock64(); }
     if (nonfinite) status = TEB_AMD_TEB_NONFINITE;
     bt.n[b] = n;
-    bt.status[b] = status; bt.iters[b] = iters; bt.trials[b] = trials; bt.optimized[b] = optimized;
+    bt.status[b] = status; bt.iters[b] = iters; bt.last_iters[b] = last_iters; bt.trials[b] = trials; bt.optimized[b] = optimized;
     bt.chi2[b] = chi2_final; bt.cost[b] = cost; bt.lambda[b] = lambda;
   }
 }

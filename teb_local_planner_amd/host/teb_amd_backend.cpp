@@ -225,6 +225,57 @@ bool TebOptimalPlannerAmd::optimizeTEB(int iterations_innerloop, int iterations_
                                   viapoint_cost_scale, alternative_time_cost) == 1;
 }
 
+// The sequence of TebOptimalPlanner::plan (src/optimal_planner.cpp:247-320) on the host band: a band that exists and whose goal moved by
+// less than force_reinit_new_goal_dist / _angular is warm-started (updateAndPruneTEB), anything else is (re)built by `init`; then the
+// start velocity, the goal-velocity flag and the optimisation - this class's, on the device.
+template <class Init>
+bool TebOptimalPlannerAmd::planOnBand(const PoseSE2& start, const PoseSE2& goal, Init init, const geometry_msgs::Twist* start_vel, bool free_goal_vel)
+{
+  ROS_ASSERT_MSG(initialized_, "Call initialize() first.");
+  bool keep = false;
+  if (teb_.isInit())
+  {
+    keep = teb_.sizePoses() > 0
+        && (goal.position() - teb_.BackPose().position()).norm() < cfg_->trajectory.force_reinit_new_goal_dist
+        && fabs(g2o::normalize_theta(goal.theta() - teb_.BackPose().theta())) < cfg_->trajectory.force_reinit_new_goal_angular;
+    if (keep) teb_.updateAndPruneTEB(start, goal, cfg_->trajectory.min_samples);
+    else teb_.clearTimedElasticBand();   // the goal jumped: start over
+  }
+  if (!keep) init();
+  if (start_vel) setVelocityStart(*start_vel);
+  if (free_goal_vel) setVelocityGoalFree();
+  else vel_goal_.first = true;           // the previously set goal velocity counts again (:274-275, :315-316)
+  return optimizeTEB(cfg_->optim.no_inner_iterations, cfg_->optim.no_outer_iterations);
+}
+
+bool TebOptimalPlannerAmd::plan(const std::vector<geometry_msgs::PoseStamped>& initial_plan, const geometry_msgs::Twist* start_vel, bool free_goal_vel)
+{
+  const PoseSE2 start(initial_plan.front().pose), goal(initial_plan.back().pose);
+  return planOnBand(start, goal, [&]() {
+    teb_.initTrajectoryToGoal(initial_plan, cfg_->robot.max_vel_x, cfg_->robot.max_vel_theta, cfg_->trajectory.global_plan_overwrite_orientation,
+                              cfg_->trajectory.min_samples, cfg_->trajectory.allow_init_with_backwards_motion); }, start_vel, free_goal_vel);
+}
+
+bool TebOptimalPlannerAmd::plan(const tf::Pose& start, const tf::Pose& goal, const geometry_msgs::Twist* start_vel, bool free_goal_vel)
+{
+  (void)free_goal_vel;   // the reference's overload forwards start_vel only (src/optimal_planner.cpp:283-288): the goal velocity stays fixed
+  return plan(PoseSE2(start), PoseSE2(goal), start_vel);
+}
+
+bool TebOptimalPlannerAmd::plan(const PoseSE2& start, const PoseSE2& goal, const geometry_msgs::Twist* start_vel, bool free_goal_vel)
+{
+  return planOnBand(start, goal, [&]() {   // no intermediate samples, dt = 1: autoResize inserts poses before the first optimisation
+    teb_.initTrajectoryToGoal(start, goal, 0, cfg_->robot.max_vel_x, cfg_->trajectory.min_samples, cfg_->trajectory.allow_init_with_backwards_motion); },
+    start_vel, free_goal_vel);
+}
+
+bool TebOptimalPlannerAmd::hasDiverged() const
+{
+  if (!cfg_->recovery.divergence_detection_enable) return false;                         // src/optimal_planner.cpp:1026-1027
+  if (!stats_available_) return false;                                                   // "no statistics yet", :1031-1033
+  return stats_back_chi2_ > cfg_->recovery.divergence_detection_max_chi_squared;         // :1036-1038
+}
+
 // ---- TebAmdBatch -------------------------------------------------------------------------------------------------
 
 TebAmdBatch::TebAmdBatch(const TebConfig& cfg, int max_tebs, int max_poses, int max_obstacles, int max_obstacle_vertices,
@@ -283,10 +334,12 @@ int TebAmdBatch::optimizeAllTEBs(const std::vector<TebOptimalPlannerAmd*>& tebs,
                                  bool alternative_time_cost)
 {
   const int B = (int)tebs.size(), S = max_poses_;
+  last_call_ok_ = h_ != NULL;
   if (!h_ || B == 0) return 0;
+  last_call_ok_ = false;   // until the results are back
   if (B > max_tebs_) { check(TEB_AMD_ERR_CAPACITY, "optimizeAllTEBs (more candidates than max_tebs)"); return 0; }
   TebOptimalPlannerAmd& first = *tebs.front();
-  if (first.cfg_->optim.optimization_activate == false) return 0;
+  if (first.cfg_->optim.optimization_activate == false) { last_call_ok_ = true; return 0; }
 
   // scene: TebConfig (dynamic_reconfigure may have changed it), obstacles, via-points
   teb_amd_config_t a;
@@ -339,7 +392,11 @@ int TebAmdBatch::optimizeAllTEBs(const std::vector<TebOptimalPlannerAmd*>& tebs,
   std::vector<double> chi2(B), cost(B), lambda(B);
   teb_amd_results_t res = { status.data(), iters.data(), trials.data(), chi2.data(), cost.data(), lambda.data() };
   if (!check(teb_amd_get_results(h_, &res), "teb_amd_get_results")) return 0;
+  std::vector<int32_t> stats(B);
+  std::vector<double> back_chi2(B);
+  if (!check(teb_amd_get_batch_statistics(h_, stats.data(), back_chi2.data()), "teb_amd_get_batch_statistics")) return 0;
   if (!check(teb_amd_download_tebs(h_, &batch), "teb_amd_download_tebs")) return 0;
+  last_call_ok_ = true;
 
   // write back: bands (autoResize may have changed the pose count), cost_, optimized_
   int ok = 0;
@@ -361,6 +418,7 @@ int TebAmdBatch::optimizeAllTEBs(const std::vector<TebOptimalPlannerAmd*>& tebs,
       t.setPoseVertexFixed(n[b] - 1, true);                     // goal pose is fixed
     }
     p.lm_iterations_ = iters[b]; p.lm_trials_ = trials[b];
+    if (iters[b] > 0) { p.stats_available_ = stats[b] != 0; p.stats_back_chi2_ = back_chi2[b]; }   // optimize() ran: it replaced the statistics
     if (compute_cost_afterwards && status[b] == TEB_AMD_TEB_OK) p.cost_ = cost[b];   // computeCurrentCost ran in the last outer iteration
     if (status[b] == TEB_AMD_TEB_OK) { p.optimized_ = true; ++ok; }
   }
@@ -619,13 +677,19 @@ int TebAmdBatch::selectBestTeb(int last_best, int initial_plan, double* best_cos
   return best;
 }
 
-int TebAmdBatch::selectBestTebDistributed(int last_best_global, int initial_plan_global, double* best_cost, int* owner_rank)
+int TebAmdBatch::selectBestTebDistributed(int last_best_global, int initial_plan_global, double* best_cost, int* owner_rank, bool* local_ok)
 {
   int32_t best = -1, owner = -1;
   double bc = 0;
-  if (!h_ || !comm_) { error_ = "selectBestTebDistributed: no communicator (setCommunicator)"; return -1; }
-  if (!check(teb_amd_select_best_distributed(h_, comm_, global_offset_, last_best_global, initial_plan_global, &best, &bc, &owner),
-             "teb_amd_select_best_distributed")) return -1;
+  if (local_ok) *local_ok = false;
+  if (!comm_) { error_ = "selectBestTebDistributed: no communicator (setCommunicator)"; return -1; }
+  // (a NULL handle still enters the exchange: the C call sends the unusable record for it)
+  const bool ok = check(teb_amd_select_best_distributed(h_, comm_, global_offset_, last_best_global, initial_plan_global, &best, &bc, &owner),
+                        "teb_amd_select_best_distributed");
+  // On a local error the C call has still been through the all-gather and reports the PEERS' choice: a caller that can follow them
+  // (local_ok given) gets it - it must enter broadcastBand with them -, any other caller gets -1 as before.
+  if (!ok && !local_ok) return -1;
+  if (local_ok) *local_ok = ok;
   if (best_cost) *best_cost = bc;
   if (owner_rank) *owner_rank = owner;
   return best;
@@ -642,6 +706,14 @@ int TebAmdBatch::selectBestTebDistributedAsFailedRank(int* owner_rank)
   (void)teb_amd_select_best_distributed(NULL, comm_, global_offset_, -1, -1, &best, &bc, &owner);   // returns this rank's error by design
   if (owner_rank) *owner_rank = owner;
   return best;
+}
+
+void TebAmdBatch::adoptBroadcastStatistics(TebOptimalPlannerAmd& mirror) const
+{
+  int32_t available = 0;
+  double back = 0;
+  if (comm_ && teb_amd_comm_last_band_statistics(comm_, &available, &back) == TEB_AMD_OK)
+  { mirror.stats_available_ = available != 0; mirror.stats_back_chi2_ = back; }
 }
 
 bool TebAmdBatch::broadcastBand(int owner_rank, int local_index, TimedElasticBand& teb)

@@ -48,8 +48,19 @@ class TebAmdBatch;
 void toAmdHcpParams(const TebConfig& cfg, teb_amd_hcp_params_t& p);
 
 /**
- * TebOptimalPlanner whose optimizeTEB() is executed by libteb_amd.so. Everything else (plan(), velocity extraction,
- * feasibility check, visualisation) is inherited unchanged; the g2o optimizer_ member is simply never used.
+ * TebOptimalPlanner whose optimisation is executed by libteb_amd.so, usable through the pointer the plugin holds (PlannerInterfacePtr
+ * planner_, src/teb_local_planner_ros.cpp:122). TebOptimalPlanner::optimizeTEB is NOT virtual (optimal_planner.h:231) and the three
+ * inherited plan() overloads call it (src/optimal_planner.cpp:279, 319): a subclass that only re-declared optimizeTEB would plan on
+ * the CPU with g2o whenever it is driven through the interface. So this class overrides every virtual that ends in the optimiser or
+ * reads its state:
+ *   plan() x 3      the reference's sequence (warm start / re-initialisation on the host TimedElasticBand, velocity flags), then
+ *                   THIS class's optimizeTEB
+ *   hasDiverged()   optimizer_->batchStatistics() is never filled here; the rule of src/optimal_planner.cpp:1023-1039 is applied to
+ *                   the statistics the launch returned (teb_amd_get_batch_statistics)
+ * Inherited unchanged: velocity extraction, isTrajectoryFeasible, visualisation, clearPlanner. computeCurrentCost(...) as a separate
+ * call still evaluates the reference's edge classes on the host (no LM iteration runs there); the cost of a plan comes back from the
+ * launch (compute_cost_afterwards). With host/patches/virtual_optimizeTEB.patch applied to the reference the plan() overrides become
+ * redundant, not wrong.
  */
 class TebOptimalPlannerAmd : public TebOptimalPlanner
 {
@@ -61,14 +72,26 @@ public:
   bool optimizeTEB(int iterations_innerloop, int iterations_outerloop, bool compute_cost_afterwards = false,
                    double obst_cost_scale = 1.0, double viapoint_cost_scale = 1.0, bool alternative_time_cost = false);
 
+  //! PlannerInterface::plan (planner_interface.h:99-125); same contracts as TebOptimalPlanner::plan (src/optimal_planner.cpp:247-320).
+  virtual bool plan(const std::vector<geometry_msgs::PoseStamped>& initial_plan, const geometry_msgs::Twist* start_vel = NULL, bool free_goal_vel = false);
+  virtual bool plan(const tf::Pose& start, const tf::Pose& goal, const geometry_msgs::Twist* start_vel = NULL, bool free_goal_vel = false);
+  virtual bool plan(const PoseSE2& start, const PoseSE2& goal, const geometry_msgs::Twist* start_vel = NULL, bool free_goal_vel = false);
+
+  //! PlannerInterface::hasDiverged (planner_interface.h:198) on the statistics of the last launch that optimised this band.
+  bool hasDiverged() const override;
+
   //! Statistics of the last run (not available from g2o in the reference): LM iterations / damped-solve trials.
   int lastLmIterations() const { return lm_iterations_; }
   int lastLmTrials() const { return lm_trials_; }
 
 private:
   friend class TebAmdBatch;
+  //! what both band-producing plan() overloads share: keep or rebuild the band, velocity flags, optimise
+  template <class Init> bool planOnBand(const PoseSE2& start, const PoseSE2& goal, Init init, const geometry_msgs::Twist* start_vel, bool free_goal_vel);
   boost::shared_ptr<TebAmdBatch> single_;   //!< lazily created batch of one
   int lm_iterations_ = 0, lm_trials_ = 0;
+  bool stats_available_ = false;            //!< optimizer_->batchStatistics() would not be empty
+  double stats_back_chi2_ = 0;              //!< its .back().chi2
 };
 typedef boost::shared_ptr<TebOptimalPlannerAmd> TebOptimalPlannerAmdPtr;
 
@@ -90,7 +113,8 @@ public:
    * Replaces the body of HomotopyClassPlanner::optimizeAllTEBs. All candidates share cfg / obstacles / via-points of
    * the first one (as in the reference, where they are constructed from the same pointers, homotopy_class_planner.cpp:434-449).
    * Cost parameters as passed by the reference: cfg.hcp.selection_obst_cost_scale, selection_viapoint_cost_scale,
-   * selection_alternative_time_cost. Returns the number of candidates whose optimizeTEB "returned true".
+   * selection_alternative_time_cost. Returns the number of candidates whose optimizeTEB "returned true"; lastCallOk() tells a
+   * library error (lastError()) from candidates that legitimately failed.
    */
   int optimizeAllTEBs(const std::vector<TebOptimalPlannerAmd*>& tebs, int iter_innerloop, int iter_outerloop,
                       bool compute_cost_afterwards, double obst_cost_scale, double viapoint_cost_scale,
@@ -114,11 +138,15 @@ public:
    * selectBestTeb over the candidates of ALL ranks (collective; one 16-byte record per rank through RCCL): indices are GLOBAL
    * (offset of the owning rank + local index, -1 = none). Returns the global index of the winner (-1: no rank holds a candidate), its
    * owner in *owner_rank. Same arithmetic as selectBestTeb: the rank that owns last_best / initial_plan applies the multipliers.
+   * A rank on which the call fails locally has still taken part in the exchange: the peers' choice is returned with *local_ok = false
+   * (without local_ok: -1), so that the caller can follow them into broadcastBand, a collective too.
    */
-  int selectBestTebDistributed(int last_best_global, int initial_plan_global, double* best_cost = NULL, int* owner_rank = NULL);
+  int selectBestTebDistributed(int last_best_global, int initial_plan_global, double* best_cost = NULL, int* owner_rank = NULL, bool* local_ok = NULL);
   int selectBestTebDistributedAsFailedRank(int* owner_rank = NULL);   // a rank whose tick failed still enters the collective (unusable record)
   /** The winner's band from its owner to every rank (collective): `teb` is rebuilt from it on every rank. */
   bool broadcastBand(int owner_rank, int local_index, TimedElasticBand& teb);
+  /** The winner's batch statistics came with its band: a mirror object answers hasDiverged() like the owner's planner. */
+  void adoptBroadcastStatistics(TebOptimalPlannerAmd& mirror) const;
 
   int maxTebs() const { return max_tebs_; }
   int maxPoses() const { return max_poses_; }
@@ -177,6 +205,7 @@ public:
                             double min_resolution_collision_check_angular, int look_ahead_idx, double feasibility_check_lookahead_distance);
 
   const std::string& lastError() const { return error_; }
+  bool lastCallOk() const { return last_call_ok_; }   //!< the last optimizeAllTEBs reached the device and read its results back
   float lastKernelMs() const;
 
 private:
@@ -188,6 +217,7 @@ private:
   int global_offset_ = 0;
   int max_tebs_, max_poses_, max_obstacles_ = 0, max_obstacle_vertices_ = 0, max_via_points_ = 0;
   std::string error_;
+  bool last_call_ok_ = true;
 };
 
 } // namespace teb_local_planner

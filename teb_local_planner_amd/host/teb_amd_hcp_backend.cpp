@@ -114,6 +114,13 @@ bool HomotopyClassPlannerAmd::plan(const PoseSE2& start, const PoseSE2& goal, co
     for (const TebOptimalPlannerAmdPtr& p : cand) raw.push_back(p.get());
     batch_->optimizeAllTEBs(raw, cfg_->optim.no_inner_iterations, cfg_->optim.no_outer_iterations, true, cfg_->hcp.selection_obst_cost_scale,
                             cfg_->hcp.selection_viapoint_cost_scale, cfg_->hcp.selection_alternative_time_cost);
+    // a library error (not: candidates whose optimisation legitimately returned false) leaves stale costs on the device: this rank
+    // must not offer them to the selection
+    if (!batch_->lastCallOk())
+    {
+      if (!batch_->sharded()) return false;
+      local_ok = false;
+    }
   }
   // ---- selectBestTeb (:564-667) over the candidates of every rank that shares the batch ----------------------------------------------------
   if (batch_->sharded())
@@ -124,9 +131,17 @@ bool HomotopyClassPlannerAmd::plan(const PoseSE2& start, const PoseSE2& goal, co
     if (best_owner_ == rank_ && best_teb_)
       for (std::size_t i = 0; i < tebs_.size(); ++i) if (tebs_[i] == best_teb_) last_global = off + (int)i;
     int owner = -1;
-    const int sel = local_ok ? batch_->selectBestTebDistributed(last_global, initial_global, NULL, &owner)
-                             : batch_->selectBestTebDistributedAsFailedRank(&owner);
+    int sel;
+    if (local_ok)
+    {   // a local failure INSIDE the exchange (after this rank's record went out) still yields the peers' choice: follow them
+      bool sel_ok = true;
+      sel = batch_->selectBestTebDistributed(last_global, initial_global, NULL, &owner, &sel_ok);
+      if (!sel_ok) local_ok = false;
+    }
+    else
+      sel = batch_->selectBestTebDistributedAsFailedRank(&owner);
     TebOptimalPlannerPtr previous = best_teb_;
+    // sel < 0 is the WORLD's verdict (no rank holds a candidate): every rank sees it and none enters the broadcast
     if (sel < 0) { best_teb_.reset(); best_global_ = -1; best_owner_ = -1; initial_plan_ = nullptr; return local_ok; }
     if (owner == rank_ && local_ok)
       best_teb_ = tebs_[sel - off];
@@ -138,6 +153,7 @@ bool HomotopyClassPlannerAmd::plan(const PoseSE2& start, const PoseSE2& goal, co
     // the winner's band on every rank (a collective: the owner takes part as well); non-owners mirror it
     TimedElasticBand scratch;
     if (!batch_->broadcastBand(owner, owner == rank_ ? sel - off : 0, owner == rank_ ? scratch : remote_best_->teb())) return false;
+    if (best_teb_ == remote_best_) batch_->adoptBroadcastStatistics(*remote_best_);   // hasDiverged() forwards to best_teb_ (:749-755)
     (void)previous;   // the switching_blocking_period rule needs one clock for all ranks: it stays with the caller in the sharded mode
     best_global_ = sel; best_owner_ = owner;
     initial_plan_ = nullptr;

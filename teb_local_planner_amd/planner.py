@@ -88,6 +88,7 @@ def lib():
         L.teb_amd_get_velocity_profile.argtypes = [vp, i32, _abi.p_f64, i32, _abi.p_i32]
         L.teb_amd_get_full_trajectory.argtypes = [vp, i32, _abi.p_f64, i32, _abi.p_i32]
         L.teb_amd_has_diverged.argtypes = [vp, i32, _abi.p_i32]
+        L.teb_amd_get_batch_statistics.argtypes = [vp, _abi.p_i32, _abi.p_f64]
         L.teb_amd_compute_h_signatures.argtypes = [vp, d, _abi.p_f64, _abi.p_i32]
         L.teb_amd_filter_equivalence_classes.argtypes = [vp, d, i32, i32, _abi.p_i32, _abi.p_i32, _abi.p_i32]
         L.teb_amd_explore_candidates.argtypes = [vp, C.POINTER(_abi.HcpParams), _abi.p_f64, _abi.p_f64, d, _abi.p_f64, i32, i32,
@@ -359,6 +360,15 @@ class TebBatchSolver:
         d = C.c_int32(0)
         _chk(lib().teb_amd_has_diverged(self._h, b, C.byref(d)), "teb_amd_has_diverged")
         return bool(d.value)
+
+    def batch_statistics(self):
+        """(available [B] bool, back_chi2 [B]): what optimizer_->batchStatistics() of every band would hold after the last optimize() -
+        not empty / .back().chi2 (zero when the band's last optimize() call stopped before its last requested iteration)."""
+        self._sync_count()
+        B = self.count
+        av = np.zeros(max(B, 1), np.int32); ch = np.zeros(max(B, 1))
+        _chk(lib().teb_amd_get_batch_statistics(self._h, _abi._ptr(av, C.c_int32), _abi._ptr(ch, C.c_double)), "teb_amd_get_batch_statistics")
+        return av[:B].astype(bool), ch[:B]
 
     # -- feasibility of the resident bands against a costmap grid (SURVEY 8f row f4, arithmetic part) -----------
     def set_costmap(self, cells, resolution, origin_x, origin_y):

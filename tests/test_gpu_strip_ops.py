@@ -184,14 +184,32 @@ def test_device_resident_tick_sequence(oracle):
 
 
 def test_has_diverged_follows_last_chi2():
+    """hasDiverged (src/optimal_planner.cpp:1023-1039) reads batchStatistics().back().chi2; g2o sizes that vector to the REQUESTED inner
+    iteration count, so the chi2 counts only when the band's last optimize() call ran all of its iterations (the iteration log tells)."""
     cfg, obst, via, batch = scenes.scene_small_mixed()
     cfg.recovery.divergence_detection_enable = True
     cfg.recovery.divergence_detection_max_chi_squared = 1e-6
     s = planner.make_solver(cfg, obst, via, batch)
     assert not s.has_diverged(0)                      # no statistics before the first optimisation
-    s.optimize(cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations, True)
+    assert not s.batch_statistics()[0].any()
+    s.set_iteration_log(True)
+    inner, outer = cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations
+    s.optimize(inner, outer, True)
     res = s.results()
-    assert all(s.has_diverged(b) == (res.chi2[b] > 1e-6) for b in range(batch.count)) and s.has_diverged(0)
+    avail, back = s.batch_statistics()
+    assert avail.all()
+    full_last_call = []
+    for b in range(batch.count):
+        # the log has one row per LM iteration over all outer iterations; the last call is complete iff the total is outer * inner or the
+        # shortfall happened in an earlier call - reconstruct from the lambda resets (lambda is re-initialised per optimize())
+        t = s.iteration_log(b)
+        assert len(t) == res.lm_iterations[b]
+        full_last_call.append(back[b] != 0.0)
+        assert back[b] in (0.0, res.chi2[b])
+        if len(t) == inner * outer:
+            assert back[b] == res.chi2[b]              # every call ran all of its iterations
+        assert s.has_diverged(b) == (back[b] > 1e-6)
+    assert any(full_last_call) and s.has_diverged(int(np.argmax(full_last_call)))
     cfg.recovery.divergence_detection_enable = False
     s.set_config(cfg)
     assert not s.has_diverged(0)

@@ -341,3 +341,185 @@ def test_drop_in_planner_class_on_random_scenes(seed):
         near_tie = len(c) > 1 and (c[1] - c[0]) <= 1e-3 * abs(c[0])
         if not near_tie and r2["best"] == r["best"]:
             assert a["best"] == r["best"], (t, a["best"], r["best"], r["costs"])
+
+
+# ---- the drop-in classes behind the pointer the plugin holds (PlannerInterfacePtr planner_, src/teb_local_planner_ros.cpp:120-125) --------
+def _plan_ticks(which, cfg, obst, starts, goals, start_vels=None, free_goal_vel=False, overload=0, plans=None, via=None, hcp=False,
+                stride=512, jacobian_mode=_abi.JACOBIAN_G2O_NUMERIC, retune_chi2=-1.0):
+    """oracle/ref_shim/backend_check_plan.cpp: n ticks of plan() + hasDiverged() + getVelocityCommand() on ONE planner object, every call
+    through a PlannerInterface pointer. which: 0 TebOptimalPlanner (reference), 1 TebOptimalPlannerAmd, 2 HomotopyClassPlanner, 3
+    HomotopyClassPlannerAmd."""
+    L = _lib()
+    c = cfg.to_c(); p = cfg.hcp_params()
+    st = _abi.f64(starts).reshape(-1, 3); gl = _abi.f64(goals).reshape(-1, 3)
+    T = len(st)
+    sv = None if start_vels is None else _abi.f64(start_vels).reshape(T, 3)
+    out = _abi.TebBatchHost(T, stride)
+    obs = out.c_struct()
+    ok = np.zeros(T, np.int32); div = np.zeros(T + 1, np.int32); g2o = np.zeros(T, np.int32); lm = np.zeros(T, np.int32); cmd = np.zeros((T, 4))
+    plans = plans or [None] * T
+    off = np.zeros(T + 1, np.int32)
+    for t in range(T):
+        off[t + 1] = off[t] + (0 if plans[t] is None else len(plans[t][0]))
+    cat = lambda k: _abi.f64(np.concatenate([np.asarray(pl[k], np.float64) for pl in plans if pl is not None] or [np.zeros(1)]))
+    px, py, pyaw = cat(0), cat(1), cat(2)
+    via = via or []
+    vx = _abi.f64([v[0] for v in via] or [0.0]); vy = _abi.f64([v[1] for v in via] or [0.0])
+    P = lambda a: C.cast(_abi._ptr(a, C.c_double), C.c_void_p) if a is not None else None
+    I = lambda a: C.cast(_abi._ptr(a, C.c_int32), C.c_void_p)
+    vp = lambda x: C.cast(C.pointer(x), C.c_void_p)
+    f = L.backend_check_plan_ticks
+    f.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_int] + \
+        [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 6 + [C.c_double]
+    rc = f(which, vp(c), vp(p) if hcp else None, vp(obst.freeze()), len(via), P(vx), P(vy), T, P(st), P(gl), P(sv), int(free_goal_vel),
+           int(overload), I(off), P(px), P(py), P(pyaw), int(jacobian_mode), vp(obs), I(ok), I(div), I(g2o), I(lm), P(cmd), float(retune_chi2))
+    assert rc == 0, rc
+    return dict(bands=[out.get_teb(t) for t in range(T)], ok=ok, diverged=div[:T], diverged_retuned=int(div[T]), g2o_iters=g2o, lm_iters=lm,
+                cmd=cmd)
+
+
+def _moving_starts(x0, y0, th0, n, step=0.15):
+    return [[x0 + step * k, y0 + 0.01 * k, th0] for k in range(n)]
+
+
+def _single_planner_scene(name):
+    """(cfg, obst, start, goal, plan) of BASELINE C1 (test_optim_node: 3 obstacles, 8 m) and C2 (single TEB, 200 poses, 100 obstacles)."""
+    from teb_local_planner_amd import scenes
+    cfg, obst, via, batch = scenes.scene_c1() if name == "c1" else scenes.scene_c2(stride=512)
+    x, y, th, _ = batch.get_teb(0)
+    return cfg, obst, [x[0], y[0], th[0]], [x[-1], y[-1], th[-1]], (x, y, th)
+
+
+def _compare_ticks(ref, amd, tol, cmd_tol):
+    worst = 0.0
+    for t, (u, v) in enumerate(zip(amd["bands"], ref["bands"])):
+        assert len(u[0]) == len(v[0]), (t, len(u[0]), len(v[0]))
+        d = max(np.abs(a - b).max(initial=0) for a, b in zip(u, v))
+        worst = max(worst, d)
+        assert d <= tol, (t, d, tol)
+    np.testing.assert_array_equal(amd["ok"], ref["ok"])
+    np.testing.assert_array_equal(amd["cmd"][:, 0], ref["cmd"][:, 0])
+    assert np.abs(amd["cmd"][:, 1:] - ref["cmd"][:, 1:]).max() <= cmd_tol
+    return worst
+
+
+@pytest.mark.parametrize("overload", [0, 1, 2])
+@pytest.mark.parametrize("scene", ["c1", "c2"])
+def test_single_planner_behind_the_interface_pointer_plans_on_the_device(scene, overload):
+    """VERDICT r04 item 1. PlannerInterfacePtr p(new TebOptimalPlannerAmd(..)); p->plan(..) for five ticks (cold start, then warm starts
+    from a moving robot pose) in each of the three overloads of planner_interface.h:99-125, against the reference's TebOptimalPlanner
+    driven the same way. TebOptimalPlanner::optimizeTEB is not virtual: the override of plan() is what keeps the drop-in off g2o - the
+    shim's SparseOptimizer counts the LM iterations this thread ran (zero for the drop-in, > 0 for the reference), lastLmIterations() says
+    the device ran them. Bands, plan()'s return value and the inherited getVelocityCommand agree with the reference planner every tick."""
+    cfg, obst, start, goal, path = _single_planner_scene(scene)
+    T = 5
+    starts = _moving_starts(*start, T); goals = [goal] * T
+    vels = [[0.0, 0, 0], [0.2, 0, 0.0], [0.3, 0, 0.02], [0.35, 0, 0.02], [0.4, 0, 0.0]]
+    plans = None
+    if overload == 2:      # the global plan re-anchored at the robot pose, as the ROS adapter hands it over
+        x, y, th = path
+        step = max(1, len(x) // 40)
+        plans = []
+        for k in range(T):
+            xs = x[::step].copy(); ys = y[::step].copy(); ys_th = th[::step].copy()
+            xs[0], ys[0], ys_th[0] = starts[k]
+            xs[-1], ys[-1], ys_th[-1] = goal
+            plans.append((xs, ys, ys_th))
+    kw = dict(start_vels=vels, overload=overload, plans=plans)
+    ref = _plan_ticks(0, cfg, obst, starts, goals, **kw)
+    amd = _plan_ticks(1, cfg, obst, starts, goals, **kw)
+    assert (ref["g2o_iters"] > 0).all() and (ref["lm_iters"] == -1).all()
+    assert (amd["g2o_iters"] == 0).all(), amd["g2o_iters"]            # not one LM iteration on the CPU
+    assert (amd["lm_iters"] > 0).all(), amd["lm_iters"]               # .. they ran on the device
+    assert amd["ok"].all()
+    worst = _compare_ticks(ref, amd, tol=2e-5, cmd_tol=1e-5)
+    print("plan() through PlannerInterface*, %s overload %d: worst state distance to the reference planner over %d ticks %.2e" % (scene, overload, T, worst))
+
+
+def test_single_planner_free_goal_velocity_and_goal_jump():
+    """free_goal_vel reaches the band (not through the tf::Pose overload: the reference drops the flag there, src/optimal_planner.cpp:283-288,
+    and so does the drop-in), and a goal that jumps beyond force_reinit_new_goal_dist re-initialises the band on both sides."""
+    cfg, obst, start, goal, _ = _single_planner_scene("c1")
+    starts = _moving_starts(*start, 4)
+    goals = [goal, goal, [goal[0] - 0.5, goal[1] + 2.5, 0.6], [goal[0] - 0.5, goal[1] + 2.5, 0.6]]
+    for overload in (0, 1):
+        ref = _plan_ticks(0, cfg, obst, starts, goals, start_vels=[[0.1, 0, 0]] * 4, free_goal_vel=True, overload=overload)
+        amd = _plan_ticks(1, cfg, obst, starts, goals, start_vels=[[0.1, 0, 0]] * 4, free_goal_vel=True, overload=overload)
+        assert (amd["g2o_iters"] == 0).all() and (amd["lm_iters"] > 0).all()
+        _compare_ticks(ref, amd, tol=2e-5, cmd_tol=1e-5)
+    fixed = _plan_ticks(1, cfg, obst, starts[:1], goals[:1], start_vels=[[0.1, 0, 0]], free_goal_vel=False, overload=0)
+    free = _plan_ticks(1, cfg, obst, starts[:1], goals[:1], start_vels=[[0.1, 0, 0]], free_goal_vel=True, overload=0)
+    dropped = _plan_ticks(1, cfg, obst, starts[:1], goals[:1], start_vels=[[0.1, 0, 0]], free_goal_vel=True, overload=1)
+    assert np.abs(free["bands"][0][3][-3:] - fixed["bands"][0][3][-3:]).max() > 1e-6       # the flag changes the end of the band
+    for a, b in zip(dropped["bands"][0], fixed["bands"][0]):
+        np.testing.assert_array_equal(a, b)                                                 # .. and is dropped by the tf::Pose overload
+
+
+@pytest.mark.parametrize("which_pair", [(0, 1), (2, 3)])
+def test_has_diverged_through_the_interface_pointer(which_pair):
+    """VERDICT r04 item 2. divergence_detection_enable with a threshold every optimisation exceeds: planner_->hasDiverged()
+    (src/teb_local_planner_ros.cpp:374) of the drop-in classes answers like the reference's planners tick by tick - from the statistics the
+    launch returned, not from the g2o object that never ran - incl. g2o's habit of sizing batchStatistics() to the requested iteration
+    count (a band whose last optimize() stopped early reads chi2 = 0 and is "not diverged"); the rule reads the LIVE configuration: raising
+    the threshold afterwards clears the flag on both sides. Same through HomotopyClassPlanner, whose hasDiverged forwards to best_teb_."""
+    hcp = which_pair[0] == 2
+    if hcp:
+        case = RG.hcp_tick_cases()["keypoint_2d_4_ticks"]
+        cfg, obst, starts, goals, vels = case["cfg"], case["obst"], case["starts"], case["goals"], case["start_vels"]
+    else:
+        cfg, obst, start, goal, _ = _single_planner_scene("c1")
+        starts = _moving_starts(*start, 4); goals = [goal] * 4; vels = [[0.0, 0, 0], [0.2, 0, 0], [0.3, 0, 0], [0.3, 0, 0]]
+    cfg.recovery.divergence_detection_enable = True
+    seen = set()
+    # (the reference's field is an int, teb_config.h:228: thresholds are whole numbers in its range)
+    for thr in (0, 5, 1000000):
+        cfg.recovery.divergence_detection_max_chi_squared = thr
+        kw = dict(start_vels=vels, hcp=hcp, retune_chi2=2.0e9 if thr < 1000000 else 0.0)
+        ref = _plan_ticks(which_pair[0], cfg, obst, starts, goals, **kw)
+        amd = _plan_ticks(which_pair[1], cfg, obst, starts, goals, **kw)
+        assert (amd["g2o_iters"] == 0).all() and (ref["g2o_iters"] > 0).all()
+        np.testing.assert_array_equal(amd["diverged"], ref["diverged"])
+        assert amd["diverged_retuned"] == ref["diverged_retuned"]
+        seen.update(int(d) for d in ref["diverged"]); seen.add(10 + ref["diverged_retuned"])
+        if thr == 1000000:
+            assert not ref["diverged"].any()
+    assert seen >= {0, 1, 10, 11}, seen      # both answers occurred, before and after the threshold moved
+    cfg.recovery.divergence_detection_enable = False
+    cfg.recovery.divergence_detection_max_chi_squared = 0
+    off = _plan_ticks(which_pair[1], cfg, obst, starts, goals, start_vels=vels, hcp=hcp)
+    assert not off["diverged"].any()
+
+
+def test_has_diverged_after_an_optimisation_that_stopped_early():
+    """g2o sizes batchStatistics() to the REQUESTED iteration count and fills one entry per executed iteration: when the LM loop of the last
+    optimize() call terminates early, .back().chi2 is still 0 and TebOptimalPlanner::hasDiverged (src/optimal_planner.cpp:1029-1038) says
+    "no" whatever chi2 was reached - with 40 inner iterations on an obstacle-free 1 m band LM stops after 20 - 30. The drop-in answers the
+    same (the kernel reports the iteration count of the band's last optimize() call); with the default 5 iterations both say "yes"."""
+    from teb_local_planner_amd.config import TebConfig
+    obst = _abi.ObstacleTable()
+    starts = [[0.02 * k, 0, 0] for k in range(4)]; goals = [[1.0, 0, 0]] * 4; vels = [[0.4, 0, 0]] * 4
+    for inner, outer, expect in ((40, 1, 0), (5, 4, 1)):
+        cfg = TebConfig()
+        cfg.recovery.divergence_detection_enable = True
+        cfg.recovery.divergence_detection_max_chi_squared = 0
+        cfg.optim.no_inner_iterations = inner; cfg.optim.no_outer_iterations = outer
+        ref = _plan_ticks(0, cfg, obst, starts, goals, start_vels=vels)
+        amd = _plan_ticks(1, cfg, obst, starts, goals, start_vels=vels)
+        assert (amd["g2o_iters"] == 0).all()
+        if not expect:
+            assert (ref["g2o_iters"] < inner * outer).all() and (amd["lm_iters"] < inner * outer).all()    # both stopped early
+        assert (ref["diverged"] == expect).all(), ref["diverged"]
+        np.testing.assert_array_equal(amd["diverged"], ref["diverged"])
+
+
+@pytest.mark.parametrize("name", sorted(RG.hcp_tick_cases()))
+def test_homotopy_planner_behind_the_interface_pointer(name):
+    """HomotopyClassPlannerAmd held as PlannerInterfacePtr: plan(), hasDiverged(), getVelocityCommand() through the base class; no LM
+    iteration on the CPU, the best band follows the reference planner's."""
+    case = RG.hcp_tick_cases()[name]
+    kw = dict(start_vels=case.get("start_vels"), plans=case.get("plans"), via=case.get("via"), hcp=True, overload=2 if case.get("plans") else 0,
+              jacobian_mode=_abi.JACOBIAN_ANALYTIC)
+    ref = _plan_ticks(2, case["cfg"], case["obst"], case["starts"], case["goals"], **kw)
+    amd = _plan_ticks(3, case["cfg"], case["obst"], case["starts"], case["goals"], **kw)
+    assert (amd["g2o_iters"] == 0).all() and (amd["lm_iters"] > 0).all() and (ref["g2o_iters"] > 0).all()
+    _compare_ticks(ref, amd, tol=2e-5, cmd_tol=1e-5)
