@@ -900,6 +900,173 @@ struct Ldl8 {   // in-place LDL^T of one 8x8 SPD block: a[r(r+1)/2 + c] holds l_
   }
 };
 
+// ---- operands by lane broadcast (the 16-lane rounds of the cyclic reduction below) ------------------------------------------------------
+// gfx90a+ takes a DPP source on the 64-bit VALU only with row_newbcast:n - lane n of every 16-lane row feeds all lanes of the row - and
+// v_fmac_f64 / v_mov_b64 have the encoding. An elimination served by one such row keeps L_i, U_i, the rows of D_i and the factor
+// DISTRIBUTED over the registers of its lanes and reads every operand of a neighbour straight out of that lane's register: no LDS
+// access between the loads of a round (24 doubles per lane) and its stores, where the 8-lane rounds streamed 196 doubles per lane through
+// the LDS pipe the four waves share (round 4: the rounds were bound by exactly that).
+// The compiler does not know these statements read another lane's register: the DPP hazard (2 wait states between the VALU write of a
+// VGPR and its read through DPP) is covered by the s_nop at the head of every statement - whatever copy or reload the register allocator
+// places in front of it has retired by then.
+template <int I> struct IC { static constexpr int value = I; constexpr operator int() const { return I; } };
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(IC<I>{}); static_for<I + 1, N>(f); }
+}
+template <int I, int N, class F> __device__ __forceinline__ void static_for_down(F&& f) {   // I, I - 1, .., N
+  if constexpr (I >= N) { f(IC<I>{}); static_for_down<I - 1, N>(f); }
+}
+template <int T> __device__ __forceinline__ double bcast16(double x) {   // x of lane T of this lane's row
+  double r;
+  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(T));
+  return r;
+}
+// The statements below are whole passes - a pivot's update, the forward / backward substitution, two columns of the Schur products - so
+// that ONE s_nop covers each (a wait state is an issue slot: s_nop 1 costs 8 cycles, measured 12.8 against 5.1 cycles per dependent
+// v_fmac_f64_dpp, tools/micro/dpp_rate_bench.hip; one in front of every instruction was a fifth of a round). Inside a statement no DPP
+// source is written: accumulators and right-hand sides are ordinary operands, which the hardware interlocks.
+#define TEB_BC(t) " row_newbcast:" #t " row_mask:0xf bank_mask:0xf\n\t"
+#define TEB_F1(t, a, x, y) "v_fmac_f64_dpp %" #a ", %" #x ", %" #y TEB_BC(t)            /* a += x(lane t) * y */
+#define TEB_FN1(t, a, x, y) "v_fmac_f64_dpp %" #a ", -%" #x ", %" #y TEB_BC(t)          /* a -= x(lane t) * y */
+#define TEB_F2(t, a, b, x, ya, yb) TEB_FN1(t, a, x, ya) TEB_FN1(t, b, x, yb)              /* two right-hand sides, one operand */
+// operands: %0 .. %7 = Y[0 .. 7], %8 .. %15 = wf[0 .. 7] (in / out), %16 .. %22 = v[0 .. 6] (the factor: l_km in lane k's v[m])
+#define TEB_CR16_FORWARD /* Y[k] -= l_km Y[m], m < k: l_km from lane k */ \
+  TEB_F2(1, 1, 9, 16, 0, 8) TEB_F2(2, 2, 10, 16, 0, 8) TEB_F2(2, 2, 10, 17, 1, 9) \
+  TEB_F2(3, 3, 11, 16, 0, 8) TEB_F2(3, 3, 11, 17, 1, 9) TEB_F2(3, 3, 11, 18, 2, 10) \
+  TEB_F2(4, 4, 12, 16, 0, 8) TEB_F2(4, 4, 12, 17, 1, 9) TEB_F2(4, 4, 12, 18, 2, 10) \
+  TEB_F2(4, 4, 12, 19, 3, 11) TEB_F2(5, 5, 13, 16, 0, 8) TEB_F2(5, 5, 13, 17, 1, 9) \
+  TEB_F2(5, 5, 13, 18, 2, 10) TEB_F2(5, 5, 13, 19, 3, 11) TEB_F2(5, 5, 13, 20, 4, 12) \
+  TEB_F2(6, 6, 14, 16, 0, 8) TEB_F2(6, 6, 14, 17, 1, 9) TEB_F2(6, 6, 14, 18, 2, 10) \
+  TEB_F2(6, 6, 14, 19, 3, 11) TEB_F2(6, 6, 14, 20, 4, 12) TEB_F2(6, 6, 14, 21, 5, 13) \
+  TEB_F2(7, 7, 15, 16, 0, 8) TEB_F2(7, 7, 15, 17, 1, 9) TEB_F2(7, 7, 15, 18, 2, 10) \
+  TEB_F2(7, 7, 15, 19, 3, 11) TEB_F2(7, 7, 15, 20, 4, 12) TEB_F2(7, 7, 15, 21, 5, 13) \
+  TEB_F2(7, 7, 15, 22, 6, 14)
+#define TEB_CR16_BACKWARD /* Y[k] -= l_mk Y[m], m > k: l_mk from lane m */ \
+  TEB_F2(7, 6, 14, 22, 7, 15) TEB_F2(6, 5, 13, 21, 6, 14) TEB_F2(7, 5, 13, 21, 7, 15) \
+  TEB_F2(5, 4, 12, 20, 5, 13) TEB_F2(6, 4, 12, 20, 6, 14) TEB_F2(7, 4, 12, 20, 7, 15) \
+  TEB_F2(4, 3, 11, 19, 4, 12) TEB_F2(5, 3, 11, 19, 5, 13) TEB_F2(6, 3, 11, 19, 6, 14) \
+  TEB_F2(7, 3, 11, 19, 7, 15) TEB_F2(3, 2, 10, 18, 3, 11) TEB_F2(4, 2, 10, 18, 4, 12) \
+  TEB_F2(5, 2, 10, 18, 5, 13) TEB_F2(6, 2, 10, 18, 6, 14) TEB_F2(7, 2, 10, 18, 7, 15) \
+  TEB_F2(2, 1, 9, 17, 2, 10) TEB_F2(3, 1, 9, 17, 3, 11) TEB_F2(4, 1, 9, 17, 4, 12) \
+  TEB_F2(5, 1, 9, 17, 5, 13) TEB_F2(6, 1, 9, 17, 6, 14) TEB_F2(7, 1, 9, 17, 7, 15) \
+  TEB_F2(1, 0, 8, 16, 1, 9) TEB_F2(2, 0, 8, 16, 2, 10) TEB_F2(3, 0, 8, 16, 3, 11) \
+  TEB_F2(4, 0, 8, 16, 4, 12) TEB_F2(5, 0, 8, 16, 5, 13) TEB_F2(6, 0, 8, 16, 6, 14) \
+  TEB_F2(7, 0, 8, 16, 7, 15)
+// operands: %0 .. %15 = acc[0 .. 15], then (X[k], Y[k]) of two columns k: acc[t] += X[k](lane t) * Y[k]
+#define TEB_CR16_SCHUR2 \
+  TEB_F1(0, 0, 16, 17) TEB_F1(1, 1, 16, 17) TEB_F1(2, 2, 16, 17) TEB_F1(3, 3, 16, 17) \
+  TEB_F1(4, 4, 16, 17) TEB_F1(5, 5, 16, 17) TEB_F1(6, 6, 16, 17) TEB_F1(7, 7, 16, 17) \
+  TEB_F1(8, 8, 16, 17) TEB_F1(9, 9, 16, 17) TEB_F1(10, 10, 16, 17) TEB_F1(11, 11, 16, 17) \
+  TEB_F1(12, 12, 16, 17) TEB_F1(13, 13, 16, 17) TEB_F1(14, 14, 16, 17) TEB_F1(15, 15, 16, 17) \
+  TEB_F1(0, 0, 18, 19) TEB_F1(1, 1, 18, 19) TEB_F1(2, 2, 18, 19) TEB_F1(3, 3, 18, 19) \
+  TEB_F1(4, 4, 18, 19) TEB_F1(5, 5, 18, 19) TEB_F1(6, 6, 18, 19) TEB_F1(7, 7, 18, 19) \
+  TEB_F1(8, 8, 18, 19) TEB_F1(9, 9, 18, 19) TEB_F1(10, 10, 18, 19) TEB_F1(11, 11, 18, 19) \
+  TEB_F1(12, 12, 18, 19) TEB_F1(13, 13, 18, 19) TEB_F1(14, 14, 18, 19) TEB_F1(15, 15, 18, 19)
+template <int K> __device__ __forceinline__ void cr16_pivot_update(double (&v)[8], double lk);   // v[m] -= a_mk(lane m) * l_jk, m = K + 1 .. 7
+template <> __device__ __forceinline__ void cr16_pivot_update<0>(double (&v)[8], double lk) {
+  asm("s_nop 1\n\t"
+  TEB_FN1(1, 0, 7, 8) TEB_FN1(2, 1, 7, 8) TEB_FN1(3, 2, 7, 8) TEB_FN1(4, 3, 7, 8)
+  TEB_FN1(5, 4, 7, 8) TEB_FN1(6, 5, 7, 8) TEB_FN1(7, 6, 7, 8)
+      : "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : "v"(v[0]), "v"(lk));
+}
+template <> __device__ __forceinline__ void cr16_pivot_update<1>(double (&v)[8], double lk) {
+  asm("s_nop 1\n\t"
+  TEB_FN1(2, 0, 6, 7) TEB_FN1(3, 1, 6, 7) TEB_FN1(4, 2, 6, 7) TEB_FN1(5, 3, 6, 7)
+  TEB_FN1(6, 4, 6, 7) TEB_FN1(7, 5, 6, 7)
+      : "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : "v"(v[1]), "v"(lk));
+}
+template <> __device__ __forceinline__ void cr16_pivot_update<2>(double (&v)[8], double lk) {
+  asm("s_nop 1\n\t"
+  TEB_FN1(3, 0, 5, 6) TEB_FN1(4, 1, 5, 6) TEB_FN1(5, 2, 5, 6) TEB_FN1(6, 3, 5, 6)
+  TEB_FN1(7, 4, 5, 6)
+      : "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : "v"(v[2]), "v"(lk));
+}
+template <> __device__ __forceinline__ void cr16_pivot_update<3>(double (&v)[8], double lk) {
+  asm("s_nop 1\n\t"
+  TEB_FN1(4, 0, 4, 5) TEB_FN1(5, 1, 4, 5) TEB_FN1(6, 2, 4, 5) TEB_FN1(7, 3, 4, 5)
+      : "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : "v"(v[3]), "v"(lk));
+}
+template <> __device__ __forceinline__ void cr16_pivot_update<4>(double (&v)[8], double lk) {
+  asm("s_nop 1\n\t"
+  TEB_FN1(5, 0, 3, 4) TEB_FN1(6, 1, 3, 4) TEB_FN1(7, 2, 3, 4)
+      : "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : "v"(v[4]), "v"(lk));
+}
+template <> __device__ __forceinline__ void cr16_pivot_update<5>(double (&v)[8], double lk) {
+  asm("s_nop 1\n\t"
+  TEB_FN1(6, 0, 2, 3) TEB_FN1(7, 1, 2, 3)
+      : "+v"(v[6]), "+v"(v[7]) : "v"(v[5]), "v"(lk));
+}
+template <> __device__ __forceinline__ void cr16_pivot_update<6>(double (&v)[8], double lk) {
+  asm("s_nop 1\n\t"
+  TEB_FN1(7, 0, 1, 2)
+      : "+v"(v[7]) : "v"(v[6]), "v"(lk));
+}
+
+
+// One elimination in the registers of a 16-lane row. Lane (q, c), q = lane bit 3, c = lane & 7, holds
+//     v[m]   row c of D_i (its lower part, m <= c, is what counts; lanes q = 1 carry a copy nobody reads)
+//     X[k]   q = 0: column c of L_i          q = 1: column c of U_i = row c of L_{i+s}
+//     wf[k]  f_i (every lane)
+// and leaves  Y = P_i X (column c of W_L / of W_U), wf = P_i f_i, acc / sx = its share of the Schur products:
+//     q = 0:  acc[t] = (L_i^T W_L)[t][c]   acc[8 + t] = (U_i^T W_L)[t][c]   sx = (L_i^T P_i f_i)[c]
+//     q = 1:  acc[t] = (L_i^T W_U)[t][c]   acc[8 + t] = (U_i^T W_U)[t][c]   sx = (U_i^T P_i f_i)[c]
+// (acc[0 .. 8) of the lanes q = 1 is the transpose of U_i^T W_L, rounded differently; not used.) Everything is stored by COLUMN c: the 8
+// lanes of a half row then touch 64 contiguous bytes per access, which the LDS serves without a bank conflict - a 64-byte row per lane in
+// 16-byte accesses (lanes 64 bytes apart: 4-way conflicts in every ds_write_b128) measured 10 % slower per round.
+// LDL^T by rows: at pivot k lane j > k scales its l_jk = a_jk / d_k and updates a_jm -= l_jk a_mk, m = k + 1 .. j, with a_mk read from
+// lane m; the triangular solves read l_km from lane k / l_mk from lane m. Operation by operation this is Ldl8::factor / solve3 and the
+// 8-lane round's products (same operands, same order of every sum; checked in IEEE arithmetic on the host) - the compiler's choice of
+// which multiply of `u * d - l * w` it fuses into the subtraction is the one thing a hand-written pass does not inherit: results agree
+// with the 8-lane rounds to the last bit or two (tools/micro/cr_round_bench.hip), not bit for bit.
+#ifndef TEB_CR16_STAMP
+#define TEB_CR16_STAMP(k)   // (tools/micro/cr_round_bench.hip: cycle stamps between the passes)
+#endif
+__device__ __forceinline__ bool cr16_eliminate(double (&v)[8], const double (&X)[8], double (&Y)[8], double (&wf)[8], double (&acc)[16], double& sx) {
+  TEB_SOLVER_FMA
+  int ok = 1;
+  TEB_CR16_STAMP(0)
+  double inv[8];
+  static_for<0, 8>([&](auto K) {
+    constexpr int k = decltype(K)::value;
+    const double dk = bcast16<k>(v[k]);
+    ok &= (dk > 0);
+    inv[k] = fast_rcp(dk);
+    if constexpr (k < 7) {
+      const double lk = v[k] * inv[k];
+      cr16_pivot_update<k>(v, lk);   // (lanes j < m: their upper part, never read)
+      v[k] = lk;                     // after all its uses as the unscaled a_jk
+    }
+  });
+  TEB_CR16_STAMP(1)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) Y[k] = X[k];
+#define TEB_CR16_RHS "+v"(Y[0]), "+v"(Y[1]), "+v"(Y[2]), "+v"(Y[3]), "+v"(Y[4]), "+v"(Y[5]), "+v"(Y[6]), "+v"(Y[7]), \
+                     "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(wf[4]), "+v"(wf[5]), "+v"(wf[6]), "+v"(wf[7])
+#define TEB_CR16_FACTOR "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6])
+  asm("s_nop 1\n\t" TEB_CR16_FORWARD : TEB_CR16_RHS : TEB_CR16_FACTOR);
+  TEB_CR16_STAMP(2)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { Y[k] *= inv[k]; wf[k] *= inv[k]; }
+  asm("s_nop 1\n\t" TEB_CR16_BACKWARD : TEB_CR16_RHS : TEB_CR16_FACTOR);
+#undef TEB_CR16_RHS
+#undef TEB_CR16_FACTOR
+  TEB_CR16_STAMP(3)
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc[t] = 0;
+  sx = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) {
+    asm("s_nop 1\n\t" TEB_CR16_SCHUR2
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]),
+          "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15])
+        : "v"(X[k]), "v"(Y[k]), "v"(X[k + 1]), "v"(Y[k + 1]));
+    sx += X[k] * wf[k];
+    sx += X[k + 1] * wf[k + 1];
+  }
+  TEB_CR16_STAMP(4)
+  return ok != 0;
+}
+
 #ifdef TEB_PROFILE
 __device__ long long g_cr_prof[8];
 __device__ long long g_crw_prof[32];   // per group width (8, 16, 32, 64 lanes): 6 sections of a round + the number of rounds
@@ -1018,22 +1185,104 @@ __device__ __forceinline__ bool cr_forward_round(double* __restrict__ D, double*
   CRR(5);
   return ok;
 }
+// One round of a level with 16 lanes per elimination (cr16_eliminate): the eliminations e0 .. e0 + kThreads / 16 - 1 of the rows
+// i = s (2 e + 1). Loads per lane: row c of D_i, its column of L_i (q = 0) or row of L_{i+s} (q = 1), f_i. Stores as in the 8-lane round:
+// q = 0 folds L_i^T W_L into D_{i-s}, writes the new L_{i+s} = - U_i^T W_L and W_L into the slot of D_i; q = 1 writes W_U into the slot
+// of L_i and, after the barrier (neighbouring eliminations share the surviving row between them), folds U_i^T W_U into D_{i+s}.
+__device__ __forceinline__ bool cr_forward_round16(double* __restrict__ D, double* __restrict__ L, double* __restrict__ f, int Nb, int s,
+                                                   int e0, int E, int bD = kBlk, int bF = 8) {
+  TEB_SOLVER_FMA
+  constexpr int kW = 1;   // (profiling build) row of the per-width counters
+  (void)kW;
+  const int tid = threadIdx.x;
+  const int grp = tid >> 4, c = tid & 7;
+  const bool up = (tid & 8) != 0;
+  const int e = e0 + grp;
+  const bool act = e < E;
+  const int i = s * (2 * e + 1);
+  const bool hasU = act && (i + s < Nb);
+  bool ok = true;
+  double Y[8], wf[8], acc[16], dm[8];
+  double sx = 0, fm = 0;
+  CRR_DECL
+  TEB_CR16_STAMP(5)
+  if (act) {
+    const double* Di = D + i * bD;
+    const double* Li = L + i * bD;
+    const double* Lp = L + (i + s) * bD;   // U_i^T, valid iff hasU
+    double v[8], X[8];
+    ld_row<8>(Di + c * 8, v);
+    ld_row<8>(f + i * bF, wf);
+    if (up) {
+      ld_row<8>((hasU ? Lp : Li) + c * 8, X);   // row c of L_{i+s} (an address inside the blocks even without an upper neighbour)
+      if (!hasU) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) X[k] = 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) X[k] = Li[k * 8 + c];
+    }
+    // what phase 1 updates is fetched now, under the elimination: nobody writes row i - s before this group does (the lower neighbour's
+    // turn at it comes after the barrier). Column c: the 8 lanes of a half row touch 64 contiguous bytes per access - conflict-free.
+    const double* Dm = D + (i - s) * bD;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) dm[t] = Dm[t * 8 + c];
+    fm = f[(i - s) * bF + c];
+    CRR(0);
+    ok = cr16_eliminate(v, X, Y, wf, acc, sx);
+    CRR(2);
+  }
+  // No barrier before the writes: within a level the eliminated rows i = s (2 e + 1) and the blocks read for them (D_i, L_i,
+  // L_{i+s}, f_i) belong to exactly one group, a group is a quarter of a wave, and the survivors' D / f are only updated by the group(s)
+  // that eliminate their neighbours: the lower one in this phase, the upper one after the barrier.
+  if (act) {
+    double* slot = (up ? L : D) + i * bD;   // W_U -> L_i, W_L -> D_i: operands of the back substitution
+#pragma unroll
+    for (int k = 0; k < 8; ++k) slot[k * 8 + c] = Y[k];
+    if (!up) {
+      double* Dm = D + (i - s) * bD;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) Dm[t * 8 + c] = dm[t] - acc[t];
+      if (hasU) {
+        double* Lp = L + (i + s) * bD;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) Lp[t * 8 + c] = -acc[8 + t];
+      }
+      f[(i - s) * bF + c] = fm - sx;
+      f[i * bF + c] = wf[c];
+    }
+  }
+  CRR(3);
+  TEB_CR16_STAMP(6)
+  __syncthreads();
+  CRR(4);
+  TEB_CR16_STAMP(7)
+  if (hasU && up) {
+    double* Dp = D + (i + s) * bD;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) dm[t] = Dp[t * 8 + c];
+    fm = f[(i + s) * bF + c];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) Dp[t * 8 + c] = dm[t] - acc[8 + t];
+    f[(i + s) * bF + c] = fm - sx;
+  }
+  TEB_CR16_STAMP(8)
+  __syncthreads();
+  CRR(5);
+  TEB_CR16_STAMP(9)
+  return ok;
+}
 // rows live at D + i * kBlk, L + i * kBlk (coupling of row i with the previous surviving row), f + i * 8; levels s_lo, 2 s_lo, .. < s_hi.
-// The group width of a round follows the number of eliminations left in the level: 8 lanes while there are more than 8 of them, then
-// 32 / 64 lanes (the coarse levels are latency chains of mostly idle lanes; the wider groups shorten the Schur products 4 / 8 x). Measured
-// alone on a CU (tools/micro/cr_round_bench.hip): 5.1 k cycles per round with 8-lane groups, 3.9 k with 32, 3.3 k with 64; 16-lane groups
-// gain too little to pay for their code (-DTEB_CR_NARROW_ONLY: 8-lane groups everywhere).
+// 16 eliminations per round. (Rounds 2 - 4 served an elimination with 8 lanes and widened the groups to 32 / 64 lanes at the coarse
+// levels to shorten the Schur products; with the operands read from registers a round costs a third of those and one width serves all
+// levels - tools/micro/cr_round_bench.hip keeps the 8-lane round for the comparison.)
 __device__ __forceinline__ bool cr_forward(double* __restrict__ D, double* __restrict__ L, double* __restrict__ f, int Nb, int s_lo,
                                            int s_hi, int bD = kBlk, int bF = 8) {
   bool ok = true;
   for (int s = s_lo; s < s_hi; s <<= 1) {
     const int E = (Nb - 1 - s) / (2 * s) + 1;
-    for (int e0 = 0; e0 < E; e0 += kThreads / 8) {
-      const int left = E - e0;
-      if (left <= kThreads / 64) ok = cr_forward_round<8>(D, L, f, Nb, s, e0, E, bD, bF) && ok;
-      else if (left <= kThreads / 32) ok = cr_forward_round<4>(D, L, f, Nb, s, e0, E, bD, bF) && ok;
-      else ok = cr_forward_round<1>(D, L, f, Nb, s, e0, E, bD, bF) && ok;
-    }
+    for (int e0 = 0; e0 < E; e0 += kThreads / 16) ok = cr_forward_round16(D, L, f, Nb, s, e0, E, bD, bF) && ok;
   }
   return ok;
 }
@@ -1435,7 +1684,7 @@ __device__ __forceinline__ void cr_copy_band(const Lds& l, int n, double* __rest
   __syncthreads();
 }
 
-constexpr int kHybridRounds = 3;   // level-0 rounds of 32 eliminations: block rows <= 172 (343 poses) -> <= 86 odd rows
+constexpr int kHybridRounds = 4;   // level-0 rounds of 16 eliminations: at most 2 (kThreads / 8) = 64 odd rows are eliminated there (E0 below)
 // Two out-of-line copies of the solve: the band's own (no callee-saved block, above) and the one the SOLVER HELPERS of a small batch
 // call. The helper's copy keeps the plain calling convention. Reason: small-batch kernels with BOTH call sites on the no-callee-saved
 // path failed on MI355X in two builds of this round (a profiling build and the band-layout small-batch kernel specialised on the
@@ -1458,13 +1707,20 @@ template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const Ld
   const Lds l = carve(lds_base, plan);
   const int tid = threadIdx.x;
   const int Nt = 4 * n, Nb = (Nt + 7) >> 3, E = Nb >> 1;
-  // Level 0 takes two rounds of 32 eliminations. A band of more than 256 poses has up to 8 odd rows beyond them; a third round for those
-  // keeps 24 of the 32 lane groups idle (7 k cycles per solve, and the bands that need it are the ones the launch waits for). Those
-  // rows are not eliminated at level 0 instead: the block rows from 2 E0 on enter the compact system as they are (odd and even,
-  // coupled by their original L blocks) and are reduced by its levels, which need no extra round for them (Nc = 80 instead of 72 rows at
-  // 287 poses: 40 / 20 / 10 / 5 / 2 / 1 eliminations instead of 36 / 18 / 9 / 4 / 2 / 1, seven rounds either way) - as long as
-  // the larger compact system fits the band region. Compact row j is block row 2 j for j <= E0 and block row j + E0 beyond.
-  const int E0 = (E > 2 * (kThreads / 8) && (size_t)(Nb - 2 * (kThreads / 8)) * (2 * kBlk + 8) <= (size_t)hbo(4 * plan.S)) ? 2 * (kThreads / 8) : E;
+  // Level 0 takes up to four rounds of 16 eliminations: 64 odd rows, a band of 256 poses. A longer band has up to 20 odd rows beyond them
+  // (337 poses); further level-0 rounds for those would keep most lane groups idle, and the bands that need them are the ones the launch
+  // waits for. Those rows are not eliminated at level 0 instead: the block rows from 2 E0 on enter the compact system as they are (odd
+  // and even, coupled by their original L blocks) and are reduced by its levels, which need no extra round for them. Compact row j is
+  // block row 2 j for j <= E0 and block row j + E0 beyond. The larger compact system always fits the band region of a launch that holds
+  // the band ((Nb - 64) (2 kBlk + 8) + 14 <= 45 (2 Nb - 1) <= hbo(4 plan.S) for every Nb <= 178; the layout ends at 337 poses, Nb = 169); a
+  // launch for which it did not would be refused here, not overrun.
+  constexpr int kLevel0Max = kHybridRounds * (kThreads / 16);
+  if (E > kLevel0Max && (size_t)(Nb - kLevel0Max) * (2 * kBlk + 8) + 14 > (size_t)hbo(4 * plan.S)) {
+    if (tid == 0) l.ired[0] = 0;   // reported like a failed factorisation
+    __syncthreads();
+    return;
+  }
+  const int E0 = E > kLevel0Max ? kLevel0Max : E;
   const int Nc = Nb - E0;   // (= the even rows alone, (Nb + 1) / 2, when every odd row is eliminated at level 0)
 #define TEB_HYB_ROW(j) ((j) <= E0 ? 2 * (j) : (j) + E0)
   // Hg: the band copy, entry (r, c), c <= r <= c + 10, at Hg[r * 11 + (r - c)]. In terms of 8x8 blocks:
@@ -1473,8 +1729,11 @@ template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const Ld
   // (global address space spelled out: a generic pointer would be read with flat_load, which also counts on the LDS counter)
   typedef const double __attribute__((address_space(1))) gdouble_t;
   gdouble_t* __restrict__ Hg = (gdouble_t*)gbuf;
+  // The L blocks start 64 (mod 128) bytes behind the D blocks: the slot writes of a round (lanes q = 0 into D_i, q = 1 into L_i, one
+  // 16-lane group of a ds_write_b64, banks = 128-byte window) then fall into different halves of the window. kBlk * 8 = 16 (mod 128).
+  const int padL = 2 * ((4 - (Nc & 7)) & 7);
   double* __restrict__ Dc = lds_base + plan.off_H;
-  double* __restrict__ Lc = Dc + Nc * kBlk;
+  double* __restrict__ Lc = Dc + Nc * kBlk + padL;
   double* __restrict__ fc = Lc + Nc * kBlk;
   // compact system = the even block rows (+ lambda); their couplings are written by the eliminations (row 0 has none and is never
   // read). The loads of a batch are issued together: one L2 round trip per batch instead of one per element.
@@ -1509,104 +1768,65 @@ template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const Ld
   if (tid == 0) l.ired[0] = 1;
   __syncthreads();
   CRP(0);
-  // level 0: 8 lanes per elimination of an odd row i = 2 e + 1 (lane c owns column c of L_i, of U_i = L_{i+1}^T and, redundantly, f_i).
-  // The records W_L = P L_i, W_U = P U_i, P f_i of the eliminated rows stay in the registers of the lanes that computed them (column c
-  // each) until the back substitution at the end: nothing but the read-only band copy crosses the LDS boundary during a solve.
-  const int grp = tid >> 3, c = tid & 7;
+  // level 0: the 16 lanes of a row eliminate an odd block row i = 2 e + 1 in their registers (cr16_eliminate), operands gathered from
+  // the band copy: only the structurally non-zero entries are fetched (L_i[k][c] = 0 for c < k - 2), + lambda on the diagonal on the fly.
+  // The records of the eliminated rows - column c of W_L = P L_i in lane (0, c), of W_U = P U_i in lane (1, c), P f_i - stay in the
+  // registers of the lanes that computed them until the back substitution at the end: nothing but the read-only band copy crosses the
+  // LDS boundary during a solve.
+  const int grp = tid >> 4, c = tid & 7;
+  const bool up = (tid & 8) != 0;
   bool ok = true;
-  double kL[kHybridRounds][8], kU[kHybridRounds][8], kf[kHybridRounds];
+  double kY[kHybridRounds][8], kf[kHybridRounds];
 #pragma unroll
   for (int rr = 0; rr < kHybridRounds; ++rr) {
-    const int e = rr * (kThreads / 8) + grp;
+    const int e = rr * (kThreads / 16) + grp;
     const bool act = e < E0;
     const int i = 2 * e + 1;
     const bool hasU = act && (i + 1 < Nb);
-    double wL[8], wU[8], wf[8], o1[8], o2[8], o3[8];
-    double s1 = 0, s2 = 0;
-    if (rr * (kThreads / 8) < E0) {   // (uniform) this round has eliminations at all
+    double Y[8], wf[8], acc[16], dm[8];
+    double sx = 0, fm = 0;
+    if (rr * (kThreads / 16) < E0) {   // (uniform) this round has eliminations at all
       if (act) {
         gdouble_t* Hi = Hg + hbo(8 * i);         // band rows of block row i (8 i is a multiple of 4: row r of the block starts at Hi + hbo(r))
         gdouble_t* Hp = Hg + hbo(8 * (i + 1));   // ... of block row i + 1 (valid iff hasU)
-        Ldl8 F;
+        double v[8], X[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
-#pragma unroll
-          for (int cc = 0; cc <= r; ++cc) F.a[Ldl8::idx(r, cc)] = Hi[hbo(r) + (r - cc)];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) F.a[Ldl8::idx(k, k)] += lambda;
-        double cl[8], cu[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          cl[k] = wL[k] = (c >= k - 2) ? Hi[hbo(k) + (8 + k - c)] : 0.0;                 // L_i[k][c]
-          cu[k] = wU[k] = (hasU && k >= c - 2) ? Hp[hbo(c) + (8 + c - k)] : 0.0;         // U_i[k][c] = L_{i+1}[c][k]
-          wf[k] = (8 * i + k < Nt) ? l.bv[8 * i + k] : 0.0;
+        for (int m = 0; m < 8; ++m) {
+          v[m] = m <= c ? Hi[hbo(c) + (c - m)] : 0.0;                                       // D_i[c][m]
+          if (m == c) v[m] += lambda;
+          X[m] = up ? ((hasU && m >= c - 2) ? Hp[hbo(c) + (8 + c - m)] : 0.0)               // U_i[m][c] = L_{i+1}[c][m]
+                    : ((c >= m - 2) ? Hi[hbo(m) + (8 + m - c)] : 0.0);                      // L_i[m][c]
+          wf[m] = (8 * i + m < Nt) ? l.bv[8 * i + m] : 0.0;
         }
-        ok = F.factor() && ok;
-        F.solve3(wL, wU, wf);
-        double dm[8];   // the entries of compact row e this lane updates, fetched before the products (nobody else writes them in this phase)
+        // the entries of compact row e this lane updates, fetched before the elimination (nobody else writes them in this phase)
 #pragma unroll
         for (int aa = 0; aa < 8; ++aa) dm[aa] = Dc[e * kBlk + aa * 8 + c];
-        const double fm = fc[e * 8 + c];
-#pragma unroll
-        for (int aa = 0; aa < 8; ++aa) { o1[aa] = 0; o2[aa] = 0; o3[aa] = 0; }
-        // The operands of the products are already in the group: lane aa holds column aa of L_i (cl) and row aa of L_{i+1} (cu). They reach
-        // the other lanes through LDS in 16-byte accesses: every lane writes its 8 values as one 64-byte row of a scratch block, "column aa
-        // of L_i" is then one contiguous read for all 8 lanes (a ds_swizzle moves 4 bytes per lane and instruction through the same pipe:
-        // 196 of them per round made level 0 the most expensive round of the solve). The scratch is the L block of compact row e + 1, which
-        // this group writes below (o2) and nobody reads before; the one elimination without an upper neighbour takes the L block of
-        // compact row 0, which is never used. Same products in the same order: bit-identical.
-        double* scr = Lc + (hasU ? e + 1 : 0) * kBlk;
-#pragma unroll
-        for (int k = 0; k < 8; k += 2) *reinterpret_cast<teb_v2d*>(scr + c * 8 + k) = teb_v2d{cl[k], cl[k + 1]};
-#pragma unroll
-        for (int aa = 0; aa < 8; ++aa) {
-          double lc[8];                                    // column aa of L_i
-          ld_row<8>(scr + aa * 8, lc);
-#pragma unroll
-          for (int k = 0; k < 8; ++k)
-            if (aa >= k - 2) o1[aa] += lc[k] * wL[k];                                       // (L_i^T W_L)[aa][c]
-          if ((aa % TEB_CR_FENCE_EVERY) == TEB_CR_FENCE_EVERY - 1) { TEB_CR_SCHED_BARRIER }
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s1 += cl[k] * wf[k];                                    // (L_i^T P f_i)[c]
-        if (hasU) {
-#pragma unroll
-          for (int k = 0; k < 8; k += 2) *reinterpret_cast<teb_v2d*>(scr + c * 8 + k) = teb_v2d{cu[k], cu[k + 1]};
-#pragma unroll
-          for (int aa = 0; aa < 8; ++aa) {
-            double lp[8];                                  // row aa of L_{i+1}
-            ld_row<8>(scr + aa * 8, lp);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              if (k >= aa - 2) {
-                o2[aa] -= lp[k] * wL[k];
-                o3[aa] += lp[k] * wU[k];
-              }
-            }
-            if ((aa % TEB_CR_FENCE_EVERY) == TEB_CR_FENCE_EVERY - 1) { TEB_CR_SCHED_BARRIER }
-          }
-#pragma unroll
-          for (int k = 0; k < 8; ++k) s2 += cu[k] * wf[k];                                  // (L_{i+1} P f_i)[c]
-        }
+        fm = fc[e * 8 + c];
+        ok = cr16_eliminate(v, X, Y, wf, acc, sx) && ok;
         // fold into the compact rows e (= row i - 1) and e + 1 (= row i + 1); two phases: neighbouring eliminations share a row
+        if (!up) {
 #pragma unroll
-        for (int aa = 0; aa < 8; ++aa) Dc[e * kBlk + aa * 8 + c] = dm[aa] - o1[aa];
-        fc[e * 8 + c] = fm - s1;
-        if (hasU) {
+          for (int aa = 0; aa < 8; ++aa) Dc[e * kBlk + aa * 8 + c] = dm[aa] - acc[aa];
+          fc[e * 8 + c] = fm - sx;
+          if (hasU) {
 #pragma unroll
-          for (int aa = 0; aa < 8; ++aa) Lc[(e + 1) * kBlk + aa * 8 + c] = o2[aa];
+            for (int aa = 0; aa < 8; ++aa) Lc[(e + 1) * kBlk + aa * 8 + c] = -acc[8 + aa];
+          }
         }
       }
       __syncthreads();
-      if (hasU) {
+      if (hasU && up) {
 #pragma unroll
-        for (int aa = 0; aa < 8; ++aa) Dc[(e + 1) * kBlk + aa * 8 + c] -= o3[aa];
-        fc[(e + 1) * 8 + c] -= s2;
+        for (int aa = 0; aa < 8; ++aa) dm[aa] = Dc[(e + 1) * kBlk + aa * 8 + c];
+        fm = fc[(e + 1) * 8 + c];
+#pragma unroll
+        for (int aa = 0; aa < 8; ++aa) Dc[(e + 1) * kBlk + aa * 8 + c] = dm[aa] - acc[8 + aa];
+        fc[(e + 1) * 8 + c] = fm - sx;
       }
       __syncthreads();
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { kL[rr][k] = act ? wL[k] : 0.0; kU[rr][k] = act ? wU[k] : 0.0; }
+    for (int k = 0; k < 8; ++k) kY[rr][k] = act ? Y[k] : 0.0;
     kf[rr] = act ? wf[c] : 0.0;
   }
   CRP(1);
@@ -1628,23 +1848,24 @@ template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const Ld
   }
 #pragma unroll
   for (int rr = 0; rr < kHybridRounds; ++rr) {
-    const int e = rr * (kThreads / 8) + grp;
+    const int e = rr * (kThreads / 16) + grp;
     const bool act = e < E0;
     const int i = 2 * e + 1;
-    const double xm = act ? fc[e * 8 + c] : 0.0;
-    const double xp = (act && i + 1 < Nb) ? fc[(e + 1) * 8 + c] : 0.0;
+    // lane (0, c): x_{i-1}[c] against column c of W_L; lane (1, c): x_{i+1}[c] against column c of W_U
+    const double xs = !act ? 0.0 : !up ? fc[e * 8 + c] : (i + 1 < Nb) ? fc[(e + 1) * 8 + c] : 0.0;
     double mine = 0;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      double t = kL[rr][r] * xm + kU[rr][r] * xp;
-      // butterfly over the 8 lanes of the group with DPP moves (no LDS crossbar): lane ^ 1, lane ^ 2 are quad permutations; after them the
-      // four lanes of a quad hold the same value, so the mirror within the half row (lane -> 7 - lane) delivers the other quad's sum
+      const double pu = kY[rr][r] * xs;                       // q = 1: W_U[r][c] x_{i+1}[c]
+      double t = kY[rr][r] * xs + dpp_move<0x128>(pu);        // q = 0: W_L[r][c] x_{i-1}[c] + the partner's product (row_ror:8: lane + 8)
+      // butterfly over the 8 lanes of the half row with DPP moves (no LDS crossbar): lane ^ 1, lane ^ 2 are quad permutations; after them
+      // the four lanes of a quad hold the same value, so the mirror within the half row (lane -> 7 - lane) delivers the other quad's sum
       t += dpp_move<0xB1>(t);    // quad_perm:[1,0,3,2]
       t += dpp_move<0x4E>(t);    // quad_perm:[2,3,0,1]
       t += dpp_move<0x141>(t);   // row_half_mirror
       mine = (c == r) ? t : mine;
     }
-    if (act && 8 * i + c < Nt) l.dxv[8 * i + c] = kf[rr] - mine;
+    if (act && !up && 8 * i + c < Nt) l.dxv[8 * i + c] = kf[rr] - mine;
   }
   __syncthreads();  CRP(4);
 #undef TEB_HYB_ROW

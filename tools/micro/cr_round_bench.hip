@@ -3,7 +3,14 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I teb_local_planner_amd/csrc tools/micro/cr_round_bench.hip -o tools/micro/cr_round_bench
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
+#include <cmath>
 #include <vector>
+// cycle stamps of ONE 16-lane round (lane 0, the last repetition): s_memtime into LDS, no memory traffic between the stamps
+__shared__ long long s_stamp[16];
+#ifdef CR_BENCH_STAMPS
+#define TEB_CR16_STAMP(k) { __builtin_amdgcn_sched_barrier(0); const long long now_ = clock64(); if (threadIdx.x == 0) s_stamp[k] = now_; __builtin_amdgcn_sched_barrier(0); }
+#endif
 #include "teb_kernel.hpp"
 using namespace tebamd;
 
@@ -29,6 +36,114 @@ __global__ void __launch_bounds__(kThreads) round_kernel(int Nb, int s, int E, i
   if (threadIdx.x == 0 && blockIdx.x == 0) sink[1] = D[1] + f[3];
 }
 
+// the 16-lane round (operands by row_newbcast from the neighbours' registers): E eliminations take ceil(E / 16) rounds
+__global__ void __launch_bounds__(kThreads) round16_kernel(int Nb, int s, int E, int reps, long long* cycles, double* sink) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* D = lds;
+  double* L = D + Nb * kBlk;
+  double* f = L + Nb * kBlk;
+  for (int q = threadIdx.x; q < Nb * kBlk; q += kThreads) {
+    const int w = q % kBlk, r = w >> 3, c = w & 7;
+    D[q] = (w < 64 && r == c) ? 20.0 + 0.01 * (q % 7) : 0.01 * ((q * 7) % 13);
+    L[q] = 0.02 * ((q * 5) % 11) - 0.1;
+  }
+  for (int q = threadIdx.x; q < Nb * 8; q += kThreads) f[q] = 0.5 + 0.001 * q;
+  __syncthreads();
+  bool ok = true;
+  const long long t0 = clock64();
+  for (int r = 0; r < reps; ++r)
+    for (int e0 = 0; e0 < E; e0 += kThreads / 16) ok = cr_forward_round16(D, L, f, Nb, s, e0, E) && ok;
+  const long long t1 = clock64();
+  if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+  if (!ok && threadIdx.x == 0) sink[0] = D[0];
+  if (threadIdx.x == 0 && blockIdx.x == 0) sink[1] = D[1] + f[3];
+#ifdef CR_BENCH_STAMPS
+  if (threadIdx.x < 16 && blockIdx.x == 0) sink[2 + threadIdx.x] = (double)(s_stamp[threadIdx.x] - s_stamp[5]);
+#endif
+}
+static void run16(int E, int grid) {
+  const int s = 1, Nb = 2 * E + 1, reps = 50;
+  long long* d_c; double* d_s;
+  hipMalloc(&d_c, grid * sizeof(long long)); hipMalloc(&d_s, 32 * sizeof(double));
+  hipFuncSetAttribute((const void*)round16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  for (int it = 0; it < 2; ++it) {
+    hipLaunchKernelGGL(round16_kernel, dim3(grid), dim3(kThreads), 150 * 1024, 0, Nb, s, E, reps, d_c, d_s);
+    hipDeviceSynchronize();
+  }
+  std::vector<long long> c(grid);
+  hipMemcpy(c.data(), d_c, grid * sizeof(long long), hipMemcpyDeviceToHost);
+  double sum = 0; for (auto v : c) sum += v;
+  const int rounds = (E + 15) / 16;
+  printf("  16-lane rows  , %3d eliminations (%d round%s), %3d workgroups: %7.0f cycles per level, %7.0f per round\n", E, rounds, rounds > 1 ? "s" : " ",
+         grid, sum / grid / reps, sum / grid / reps / rounds);
+#ifdef CR_BENCH_STAMPS
+  if (grid == 1) {
+    double st[18];
+    hipMemcpy(st, d_s, sizeof st, hipMemcpyDeviceToHost);
+    const double* t = st + 2;
+    printf("      last round, lane 0, cycles since entry: loads done %.0f | factor %.0f | forward %.0f | scale + backward %.0f | products %.0f | stores 1 %.0f | barrier %.0f | stores 2 %.0f | barrier %.0f\n",
+           t[0], t[1], t[2], t[3], t[4], t[6], t[7], t[8], t[9]);
+  }
+#endif
+  hipFree(d_c); hipFree(d_s);
+}
+
+// same system through one level of 8-lane rounds and of 16-lane rounds: every entry a later level or the back substitution reads must
+// come out with the same bits (D of the surviving rows: lower triangle; the slots of the eliminated rows, the new couplings, f: all)
+template <int WHICH>
+__global__ void __launch_bounds__(kThreads) level_kernel(int Nb, int E, double* out) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* D = lds;
+  double* L = D + Nb * kBlk;
+  double* f = L + Nb * kBlk;
+  for (int q = threadIdx.x; q < Nb * kBlk; q += kThreads) {
+    const int w = q % kBlk, r = w >> 3, c = w & 7, j = q / kBlk;
+    const int lo = r > c ? c : r, hi = r > c ? r : c;
+    D[q] = w >= 64 ? 0.0 : (r == c) ? 20.0 + 0.37 * ((j * 5 + r) % 7) : 0.6 * (((j * 31 + hi * 8 + lo) * 7) % 13) / 13.0 - 0.3;   // symmetric, diagonally dominant
+    L[q] = w >= 64 ? 0.0 : 0.9 * (((q * 5) % 11) / 11.0) - 0.45;
+  }
+  for (int q = threadIdx.x; q < Nb * 8; q += kThreads) f[q] = 0.5 + 0.013 * ((q * 3) % 17);
+  __syncthreads();
+  bool ok = true;
+  if (WHICH == 0) { for (int e0 = 0; e0 < E; e0 += kThreads / 8) ok = cr_forward_round<1>(D, L, f, Nb, 1, e0, E) && ok; }
+  else { for (int e0 = 0; e0 < E; e0 += kThreads / 16) ok = cr_forward_round16(D, L, f, Nb, 1, e0, E) && ok; }
+  __syncthreads();
+  for (int q = threadIdx.x; q < (2 * Nb * kBlk + Nb * 8); q += kThreads) out[q] = lds[q];
+  if (threadIdx.x == 0) out[2 * Nb * kBlk + Nb * 8] = ok ? 1.0 : 0.0;
+}
+static void compare_levels(int E) {
+  const int Nb = 2 * E + 1;
+  const size_t count = (size_t)2 * Nb * kBlk + Nb * 8 + 1;
+  double* d[2];
+  std::vector<double> h[2];
+  for (int w = 0; w < 2; ++w) {
+    hipMalloc(&d[w], count * sizeof(double));
+    if (w == 0) { hipFuncSetAttribute((const void*)level_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                  hipLaunchKernelGGL(level_kernel<0>, dim3(1), dim3(kThreads), 150 * 1024, 0, Nb, E, d[w]); }
+    else        { hipFuncSetAttribute((const void*)level_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                  hipLaunchKernelGGL(level_kernel<1>, dim3(1), dim3(kThreads), 150 * 1024, 0, Nb, E, d[w]); }
+    hipDeviceSynchronize();
+    h[w].resize(count);
+    hipMemcpy(h[w].data(), d[w], count * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(d[w]);
+  }
+  long diff = 0, checked = 0; double worst = 0;
+  for (int j = 0; j < Nb; ++j)
+    for (int w = 0; w < 64; ++w) {
+      const int r = w >> 3, c = w & 7;
+      for (int which = 0; which < 2; ++which) {   // D, L
+        if (which == 0 && (j % 2 == 0) && c > r) continue;   // upper triangle of a surviving diagonal block: never read
+        if (which == 1 && j == 0) continue;                  // row 0 has no coupling
+        const size_t q = (size_t)which * Nb * kBlk + (size_t)j * kBlk + w;
+        ++checked;
+        if (memcmp(&h[0][q], &h[1][q], 8)) { ++diff; worst = fmax(worst, fabs(h[0][q] - h[1][q])); }
+      }
+    }
+  for (int q = 0; q < Nb * 8; ++q) { ++checked; const size_t a = (size_t)2 * Nb * kBlk + q; if (memcmp(&h[0][a], &h[1][a], 8)) { ++diff; worst = fmax(worst, fabs(h[0][a] - h[1][a])); } }
+  printf("  level of %3d eliminations, 8-lane vs 16-lane rounds: %ld of %ld entries differ (worst %.3e), ok %g / %g\n", E, diff, checked, worst,
+         h[0][count - 1], h[1][count - 1]);
+}
+
 template <int M>
 static void run(int E, int grid) {
   const int s = 1, Nb = 2 * E + 1, reps = 50;
@@ -49,7 +164,9 @@ static void run(int E, int grid) {
 }
 
 int main() {
+  for (int E : {1, 5, 16, 32, 58}) compare_levels(E);
   for (int grid : {1, 256}) {
+    run16(1, grid); run16(8, grid); run16(16, grid); run16(32, grid); run16(58, grid);
     run<1>(1, grid); run<1>(8, grid); run<1>(16, grid); run<1>(32, grid);
     run<2>(1, grid); run<2>(16, grid);
     run<4>(1, grid); run<4>(8, grid);
