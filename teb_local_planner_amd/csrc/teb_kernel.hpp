@@ -941,17 +941,35 @@ template <int T> __device__ __forceinline__ double bcast16(double x) {   // x of
   TEB_F2(7, 7, 15, 16, 0, 8) TEB_F2(7, 7, 15, 17, 1, 9) TEB_F2(7, 7, 15, 18, 2, 10) \
   TEB_F2(7, 7, 15, 19, 3, 11) TEB_F2(7, 7, 15, 20, 4, 12) TEB_F2(7, 7, 15, 21, 5, 13) \
   TEB_F2(7, 7, 15, 22, 6, 14)
-#define TEB_CR16_BACKWARD /* Y[k] -= l_mk Y[m], m > k: l_mk from lane m */ \
-  TEB_F2(7, 6, 14, 22, 7, 15) TEB_F2(6, 5, 13, 21, 6, 14) TEB_F2(7, 5, 13, 21, 7, 15) \
-  TEB_F2(5, 4, 12, 20, 5, 13) TEB_F2(6, 4, 12, 20, 6, 14) TEB_F2(7, 4, 12, 20, 7, 15) \
-  TEB_F2(4, 3, 11, 19, 4, 12) TEB_F2(5, 3, 11, 19, 5, 13) TEB_F2(6, 3, 11, 19, 6, 14) \
-  TEB_F2(7, 3, 11, 19, 7, 15) TEB_F2(3, 2, 10, 18, 3, 11) TEB_F2(4, 2, 10, 18, 4, 12) \
-  TEB_F2(5, 2, 10, 18, 5, 13) TEB_F2(6, 2, 10, 18, 6, 14) TEB_F2(7, 2, 10, 18, 7, 15) \
-  TEB_F2(2, 1, 9, 17, 2, 10) TEB_F2(3, 1, 9, 17, 3, 11) TEB_F2(4, 1, 9, 17, 4, 12) \
-  TEB_F2(5, 1, 9, 17, 5, 13) TEB_F2(6, 1, 9, 17, 6, 14) TEB_F2(7, 1, 9, 17, 7, 15) \
-  TEB_F2(1, 0, 8, 16, 1, 9) TEB_F2(2, 0, 8, 16, 2, 10) TEB_F2(3, 0, 8, 16, 3, 11) \
-  TEB_F2(4, 0, 8, 16, 4, 12) TEB_F2(5, 0, 8, 16, 5, 13) TEB_F2(6, 0, 8, 16, 6, 14) \
-  TEB_F2(7, 0, 8, 16, 7, 15)
+// The backward pass starts every row with the product of its first term rounded on its own and the scaling by 1 / d_k fused into the
+// subtraction - u_k = fma(u_k, 1 / d_k, - (l_{k+1,k} u_{k+1})) - because that is what the compiler made of Ldl8::solve3 in the 8-lane
+// rounds of rounds 2 - 4 (`u[k] *= di; .. u[k] -= l * u[m]` under fp contract(fast): the multiply that feeds the subtraction from the
+// left is the one that gets fused); with it the 16-lane rounds reproduce those rounds bit for bit (tools/micro/cr_round_bench.hip) and
+// every fingerprint, golden vector and reference comparison of the earlier rounds stands. Two statements (operand limit): rows 6 .. 4,
+// rows 3 .. 0. Operands: %0 .. %7 = Y, %8 .. %15 = wf, three scratch registers, then v[k] and 1 / d_k of the statement's rows.
+#define TEB_CR16_BACKWARD_HI /* k = 6, 5, 4: scratch %16 .. %18 (outputs come first), v[k] = %19 .. %21, inv[k] = %22 .. %24 */ \
+  "v_mov_b64_dpp %16, %19" TEB_BC(7) "v_mul_f64 %17, %16, %7\n\tv_mul_f64 %18, %16, %15\n\t" \
+  "v_fma_f64 %6, %6, %22, -%17\n\tv_fma_f64 %14, %14, %22, -%18\n\t" "v_mov_b64_dpp %16, %20" TEB_BC(6) \
+  "v_mul_f64 %17, %16, %6\n\tv_mul_f64 %18, %16, %14\n\t" "v_fma_f64 %5, %5, %23, -%17\n\tv_fma_f64 %13, %13, %23, -%18\n\t" \
+  TEB_F2(7, 5, 13, 20, 7, 15) "v_mov_b64_dpp %16, %21" TEB_BC(5) \
+  "v_mul_f64 %17, %16, %5\n\tv_mul_f64 %18, %16, %13\n\t" "v_fma_f64 %4, %4, %24, -%17\n\tv_fma_f64 %12, %12, %24, -%18\n\t" \
+  TEB_F2(6, 4, 12, 21, 6, 14) TEB_F2(7, 4, 12, 21, 7, 15)
+#define TEB_CR16_BACKWARD_LO /* k = 3 .. 0: scratch %16 .. %18, v[k] = %19 .. %22, inv[k] = %23 .. %26 */ \
+  "v_mov_b64_dpp %16, %19" TEB_BC(4) "v_mul_f64 %17, %16, %4\n\tv_mul_f64 %18, %16, %12\n\t" \
+  "v_fma_f64 %3, %3, %23, -%17\n\tv_fma_f64 %11, %11, %23, -%18\n\t" TEB_F2(5, 3, 11, 19, 5, 13) \
+  TEB_F2(6, 3, 11, 19, 6, 14) TEB_F2(7, 3, 11, 19, 7, 15) \
+  "v_mov_b64_dpp %16, %20" TEB_BC(3) "v_mul_f64 %17, %16, %3\n\tv_mul_f64 %18, %16, %11\n\t" \
+  "v_fma_f64 %2, %2, %24, -%17\n\tv_fma_f64 %10, %10, %24, -%18\n\t" TEB_F2(4, 2, 10, 20, 4, 12) \
+  TEB_F2(5, 2, 10, 20, 5, 13) TEB_F2(6, 2, 10, 20, 6, 14) \
+  TEB_F2(7, 2, 10, 20, 7, 15) "v_mov_b64_dpp %16, %21" TEB_BC(2) \
+  "v_mul_f64 %17, %16, %2\n\tv_mul_f64 %18, %16, %10\n\t" "v_fma_f64 %1, %1, %25, -%17\n\tv_fma_f64 %9, %9, %25, -%18\n\t" \
+  TEB_F2(3, 1, 9, 21, 3, 11) TEB_F2(4, 1, 9, 21, 4, 12) \
+  TEB_F2(5, 1, 9, 21, 5, 13) TEB_F2(6, 1, 9, 21, 6, 14) \
+  TEB_F2(7, 1, 9, 21, 7, 15) "v_mov_b64_dpp %16, %22" TEB_BC(1) \
+  "v_mul_f64 %17, %16, %1\n\tv_mul_f64 %18, %16, %9\n\t" "v_fma_f64 %0, %0, %26, -%17\n\tv_fma_f64 %8, %8, %26, -%18\n\t" \
+  TEB_F2(2, 0, 8, 22, 2, 10) TEB_F2(3, 0, 8, 22, 3, 11) \
+  TEB_F2(4, 0, 8, 22, 4, 12) TEB_F2(5, 0, 8, 22, 5, 13) \
+  TEB_F2(6, 0, 8, 22, 6, 14) TEB_F2(7, 0, 8, 22, 7, 15)
 // operands: %0 .. %15 = acc[0 .. 15], then (X[k], Y[k]) of two columns k: acc[t] += X[k](lane t) * Y[k]
 #define TEB_CR16_SCHUR2 \
   TEB_F1(0, 0, 16, 17) TEB_F1(1, 1, 16, 17) TEB_F1(2, 2, 16, 17) TEB_F1(3, 3, 16, 17) \
@@ -1045,9 +1063,13 @@ __device__ __forceinline__ bool cr16_eliminate(double (&v)[8], const double (&X)
 #define TEB_CR16_FACTOR "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6])
   asm("s_nop 1\n\t" TEB_CR16_FORWARD : TEB_CR16_RHS : TEB_CR16_FACTOR);
   TEB_CR16_STAMP(2)
-#pragma unroll
-  for (int k = 0; k < 8; ++k) { Y[k] *= inv[k]; wf[k] *= inv[k]; }
-  asm("s_nop 1\n\t" TEB_CR16_BACKWARD : TEB_CR16_RHS : TEB_CR16_FACTOR);
+  Y[7] *= inv[7]; wf[7] *= inv[7];
+  {
+    double sl, s1, s2;   // scratch of the statements: l_{k+1,k} and the two first-term products
+    asm("s_nop 1\n\t" TEB_CR16_BACKWARD_HI : TEB_CR16_RHS, "=&v"(sl), "=&v"(s1), "=&v"(s2) : "v"(v[6]), "v"(v[5]), "v"(v[4]), "v"(inv[6]), "v"(inv[5]), "v"(inv[4]));
+    asm("s_nop 1\n\t" TEB_CR16_BACKWARD_LO : TEB_CR16_RHS, "=&v"(sl), "=&v"(s1), "=&v"(s2)
+        : "v"(v[3]), "v"(v[2]), "v"(v[1]), "v"(v[0]), "v"(inv[3]), "v"(inv[2]), "v"(inv[1]), "v"(inv[0]));
+  }
 #undef TEB_CR16_RHS
 #undef TEB_CR16_FACTOR
   TEB_CR16_STAMP(3)
@@ -1082,115 +1104,21 @@ __device__ long long g_crw_prof[32];   // per group width (8, 16, 32, 64 lanes):
 #endif
 // ---- pieces of the block cyclic reduction, usable on blocks in either memory (all three layouts run their LDS-resident levels
 //      through them; the HBM layout runs its finer levels on HBM-resident blocks and the coarser ones on a compact copy in LDS).
-// One round of a level: the eliminations e0 .. of the rows i = s (2 e + 1), 8 M lanes each. Lane (q, c) of a group, q < M, owns column c
-// of the three Schur products and, of that column, the rows q R .. q R + R - 1 (R = 8 / M); the factorisation of D_i and the three
-// triangular solves are repeated by the M lanes that share a column (they cost latency, not throughput, at the levels where M > 1: there
-// the machine is mostly idle). Every output element is summed in the same order for every M, so the result does not depend on M.
-// bD / bF: distance in doubles between consecutive block rows of the system in D, L / in f (kBlk / 8 for a contiguous system; the
-// interface rows of the partitioned solve are reduced where they lie, every q-th block row: q kBlk / 8 q).
-template <int M>
-__device__ __forceinline__ bool cr_forward_round(double* __restrict__ D, double* __restrict__ L, double* __restrict__ f, int Nb, int s,
-                                                 int e0, int E, int bD = kBlk, int bF = 8) {
-  TEB_SOLVER_FMA
-  constexpr int R = 8 / M;
-  constexpr int kW = M == 1 ? 0 : M == 2 ? 1 : M == 4 ? 2 : 3;   // (profiling build) row of the per-width counters
-  (void)kW;
-  const int tid = threadIdx.x;
-  const int grp = tid / (8 * M), c = tid & 7, q = (tid >> 3) & (M - 1), a0 = q * R;
-  const int e = e0 + grp;
-  const bool act = e < E;
-  const int i = s * (2 * e + 1);
-  const bool hasU = act && (i + s < Nb);
-  bool ok = true;
-  double wL[8], wU[8], wf[8], o1[R], o2[R], o3[R];
-  double s1 = 0, s2 = 0;
-  CRR_DECL
-  if (act) {
-    const double* Di = D + i * bD;
-    const double* Li = L + i * bD;
-    const double* Lp = L + (i + s) * bD;   // U_i^T, valid iff hasU
-    Ldl8 F;
-    F.load(Di);
-    ok = F.factor();
-    CRR(0);
-    double cu[8];
-    ld_row<8>((hasU ? Lp : Li) + c * 8, cu);   // row c of L_{i+s} (an address inside the blocks even without an upper neighbour)
-    ld_row<8>(f + i * bF, wf);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      wL[k] = Li[k * 8 + c];
-      wU[k] = hasU ? cu[k] : 0.0;
-    }
-    F.solve3(wL, wU, wf);
-    CRR(1);
-#pragma unroll
-    for (int t = 0; t < R; ++t) { o1[t] = 0; o2[t] = 0; o3[t] = 0; }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      double li[R];
-      ld_row<R>(Li + k * 8 + a0, li);
-#pragma unroll
-      for (int t = 0; t < R; ++t) o1[t] += li[t] * wL[k];
-      s1 += Li[k * 8 + c] * wf[k];
-      if ((k % TEB_CR_FENCE_EVERY) == TEB_CR_FENCE_EVERY - 1) { TEB_CR_SCHED_BARRIER }
-    }
-    if (hasU) {
-#pragma unroll
-      for (int t = 0; t < R; ++t) {
-        double lp[8];
-        ld_row<8>(Lp + (a0 + t) * 8, lp);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          o2[t] -= lp[k] * wL[k];
-          o3[t] += lp[k] * wU[k];
-        }
-        if ((t % TEB_CR_FENCE_EVERY) == TEB_CR_FENCE_EVERY - 1) { TEB_CR_SCHED_BARRIER }
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) s2 += cu[k] * wf[k];
-    }
-  }
-  CRR(2);
-  // No barrier before the writes: within a level the eliminated rows i = s (2 e + 1) and the blocks read for them (D_i, L_i,
-  // L_{i+s}, f_i) belong to exactly one group, a group never straddles two waves (8 M <= 64), and the survivors' D / f are only written
-  // (never read) in this level.
-  if (act) {
-    double* Dm = D + (i - s) * bD;
-    double* Di = D + i * bD;
-    double* Li = L + i * bD;
-#pragma unroll
-    for (int t = 0; t < R; ++t) Dm[(a0 + t) * 8 + c] -= o1[t];
-    if (hasU) {
-      double* Lp = L + (i + s) * bD;
-#pragma unroll
-      for (int t = 0; t < R; ++t) Lp[(a0 + t) * 8 + c] = o2[t];
-    }
-    if (q == 0) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { Di[k * 8 + c] = wL[k]; Li[k * 8 + c] = wU[k]; }
-      f[(i - s) * bF + c] -= s1;
-      f[i * bF + c] = wf[c];
-    }
-  }
-  CRR(3);
-  __syncthreads();
-  CRR(4);
-  if (hasU) {
-    double* Dp = D + (i + s) * bD;
-#pragma unroll
-    for (int t = 0; t < R; ++t) Dp[(a0 + t) * 8 + c] -= o3[t];
-    if (q == 0) f[(i + s) * bF + c] -= s2;
-  }
-  __syncthreads();
-  CRR(5);
-  return ok;
-}
+// bD / bF: distance in doubles between consecutive block rows of the system in D, L / in f (kBlk / 8 for a contiguous system).
 // One round of a level with 16 lanes per elimination (cr16_eliminate): the eliminations e0 .. e0 + kThreads / 16 - 1 of the rows
-// i = s (2 e + 1). Loads per lane: row c of D_i, its column of L_i (q = 0) or row of L_{i+s} (q = 1), f_i. Stores as in the 8-lane round:
-// q = 0 folds L_i^T W_L into D_{i-s}, writes the new L_{i+s} = - U_i^T W_L and W_L into the slot of D_i; q = 1 writes W_U into the slot
-// of L_i and, after the barrier (neighbouring eliminations share the surviving row between them), folds U_i^T W_U into D_{i+s}.
+// i = s (2 e + 1). Loads per lane: row c of D_i, its column of L_i (q = 0) or row of L_{i+s} (q = 1), f_i. Stores, all by column c
+// (the 8 lanes of a half row touch 64 contiguous bytes per access: conflict-free): q = 0 folds L_i^T W_L into D_{i-s}, writes the new
+// L_{i+s} = - U_i^T W_L and W_L into the slot of D_i; q = 1 writes W_U into the slot of L_i and, after the barrier (neighbouring
+// eliminations share the surviving row between them), folds U_i^T W_U into D_{i+s}.
+// A surviving row receives two updates: L^T W_L of the elimination above it (phase 1) and U^T W_U of the one below (phase 2), in that
+// order inside a round. Rounds 2 - 4 ran 32 eliminations per round; with 16, the row between the eliminations 16 j + 15 and 16 j + 16,
+// j even, would get the two in the other order - other bits in its 64 entries. A pair of rounds therefore behaves like one of the old
+// ones: the first of a pair (PAIR = 1) leaves the phase-2 update of its last group pending (registers of those lanes), the second
+// (PAIR = 2) applies it after its own barrier. PAIR = 0: a round on its own.
+struct Cr16Pending { double acc[8]; double sx; int row; };   // U^T W_U column c and (U^T P f)[c] of the elimination below `row`; row < 0: nothing pending
+template <int PAIR>
 __device__ __forceinline__ bool cr_forward_round16(double* __restrict__ D, double* __restrict__ L, double* __restrict__ f, int Nb, int s,
-                                                   int e0, int E, int bD = kBlk, int bF = 8) {
+                                                   int e0, int E, Cr16Pending& pend, int bD = kBlk, int bF = 8) {
   TEB_SOLVER_FMA
   constexpr int kW = 1;   // (profiling build) row of the per-width counters
   (void)kW;
@@ -1224,7 +1152,7 @@ __device__ __forceinline__ bool cr_forward_round16(double* __restrict__ D, doubl
       for (int k = 0; k < 8; ++k) X[k] = Li[k * 8 + c];
     }
     // what phase 1 updates is fetched now, under the elimination: nobody writes row i - s before this group does (the lower neighbour's
-    // turn at it comes after the barrier). Column c: the 8 lanes of a half row touch 64 contiguous bytes per access - conflict-free.
+    // turn at it comes after the barrier, or is pending)
     const double* Dm = D + (i - s) * bD;
 #pragma unroll
     for (int t = 0; t < 8; ++t) dm[t] = Dm[t * 8 + c];
@@ -1235,7 +1163,7 @@ __device__ __forceinline__ bool cr_forward_round16(double* __restrict__ D, doubl
   }
   // No barrier before the writes: within a level the eliminated rows i = s (2 e + 1) and the blocks read for them (D_i, L_i,
   // L_{i+s}, f_i) belong to exactly one group, a group is a quarter of a wave, and the survivors' D / f are only updated by the group(s)
-  // that eliminate their neighbours: the lower one in this phase, the upper one after the barrier.
+  // that eliminate their neighbours: the upper one in this phase, the lower one after the barrier.
   if (act) {
     double* slot = (up ? L : D) + i * bD;   // W_U -> L_i, W_L -> D_i: operands of the back substitution
 #pragma unroll
@@ -1258,7 +1186,24 @@ __device__ __forceinline__ bool cr_forward_round16(double* __restrict__ D, doubl
   __syncthreads();
   CRR(4);
   TEB_CR16_STAMP(7)
-  if (hasU && up) {
+  // phase 2. The last group of the first round of a pair keeps its update when the second round has an elimination above that row.
+  const bool keep = PAIR == 1 && grp == kThreads / 16 - 1 && e + 1 < E;
+  if (PAIR == 2 && pend.row >= 0 && up) {   // (the lanes that kept it: same group, same half)
+    double* Dp = D + pend.row * bD;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) dm[t] = Dp[t * 8 + c];
+    fm = f[pend.row * bF + c];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) Dp[t * 8 + c] = dm[t] - pend.acc[t];
+    f[pend.row * bF + c] = fm - pend.sx;
+  }
+  if (PAIR == 1) {
+    pend.row = (keep && hasU && up) ? i + s : -1;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) pend.acc[t] = acc[8 + t];
+    pend.sx = sx;
+  }
+  if (hasU && up && !keep) {
     double* Dp = D + (i + s) * bD;
 #pragma unroll
     for (int t = 0; t < 8; ++t) dm[t] = Dp[t * 8 + c];
@@ -1274,15 +1219,23 @@ __device__ __forceinline__ bool cr_forward_round16(double* __restrict__ D, doubl
   return ok;
 }
 // rows live at D + i * kBlk, L + i * kBlk (coupling of row i with the previous surviving row), f + i * 8; levels s_lo, 2 s_lo, .. < s_hi.
-// 16 eliminations per round. (Rounds 2 - 4 served an elimination with 8 lanes and widened the groups to 32 / 64 lanes at the coarse
-// levels to shorten the Schur products; with the operands read from registers a round costs a third of those and one width serves all
-// levels - tools/micro/cr_round_bench.hip keeps the 8-lane round for the comparison.)
+// (Rounds 2 - 4 served an elimination with 8 lanes, 32 per round, and widened the groups to 32 / 64 lanes at the coarse levels to shorten
+// the Schur products read from LDS; with the operands read from registers one width serves all levels -
+// tools/micro/cr_round_bench.hip keeps the 8-lane round for the comparison: same bits.)
 __device__ __forceinline__ bool cr_forward(double* __restrict__ D, double* __restrict__ L, double* __restrict__ f, int Nb, int s_lo,
                                            int s_hi, int bD = kBlk, int bF = 8) {
   bool ok = true;
+  Cr16Pending pend;
+  pend.row = -1;
   for (int s = s_lo; s < s_hi; s <<= 1) {
     const int E = (Nb - 1 - s) / (2 * s) + 1;
-    for (int e0 = 0; e0 < E; e0 += kThreads / 16) ok = cr_forward_round16(D, L, f, Nb, s, e0, E, bD, bF) && ok;
+    for (int e0 = 0; e0 < E; e0 += kThreads / 8) {
+      if (E - e0 > kThreads / 16) {
+        ok = cr_forward_round16<1>(D, L, f, Nb, s, e0, E, pend, bD, bF) && ok;
+        ok = cr_forward_round16<2>(D, L, f, Nb, s, e0 + kThreads / 16, E, pend, bD, bF) && ok;
+      } else
+        ok = cr_forward_round16<0>(D, L, f, Nb, s, e0, E, pend, bD, bF) && ok;
+    }
   }
   return ok;
 }
@@ -1684,7 +1637,7 @@ __device__ __forceinline__ void cr_copy_band(const Lds& l, int n, double* __rest
   __syncthreads();
 }
 
-constexpr int kHybridRounds = 4;   // level-0 rounds of 16 eliminations: at most 2 (kThreads / 8) = 64 odd rows are eliminated there (E0 below)
+constexpr int kHybridRounds = 2;   // level-0 rounds of 32 eliminations: at most 2 (kThreads / 8) = 64 odd rows are eliminated there (E0 below)
 // Two out-of-line copies of the solve: the band's own (no callee-saved block, above) and the one the SOLVER HELPERS of a small batch
 // call. The helper's copy keeps the plain calling convention. Reason: small-batch kernels with BOTH call sites on the no-callee-saved
 // path failed on MI355X in two builds of this round (a profiling build and the band-layout small-batch kernel specialised on the
@@ -1707,14 +1660,14 @@ template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const Ld
   const Lds l = carve(lds_base, plan);
   const int tid = threadIdx.x;
   const int Nt = 4 * n, Nb = (Nt + 7) >> 3, E = Nb >> 1;
-  // Level 0 takes up to four rounds of 16 eliminations: 64 odd rows, a band of 256 poses. A longer band has up to 20 odd rows beyond them
-  // (337 poses); further level-0 rounds for those would keep most lane groups idle, and the bands that need them are the ones the launch
-  // waits for. Those rows are not eliminated at level 0 instead: the block rows from 2 E0 on enter the compact system as they are (odd
-  // and even, coupled by their original L blocks) and are reduced by its levels, which need no extra round for them. Compact row j is
+  // Level 0 takes up to two rounds of 32 eliminations: 64 odd rows, a band of 256 poses. A longer band has up to 20 odd rows beyond them
+  // (337 poses); a third round for those would keep most lane groups idle, and the bands that need it are the ones the launch waits
+  // for. Those rows are not eliminated at level 0 instead: the block rows from 2 E0 on enter the compact system as they are (odd and
+  // even, coupled by their original L blocks) and are reduced by its levels, which need no extra round for them. Compact row j is
   // block row 2 j for j <= E0 and block row j + E0 beyond. The larger compact system always fits the band region of a launch that holds
   // the band ((Nb - 64) (2 kBlk + 8) + 14 <= 45 (2 Nb - 1) <= hbo(4 plan.S) for every Nb <= 178; the layout ends at 337 poses, Nb = 169); a
   // launch for which it did not would be refused here, not overrun.
-  constexpr int kLevel0Max = kHybridRounds * (kThreads / 16);
+  constexpr int kLevel0Max = kHybridRounds * (kThreads / 8);
   if (E > kLevel0Max && (size_t)(Nb - kLevel0Max) * (2 * kBlk + 8) + 14 > (size_t)hbo(4 * plan.S)) {
     if (tid == 0) l.ired[0] = 0;   // reported like a failed factorisation
     __syncthreads();
@@ -1768,65 +1721,104 @@ template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const Ld
   if (tid == 0) l.ired[0] = 1;
   __syncthreads();
   CRP(0);
-  // level 0: the 16 lanes of a row eliminate an odd block row i = 2 e + 1 in their registers (cr16_eliminate), operands gathered from
-  // the band copy: only the structurally non-zero entries are fetched (L_i[k][c] = 0 for c < k - 2), + lambda on the diagonal on the fly.
-  // The records of the eliminated rows - column c of W_L = P L_i in lane (0, c), of W_U = P U_i in lane (1, c), P f_i - stay in the
-  // registers of the lanes that computed them until the back substitution at the end: nothing but the read-only band copy crosses the
-  // LDS boundary during a solve.
-  const int grp = tid >> 4, c = tid & 7;
-  const bool up = (tid & 8) != 0;
+  // level 0: 8 lanes per elimination of an odd row i = 2 e + 1 (lane c owns column c of L_i, of U_i = L_{i+1}^T and, redundantly, f_i).
+  // The records W_L = P L_i, W_U = P U_i, P f_i of the eliminated rows stay in the registers of the lanes that computed them (column c
+  // each) until the back substitution at the end: nothing but the read-only band copy crosses the LDS boundary during a solve.
+  const int grp = tid >> 3, c = tid & 7;
   bool ok = true;
-  double kY[kHybridRounds][8], kf[kHybridRounds];
+  double kL[kHybridRounds][8], kU[kHybridRounds][8], kf[kHybridRounds];
 #pragma unroll
   for (int rr = 0; rr < kHybridRounds; ++rr) {
-    const int e = rr * (kThreads / 16) + grp;
+    const int e = rr * (kThreads / 8) + grp;
     const bool act = e < E0;
     const int i = 2 * e + 1;
     const bool hasU = act && (i + 1 < Nb);
-    double Y[8], wf[8], acc[16], dm[8];
-    double sx = 0, fm = 0;
-    if (rr * (kThreads / 16) < E0) {   // (uniform) this round has eliminations at all
+    double wL[8], wU[8], wf[8], o1[8], o2[8], o3[8];
+    double s1 = 0, s2 = 0;
+    if (rr * (kThreads / 8) < E0) {   // (uniform) this round has eliminations at all
       if (act) {
         gdouble_t* Hi = Hg + hbo(8 * i);         // band rows of block row i (8 i is a multiple of 4: row r of the block starts at Hi + hbo(r))
         gdouble_t* Hp = Hg + hbo(8 * (i + 1));   // ... of block row i + 1 (valid iff hasU)
-        double v[8], X[8];
+        Ldl8 F;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          v[m] = m <= c ? Hi[hbo(c) + (c - m)] : 0.0;                                       // D_i[c][m]
-          if (m == c) v[m] += lambda;
-          X[m] = up ? ((hasU && m >= c - 2) ? Hp[hbo(c) + (8 + c - m)] : 0.0)               // U_i[m][c] = L_{i+1}[c][m]
-                    : ((c >= m - 2) ? Hi[hbo(m) + (8 + m - c)] : 0.0);                      // L_i[m][c]
-          wf[m] = (8 * i + m < Nt) ? l.bv[8 * i + m] : 0.0;
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+          for (int cc = 0; cc <= r; ++cc) F.a[Ldl8::idx(r, cc)] = Hi[hbo(r) + (r - cc)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) F.a[Ldl8::idx(k, k)] += lambda;
+        double cl[8], cu[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          cl[k] = wL[k] = (c >= k - 2) ? Hi[hbo(k) + (8 + k - c)] : 0.0;                 // L_i[k][c]
+          cu[k] = wU[k] = (hasU && k >= c - 2) ? Hp[hbo(c) + (8 + c - k)] : 0.0;         // U_i[k][c] = L_{i+1}[c][k]
+          wf[k] = (8 * i + k < Nt) ? l.bv[8 * i + k] : 0.0;
         }
-        // the entries of compact row e this lane updates, fetched before the elimination (nobody else writes them in this phase)
+        ok = F.factor() && ok;
+        F.solve3(wL, wU, wf);
+        double dm[8];   // the entries of compact row e this lane updates, fetched before the products (nobody else writes them in this phase)
 #pragma unroll
         for (int aa = 0; aa < 8; ++aa) dm[aa] = Dc[e * kBlk + aa * 8 + c];
-        fm = fc[e * 8 + c];
-        ok = cr16_eliminate(v, X, Y, wf, acc, sx) && ok;
-        // fold into the compact rows e (= row i - 1) and e + 1 (= row i + 1); two phases: neighbouring eliminations share a row
-        if (!up) {
+        const double fm = fc[e * 8 + c];
 #pragma unroll
-          for (int aa = 0; aa < 8; ++aa) Dc[e * kBlk + aa * 8 + c] = dm[aa] - acc[aa];
-          fc[e * 8 + c] = fm - sx;
-          if (hasU) {
+        for (int aa = 0; aa < 8; ++aa) { o1[aa] = 0; o2[aa] = 0; o3[aa] = 0; }
+        // The operands of the products are already in the group: lane aa holds column aa of L_i (cl) and row aa of L_{i+1} (cu). They reach
+        // the other lanes through LDS in 16-byte accesses: every lane writes its 8 values as one 64-byte row of a scratch block, "column aa
+        // of L_i" is then one contiguous read for all 8 lanes (a ds_swizzle moves 4 bytes per lane and instruction through the same pipe:
+        // 196 of them per round made level 0 the most expensive round of the solve). The scratch is the L block of compact row e + 1, which
+        // this group writes below (o2) and nobody reads before; the one elimination without an upper neighbour takes the L block of
+        // compact row 0, which is never used. Same products in the same order: bit-identical.
+        double* scr = Lc + (hasU ? e + 1 : 0) * kBlk;
 #pragma unroll
-            for (int aa = 0; aa < 8; ++aa) Lc[(e + 1) * kBlk + aa * 8 + c] = -acc[8 + aa];
+        for (int k = 0; k < 8; k += 2) *reinterpret_cast<teb_v2d*>(scr + c * 8 + k) = teb_v2d{cl[k], cl[k + 1]};
+#pragma unroll
+        for (int aa = 0; aa < 8; ++aa) {
+          double lc[8];                                    // column aa of L_i
+          ld_row<8>(scr + aa * 8, lc);
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (aa >= k - 2) o1[aa] += lc[k] * wL[k];                                       // (L_i^T W_L)[aa][c]
+          if ((aa % TEB_CR_FENCE_EVERY) == TEB_CR_FENCE_EVERY - 1) { TEB_CR_SCHED_BARRIER }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s1 += cl[k] * wf[k];                                    // (L_i^T P f_i)[c]
+        if (hasU) {
+#pragma unroll
+          for (int k = 0; k < 8; k += 2) *reinterpret_cast<teb_v2d*>(scr + c * 8 + k) = teb_v2d{cu[k], cu[k + 1]};
+#pragma unroll
+          for (int aa = 0; aa < 8; ++aa) {
+            double lp[8];                                  // row aa of L_{i+1}
+            ld_row<8>(scr + aa * 8, lp);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              if (k >= aa - 2) {
+                o2[aa] -= lp[k] * wL[k];
+                o3[aa] += lp[k] * wU[k];
+              }
+            }
+            if ((aa % TEB_CR_FENCE_EVERY) == TEB_CR_FENCE_EVERY - 1) { TEB_CR_SCHED_BARRIER }
           }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) s2 += cu[k] * wf[k];                                  // (L_{i+1} P f_i)[c]
+        }
+        // fold into the compact rows e (= row i - 1) and e + 1 (= row i + 1); two phases: neighbouring eliminations share a row
+#pragma unroll
+        for (int aa = 0; aa < 8; ++aa) Dc[e * kBlk + aa * 8 + c] = dm[aa] - o1[aa];
+        fc[e * 8 + c] = fm - s1;
+        if (hasU) {
+#pragma unroll
+          for (int aa = 0; aa < 8; ++aa) Lc[(e + 1) * kBlk + aa * 8 + c] = o2[aa];
         }
       }
       __syncthreads();
-      if (hasU && up) {
+      if (hasU) {
 #pragma unroll
-        for (int aa = 0; aa < 8; ++aa) dm[aa] = Dc[(e + 1) * kBlk + aa * 8 + c];
-        fm = fc[(e + 1) * 8 + c];
-#pragma unroll
-        for (int aa = 0; aa < 8; ++aa) Dc[(e + 1) * kBlk + aa * 8 + c] = dm[aa] - acc[8 + aa];
-        fc[(e + 1) * 8 + c] = fm - sx;
+        for (int aa = 0; aa < 8; ++aa) Dc[(e + 1) * kBlk + aa * 8 + c] -= o3[aa];
+        fc[(e + 1) * 8 + c] -= s2;
       }
       __syncthreads();
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) kY[rr][k] = act ? Y[k] : 0.0;
+    for (int k = 0; k < 8; ++k) { kL[rr][k] = act ? wL[k] : 0.0; kU[rr][k] = act ? wU[k] : 0.0; }
     kf[rr] = act ? wf[c] : 0.0;
   }
   CRP(1);
@@ -1848,24 +1840,23 @@ template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const Ld
   }
 #pragma unroll
   for (int rr = 0; rr < kHybridRounds; ++rr) {
-    const int e = rr * (kThreads / 16) + grp;
+    const int e = rr * (kThreads / 8) + grp;
     const bool act = e < E0;
     const int i = 2 * e + 1;
-    // lane (0, c): x_{i-1}[c] against column c of W_L; lane (1, c): x_{i+1}[c] against column c of W_U
-    const double xs = !act ? 0.0 : !up ? fc[e * 8 + c] : (i + 1 < Nb) ? fc[(e + 1) * 8 + c] : 0.0;
+    const double xm = act ? fc[e * 8 + c] : 0.0;
+    const double xp = (act && i + 1 < Nb) ? fc[(e + 1) * 8 + c] : 0.0;
     double mine = 0;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const double pu = kY[rr][r] * xs;                       // q = 1: W_U[r][c] x_{i+1}[c]
-      double t = kY[rr][r] * xs + dpp_move<0x128>(pu);        // q = 0: W_L[r][c] x_{i-1}[c] + the partner's product (row_ror:8: lane + 8)
-      // butterfly over the 8 lanes of the half row with DPP moves (no LDS crossbar): lane ^ 1, lane ^ 2 are quad permutations; after them
-      // the four lanes of a quad hold the same value, so the mirror within the half row (lane -> 7 - lane) delivers the other quad's sum
+      double t = kL[rr][r] * xm + kU[rr][r] * xp;
+      // butterfly over the 8 lanes of the group with DPP moves (no LDS crossbar): lane ^ 1, lane ^ 2 are quad permutations; after them the
+      // four lanes of a quad hold the same value, so the mirror within the half row (lane -> 7 - lane) delivers the other quad's sum
       t += dpp_move<0xB1>(t);    // quad_perm:[1,0,3,2]
       t += dpp_move<0x4E>(t);    // quad_perm:[2,3,0,1]
       t += dpp_move<0x141>(t);   // row_half_mirror
       mine = (c == r) ? t : mine;
     }
-    if (act && !up && 8 * i + c < Nt) l.dxv[8 * i + c] = kf[rr] - mine;
+    if (act && 8 * i + c < Nt) l.dxv[8 * i + c] = kf[rr] - mine;
   }
   __syncthreads();  CRP(4);
 #undef TEB_HYB_ROW

@@ -1,5 +1,6 @@
-// Micro-benchmark of one round of the block cyclic reduction (cr_forward_round<M>) on LDS-resident blocks: cycles per round for each
-// group width with 1 .. 4 waves of the workgroup active, alone on a CU (1 workgroup) or with every CU busy (256 workgroups).
+// Micro-benchmark of one round of the block cyclic reduction on LDS-resident blocks: the product's round of 16-lane rows (operands by
+// DPP, cr_forward_round16) and the LDS-operand round of rounds 2 - 4 (cr_forward_round<M>, below) per group width, with 1 .. 4 waves of the
+// workgroup active, alone on a CU (1 workgroup) or with every CU busy (256 workgroups); and how far their results are apart.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I teb_local_planner_amd/csrc tools/micro/cr_round_bench.hip -o tools/micro/cr_round_bench
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -13,6 +14,109 @@ __shared__ long long s_stamp[16];
 #endif
 #include "teb_kernel.hpp"
 using namespace tebamd;
+
+// The round of rounds 2 - 4 (kept here for the comparison): 8 M lanes per elimination, lane (q, c) owns rows q R .. q R + R - 1 of column
+// c of the three Schur products, every lane factors D_i in its own registers (Ldl8) and streams the product operands - the whole of L_i
+// and L_{i+s} - from LDS: 196 doubles per lane and round at M = 1, the pipe the four waves share.
+namespace tebamd {
+template <int M>
+__device__ __forceinline__ bool cr_forward_round(double* __restrict__ D, double* __restrict__ L, double* __restrict__ f, int Nb, int s,
+                                                 int e0, int E, int bD = kBlk, int bF = 8) {
+  TEB_SOLVER_FMA
+  constexpr int R = 8 / M;
+  constexpr int kW = M == 1 ? 0 : M == 2 ? 1 : M == 4 ? 2 : 3;   // (profiling build) row of the per-width counters
+  (void)kW;
+  const int tid = threadIdx.x;
+  const int grp = tid / (8 * M), c = tid & 7, q = (tid >> 3) & (M - 1), a0 = q * R;
+  const int e = e0 + grp;
+  const bool act = e < E;
+  const int i = s * (2 * e + 1);
+  const bool hasU = act && (i + s < Nb);
+  bool ok = true;
+  double wL[8], wU[8], wf[8], o1[R], o2[R], o3[R];
+  double s1 = 0, s2 = 0;
+  CRR_DECL
+  if (act) {
+    const double* Di = D + i * bD;
+    const double* Li = L + i * bD;
+    const double* Lp = L + (i + s) * bD;   // U_i^T, valid iff hasU
+    Ldl8 F;
+    F.load(Di);
+    ok = F.factor();
+    CRR(0);
+    double cu[8];
+    ld_row<8>((hasU ? Lp : Li) + c * 8, cu);   // row c of L_{i+s} (an address inside the blocks even without an upper neighbour)
+    ld_row<8>(f + i * bF, wf);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      wL[k] = Li[k * 8 + c];
+      wU[k] = hasU ? cu[k] : 0.0;
+    }
+    F.solve3(wL, wU, wf);
+    CRR(1);
+#pragma unroll
+    for (int t = 0; t < R; ++t) { o1[t] = 0; o2[t] = 0; o3[t] = 0; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      double li[R];
+      ld_row<R>(Li + k * 8 + a0, li);
+#pragma unroll
+      for (int t = 0; t < R; ++t) o1[t] += li[t] * wL[k];
+      s1 += Li[k * 8 + c] * wf[k];
+      if ((k % TEB_CR_FENCE_EVERY) == TEB_CR_FENCE_EVERY - 1) { TEB_CR_SCHED_BARRIER }
+    }
+    if (hasU) {
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+        double lp[8];
+        ld_row<8>(Lp + (a0 + t) * 8, lp);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          o2[t] -= lp[k] * wL[k];
+          o3[t] += lp[k] * wU[k];
+        }
+        if ((t % TEB_CR_FENCE_EVERY) == TEB_CR_FENCE_EVERY - 1) { TEB_CR_SCHED_BARRIER }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s2 += cu[k] * wf[k];
+    }
+  }
+  CRR(2);
+  // No barrier before the writes: within a level the eliminated rows i = s (2 e + 1) and the blocks read for them (D_i, L_i,
+  // L_{i+s}, f_i) belong to exactly one group, a group never straddles two waves (8 M <= 64), and the survivors' D / f are only written
+  // (never read) in this level.
+  if (act) {
+    double* Dm = D + (i - s) * bD;
+    double* Di = D + i * bD;
+    double* Li = L + i * bD;
+#pragma unroll
+    for (int t = 0; t < R; ++t) Dm[(a0 + t) * 8 + c] -= o1[t];
+    if (hasU) {
+      double* Lp = L + (i + s) * bD;
+#pragma unroll
+      for (int t = 0; t < R; ++t) Lp[(a0 + t) * 8 + c] = o2[t];
+    }
+    if (q == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { Di[k * 8 + c] = wL[k]; Li[k * 8 + c] = wU[k]; }
+      f[(i - s) * bF + c] -= s1;
+      f[i * bF + c] = wf[c];
+    }
+  }
+  CRR(3);
+  __syncthreads();
+  CRR(4);
+  if (hasU) {
+    double* Dp = D + (i + s) * bD;
+#pragma unroll
+    for (int t = 0; t < R; ++t) Dp[(a0 + t) * 8 + c] -= o3[t];
+    if (q == 0) f[(i + s) * bF + c] -= s2;
+  }
+  __syncthreads();
+  CRR(5);
+  return ok;
+}
+}  // namespace tebamd
 
 template <int M>
 __global__ void __launch_bounds__(kThreads) round_kernel(int Nb, int s, int E, int reps, long long* cycles, double* sink) {
@@ -52,7 +156,7 @@ __global__ void __launch_bounds__(kThreads) round16_kernel(int Nb, int s, int E,
   bool ok = true;
   const long long t0 = clock64();
   for (int r = 0; r < reps; ++r)
-    for (int e0 = 0; e0 < E; e0 += kThreads / 16) ok = cr_forward_round16(D, L, f, Nb, s, e0, E) && ok;
+    ok = cr_forward(D, L, f, 2 * E + 1, s, 2 * s) && ok;   // one level: ceil(E / 16) rounds
   const long long t1 = clock64();
   if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
   if (!ok && threadIdx.x == 0) sink[0] = D[0];
@@ -106,7 +210,7 @@ __global__ void __launch_bounds__(kThreads) level_kernel(int Nb, int E, double* 
   __syncthreads();
   bool ok = true;
   if (WHICH == 0) { for (int e0 = 0; e0 < E; e0 += kThreads / 8) ok = cr_forward_round<1>(D, L, f, Nb, 1, e0, E) && ok; }
-  else { for (int e0 = 0; e0 < E; e0 += kThreads / 16) ok = cr_forward_round16(D, L, f, Nb, 1, e0, E) && ok; }
+  else ok = cr_forward(D, L, f, Nb, 1, 2);   // one level
   __syncthreads();
   for (int q = threadIdx.x; q < (2 * Nb * kBlk + Nb * 8); q += kThreads) out[q] = lds[q];
   if (threadIdx.x == 0) out[2 * Nb * kBlk + Nb * 8] = ok ? 1.0 : 0.0;
