@@ -699,6 +699,26 @@ def main():
                     k1, w1, _ = time_solver(torch, s1, cc, 3)
                     s1.close()
                     sec[nm]["one_cu_per_band"] = {"kernel_ms": k1, "ms_per_step": w1}
+                # the reference's own code and its second build on the same bands (checker, outside every timed region): VERDICT r04 item 6
+                try:
+                    from oracle import ref_py as _rp, refcode_compare as _RC
+                    if os.path.exists(_rp.SO):
+                        pack = _rp.optimize_batch(cc, oo, vv, bb, threads=min(bb.count, os.cpu_count() or 1), trace=True)
+                        sx = planner.make_solver(cc, oo, vv, bb)
+                        sx.set_iteration_log(True)
+                        sx.optimize(cc.optim.no_inner_iterations, cc.optim.no_outer_iterations, True, cc.hcp.selection_obst_cost_scale,
+                                    cc.hcp.selection_viapoint_cost_scale, cc.hcp.selection_alternative_time_cost)
+                        rx2 = sx.results(); ox2 = sx.download(bb.copy()); tx2 = [sx.iteration_log(b) for b in range(bb.count)]
+                        sx.close()
+                        rp = _RC.compare_with_reference_code(ox2, rx2, tx2, pack[0], pack[1], pack[2], pack[4])
+                        rr = noise_floor(_RC, cc, oo, vv, bb, pack, ox2, bb.count)
+                        sec[nm]["vs_reference_code"] = {
+                            "bands": rp["bands"], "pose_counts_equal": rp["pose_counts_equal"], "success_equal": rp["success_equal"],
+                            "lm_sequences_equal": rp["lm_sequences_equal"], "bands_outside_T3": rp["bands_outside_T3"], "state_err": rp["state_err"],
+                            "best_index_equal": bool(int(_RC.select_best_of_costs(rx2.cost)) == int(_RC.select_best_of_costs(pack[2]))),
+                            "ref_vs_ref": {k: rr.get(k) for k in ("bands_outside_T3", "state_err", "pose_counts_equal", "device_over_ref_vs_ref", "error") if k in rr}}
+                except Exception as e:   # noqa: BLE001
+                    sec[nm]["vs_reference_code"] = {"error": str(e)[:200]}
             out["secondary"] = sec
 
         # ---- CPU baseline: the oracle in the reference-faithful mode (g2o central differences), thread per TEB

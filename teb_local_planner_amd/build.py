@@ -155,8 +155,9 @@ def build(force=False, verbose=False, variant="product", jobs=None, extra_define
         newest = newest_kernel if src == "teb_opt_inst.hip" else newest_all
         if not force and os.path.exists(o) and os.path.getmtime(o) >= newest:
             return o
-        if src == "teb_amd.hip":   # the host side carries the kernel sources for the run-time compiler (teb_rtc.hpp)
-            defs = defs + ["-DTEB_AMD_RTC_EMBEDDED", "-I" + os.path.dirname(embedded)]
+        if src == "teb_amd.hip":   # the host side carries the kernel sources for the run-time compiler (teb_rtc.hpp) and the variant's defines
+            defs = defs + ["-DTEB_AMD_RTC_EMBEDDED", "-I" + os.path.dirname(embedded),
+                           '-DTEB_AMD_VARIANT_DEFINES="%s"' % " ".join(list(v["defines"]) + list(extra_defines))]
         cmd = [hipcc] + HIPCC_FLAGS + v["defines"] + list(extra_defines) + defs + list(unit_flags.get(obj, [])) + ["-c", os.path.join(CSRC, src), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)

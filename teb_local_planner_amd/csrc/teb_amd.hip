@@ -325,6 +325,9 @@ int profile_matches(const teb_amd_handle* h, const OptArgs& args, const SceneDev
 std::shared_ptr<RtcKernel> rtc_lookup(const teb_amd_handle* h, const OptArgs& args, const SceneDev& sc, int solver, bool small, int pf, bool wait) {
   if (!((pf != 1 || h->opt.compile_for_config >= 3) && h->opt.compile_for_config > 0 && !h->opt.generic_config_path && !args.debug_linearize)) return nullptr;   // (3: even for a default configuration - measurement only)
   const teb_amd_config_t& c = h->cfg;
+#ifdef TEB_AMD_ANALYTIC_ONLY
+  if (c.jacobian_mode != TEB_AMD_JACOBIAN_ANALYTIC) return nullptr;   // this variant has no numeric mode: the run-time compiler must not add one
+#endif
   RtcKey key;
   key.flags = 0;
   int bit = 0;
@@ -742,7 +745,7 @@ int teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max
   A(h->chi2.alloc(max_tebs)); A(h->cost.alloc(max_tebs)); A(h->lambda.alloc(max_tebs));
   A(h->Hbackup.alloc((size_t)max_tebs * h->hmat_stride));
   A(h->clk.alloc(4));
-  h->hband_stride = solver == SOLVER_BANDG ? (size_t)hbo(4 * max_poses) + 2 : 0;
+  h->hband_stride = solver == SOLVER_BANDG ? (((size_t)hbo(4 * max_poses) + 2 + 1) & ~(size_t)1) : 0;   // even: the bands' slices are zeroed in 16-byte stores
   A(h->Hband.alloc((size_t)max_tebs * h->hband_stride));
   A(h->snap_n.alloc(max_tebs)); A(h->snap_x.alloc(BS)); A(h->snap_y.alloc(BS)); A(h->snap_th.alloc(BS)); A(h->snap_dt.alloc(BS));
   A(h->dbg_H.alloc((size_t)4 * max_poses * kBand)); A(h->dbg_b.alloc((size_t)4 * max_poses)); A(h->dbg_chi2.alloc(4));
@@ -847,7 +850,7 @@ int commit_obstacles(teb_amd_handle* h) {
       (size_t)make_lds_plan(h->stride, SOLVER_BAND, M).total_bytes > h->lds_limit &&
       (size_t)make_lds_plan(h->stride, SOLVER_BANDG, M).total_bytes <= h->lds_limit) {
     if (h->hband_stride == 0) {
-      h->hband_stride = (size_t)hbo(4 * h->stride) + 2;
+      h->hband_stride = ((size_t)hbo(4 * h->stride) + 2 + 1) & ~(size_t)1;
       h->Hband.free();
       HIPCHK(h->Hband.alloc((size_t)h->max_tebs * h->hband_stride));
     }

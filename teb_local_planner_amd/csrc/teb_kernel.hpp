@@ -76,8 +76,10 @@ __host__ __device__ inline int nb_for(int S) { return (4 * S + 7) / 8; }
 __host__ __device__ inline size_t hmat_doubles(int S, int solver) {  // (LDS-resident part)
   if (solver == SOLVER_BANDG) return (size_t)6 * S + 256;   // only the scratch of autoResize (edit script + new poses + split stack + runs)
   if (solver == SOLVER_CR) return (size_t)nb_for(S) * (2 * kBlk + 8);
-  const size_t band = (size_t)hbo(4 * S), compact = (size_t)((nb_for(S) + 1) / 2) * (2 * kBlk + 8);   // hybrid solve: even block rows in LDS
-  return band > compact ? band : compact;
+  // hybrid solve: even block rows in LDS (+ up to 14 doubles between its D and L regions, cr_solve_hybrid_impl). Rounded up to an even
+  // count: the regions behind it (b, dx) are zeroed and copied in 16-byte accesses and must start on 16-byte boundaries (45 S is odd for odd S).
+  const size_t band = (size_t)hbo(4 * S), compact = (size_t)((nb_for(S) + 1) / 2) * (2 * kBlk + 8) + 14;
+  return ((band > compact ? band : compact) + 1) & ~(size_t)1;
 }
 // per-band HBM scratch of the solves: SOLVER_CR keeps a copy of H there; SOLVER_BAND / BANDG the 8x8 blocks (D, L, f) the reduction
 // works on (the hybrid solve only reads them)

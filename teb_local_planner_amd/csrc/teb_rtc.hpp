@@ -17,6 +17,7 @@
 // keyed by the sources' hash, the flag values, the instantiation and the compiler's version, written atomically, checked on load.
 #pragma once
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -110,9 +111,40 @@ inline unsigned long long rtc_fnv(const void* data, size_t n, unsigned long long
   return h;
 }
 
+// The defines of the build variant this library is (build.py passes them to the host translation unit, e.g. "-DTEB_AMD_MFMA_SCHUR
+// -DTEB_AMD_ANALYTIC_ONLY" for libteb_amd_mfma.so): a kernel compiled at run time has to be the SAME variant as the pre-built ones it
+// replaces mid-run - other Schur arithmetic would change the bands when the module becomes ready - and they are part of
+// the disk-cache key (two variants of the library must not share code objects).
+#ifndef TEB_AMD_VARIANT_DEFINES
+#define TEB_AMD_VARIANT_DEFINES ""
+#endif
+inline std::vector<std::string> rtc_variant_defines() {
+  std::vector<std::string> out;
+  const std::string all = TEB_AMD_VARIANT_DEFINES;
+  size_t i = 0;
+  while (i < all.size()) {
+    while (i < all.size() && all[i] == ' ') ++i;
+    size_t j = i;
+    while (j < all.size() && all[j] != ' ') ++j;
+    if (j > i) out.push_back(all.substr(i, j - i));
+    i = j;
+  }
+  return out;
+}
+
 struct RtcCache {
   std::mutex mu;
   std::map<RtcKey, std::shared_ptr<RtcKernel>> kernels;
+  // the compiler threads, joined when the library goes (exit, dlclose): a thread still inside hiprtcCompileProgram must not outlive the
+  // function-local statics it uses (this object, rtc_api()). rtc_api() is constructed first, i.e. destroyed after this object.
+  std::vector<std::thread> workers;
+  RtcCache() { (void)rtc_api(); }
+  ~RtcCache() { join_workers(); }
+  void join_workers() {
+    std::vector<std::thread> w;
+    { std::lock_guard<std::mutex> lock(mu); w.swap(workers); }
+    for (std::thread& t : w) if (t.joinable()) t.join();
+  }
   std::string csrc_dir, rocm_include, disk_dir;
   unsigned long long source_hash = 0;
   bool embedded = false;        // the sources compiled are the copy inside the library
@@ -194,10 +226,22 @@ inline std::string rtc_disk_path(const RtcEnv& env, unsigned long long key) {
   snprintf(name, sizeof name, "/%016llx.co", key);
   return env.disk_dir + name;
 }
+// A code object read from disk runs in this process's GPU context: the directory has to be the user's own (owner = effective uid, no
+// write permission for group / others) and the file is opened without following a symbolic link. The checksum inside the file detects
+// corruption (a torn write, a bad disk); it is no protection against someone who can write the directory - the ownership test is.
+inline bool rtc_disk_dir_trusted(const std::string& dir) {
+  struct stat st;
+  if (lstat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+  return st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
 inline bool rtc_disk_load(const RtcEnv& env, unsigned long long key, RtcKernel& k) {
-  if (env.disk_dir.empty()) return false;
-  FILE* f = fopen(rtc_disk_path(env, key).c_str(), "rb");
-  if (!f) return false;
+  if (env.disk_dir.empty() || !rtc_disk_dir_trusted(env.disk_dir)) return false;
+  const int fd = open(rtc_disk_path(env, key).c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+  if (fd < 0) return false;
+  struct stat fst;
+  if (fstat(fd, &fst) != 0 || !S_ISREG(fst.st_mode) || fst.st_uid != geteuid()) { close(fd); return false; }
+  FILE* f = fdopen(fd, "rb");
+  if (!f) { close(fd); return false; }
   bool ok = false;
   char magic[8];
   unsigned long long fkey = 0, clen = 0, sum = 0;
@@ -222,12 +266,15 @@ inline bool rtc_disk_store(const RtcEnv& env, unsigned long long key, const RtcK
   const size_t slash = env.disk_dir.find_last_of('/');
   if (slash != std::string::npos && slash > 0) (void)mkdir(env.disk_dir.substr(0, slash).c_str(), 0700);
   (void)mkdir(env.disk_dir.c_str(), 0700);
+  if (!rtc_disk_dir_trusted(env.disk_dir)) return false;   // (somebody else's directory, or one others can write: no cache)
   const std::string path = rtc_disk_path(env, key);
   char tmp[64];
   snprintf(tmp, sizeof tmp, ".tmp.%ld", (long)getpid());
   const std::string tpath = path + tmp;
-  FILE* f = fopen(tpath.c_str(), "wb");
-  if (!f) return false;
+  const int fd = open(tpath.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+  if (fd < 0) return false;
+  FILE* f = fdopen(fd, "wb");
+  if (!f) { close(fd); (void)unlink(tpath.c_str()); return false; }
   const unsigned int llen = (unsigned int)k.lowered.size();
   const unsigned long long clen = k.code.size(), sum = rtc_fnv(k.code.data(), k.code.size());
   bool ok = fwrite("TEBRTC01", 1, 8, f) == 8 && fwrite(&key, 8, 1, f) == 1 && fwrite(&llen, 4, 1, f) == 1 && fwrite(&clen, 8, 1, f) == 1 &&
@@ -248,6 +295,7 @@ inline void rtc_compile(const RtcKey key, std::shared_ptr<RtcKernel> k, const Rt
   std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                                    "-DM_PI=3.14159265358979323846", "-DHUGE_VAL=__builtin_huge_val()",   // (hipRTC's built-in headers lack the two math.h macros)
                                    "-DTEB_AMD_DEFAULTS_PROFILE=1", "-DTEB_AMD_PROFILE_CUSTOM=1"};
+  for (const std::string& d : rtc_variant_defines()) opts.push_back(d);   // (part of the disk key below: the options are hashed)
   const std::vector<std::string>& names = rtc_flag_names();
   for (size_t i = 0; i < names.size(); ++i) opts.push_back("-DTEB_PF_VALUE_" + names[i] + "=" + (((key.flags >> i) & 1ull) ? "true" : "false"));
   // the key of the disk cache: sources, options (flag values, target), instantiation, compiler version
@@ -314,7 +362,7 @@ inline std::shared_ptr<RtcKernel> rtc_request(const RtcKey& key, bool wait, std:
       c.kernels[key] = k;
       RtcEnv env;
       env.csrc_dir = c.csrc_dir; env.rocm_include = c.rocm_include; env.disk_dir = c.disk_dir; env.source_hash = c.source_hash; env.embedded = c.embedded;
-      std::thread(rtc_compile, key, k, env).detach();
+      c.workers.emplace_back(rtc_compile, key, k, env);   // joined by ~RtcCache / teb_amd_debug_rtc_join
     }
   }
   if (wait)

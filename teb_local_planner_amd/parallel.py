@@ -109,3 +109,56 @@ class RcclComm:
             self.close()
         except Exception:
             pass
+
+
+def broadcast_band(owner_rank, band, capacity, local_status=0, group=None, device=None):
+    """Mirror of teb_amd_broadcast_band (csrc/teb_amd.hip) on a torch.distributed group: round 1 an all-gather of (status, capacity) per
+    rank - every rank learns of a peer's error or of differing capacities BEFORE the broadcast and all return the same verdict -, round
+    2 the winner's strip [n | x | y | theta | dt | statistics] from its owner. band: (x, y, theta, dt, available, back_chi2) on the owner
+    (ignored elsewhere). Returns (ok, band or None)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rec = torch.tensor([float(local_status), float(capacity)], dtype=torch.float64, device=device)
+    out = [torch.empty_like(rec) for _ in range(world)]
+    dist.all_gather(out, rec, group=group)
+    allv = torch.stack(out).cpu().numpy()
+    if (allv[:, 0] != 0).any() or (allv[:, 1] != capacity).any():
+        return False, None
+    msg = torch.zeros(3 + 4 * capacity, dtype=torch.float64, device=device)
+    if dist.get_rank(group) == owner_rank:
+        x, y, th, dt, avail, back = band
+        n = len(x)
+        msg[0] = n
+        for k, a in enumerate((x, y, th)):
+            msg[1 + k * capacity:1 + k * capacity + n] = torch.as_tensor(np.asarray(a, np.float64))
+        msg[1 + 3 * capacity:1 + 3 * capacity + n - 1] = torch.as_tensor(np.asarray(dt, np.float64))
+        msg[1 + 4 * capacity] = float(avail); msg[2 + 4 * capacity] = float(back)
+    dist.broadcast(msg, src=owner_rank, group=group)
+    m = msg.cpu().numpy()
+    n = int(m[0])
+    if n > capacity:
+        return False, None
+    return True, (m[1:1 + n].copy(), m[1 + capacity:1 + capacity + n].copy(), m[1 + 2 * capacity:1 + 2 * capacity + n].copy(),
+                  m[1 + 3 * capacity:1 + 3 * capacity + max(n - 1, 0)].copy(), bool(m[1 + 4 * capacity]), float(m[2 + 4 * capacity]))
+
+
+def sharded_plan_exchange(local_ok, local_record, local_bands, owner_of, capacity, fail_inside_selection=False, group=None, device=None):
+    """The collective sequence of HomotopyClassPlannerAmd::plan() in its sharded mode (host/teb_amd_hcp_backend.cpp), as the ranks of a
+    torch.distributed group run it - what keeps a tick deadlock-free when ONE rank fails somewhere in its own work:
+      1. every rank enters the selection all-gather; a rank whose exploration / upload / optimisation failed (local_ok False) sends the
+         unusable record; a rank on which the selection call itself fails AFTER its record went out (fail_inside_selection) learns the
+         peers' choice all the same;
+      2. no rank holds a candidate (index < 0): every rank sees that and none enters the broadcast;
+      3. otherwise every rank - the failed ones too - enters the broadcast of the winner's band, statistics included.
+    local_record: (cost, global index) of this rank's best candidate; local_bands: {global index: band tuple}; owner_of(global index) -> rank.
+    Returns (ok, global index, band): ok False on the rank that failed, the winner and its band on every rank that can know them."""
+    cost, index = local_record if local_ok else UNUSABLE_RECORD
+    gc, gi = select_best_distributed(cost, index, group=group, device=device)
+    if fail_inside_selection:
+        local_ok = False            # (teb_amd_select_best_distributed returned this rank's error together with the peers' choice)
+    if gi < 0:
+        return local_ok, -1, None
+    owner = owner_of(gi)
+    ok, band = broadcast_band(owner, local_bands.get(gi), capacity, group=group, device=device)
+    return bool(local_ok and ok), gi, band

@@ -55,6 +55,22 @@ def _worker(rank, world, port, case, q):
             c, i = parallel.UNUSABLE_RECORD if failed else parallel.local_best(costs[lo:hi], offset=lo)
             gc, gi = parallel.select_best_distributed(c, i)
             q.put((rank, gc, gi, failed, lo, hi))
+        elif isinstance(case, str) and case.startswith("sharded_plan"):
+            # HomotopyClassPlannerAmd::plan() sharded (host/teb_amd_hcp_backend.cpp): selection all-gather -> winner broadcast, with rank 1
+            # failing (a) before the selection (exploration / optimise error), (b) inside the selection call after its record went out
+            costs = np.array([5.0, 1.0, 9.0, 3.0, 7.0, 4.0])
+            lo, hi = parallel.shard_range(len(costs), rank, world)
+            bands = {g: (np.arange(4.0) + g, np.arange(4.0) * 2 + g, np.zeros(4) + 0.1 * g, np.ones(3) * (1 + g), g % 2 == 0, 10.0 * g) for g in range(lo, hi)}
+            owner_of = lambda g: next(r for r in range(world) if parallel.shard_range(len(costs), r, world)[0] <= g < parallel.shard_range(len(costs), r, world)[1])
+            failing = rank == 1
+            mode = case.split(":")[1]
+            if mode == "nobody_has_a_candidate":
+                out = parallel.sharded_plan_exchange(True, parallel.UNUSABLE_RECORD, {}, owner_of, 8)
+            else:
+                out = parallel.sharded_plan_exchange(not (failing and mode == "before"), parallel.local_best(costs[lo:hi], offset=lo), bands, owner_of, 8,
+                                                     fail_inside_selection=failing and mode == "inside")
+            ok, gi, band = out
+            q.put((rank, ok, gi, None if band is None else [np.asarray(a).tolist() if hasattr(a, "__len__") else a for a in band], lo, hi))
         else:
             res = []
             for cs in case:
@@ -138,3 +154,27 @@ def test_a_failing_rank_sends_the_unusable_record_and_nobody_hangs(world):
     want = int(np.argmin(masked))
     for rank, gc, gi, failed, lo, hi in outs:
         assert gi == want and gc == costs[want], (rank, gc, gi, want)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("mode", ["before", "inside", "nobody_has_a_candidate"])
+def test_sharded_plan_tick_survives_a_failing_rank(world, mode):
+    """The collective sequence of the sharded HomotopyClassPlannerAmd::plan() (parallel.sharded_plan_exchange mirrors
+    host/teb_amd_hcp_backend.cpp): rank 1 fails before the selection (its candidates take no part) or inside the selection
+    call after its record went out (its candidate may still win: the peers saw a valid record) - either way every rank passes the
+    all-gather AND the broadcast, the healthy ranks hold the winner's band with its batch statistics, the failed rank reports False."""
+    outs = _run(world, "sharded_plan:" + mode)
+    costs = np.array([5.0, 1.0, 9.0, 3.0, 7.0, 4.0])
+    lo1, hi1 = parallel.shard_range(len(costs), 1, world)
+    if mode == "nobody_has_a_candidate":
+        assert all(ok and gi == -1 and band is None for _, ok, gi, band, _, _ in outs)
+        return
+    masked = costs.copy()
+    if mode == "before":
+        masked[lo1:hi1] = np.inf
+    want = int(np.argmin(masked))
+    for rank, ok, gi, band, lo, hi in outs:
+        assert gi == want, (rank, gi, want)
+        assert ok == (rank != 1)
+        assert band is not None and band[0] == (np.arange(4.0) + want).tolist() and band[3] == [1.0 + want] * 3
+        assert band[4] == (want % 2 == 0) and band[5] == 10.0 * want            # the statistics hasDiverged reads came with the band

@@ -66,3 +66,44 @@ def test_measured_configurations_pass_with_the_matrix_build():
     print(r.stdout[-3000:], r.stderr[-1000:])
     assert r.returncode == 0, r.stdout[-3000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+_RTC_CHILD = r'''
+import hashlib, json, sys, tempfile, os
+os.environ["TEB_AMD_RTC_CACHE"] = tempfile.mkdtemp()
+import numpy as np
+from teb_local_planner_amd import planner, scenes, _abi
+def run(**opt):
+    cfg, obst, via, batch = scenes.scene_c3(B=8, n=120, M=80, stride=208)
+    cfg.optim.weight_shortest_path = 1.0          # off the defaults: the matrix build launches its generic kernel, or the one compiled for it
+    s = planner.make_solver(cfg, obst, via, batch, options=_abi.Options(**opt))
+    s.optimize(5, 4, True, 100.0, 1.0, False); s.synchronize()
+    out = s.download(batch.copy()); r = s.results()
+    h = hashlib.sha256()
+    for a in (out.n, out.x, out.y, out.theta, out.dt, r.cost, r.chi2, r.lm_trials): h.update(np.ascontiguousarray(a).tobytes())
+    p = s.last_config_profile(); s.close()
+    return h.hexdigest(), p
+a, pa = run()
+b, pb = run(compile_for_config=2)
+cfg, obst, via, batch = scenes.scene_c1(); cfg.jacobian_mode = _abi.JACOBIAN_G2O_NUMERIC
+try:
+    s = planner.make_solver(cfg, obst, via, batch, options=_abi.Options(compile_for_config=2)); s.optimize(5, 4, True, 100.0, 1.0, False); numeric = "ran"
+except planner.TebAmdError as e:
+    numeric = "refused"
+print(json.dumps(dict(same=a == b, prebuilt=pa, compiled=pb, numeric=numeric)))
+'''
+
+
+def test_run_time_compiled_kernel_is_the_same_variant():
+    """ADVICE r04: a kernel compiled at run time (teb_amd_options_t::compile_for_config) in the MATRIX build carries the build's defines
+    (-DTEB_AMD_MFMA_SCHUR ..: csrc/teb_rtc.hpp appends TEB_AMD_VARIANT_DEFINES to the compiler's options and to the disk-cache key), so it
+    is the same arithmetic as the pre-built kernels it replaces mid-run - bit-identical bands - and it does not add the numeric Jacobian
+    mode to a variant that was built without it."""
+    import json
+    r = subprocess.run([sys.executable, "-c", _RTC_CHILD], env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=600)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["compiled"] == 4 and d["prebuilt"] != 4          # the second run launched the instantiation compiled for the configuration
+    assert d["same"], d
+    assert d["numeric"] == "refused"

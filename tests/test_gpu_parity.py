@@ -526,11 +526,12 @@ def test_empty_scene_and_minimal_and_ragged_bands(oracle):
     np.testing.assert_allclose(res.cost[:4], rres.cost[:4], rtol=1e-8)
 
 
-@pytest.mark.parametrize("n,solver", [(238, "cr"), (336, "band"), (338, "bandg"), (500, "bandg"), (512, "bandg")])
+@pytest.mark.parametrize("n,solver", [(238, "cr"), (336, "band"), (337, "band"), (338, "bandg"), (500, "bandg"), (501, "bandg"), (512, "bandg")])
 def test_maximum_pose_capacities(oracle, n, solver):
     """S = 238 is the largest band the block-cyclic-reduction solver holds in LDS (without the obstacle cache), S = 337 the largest for
     the band in LDS (45 doubles per pose: one padding double against bank conflicts); longer bands (the reference's max_samples default is 500) keep the band form of the normal matrix in HBM, up to
-    512 poses (two per lane)."""
+    512 poses (two per lane). 337 and 501: odd capacities (45 S is odd: the regions behind the band must still start on 16-byte
+    boundaries)."""
     cfg, obst, via, _ = scenes.scene_small_mixed(footprint="point")
     cfg.trajectory.teb_autosize = False
     cfg.trajectory.max_samples = 500

@@ -10,9 +10,10 @@ the closed-form mode (the benchmarked one) and in the g2o-numeric mode (the refe
 
 What is asserted, per configuration and mode (SURVEY section 8(c), T3 "vs the faithful oracle"):
   * same success flag on every band;
-  * pose counts after the four autoResize / optimise rounds agree on at least POSE_COUNT_FLOOR of the bands;
-  * of the bands whose pose count agrees, at least T3_FLOOR are within T3 (<= 1e-3 m / rad / s, chi^2 <= 1e-3 relative) of the
-    reference's result; every band that is not is PRINTED with the LM iteration at which the two runs part (the accept / reject
+  * pose counts after the four autoResize / optimise rounds agree on every band (POSE_COUNT_FLOOR = 1);
+  * the bands that are NOT within T3 (<= 1e-3 m / rad / s, chi^2 <= 1e-3 relative) of the reference's result are exactly bands on which
+    two builds of the reference are not within T3 of each other (round 5; a floor of 97 % of the bands before: seven bands could drift
+    where none or three do); every such band is PRINTED with the LM iteration at which the two runs part (the accept / reject
     sequence, or - same decisions throughout - the first chi^2 that differs by 1e-6) - and for each of them the CPU oracle's own two
     Jacobian modes must disagree as well (by more than 2e-6 on that band, i.e. tests/sensitivity.py does not call it well conditioned):
     the distance is the reference's numeric-differentiation noise acting on an ill-conditioned band, not the device;
@@ -37,8 +38,7 @@ from oracle import ref_py, ref_alt_py, refcode_compare as RC  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 THREADS = os.cpu_count() or 1
-POSE_COUNT_FLOOR = 0.97
-T3_FLOOR = 0.97
+POSE_COUNT_FLOOR = 1.0    # (0.97 until round 4; every band of every measured configuration ends with the reference's pose count)
 NUMERIC_STATE_FLOOR = 0.95
 
 CASES = {
@@ -125,8 +125,9 @@ def test_measured_configuration_matches_reference_code(oracle, name, mode):
         assert per_band[b] is None or per_band[b] >= 0.1 * o["state_err"] or per_band[b] >= RC.T3_STATE, (o, per_band[b])
     print("   reference vs its second build: state err %s, outside T3 %d (bands %s), best index %d; device / (K x that) worst %.2f" % (
         rr["state_err"], rr["bands_outside_T3"], [o["band"] for o in rr["outside"]], best_alt, worst))
-    inside = rep["pose_counts_equal"] - rep["bands_outside_T3"]
-    assert inside >= int(np.floor(T3_FLOOR * rep["pose_counts_equal"])), rep
+    # beyond T3 only where the reference's own two builds are beyond T3 of each other (or end with different pose counts)
+    noisy = {o["band"] for o in rr["outside"]} | {b for b in range(B) if per_band[b] is None}
+    assert {o["band"] for o in rep["outside"]} <= noisy, ([o["band"] for o in rep["outside"]], sorted(noisy))
     # every band beyond T3 (or with another pose count) must be one on which the reference's own linearisation noise decides: the CPU
     # oracle's two Jacobian modes - neither involves the device - disagree there too
     suspects = [o["band"] for o in rep["outside"]] + [o["band"] for o in rep["pose_count_mismatch"]]
