@@ -56,8 +56,10 @@ def latency_model(probe, n, inner_trials, static_edges_per_pose, dyn_near_per_po
     # sides through it (7 forward + 1 scale + 7 backward dependent steps), 8-term Schur dot products, read-modify-write of the
     # neighbours in two barrier-separated phases
     factor = 8 * (rcp + 2 * fma)
-    round_lds = lds + factor + 15 * fma + 8 * fma + 2 * (lds + bar)
-    round_l2 = l2 + factor + 15 * fma + 8 * fma + lds + 2 * (lds + bar)          # level 0 of the hybrid solve gathers from the band copy (L2)
+    # (round 5) levels on LDS blocks: 16 lanes per elimination, 16 eliminations per round, the operands of the pivot chain and of the
+    # substitutions come from the neighbours' registers: one more lane-to-lane move per pivot (half a two-dword DPP move: dpp / 2)
+    round_lds = lds + factor + 8 * dpp / 2 + 15 * fma + 8 * fma + 2 * (lds + bar)
+    round_l2 = l2 + factor + 15 * fma + 8 * fma + lds + 2 * (lds + bar)          # level 0 of the hybrid solve gathers from the band copy (L2): 8-lane groups, 32 per round
     rounds = 0
     e = nb // 2                                                                  # eliminations of level 0
     solve = 0.0
@@ -72,8 +74,8 @@ def latency_model(probe, n, inner_trials, static_edges_per_pose, dyn_near_per_po
     levels = 0
     while s_ < m:
         el = (m - 1 - s_) // (2 * s_) + 1
-        solve += ((el + 31) // 32) * round_lds
-        rounds += (el + 31) // 32
+        solve += ((el + 15) // 16) * round_lds
+        rounds += (el + 15) // 16
         levels += 1
         s_ *= 2
     solve += lds + factor + 15 * fma                                             # top block
@@ -448,6 +450,27 @@ def main():
                 out["roofline"]["latency_model"] = lm
         except Exception as e:   # noqa: BLE001
             out["roofline"]["latency_model"] = {"error": str(e)[:200]}
+        # phase split measured on the PRODUCT kernel (teb_amd_set_phase_log: s_memtime at the phase boundaries, lane 0 of every band's
+        # workgroup), one extra launch outside the timed region; the same launch with the log off beside it
+        try:
+            s.set_phase_log(True)
+            s.restore(); torch.cuda.synchronize()
+            hp.optimizeAllTEBs(inner, outer); s.synchronize()
+            k_on = float(s.last_kernel_ms())
+            plog = s.phase_log()
+            s.set_phase_log(False)
+            tot = plog[:, :7].sum(axis=1)
+            slow = int(np.argmax(plog[:, 8]))
+            share = plog[:, :7] / np.maximum(tot[:, None], 1.0)
+            out["roofline"]["phases"] = {
+                "what": "shader cycles per phase of every band's workgroup in the product kernel (include/teb_amd_debug.h: teb_amd_set_phase_log)",
+                "share_mean_of_bands": {nm: float(share[:, k].mean()) for k, nm in enumerate(planner.TebBatchSolver.PHASES)},
+                "share_slowest_band": {nm: float(share[slow, k]) for k, nm in enumerate(planner.TebBatchSolver.PHASES)},
+                "slowest_band": slow, "slowest_band_mcycles": float(plog[slow, 8]) * 1e-6, "covered": float((tot / np.maximum(plog[:, 8], 1.0)).mean()),
+                "cu_utilisation_mean_over_max": float(plog[:, 8].mean() / plog[:, 8].max()),
+                "kernel_ms_with_the_log": k_on, "kernel_ms_without": kms, "instrumented_over_product": k_on / kms}
+        except Exception as e:   # noqa: BLE001
+            out["roofline"]["phases"] = {"error": str(e)[:200]}
         if traffic_note:
             out["roofline"]["traffic_note"] = traffic_note
         if fp64:

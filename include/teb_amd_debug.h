@@ -84,6 +84,18 @@ int teb_amd_debug_rtc_compile(uint64_t flag_values, int32_t solver, int32_t jaco
  * with compile_for_config). */
 int teb_amd_debug_rtc_cache(int32_t* embedded, int32_t* disk_hits, int32_t* disk_writes, char* cache_dir, int32_t capacity);
 
+/*
+ * Phase split of the PRODUCT kernel, opt-in (one scalar branch per phase boundary when off; ~ 14 clock reads per LM iteration and band
+ * when on, < 1 % of the launch): shader cycles of every band's workgroup per phase of the last teb_amd_optimize_batch -
+ * TEB_AMD_PHASE_LOG_SLOTS doubles per band: [0] autoResize (src/timed_elastic_band.cpp:227-286), [1] buildGraph side data (obstacle
+ * association, via-point attachment, time stamps of the dynamic edges; src/optimal_planner.cpp:444-718), [2] linearisation (buildSystem),
+ * [3] backup of H for rejected trials (blocks layout), [4] the damped solves, [5] update + computeActiveErrors of the trials, [6] accept /
+ * restore, [7] spare, [8] the workgroup from entry to exit. teb_amd_get_phase_log synchronises; *bands = min(count, capacity_bands).
+ */
+#define TEB_AMD_PHASE_LOG_SLOTS 9
+int teb_amd_set_phase_log(teb_amd_handle_t* h, int32_t enable);
+int teb_amd_get_phase_log(teb_amd_handle_t* h, double* cycles, int32_t capacity_bands, int32_t* bands);
+
 /* per-TEB flags of the last launch: bit0 association list overflow, bit1 autoResize capacity overflow */
 int teb_amd_debug_assoc_overflow(teb_amd_handle_t* h, int32_t* flags);
 

@@ -32,11 +32,14 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-cont
 # tick run it): the specialised kernels are small enough (~ 90 KB) for the solve to be inlined there without the spills that made it
 # 21 % slower in the generic kernel - C2 1.36 -> 1.31 ms, C3 1.57 -> 1.48 (same box, alternating); in the band layout and in the
 # full-batch kinds it still loses (headline 2.59 -> 3.08 ms), so those keep the call.
-# -DTEB_AMD_SOLVE_CSR on the GENERIC small-batch band-layout point-like instantiation (opt_0_0_2: reached with generic_config_path, legacy
-# association, divergence detection or the cross-check options on a batch with solver helpers): with the no-callee-saved call of the solve
-# this one kernel faulted (memory aperture violation) as soon as obstacle_cost_exponent != 1 sent the edge loops through pow() - the
-# pre-built light / wide / defaults kinds and the kernels compiled at run time run the same configuration clean and bit-identical
-# (round 4, tools/rtc_bisect.py; the same class of backend interaction as the two-call-site case of round 3).
+# -DTEB_AMD_SOLVE_CSR (the out-of-line solve on the plain calling convention: the callee saves its callee-saved block) on every kind that
+# keeps the cost terms at run time - generic kinds 0 .. 3, light kinds 10, 11. Without it some of these big kernels fault (memory aperture
+# violation at the first LM iteration): round 4 met three of them, in round 5's tree it is the full-batch light kind of the band layout
+# (opt_0_0_10). Bisected on MI355X (profiles/fault_bisect_r05.txt, tools/fault_probe.py): not pow() (inlined), not the data (one band, one
+# iteration), not the stack size; `-mllvm -enable-ipra=0` on the ONE unit cures it like this flag does - the no-callee-saved call relies on
+# LLVM's interprocedural register allocation handing the caller the callee's clobber set, and that combination is what miscompiles units of
+# this size (which units: moves with their register allocation). The defaults / wide kinds keep the cheaper call: they are the kernels every
+# test and every bench of this repository runs. Kernels compiled at run time take the plain convention too (csrc/teb_rtc.hpp).
 UNIT_FLAGS = {"opt_0_0_0.o": ["-DTEB_AMD_POINTS_KEEP_GENERIC"], "opt_1_0_5.o": ["-DTEB_AMD_INLINE_SOLVE"]}
 # The instantiations that keep EVERY cost term at run time (generic kinds 0 .. 3, light kinds 10, 11) call the solve on the plain
 # convention (-DTEB_AMD_SOLVE_CSR): see the note above UNIT_FLAGS.

@@ -198,6 +198,8 @@ struct teb_amd_handle {
   int mcu_debug_flags = 0;
   DevBuf<double> iter_log;   // teb_amd_set_iteration_log: [max_tebs][TEB_AMD_ITERATION_LOG_ROWS][4]
   bool iter_log_on = false;
+  DevBuf<double> phase_log;  // teb_amd_set_phase_log: [max_tebs][kPhaseLogSlots]
+  bool phase_log_on = false;
   bool opt_backup_ready = false;
   size_t hband_stride = 0;
   // snapshot
@@ -794,6 +796,7 @@ void teb_amd_destroy(teb_amd_handle_t* h) {
   for (auto* q : gi) q->free();
   h->ob_n.free();
   h->iter_log.free();
+  h->phase_log.free();
   h->mcu_ctl.free(); h->mcu_pub.free(); h->mcu_items.free(); h->mcu_spec.free();
   if (h->mcu_trace) (void)hipHostFree(h->mcu_trace);
   if (h->pack_host) (void)hipHostFree(h->pack_host);
@@ -1087,6 +1090,7 @@ int teb_amd_optimize_batch(teb_amd_handle_t* h, int32_t inner, int32_t outer, in
   a.inner = inner; a.outer = outer; a.compute_cost = compute_cost; a.no_near_cache = h->opt.no_near_cache != 0; a.band_ldlt = h->solver == SOLVER_BANDG ? 0 : h->band_ldlt; a.Hband = h->Hband.p; a.hband_stride = h->hband_stride;
   a.obst_scale = obst_cost_scale; a.via_scale = viapoint_cost_scale; a.alt_time = alternative_time_cost;
   if (h->iter_log_on) { a.iter_log = h->iter_log.p; a.iter_log_cap = TEB_AMD_ITERATION_LOG_ROWS; }
+  if (h->phase_log_on) a.phase_log = h->phase_log.p;
 #ifdef TEB_PROFILE
   a.dbg_H = h->dbg_H.p;
 #endif
@@ -1105,6 +1109,32 @@ int teb_amd_set_iteration_log(teb_amd_handle_t* h, int32_t enable) {
     HIPCHK(hipMemsetAsync(h->iter_log.p, 0, count * sizeof(double), h->stream));
   }
   h->iter_log_on = enable != 0;
+  return TEB_AMD_OK;
+}
+
+// Where a launch spends its time, measured on the product kernel itself: shader cycles per phase of every band's workgroup (lane 0,
+// s_memtime at the phase boundaries of the outer / LM loop; kPhaseLogSlots values per band, teb_amd_debug.h names them).
+static_assert(kPhaseLogSlots == TEB_AMD_PHASE_LOG_SLOTS, "teb_amd_debug.h and teb_device.hpp disagree");
+int teb_amd_set_phase_log(teb_amd_handle_t* h, int32_t enable) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (enable && !h->phase_log.p) {
+    const size_t count = (size_t)h->max_tebs * kPhaseLogSlots;
+    HIPCHK(h->phase_log.alloc(count));
+    HIPCHK(hipMemsetAsync(h->phase_log.p, 0, count * sizeof(double), h->stream));
+  }
+  h->phase_log_on = enable != 0;
+  return TEB_AMD_OK;
+}
+int teb_amd_get_phase_log(teb_amd_handle_t* h, double* cycles, int32_t capacity_bands, int32_t* bands) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!h->phase_log_on || !h->phase_log.p) return fail(TEB_AMD_ERR_INVALID_ARG, "the phase log is off (teb_amd_set_phase_log)");
+  if (!cycles || capacity_bands < 0) return fail(TEB_AMD_ERR_INVALID_ARG, "null argument");
+  const int nb = std::min((int)capacity_bands, h->B);
+  if (nb > 0) HIPCHK(hipMemcpyAsync(cycles, h->phase_log.p, (size_t)nb * kPhaseLogSlots * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (bands) *bands = nb;
   return TEB_AMD_OK;
 }
 

@@ -283,6 +283,8 @@ struct OptArgs {
   double* dbg_H;         // [4*stride*kBand] of TEB 0
   double* dbg_b;         // [4*stride]
   double* dbg_chi2;      // [4]
+  double* phase_log;     // opt-in (teb_amd_set_phase_log): [B][kPhaseLogSlots] shader cycles per phase of the band's workgroup; else nullptr
 };
+constexpr int kPhaseLogSlots = 9;   // autoResize | association + via-points + time stamps | linearise | H backup | solve | update + evaluate | accept / restore | (spare) | whole workgroup
 
 }  // namespace tebamd

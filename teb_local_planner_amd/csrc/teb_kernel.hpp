@@ -23,9 +23,14 @@ namespace tebamd {
 #define PROF_START() prof_t0 = clock64()
 #define PROF_END(k) prof_acc[k] += clock64() - prof_t0
 #else
-#define PROF_DECL
-#define PROF_START()
-#define PROF_END(k)
+// The phase split of the PRODUCT kernel: with OptArgs::phase_log set, lane 0 of every workgroup adds up the shader
+// cycles (s_memtime) between the seven phase boundaries of the LM loop in ten words of the reduction scratch (LDS: no register lives
+// across the loop for it) and writes them out with the results - ~ 14 clock reads per LM iteration, < 1 % of the launch; off (nullptr,
+// the default): one scalar branch per boundary. The -DTEB_PROFILE build keeps the finer counters (rounds of the solve, edge groups).
+#define PROF_DECL const bool plog_ = args.phase_log != nullptr; long long* const plog_acc_ = reinterpret_cast<long long*>(l.red + 40); \
+  if (plog_ && threadIdx.x == 0) { for (int q_ = 0; q_ < 9; ++q_) plog_acc_[q_] = 0; plog_acc_[9] = clock64(); }
+#define PROF_START() do { if (plog_ && threadIdx.x == 0) plog_acc_[8] = clock64(); } while (0)
+#define PROF_END(k) do { if (plog_ && threadIdx.x == 0) plog_acc_[k] += clock64() - plog_acc_[8]; } while (0)
 #endif
 
 #ifdef TEB_PROFILE
@@ -3185,6 +3190,13 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
   if (tid == 0 && b == 0 && args.dbg_H) {
     prof_acc[7] = (long long)l.ired[12] + 1000000000LL * l.ired[13];   // autoResize: cycles inside the sequential sweeps + 1e9 * #sweeps
     for (int q = 0; q < 8; ++q) args.dbg_H[q] = (double)prof_acc[q];
+  }
+#endif
+#ifndef TEB_PROFILE
+  if (plog_ && tid == 0) {
+    double* out = args.phase_log + (size_t)b * kPhaseLogSlots;
+    for (int q = 0; q < 8; ++q) out[q] = (double)plog_acc_[q];
+    out[8] = (double)(clock64() - plog_acc_[9]);
   }
 #endif
   if (tid == 0) {

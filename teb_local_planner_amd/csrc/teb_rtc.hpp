@@ -294,7 +294,15 @@ inline void rtc_compile(const RtcKey key, std::shared_ptr<RtcKernel> k, const Rt
   snprintf(name, sizeof name, "tebamd::teb_optimize_kernel<%d, %d, %d>", key.solver, key.jmode, key.scene);
   std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                                    "-DM_PI=3.14159265358979323846", "-DHUGE_VAL=__builtin_huge_val()",   // (hipRTC's built-in headers lack the two math.h macros)
-                                   "-DTEB_AMD_DEFAULTS_PROFILE=1", "-DTEB_AMD_PROFILE_CUSTOM=1"};
+                                   "-DTEB_AMD_DEFAULTS_PROFILE=1", "-DTEB_AMD_PROFILE_CUSTOM=1",
+                                   // The out-of-line solve on the PLAIN calling convention (the callee saves its callee-saved block): the
+                                   // convention without it relies on LLVM's interprocedural register allocation handing the caller the callee's
+                                   // exact clobber set, and that combination miscompiles some instantiations (round 5: the full-batch light
+                                   // kind in the band layout faults at its first LM iteration; -mllvm -enable-ipra=0 on that one unit cures it,
+                                   // so does this flag; tools/fault_probe.py). The pre-built kinds that keep the cheaper
+                                   // call are the ones every test and bench of the repository runs; a kernel compiled here is one of 2^20
+                                   // nobody has run before, so it takes the convention that has never failed (cost: ~ 3 % of its launch).
+                                   "-DTEB_AMD_SOLVE_CSR=1"};
   for (const std::string& d : rtc_variant_defines()) opts.push_back(d);   // (part of the disk key below: the options are hashed)
   const std::vector<std::string>& names = rtc_flag_names();
   for (size_t i = 0; i < names.size(); ++i) opts.push_back("-DTEB_PF_VALUE_" + names[i] + "=" + (((key.flags >> i) & 1ull) ? "true" : "false"));

@@ -198,6 +198,23 @@ class TebBatchSolver:
         """Opt-in per-iteration log of the LM loop (g2o's verbose line as data, src/optimal_planner.cpp:384)."""
         _chk(lib().teb_amd_set_iteration_log(self._h, int(bool(enable))), "teb_amd_set_iteration_log")
 
+    PHASES = ("autoresize", "graph side data", "linearize", "H backup", "solve", "update + evaluate", "accept / restore")
+
+    def set_phase_log(self, enable=True):
+        """Phase split of the product kernel (include/teb_amd_debug.h): shader cycles per phase of every band's workgroup."""
+        L = lib()
+        L.teb_amd_set_phase_log.argtypes = [C.c_void_p, C.c_int32]
+        _chk(L.teb_amd_set_phase_log(self._h, int(bool(enable))), "teb_amd_set_phase_log")
+
+    def phase_log(self):
+        """[B, 9] shader cycles of the last optimize(): the seven PHASES, a spare slot, the whole workgroup."""
+        L = lib()
+        L.teb_amd_get_phase_log.argtypes = [C.c_void_p, _abi.p_f64, C.c_int32, _abi.p_i32]
+        self._sync_count()
+        out = np.zeros((max(self.count, 1), 9)); nb = C.c_int32(0)
+        _chk(L.teb_amd_get_phase_log(self._h, _abi._ptr(out, C.c_double), self.count, C.byref(nb)), "teb_amd_get_phase_log")
+        return out[:nb.value]
+
     def iteration_log(self, b, capacity_rows=256):
         """[iterations, 4] of band b after the last optimize(): chi2 after the iteration, lambda after it, damping trials, pose count."""
         rows = np.zeros((int(capacity_rows), 4))
