@@ -2,7 +2,8 @@
 // instantiates instead of HomotopyClassPlanner (src/teb_local_planner_ros.cpp creates it when enable_homotopy_class_planning is set).
 // plan() keeps the reference's sequence (src/homotopy_class_planner.cpp:107-125) and its members (tebs_, best_teb_, equivalence_classes_,
 // initial_plan_teb_, ...) stay meaningful for everything the class inherits unchanged (getVelocityCommand, isTrajectoryFeasible,
-// visualize, hasDiverged, ...):
+// visualize, ...). hasDiverged() is inherited too: it forwards to best_teb_ (:749-755), a TebOptimalPlannerAmd, which answers from the
+// statistics the launch returned (in the sharded mode a mirror of the winner carries the statistics that came with its band):
 //   updateAllTEBs                         inherited (O(n) per candidate on the host objects)
 //   exploreEquivalenceClassesAndInitTebs  TebAmdBatch::exploreEquivalenceClassesAndInitTebs (signatures, class list, detours, graph,
 //                                         candidate bands, via-point flags on the device)
