@@ -75,17 +75,13 @@ __global__ void __launch_bounds__(256) k(double* p, long long* out, int reps) {
                         "s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\tv_fmac_f64_dpp %1, %0, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
                         "s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\tv_fmac_f64_dpp %1, %0, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
                         "s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\tv_fmac_f64_dpp %1, %0, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(a0), "+v"(a1) : "v"(y));)
-    } else if (MODE == 12 || MODE == 13 || MODE == 14) {   // the passes of cr16_eliminate as they stand in the product header
+    } else if (MODE == 12 || MODE == 14) {   // the passes of cr16_eliminate as they stand in the product header
       double Y[8] = {a0, a1, a2, a3, a4, a5, a6, a7}, wf[8] = {a7, a6, a5, a4, a3, a2, a1, a0}, v[8] = {x, y, x + 1, y + 1, x + 2, y + 2, x + 3, y + 3};
       double acc[16];
       for (int t = 0; t < 16; ++t) acc[t] = a0 + t;
       for (int u = 0; u < 8; ++u) {
         if (MODE == 12)
           asm volatile("s_nop 1\n\t" TEB_CR16_FORWARD : "+v"(Y[0]), "+v"(Y[1]), "+v"(Y[2]), "+v"(Y[3]), "+v"(Y[4]), "+v"(Y[5]), "+v"(Y[6]), "+v"(Y[7]),
-                       "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(wf[4]), "+v"(wf[5]), "+v"(wf[6]), "+v"(wf[7])
-                       : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]));
-        else if (MODE == 13)
-          asm volatile("s_nop 1\n\t" TEB_CR16_BACKWARD : "+v"(Y[0]), "+v"(Y[1]), "+v"(Y[2]), "+v"(Y[3]), "+v"(Y[4]), "+v"(Y[5]), "+v"(Y[6]), "+v"(Y[7]),
                        "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(wf[4]), "+v"(wf[5]), "+v"(wf[6]), "+v"(wf[7])
                        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]));
         else
@@ -149,7 +145,6 @@ int main() {
   run<10>("v_mov_b64_dpp chain through the DPP source, s_nop 1 each", 64);
   run<11>("v_fmac_f64_dpp chain through the DPP source, s_nop 1 each", 64);
   run<12>("TEB_CR16_FORWARD (56 fmac + nop), cycles per fmac", 8 * 56);
-  run<13>("TEB_CR16_BACKWARD (56 fmac + nop), cycles per fmac", 8 * 56);
   run<14>("TEB_CR16_SCHUR2 (32 fmac + nop), cycles per fmac", 8 * 32);
   run<15>("v_fmac_f64_dpp with negated source, independent", 64);
   run<16>("v_fmac_f64_dpp two alternating accumulators", 64);
