@@ -29,6 +29,10 @@ extern "C" {
 #endif
 
 #define TEB_AMD_ABI_VERSION 3
+/* Largest pose capacity a handle can be created with on MI355X (band in HBM, four poses per lane; what 160 KB of LDS hold beside the
+ * state strips: 951, rounded down to a multiple of 8). trajectory.max_samples (teb_config.h:78) is a parameter of the reference, 500 only
+ * by default: bindings size a handle with min(max_samples + 1, TEB_AMD_MAX_POSES). teb_amd_capacity reports the device's own figure. */
+#define TEB_AMD_MAX_POSES 944
 
 /* ---- status codes (library calls) ------------------------------------------------------------- */
 enum {
@@ -235,7 +239,7 @@ void teb_amd_config_default(teb_amd_config_t* cfg);   /* TebConfig::TebConfig(),
 enum { TEB_AMD_LAYOUT_AUTO = 0,        /* by capacity and obstacle count, and per launch by the current pose counts (see create) */
        TEB_AMD_LAYOUT_BLOCKS_LDS = 1,  /* normal matrix as 8x8 blocks in LDS, cyclic reduction in place (<= 238 poses)           */
        TEB_AMD_LAYOUT_BAND_LDS = 2,    /* band in LDS, cyclic reduction: level 0 from a band copy in HBM (<= 337 poses)         */
-       TEB_AMD_LAYOUT_BAND_HBM = 3 };  /* band in HBM as well (<= 512 poses)                                                    */
+       TEB_AMD_LAYOUT_BAND_HBM = 3 };  /* band in HBM as well (<= TEB_AMD_MAX_POSES poses)                                      */
 enum { TEB_AMD_HSIG3D_AUTO = 0, TEB_AMD_HSIG3D_WIDE = 1, TEB_AMD_HSIG3D_SMALL = 2 };
 typedef struct teb_amd_options {
   int32_t struct_size;            /* sizeof(teb_amd_options_t) of the caller (forward compatibility); 0 = this header's         */
@@ -286,8 +290,8 @@ void teb_amd_options_default(teb_amd_options_t* opt);
 /*
  * create: one solver per GPU / host thread. device = HIP ordinal. stream = hipStream_t (as void*) to
  * launch on, or NULL for the handle's own stream. Fails (never falls back to CPU) when no gfx950 device.
- * max_poses = pose capacity of every band (trajectory.max_samples + 1 covers whatever autoResize can produce); up to 512
- * (teb_amd_capacity). Layouts: normal matrix as 8x8 blocks in LDS up to 238 poses (208 beside a 500-obstacle cache) - the
+ * max_poses = pose capacity of every band (trajectory.max_samples + 1 covers whatever autoResize can produce); up to
+ * TEB_AMD_MAX_POSES (teb_amd_capacity). Layouts: normal matrix as 8x8 blocks in LDS up to 238 poses (208 beside a 500-obstacle cache) - the
  * fastest -, as a band in LDS up to 337, as a band in HBM beyond. Each launch uses the fastest layout that holds the current
  * bands with 10 % room to grow and is repeated in the capacity's own layout if autoResize outgrows that (teb_amd_options_t::fixed_layout:
  * always the capacity's layout); results do not depend on the layout.

@@ -11,6 +11,7 @@ MAX_FOOTPRINT_VERTICES = 64
 
 # status codes
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED = range(6)
+MAX_POSES = 944   # TEB_AMD_MAX_POSES of include/teb_amd.h (tests/test_abi.py keeps the two equal)
 TEB_OK, TEB_FAILED, TEB_NONFINITE = range(3)
 FOOTPRINT_POINT, FOOTPRINT_CIRCULAR, FOOTPRINT_TWO_CIRCLES, FOOTPRINT_LINE, FOOTPRINT_POLYGON = range(5)
 OBST_POINT, OBST_CIRCULAR, OBST_LINE, OBST_PILL, OBST_POLYGON = range(5)

@@ -696,11 +696,15 @@ int teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max
   // bands too long for the LDS band (> 337 poses; the reference's max_samples default is 500): the band form of the normal matrix
   // moves to HBM (SOLVER_BANDG: 44 doubles per pose, L2-resident), everything else stays as it is
   if (solver == SOLVER_BAND && lds_bytes_for(max_poses, SOLVER_BAND) > lds_limit) solver = SOLVER_BANDG;
+  // more than two poses per lane: only the band-in-HBM instantiations are compiled for it (teb_device.hpp: kPoseIterBandHbm)
+  static_assert(TEB_AMD_MAX_POSES <= kThreads * 4, "TEB_AMD_MAX_POSES of include/teb_amd.h exceeds four poses per lane");
+  if (max_poses > kThreads * 2) solver = SOLVER_BANDG;   // (the LDS layouts end at 337 poses: the checks above have already moved it there)
   const size_t lds = lds_bytes_for(max_poses, solver);
-  if (max_poses > kThreads * kMaxPoseIter || lds > lds_limit) {
+  const int thread_limit = kThreads * (solver == SOLVER_BANDG ? kPoseIterBandHbm : 2);
+  if (max_poses > thread_limit || lds > lds_limit) {
     char buf[256];
     std::snprintf(buf, sizeof buf, "max_poses=%d needs %zu B of LDS per workgroup (device limit %zu B, thread limit %d poses)",
-                  max_poses, lds, lds_limit, kThreads * kMaxPoseIter);
+                  max_poses, lds, lds_limit, thread_limit);
     return fail(TEB_AMD_ERR_CAPACITY, buf);
   }
   const size_t assoc_bytes = sizeof(int) * (size_t)max_tebs * max_poses * (size_t)(max_obstacles > 0 ? max_obstacles : 1);
@@ -2352,8 +2356,8 @@ int teb_amd_capacity(teb_amd_handle_t* h, int32_t* lds_bytes, int32_t* max_poses
   if (max_poses_supported) {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, h->device));
-    int S = kThreads * kMaxPoseIter;
-    while (S > 2 && lds_bytes_for(S, SOLVER_BANDG) > h->lds_limit) --S;   // band in HBM: 512 poses (two per lane)
+    int S = kThreads * kPoseIterBandHbm;
+    while (S > 2 && lds_bytes_for(S, SOLVER_BANDG) > h->lds_limit) --S;   // band in HBM: four poses per lane, as many as its LDS strips hold
     *max_poses_supported = S;
   }
   return TEB_AMD_OK;

@@ -194,7 +194,21 @@ constexpr int kBand = 11;           // diagonal + scalar half-bandwidth 10 (SURV
 // i.e. on 8 distinct bank positions (8-way conflicts in every read-modify-write of the scatter, a quarter of all LDS cycles of the kernel);
 // 45 doubles apart they spread over 32. One layout for every band buffer (LDS band, its HBM copy, the HBM band of long bands).
 __host__ __device__ constexpr int hbo(int r) { return r * kBand + (r >> 2); }
-constexpr int kMaxPoseIter = 2;     // poses handled per thread: n <= kThreads * kMaxPoseIter
+// Poses handled per thread: n <= kThreads * kMaxPoseIter. A property of the TRANSLATION UNIT: everything sized by it lives in registers
+// (near-mask cache, pose backups of the LM loop, the gather of autoResize), so the layouts that hold at most 337 poses are compiled with 2
+// and only the band-in-HBM instantiations (teb_opt_inst.hip, and teb_rtc.hpp for the kernels compiled at run time) with
+// kPoseIterBandHbm = 4: bands beyond 512 poses (max_samples is a parameter of the reference, teb_config.h:78, 258; 500 is only its
+// default) - as many as the LDS strips of that layout hold (21 doubles per pose: ~ 950 poses on MI355X, teb_amd_capacity).
+#ifndef TEB_AMD_POSE_ITER
+#define TEB_AMD_POSE_ITER 2
+#endif
+constexpr int kMaxPoseIter = TEB_AMD_POSE_ITER;
+#ifdef TEB_AMD_SINGLE_TU
+constexpr int kPoseIterBandHbm = kMaxPoseIter;   // (profiling builds: every instantiation inside the host's translation unit)
+#else
+constexpr int kPoseIterBandHbm = 4;
+#endif
+static_assert(kMaxPoseIter >= 2 && kMaxPoseIter <= 4, "pose descriptors of autoResize (kNewPose = 1024) and its 16 interval masks hold 1024 poses");
 
 // LDS layout of one workgroup, computed on the host (offsets in doubles from the dynamic-LDS base).
 struct LdsPlan {

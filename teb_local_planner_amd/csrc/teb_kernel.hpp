@@ -62,11 +62,11 @@ __device__ long long g_lin_prof[16];  // thread 0 of workgroup 0: sections of li
 //   SOLVER_BAND : Hb[4S][11] lower band in LDS (S <= 343); solved by the hybrid cyclic reduction (cr_solve_hybrid: level 0 from a
 //                 band-form copy in HBM into a compact even-row system in LDS) or, teb_amd_options_t::band_ldlt, by the sequential
 //                 in-LDS LDL^T of wave 0
-//   SOLVER_BANDG: the same band in a per-band HBM buffer (S <= 512, or when the obstacle cache would not fit beside the LDS band)
+//   SOLVER_BANDG: the same band in a per-band HBM buffer (S beyond the LDS band, or when the obstacle cache would not fit beside the LDS band)
 //   SOLVER_CR   : block-tridiagonal in 8x8 blocks (two 4-scalar pose groups per block row): D_j (full, symmetric)
 //                 and L_j (coupling to block row j-1), solved by block cyclic reduction with all 256 threads
 //                 (log2(n/2) levels instead of 4n sequential pivots). Needs ~680*S bytes of LDS: S <= 238.
-enum { SOLVER_BAND = 0, SOLVER_CR = 1, SOLVER_BANDG = 2 };   // BANDG: the band lives in HBM (bands too long for the LDS band: up to 512 poses)
+enum { SOLVER_BAND = 0, SOLVER_CR = 1, SOLVER_BANDG = 2 };   // BANDG: the band lives in HBM (bands too long for the LDS band: up to kThreads * kPoseIterBandHbm poses, LDS permitting)
 typedef double teb_v2d __attribute__((ext_vector_type(2)));   // two doubles in one 16-byte access
 constexpr int kBlk = 66;   // padded stride (doubles) of one 8x8 block: spreads concurrent eliminations over LDS banks
 
@@ -303,7 +303,8 @@ __device__ __forceinline__ void dyn_chunk(const SceneDev& sc, int sl, int nsl, i
 // optimize(); only the pose moves. A mask taken at the reference position r with the threshold widened by m holds every obstacle
 // that is near at any position p with |p - r| <= m (triangle inequality), and a superset is all pass 2 needs: the edges it
 // evaluates beyond the true threshold contribute exact zeros, like in the full loop. So each lane keeps (mask, r) per pose it serves
-// (kMaxPoseIter of them, in registers) and recomputes only when its pose has left the disc - or when the graph was rebuilt (r = NaN).
+// (two of them, in registers: the passes beyond the second of a band-in-HBM kernel recompute their masks every time) and recomputes only
+// when its pose has left the disc - or when the graph was rebuilt (r = NaN).
 // m = kNearMarginFactor x the culling distance: the wider the disc the rarer the recomputation and the more zero edges in pass 2
 // (headline kernel 4.21 ms without the cache; 4.04 / 3.99 / 3.96 / 3.99 ms at factor 0.5 / 1 / 2 / 3).
 constexpr double kNearMarginFactor = 1.5;   // margin of the cached near masks in units of the culling distance (1, 2, 3 measured: DESIGN.md section 3)
@@ -317,7 +318,8 @@ template <int MODE, bool FAST>
 __device__ __forceinline__ unsigned long long dyn_near_cached(const teb_amd_config_t& c, const SceneDev& sc, const Lds& l, int i, int sl, int nsl,
                                                               NearCache& nc, int pass) {
   if (!(FAST && i >= 1 && c.include_dynamic_obstacles && c.weight_obstacle != 0)) return 0;
-  const double m = nc.off ? 0.0 : kNearMarginFactor * dyn_far_distance(c);
+  const bool uncached = nc.off || (kMaxPoseIter > 2 && pass >= 2);   // two slots per lane: the third and fourth pass of a long band take the exact mask
+  const double m = uncached ? 0.0 : kNearMarginFactor * dyn_far_distance(c);
   const double x = l.sx[i], y = l.sy[i];
   const double rx = pass == 0 ? nc.rx0 : nc.rx1, ry = pass == 0 ? nc.ry0 : nc.ry1;
   unsigned long long mask = pass == 0 ? nc.m0 : nc.m1;
@@ -325,11 +327,11 @@ __device__ __forceinline__ unsigned long long dyn_near_cached(const teb_amd_conf
   const double lim = fmax(m * (1.0 - 1e-6) - 2e-6, 0.0);   // (the numeric mode evaluates residuals 1e-9 away from the pose and culls 1e-6 wider)
   // left the disc, or no mask yet (NaN reference). When one lane of the wave has to recompute, the whole wave walks the loop anyway: every
   // lane then refreshes its mask at its current position (a fresh disc costs the others nothing and postpones their next recomputation)
-  if (nc.off || __any(!(ddx * ddx + ddy * ddy <= lim * lim))) {
+  if (uncached || __any(!(ddx * ddx + ddy * ddy <= lim * lim))) {
     int d_lo, d_hi;
     dyn_chunk(sc, sl, nsl, d_lo, d_hi);
     mask = dyn_near_mask<MODE>(c, sc, l, i, d_lo, d_lo + 64 < d_hi ? d_lo + 64 : d_hi, m);
-    if (pass == 0) { nc.m0 = mask; nc.rx0 = x; nc.ry0 = y; } else { nc.m1 = mask; nc.rx1 = x; nc.ry1 = y; }
+    if (pass == 0) { nc.m0 = mask; nc.rx0 = x; nc.ry0 = y; } else if (!(kMaxPoseIter > 2 && pass >= 2)) { nc.m1 = mask; nc.rx1 = x; nc.ry1 = y; }
 #ifdef TEB_PROFILE
     atomicAdd(&g_near_recomputed, 1ull);
 #endif
@@ -1040,9 +1042,9 @@ template <> __device__ __forceinline__ void cr16_pivot_update<6>(double (&v)[8],
 // 16-byte accesses (lanes 64 bytes apart: 4-way conflicts in every ds_write_b128) measured 10 % slower per round.
 // LDL^T by rows: at pivot k lane j > k scales its l_jk = a_jk / d_k and updates a_jm -= l_jk a_mk, m = k + 1 .. j, with a_mk read from
 // lane m; the triangular solves read l_km from lane k / l_mk from lane m. Operation by operation this is Ldl8::factor / solve3 and the
-// 8-lane round's products (same operands, same order of every sum; checked in IEEE arithmetic on the host) - the compiler's choice of
-// which multiply of `u * d - l * w` it fuses into the subtraction is the one thing a hand-written pass does not inherit: results agree
-// with the 8-lane rounds to the last bit or two (tools/micro/cr_round_bench.hip), not bit for bit.
+// 8-lane round's products (same operands, same order of every sum; checked in IEEE arithmetic on the host), down to the compiler's
+// choice in the back substitution of rounds 2 - 4 - it fused the FIRST term, u_k = fma(u_k, 1/d_k, -(l u_{k+1})), which the
+// TEB_CR16_BACKWARD blocks spell out: results equal the 8-lane rounds bit for bit (tools/micro/cr_round_bench.hip compares them).
 #ifndef TEB_CR16_STAMP
 #define TEB_CR16_STAMP(k)   // (tools/micro/cr_round_bench.hip: cycle stamps between the passes)
 #endif
@@ -2297,7 +2299,40 @@ struct AssocScan {
   int left, right, cnt;
 };
 // scans static-list positions [k_lo, k_hi) for pose i; forced inclusions go to `emit(position)` in list order
-template <bool FAST, typename Emit>
+// Pass 1 of the association of a point-like scene without radii, for a scan whose bounds are WAVE-UNIFORM (one lane per pose, the whole
+// list): bit j of the result = obstacle ka + j of the static list is within thr of (x, y) or the comparison is unordered; kb - ka <= 32.
+// The obstacle is the same for every lane, so its coordinates come through the scalar cache (constant address space: s_load_dwordx16 for
+// 8 values, no VGPR, no LDS: with the LDS copy the four waves of the workgroup scanning at once are bound by the LDS pipe, 32 cycles per
+// obstacle, and measured 112) and enter the subtraction as its scalar operand; the lane's bit is shifted in from VCC by ONE add-with-carry
+// (the first obstacle ends up in the highest bit: reversed once at the end) instead of a conditional move and an OR with a computed
+// constant. Six vector instructions per obstacle instead of ten and two LDS reads. The squared distance is contracted into one fma: a
+// mask only has to be a SUPERSET of the obstacles the scan can care about (pass 2 takes their exact distances and makes the reference's
+// decisions), the guard band of 1e-12 on the threshold is four orders of magnitude wider than the one rounding that differs - lists
+// bit-identical (tests/test_gpu_parity.py: test_linearisation_and_association; the fingerprints).
+__device__ __forceinline__ unsigned assoc_near_bits(const SceneDev& sc, int ka, int kb, double x, double y, double thr2) {
+  typedef const __attribute__((address_space(4))) double* kptr;
+  const kptr gx = (kptr)(unsigned long long)sc.lox, gy = (kptr)(unsigned long long)sc.loy;
+  unsigned m = 0;
+  const int nk = kb - ka;
+  auto one = [&](double ox, double oy) {
+    const double ddx = x - ox, ddy = y - oy;
+    const double d2 = __builtin_fma(ddy, ddy, ddx * ddx);
+    asm("v_cmp_ngt_f64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(d2), "v"(thr2) : "vcc");   // m = 2 m + !(d2 > thr2)
+  };
+  int k = ka;
+  // batches of 8 (two s_load_dwordx16). Not double-buffered: the kernel has no 32 scalar registers to spare here - the compiler parks a
+  // prefetched batch in VGPR lanes (64 v_writelane / v_readlane per batch) and waits for it at once
+  for (; k + 8 <= kb; k += 8) {
+    double ox[8], oy[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { ox[u] = gx[k + u]; oy[u] = gy[k + u]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) one(ox[u], oy[u]);
+  }
+  for (; k < kb; ++k) one(gx[k], gy[k]);
+  return nk > 0 ? __builtin_bitreverse32(m) >> (32 - nk) : 0u;
+}
+template <bool FAST, bool UNIFORM = false, typename Emit>
 __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const SceneDev& sc, const Lds& l, int i, int k_lo, int k_hi, AssocScan& r,
                                            Emit emit) {
   const double x = l.sx[i], y = l.sy[i];
@@ -2312,6 +2347,19 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
     if (ox_ * vy_ - vx_ * oy_ > 0) { if (dist < r.left_min) { r.left_min = dist; r.left = k; } }
     else { if (dist < r.right_min) { r.right_min = dist; r.right = k; } }
   };
+  // the same decisions as selects, for the candidates of the point-like path (round 5: seven nested exec-mask branches per candidate cost
+  // 12 % of pass 2; the rare forced inclusion keeps its branch)
+  auto visit_sel = [&](int k, double dist, double ccx, double ccy) {
+    const bool forced = dist < force;
+    const bool cand = !forced && !(dist > cutoff);
+    const double vx_ = ccx - x, vy_ = ccy - y;
+    const bool on_left = ox_ * vy_ - vx_ * oy_ > 0;
+    const bool ul = cand && on_left && dist < r.left_min, ur = cand && !on_left && dist < r.right_min;
+    r.left_min = ul ? dist : r.left_min; r.left = ul ? k : r.left;
+    r.right_min = ur ? dist : r.right_min; r.right = ur ? k : r.right;
+    if (forced) { emit(k); ++r.cnt; }
+  };
+  (void)visit_sel; (void)visit;
   int k0 = k_lo;
   TEB_IF_FAST(FAST) {
     // Far-field culling, exact: an obstacle beyond max(cutoff, force) (+ a relative guard band of 1e-12 against the rounding of the
@@ -2329,6 +2377,10 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
         const bool all = thr <= 0;
         unsigned lo = 0, hi = 0;
         const int km = k0 + 32 < ke ? k0 + 32 : ke;
+        if constexpr (UNIFORM) {
+          lo = assoc_near_bits(sc, k0, km, x, y, thr2);
+          hi = assoc_near_bits(sc, km, ke, x, y, thr2);
+        } else {
 #pragma unroll 4
         for (int k = k0; k < km; ++k) {
           const double ddx = x - l.obx[k], ddy = y - l.oby[k];
@@ -2340,6 +2392,7 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
           const double ddx = x - l.obx[k], ddy = y - l.oby[k];
           const double d2 = ddx * ddx + ddy * ddy;
           hi |= !(d2 > thr2) ? 1u << (k - km) : 0u;
+        }
         }
         near = ((unsigned long long)hi << 32) | lo;
         if (all) near = ke - k0 >= 64 ? ~0ull : ((1ull << (ke - k0)) - 1ull);
@@ -2357,8 +2410,9 @@ __device__ __forceinline__ void assoc_scan(const teb_amd_config_t& c, const Scen
         const int k = k0 + __ffsll((long long)near) - 1;
         near &= near - 1;
         const double ccx = l.obx[k], ccy = l.oby[k];
-        const double dist = pointlike_distance<false>(c, x, y, ccx, ccy, l.obr[k], nullptr);
-        visit(k, dist, ccx, ccy);
+        // (no radii in the list: the subtraction of an exact zero is skipped with its LDS read)
+        const double dist = pointlike_distance<false>(c, x, y, ccx, ccy, TEB_CFGI(RADIUS_FREE) ? 0.0 : l.obr[k], nullptr);
+        visit_sel(k, dist, ccx, ccy);
       }
     }
     k0 = k_hi;
@@ -2423,7 +2477,7 @@ __device__ inline void associate_range(const teb_amd_config_t& c, const SceneDev
     // the sequential scan of the whole list by one lane, writing straight into the list (also the fallback of the sliced scan)
     auto sequential = [&]() {
       AssocScan r = {kMax, kMax, -1, -1, 0};
-      assoc_scan<FAST>(c, sc, l, i, 0, sc.n_static, r, [&](int k) { if (r.cnt < cap) st_list<SHARED>(&assoc[(size_t)r.cnt * stride + i], k); else *overflow = 1; });
+      assoc_scan<FAST, true>(c, sc, l, i, 0, sc.n_static, r, [&](int k) { if (r.cnt < cap) st_list<SHARED>(&assoc[(size_t)r.cnt * stride + i], k); else *overflow = 1; });
       int cnt = r.cnt;
       if (r.left >= 0) { if (cnt < cap) st_list<SHARED>(&assoc[(size_t)cnt * stride + i], r.left); else *overflow = 1; ++cnt; }
       if (r.right >= 0) { if (cnt < cap) st_list<SHARED>(&assoc[(size_t)cnt * stride + i], r.right); else *overflow = 1; ++cnt; }

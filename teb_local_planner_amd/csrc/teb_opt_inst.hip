@@ -14,6 +14,9 @@
 #if defined(TEB_INST_SCENE) && TEB_INST_SCENE >= 10
 #define TEB_AMD_PROFILE_LIGHT 1   // point-like kinds 10, 11: every cost-term flag at run time, the never-reached bulk folded
 #endif
+#if defined(TEB_INST_SOLVER) && TEB_INST_SOLVER == 2 && !defined(TEB_AMD_POSE_ITER)
+#define TEB_AMD_POSE_ITER 4   // band in HBM: up to four poses per lane (teb_device.hpp: kPoseIterBandHbm)
+#endif
 #include "teb_kernel.hpp"
 #include "teb_opt_launch.hpp"
 
@@ -26,5 +29,7 @@ static_assert(tebamd::SCENE_POINTS == 0 && tebamd::SCENE_GENERIC == 1 && tebamd:
               tebamd::SCENE_POINTS_DEFAULTS == 4 && tebamd::SCENE_POINTS_SMALL_DEFAULTS == 5 && tebamd::SCENE_GENERIC_DEFAULTS == 6 &&
               tebamd::SCENE_GENERIC_SMALL_DEFAULTS == 7 && tebamd::SCENE_POINTS_WIDE == 8 && tebamd::SCENE_POINTS_SMALL_WIDE == 9 && tebamd::SCENE_POINTS_LIGHT == 10 && tebamd::SCENE_POINTS_SMALL_LIGHT == 11,
               "teb_opt_launch.hpp numbers the scene kinds");
+
+static_assert(TEB_INST_SOLVER != 2 || tebamd::kMaxPoseIter == tebamd::kPoseIterBandHbm, "the host sizes band-in-HBM handles for kPoseIterBandHbm poses per lane");
 
 TEB_OPT_DEFINE(TEB_INST_SOLVER, TEB_INST_JMODE, TEB_INST_SCENE)

@@ -303,6 +303,7 @@ inline void rtc_compile(const RtcKey key, std::shared_ptr<RtcKernel> k, const Rt
                                    // call are the ones every test and bench of the repository runs; a kernel compiled here is one of 2^20
                                    // nobody has run before, so it takes the convention that has never failed (cost: ~ 3 % of its launch).
                                    "-DTEB_AMD_SOLVE_CSR=1"};
+  if (key.solver == 2) opts.push_back("-DTEB_AMD_POSE_ITER=" + std::to_string(kPoseIterBandHbm));   // band in HBM: as the pre-built units (teb_opt_inst.hip)
   for (const std::string& d : rtc_variant_defines()) opts.push_back(d);   // (part of the disk key below: the options are hashed)
   const std::vector<std::string>& names = rtc_flag_names();
   for (size_t i = 0; i < names.size(); ++i) opts.push_back("-DTEB_PF_VALUE_" + names[i] + "=" + (((key.flags >> i) & 1ull) ? "true" : "false"));

@@ -214,7 +214,7 @@ bool TebOptimalPlannerAmd::optimizeTEB(int iterations_innerloop, int iterations_
   // Capacities: whatever autoResize can produce (max_samples + 1 poses; the layout is chosen per launch, so a large capacity does not
   // slow down short bands), and head-room over the obstacle / vertex / via-point counts of THIS tick - the costmap converter changes
   // them every tick, so the handle is rebuilt with room to spare whenever a count outgrows it.
-  const int need_poses = std::max(teb_.sizePoses(), std::min(cfg_->trajectory.max_samples + 1, 512));
+  const int need_poses = std::max(teb_.sizePoses(), std::min(cfg_->trajectory.max_samples + 1, TEB_AMD_MAX_POSES));
   const int n_obst = (int)probe.type.size(), n_vert = probe.vertices(), n_via = via_points_ ? (int)via_points_->size() : 0;
   if (!single_ || !single_->valid() || teb_.sizePoses() > single_->maxPoses() || n_obst > single_->maxObstacles() ||
       n_vert > single_->maxObstacleVertices() || n_via > single_->maxViaPoints())

@@ -24,7 +24,7 @@ namespace teb_local_planner {
 class HomotopyClassPlannerAmd : public HomotopyClassPlanner
 {
 public:
-  /** max_tebs >= hcp.max_number_classes; max_poses = pose capacity per candidate (trajectory.max_samples + 1 <= 512 covers autoResize). */
+  /** max_tebs >= hcp.max_number_classes; max_poses = pose capacity per candidate (trajectory.max_samples + 1 <= TEB_AMD_MAX_POSES covers autoResize). */
   HomotopyClassPlannerAmd(const TebConfig& cfg, ObstContainer* obstacles = NULL, TebVisualizationPtr visualization = TebVisualizationPtr(),
                           const ViaPointContainer* via_points = NULL, int max_tebs = 16, int max_poses = 512, int max_obstacles = 512,
                           int max_obstacle_vertices = 4096, int max_via_points = 256, int device = 0);

@@ -548,8 +548,8 @@ class TebOptimalPlanner:
         self.cfg_ = cfg
         self.obstacles_ = obstacles if obstacles is not None else _abi.ObstacleTable()
         self.via_points_ = list(via_points or [])
-        # capacity = whatever autoResize may produce (max_samples + 1 <= 512); pass a smaller max_poses for the faster LDS layouts
-        self.max_poses = max_poses or min(cfg.trajectory.max_samples + 1, 512)
+        # capacity = whatever autoResize may produce (max_samples + 1, at most TEB_AMD_MAX_POSES); pass a smaller max_poses for the faster LDS layouts
+        self.max_poses = max_poses or min(cfg.trajectory.max_samples + 1, _abi.MAX_POSES)
         self.teb_ = _abi.TebBatchHost(1, self.max_poses)
         self.cost_ = float("nan")
         self.optimized_ = False
@@ -712,7 +712,7 @@ class HomotopyClassPlanner:
             self.solver = make_solver(cfg, obstacles, via_points, batch, device=device, stream=stream, max_tebs=max_tebs,
                                       max_poses=max_poses)
         else:
-            # pose capacity: 224 keeps the normal matrix as 8x8 blocks in LDS (the fastest layout, <= 238 poses); pass up to 512 for longer bands
+            # pose capacity: 224 keeps the normal matrix as 8x8 blocks in LDS (the fastest layout, <= 238 poses); pass up to _abi.MAX_POSES for longer bands
             self.solver = TebBatchSolver(cfg, max_tebs or max(cfg.hcp.max_number_classes, 1), max_poses or 224, max(len(obstacles), 1),
                                          max(len(obstacles.vert_x), 1), max(len(self.via_points_), 1), device=device, stream=stream)
             self.solver.set_obstacles(obstacles)

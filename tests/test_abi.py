@@ -41,6 +41,15 @@ def test_struct_sizes_match_ctypes_mirror():
     assert L.teb_amd_sizeof_results() == C.sizeof(_abi.Results)
 
 
+def test_max_poses_constant_matches_the_header():
+    src = open(os.path.join(ROOT, "include", "teb_amd.h")).read()
+    m = re.search(r"#define\s+TEB_AMD_MAX_POSES\s+(\d+)", src)
+    assert m and int(m.group(1)) == _abi.MAX_POSES
+    # what the band-in-HBM layout needs in LDS at that capacity (21 doubles per pose + 368, csrc/teb_kernel.hpp: make_lds_plan) fits MI355X's
+    # 160 KB minus the 1 KiB the library keeps for the kernel's static LDS
+    assert (21 * _abi.MAX_POSES + 368) * 8 <= 160 * 1024 - 1024 < (21 * (_abi.MAX_POSES + 8) + 368) * 8
+
+
 def test_default_config_matches_reference_defaults():
     """teb_amd_config_default == TebConfig() of the Python mirror == teb_config.h:245-390."""
     L = planner.lib()

@@ -313,7 +313,7 @@ def test_c5_carlike_polygon_full_size(oracle):
 def test_capacity_errors_are_loud():
     cfg, obst, via, batch = scenes.scene_c1()
     with pytest.raises(planner.TebAmdError) as e:
-        planner.TebBatchSolver(cfg, 1, 600, 4, 1, 1)
+        planner.TebBatchSolver(cfg, 1, 1100, 4, 1, 1)             # (600 until round 5: the band-in-HBM layout now holds ~ 950 poses)
     assert e.value.code == _abi.ERR_CAPACITY
     s = planner.make_solver(cfg, obst, via, batch)
     big = _abi.ObstacleTable()
@@ -539,15 +539,69 @@ def test_maximum_pose_capacities(oracle, n, solver):
     batch = _straight_batch(cfg, [n, n - 7], n, rng)
     s = planner.make_solver(cfg, obst, via, batch)
     lds, cap = s.capacity()
-    assert cap >= n and cap == 512
+    assert cap >= n and _abi.MAX_POSES <= cap <= 1024        # the band-in-HBM layout: four poses per lane, LDS permitting (951 on MI355X)
     s.optimize(3, 2, True, cfg.hcp.selection_obst_cost_scale, cfg.hcp.selection_viapoint_cost_scale,
                cfg.hcp.selection_alternative_time_cost)
     res = s.results(); out = s.download(batch.copy()); s.close()
     ref, rres = oracle.optimize_batch(cfg, obst, via, batch, inner=3, outer=2)
     assert_full_parity(out, res, ref, rres, pos_tol=1e-7, rtol=1e-7)
-    with pytest.raises(planner.TebAmdError) as e:             # two poses per lane: 513 poses do not fit
-        planner.TebBatchSolver(cfg, 1, 513, 4, 4, 1)
+    with pytest.raises(planner.TebAmdError) as e:             # beyond what the LDS strips of the band-in-HBM layout hold
+        planner.TebBatchSolver(cfg, 1, cap + 1, 4, 4, 1)
     assert e.value.code == _abi.ERR_CAPACITY
+
+
+def _long_scene(n, kind, rng, stride=None, ns=None):
+    """Bands of ~ n poses (0.25 m per pose) with obstacles ALONG them: static ones every few metres and dynamic ones placed so that their
+    predicted position at the time stamp of poses in every pass (0 .. 255, 256 .. 511, 512 .. ) lies next to the band."""
+    cfg, mixed, via, _ = scenes.scene_small_mixed(footprint="point" if kind == "points" else "circular")
+    batch = _straight_batch(cfg, ns or [n, n - 13], stride or n, rng)
+    px, py, th, dt = batch.get_teb(0)
+    t = np.concatenate([[0.0], np.cumsum(dt)])
+    obst = _abi.ObstacleTable() if kind == "points" else mixed
+    for k in range(0, len(px), 9):
+        side = 1.0 if (k // 9) % 2 else -1.0
+        if kind == "points" or k % 27:
+            obst.add_point(px[k] + 0.1, py[k] + side * rng.uniform(0.35, 0.9))
+        else:
+            obst.add_polygon([(px[k], py[k] + side * 0.6), (px[k] + 0.4, py[k] + side * 0.6), (px[k] + 0.2, py[k] + side * 1.0)])
+    for k in range(20, len(px), 67):                          # dynamic: at pose k's time stamp 0.45 m beside pose k
+        vx, vy = rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.1)
+        obst.add_point(px[k] - vx * t[k] + 0.1, py[k] - vy * t[k] + 0.45, vel=(vx, vy))
+    return cfg, obst, via, batch
+
+
+@pytest.mark.parametrize("n,kind", [(513, "points"), (700, "points"), (769, "points"), (_abi.MAX_POSES, "points"), (640, "mixed")])
+def test_bands_beyond_512_poses(oracle, n, kind):
+    """trajectory.max_samples is a parameter of the reference (teb_config.h:78, 258; 500 is its default): bands of more than 512 poses run
+    the band-in-HBM instantiations with three or four poses per lane. 513 / 769: the first pose of a third / fourth
+    pass; 700: a leftover pass that is sliced; MAX_POSES: the capacity limit; "mixed": generic shapes (polygon distances, circular robot)."""
+    rng = np.random.default_rng(n)
+    cfg, obst, via, batch = _long_scene(n, kind, rng)
+    cfg.trajectory.teb_autosize = False
+    cfg.trajectory.max_samples = 1000
+    s = planner.make_solver(cfg, obst, via, batch)
+    s.optimize(2, 2, True, cfg.hcp.selection_obst_cost_scale, cfg.hcp.selection_viapoint_cost_scale,
+               cfg.hcp.selection_alternative_time_cost)
+    res = s.results(); out = s.download(batch.copy()); s.close()
+    ref, rres = oracle.optimize_batch(cfg, obst, via, batch, inner=2, outer=2)
+    assert (rres.status == _abi.TEB_OK).all()
+    assert_full_parity(out, res, ref, rres, pos_tol=1e-7, rtol=1e-7)
+
+
+def test_band_beyond_512_poses_with_autoresize_and_dynamic_obstacles(oracle):
+    """A 480-pose band whose time differences call for more samples grows past 512 poses inside the kernel (max_samples 900); dynamic
+    obstacles beside poses of every pass exercise the near masks of the third pass, which are not cached (two slots per lane)."""
+    rng = np.random.default_rng(91)
+    cfg, obst, via, batch = _long_scene(480, "points", rng, stride=_abi.MAX_POSES, ns=[480, 300])
+    cfg.trajectory.max_samples = 900          # (a sweep may stop at max_samples intervals = 901 poses: the capacity must cover max_samples + 1)
+    batch.dt[0, :200] *= 1.7            # above dt_ref + dt_hysteresis: these intervals are split
+    s = planner.make_solver(cfg, obst, via, batch)
+    s.optimize(3, 2, True, cfg.hcp.selection_obst_cost_scale, cfg.hcp.selection_viapoint_cost_scale,
+               cfg.hcp.selection_alternative_time_cost)
+    res = s.results(); out = s.download(batch.copy()); s.close()
+    ref, rres = oracle.optimize_batch(cfg, obst, via, batch, inner=3, outer=2)
+    assert int(out.n.max()) > 512
+    assert_full_parity(out, res, ref, rres, pos_tol=1e-7, rtol=1e-7)
 
 
 @pytest.mark.parametrize("n", [300, 400])
