@@ -43,6 +43,15 @@ __device__ unsigned long long g_near_recomputed, g_near_queries;   // lanes that
 __device__ long long g_lin_prof[16];  // thread 0 of workgroup 0: sections of linearize()
 #define LNP_DECL long long lnp_t0 = clock64(), lnp_t1;
 #define LNP(k) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); lnp_t1 = clock64(); __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && threadIdx.x == 0) g_lin_prof[k] += lnp_t1 - lnp_t0; lnp_t0 = lnp_t1; } while (0)
+#elif defined(TEB_AMD_STAMP)
+// (diagnostic build, -DTEB_AMD_STAMP=<id>: ONE section of the edge loops of the otherwise unchanged product kernel into the spare slot 7 of
+// the phase log - no waits, no scheduling fences, lane 1 / lane 0 of wave 0. ids: evaluate {0 static, 1 dynamic, 2 between-pose terms},
+// linearise {3, 4, 5 the same}, 10 + the sections of linearize() {0 zero H b, 1 trig, 2 near masks, 3 edges, 4 slice reduction, 5 scatter,
+// 6 fixed rows + chi2 sum}, 18 .. 21 graph side data {trig, association, time stamps, via-points}; tools/stamp_sections.py)
+#define EVP_DECL long long evp_t0 = clock64();
+#define EVP(k) do { const long long t_ = clock64(); if ((k) == (TEB_AMD_STAMP) && threadIdx.x == 1) reinterpret_cast<long long*>(l.red + 40)[7] += t_ - evp_t0; evp_t0 = t_; } while (0)
+#define LNP_DECL long long lnp_t0 = clock64();
+#define LNP(k) do { const long long t_ = clock64(); if ((k) + 10 == (TEB_AMD_STAMP) && threadIdx.x == 0) reinterpret_cast<long long*>(l.red + 40)[7] += t_ - lnp_t0; lnp_t0 = t_; } while (0)
 #else
 #define EVP_DECL
 #define EVP(k)
@@ -393,6 +402,12 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
             TEB_EDGE(M_POSE0, CAT_OBST, edge_obstacle_fast<J_>(c, ox, oy, orad, W, t.w_obst, t.inflated, ACC_));
           }
         } else {
+          // the first batch does not wait for the count: rows 0 .. of the list exist whatever it is (capacity = every obstacle), so
+          // its loads are issued together with the load of cnt - one L2 round trip instead of two in front of every edge loop; every
+          // further batch is fetched while the one before it is evaluated (round 5: each used to expose its own round trip)
+          int cur[kStaticBatch];
+#pragma unroll
+          for (int u = 0; u < kStaticBatch; ++u) cur[u] = pre[u];
           for (int k0 = sl; k0 < cnt; k0 += kStaticBatch * nsl) {
             int pp[kStaticBatch];
             bool valid[kStaticBatch];
@@ -400,16 +415,15 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
             for (int u = 0; u < kStaticBatch; ++u) {
               const int kq = k0 + u * nsl;
               valid[u] = kq < cnt;
-              // the first batch does not wait for the count: rows 0 .. of the list exist whatever it is (capacity = every obstacle), so
-              // its loads are issued together with the load of cnt - one L2 round trip instead of two in front of every edge loop
-              if (k0 == sl) pp[u] = valid[u] ? pre[u] : 0;   // (rows beyond the count hold whatever the buffer held: never an index)
-              else pp[u] = valid[u] ? t.assoc[(size_t)kq * t.stride + i] : 0;
+              pp[u] = valid[u] ? cur[u] : 0;   // (rows beyond the count hold whatever the buffer held: never an index)
+              const int kn = kq + kStaticBatch * nsl;
+              cur[u] = kn < cnt ? t.assoc[(size_t)kn * t.stride + i] : 0;   // the next batch: in flight during this one
             }
             double dist[kStaticBatch], g0[kStaticBatch], g1[kStaticBatch];
 #pragma unroll
             for (int u = 0; u < kStaticBatch; ++u) {
               double gr[2];
-              dist[u] = pointlike_distance<JAC>(c, w.x0, w.y0, l.obx[pp[u]], l.oby[pp[u]], l.obr[pp[u]], gr);
+              dist[u] = pointlike_distance<JAC>(c, w.x0, w.y0, l.obx[pp[u]], l.oby[pp[u]], TEB_CFGI(RADIUS_FREE) ? 0.0 : l.obr[pp[u]], gr);   // (no radii in the static list: an exact zero, not read)
               g0[u] = JAC ? gr[0] : 0.0; g1[u] = JAC ? gr[1] : 0.0;
             }
 #pragma unroll
@@ -584,6 +598,17 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
 // them) are free of conflicts with ALL lanes busy in each, and every entry receives its up to three contributions in the fixed order
 // lane p, p-1, p-2 - deterministic, no atomics. In the block layout only the lower triangle of a diagonal block is kept (the
 // factorisation reads nothing else).
+// One contribution to an entry of the LDS normal matrix / right-hand side. The three scatter steps leave exactly one writer per entry
+// and step, so this is no race either way; as an LDS atomic (ds_add_f64: one IEEE addition in the LDS unit, no return value) it is ONE
+// instruction per entry instead of a read, an add and a write with the round trip in between: linearize() - 8 %, headline - 1.6 %,
+// C2 - 3 % (round 5; bit-identical). Where the old value is already in a register the plain store wins: the same change in the rounds
+// of the cyclic reduction, whose reads are prefetched under the elimination, cost 2 % (profiles/ab_edge_loops_r05.txt). (HBM band of
+// long bands: plain update.)
+template <int SOLVER>
+__device__ __forceinline__ void hmat_add(double* p, double v) {
+  if constexpr (SOLVER == SOLVER_BANDG) *p += v;
+  else (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 template <int SOLVER, int K>
 __device__ __forceinline__ void scatter(const Accum& A, const Lds& l, int i, int n) {
   const int base = 4 * i;
@@ -593,7 +618,7 @@ __device__ __forceinline__ void scatter(const Accum& A, const Lds& l, int i, int
     int ra = base + a;
     bool fa = (ra < 3) || (ra >= last_pose);
     if (fa) continue;
-    l.bv[ra] -= A.g[a];
+    hmat_add<SOLVER_BAND>(&l.bv[ra], -A.g[a]);   // (b lives in LDS in every layout; x - g == x + (-g))
 #pragma unroll
     for (int b = 0; b <= a; ++b) {
       int rb = base + b;
@@ -601,11 +626,11 @@ __device__ __forceinline__ void scatter(const Accum& A, const Lds& l, int i, int
       if (fb) continue;
       const double v = A.H[a * (a + 1) / 2 + b];
       if (SOLVER != SOLVER_CR) {
-        l.Hb[hbo(ra) + (a - b)] += v;
+        hmat_add<SOLVER>(&l.Hb[hbo(ra) + (a - b)], v);
       } else {
         const int jr = ra >> 3, jc = rb >> 3;   // window spans at most two consecutive block rows
-        if (jr == jc) l.Db[jr * kBlk + (ra & 7) * 8 + (rb & 7)] += v;
-        else l.Lb[jr * kBlk + (ra & 7) * 8 + (rb & 7)] += v;
+        if (jr == jc) hmat_add<SOLVER>(&l.Db[jr * kBlk + (ra & 7) * 8 + (rb & 7)], v);
+        else hmat_add<SOLVER>(&l.Lb[jr * kBlk + (ra & 7) * 8 + (rb & 7)], v);
       }
     }
   }

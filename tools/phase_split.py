@@ -46,6 +46,15 @@ def report(which):
         out.append("   %-20s %13.1f %% %13.1f %% %16.0f" % (name, 100 * share[:, k].mean(), 100 * share[slow, k], log[slow, k]))
     out.append("   phases cover %.1f %% of the workgroup's cycles (mean); slowest band %d: %.0f cycles = %.3f ms at %.0f MHz; CU utilisation (mean / max) %.2f" % (
         100 * (tot / log[:, 8]).mean(), slow, log[slow, 8], ms_on, log[slow, 8] / (ms_on * 1e3), log[:, 8].mean() / log[:, 8].max()))
+    long_ = n > 256
+    if long_.any() and (~long_).any():   # what crossing 256 poses costs, phase by phase (cycles per LM trial of the band)
+        tr = res.lm_trials.astype(float)
+        out.append("   cycles per LM trial, bands <= 256 poses (%d) | > 256 poses (%d):" % ((~long_).sum(), long_.sum()))
+        for k, name in enumerate(planner.TebBatchSolver.PHASES):
+            a, b = (log[~long_, k] / tr[~long_]).mean(), (log[long_, k] / tr[long_]).mean()
+            out.append("   %-20s %10.0f | %10.0f   (%+.0f)" % (name, a, b, b - a))
+        a, b = (log[~long_, 8] / tr[~long_]).mean(), (log[long_, 8] / tr[long_]).mean()
+        out.append("   %-20s %10.0f | %10.0f   (%+.0f = %+.1f %%)" % ("whole workgroup", a, b, b - a, 100 * (b - a) / a))
     return "\n".join(out)
 
 
