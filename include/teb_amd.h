@@ -282,7 +282,12 @@ typedef struct teb_amd_options {
                                   /* Code objects are kept in $TEB_AMD_RTC_CACHE (default $XDG_CACHE_HOME/teb_amd or ~/.cache/teb_amd; */
                                   /* "off" = no disk cache), keyed by sources, flag values, instantiation and compiler version: the   */
                                   /* next process loads them in milliseconds. Where something is missing, or the compilation fails,   */
-                                  /* the pre-built kernels run - it is never an error.                                                 */
+                                  /* the pre-built kernels run - it is never an error. The key holds scene-dependent flags too (via-  */
+                                  /* points present, radii in the static list) and the layout of the launch: when one of them flips   */
+                                  /* in a live planner, mode 1 runs the pre-built kernel until the new module is ready, mode 2 blocks  */
+                                  /* that tick for the compiler - mode 2 is for benchmarks and tests, mode 1 for a robot. The disk    */
+                                  /* cache is only used when its directory belongs to the calling user and nobody else can write it;  */
+                                  /* its checksum detects corruption, it is no authentication.                                        */
   int32_t reserved[4];            /* must be 0                                                                                  */
 } teb_amd_options_t;
 void teb_amd_options_default(teb_amd_options_t* opt);
