@@ -588,6 +588,41 @@ def test_bands_beyond_512_poses(oracle, n, kind):
     assert_full_parity(out, res, ref, rres, pos_tol=1e-7, rtol=1e-7)
 
 
+@pytest.mark.parametrize("variant", ["holonomic", "carlike", "legacy_association", "arc_length_exponent", "g2o_numeric", "shortest_path_vel_ratio",
+                                     "divergence_statistics", "generic_kernel"])
+def test_bands_beyond_512_poses_off_the_defaults(oracle, variant):
+    """The band-in-HBM instantiations with more than two poses per lane exist in every kind (generic, light, numeric mode ..): 600 and 587
+    poses with one option off the defaults each, against the oracle."""
+    rng = np.random.default_rng(600)
+    cfg, obst, via, batch = _long_scene(600, "mixed" if variant == "carlike" else "points", rng)
+    cfg.trajectory.teb_autosize = False
+    cfg.trajectory.max_samples = 1000
+    options, tol = None, 1e-7
+    if variant == "holonomic":
+        cfg.robot.max_vel_y = 0.3; cfg.optim.weight_kinematics_nh = 1.0
+    elif variant == "carlike":
+        cfg.robot.min_turning_radius = 1.0
+    elif variant == "legacy_association":
+        cfg.obstacles.legacy_obstacle_association = True
+    elif variant == "arc_length_exponent":
+        cfg.trajectory.exact_arc_length = True; cfg.optim.obstacle_cost_exponent = 1.5
+    elif variant == "g2o_numeric":
+        cfg.jacobian_mode = _abi.JACOBIAN_G2O_NUMERIC; tol = 1e-6   # (central differences: test_numeric_jacobians_on_long_bands)
+    elif variant == "shortest_path_vel_ratio":
+        cfg.optim.weight_shortest_path = 1.0; cfg.optim.weight_velocity_obstacle_ratio = 0.5
+    elif variant == "divergence_statistics":
+        cfg.recovery.divergence_detection_enable = True
+    elif variant == "generic_kernel":
+        options = _abi.Options(generic_config_path=True)
+    s = planner.make_solver(cfg, obst, via, batch, options=options)
+    s.optimize(2, 2, True, cfg.hcp.selection_obst_cost_scale, cfg.hcp.selection_viapoint_cost_scale,
+               cfg.hcp.selection_alternative_time_cost)
+    res = s.results(); out = s.download(batch.copy()); s.close()
+    ref, rres = oracle.optimize_batch(cfg, obst, via, batch, inner=2, outer=2)
+    assert (rres.status == _abi.TEB_OK).all()
+    assert_full_parity(out, res, ref, rres, pos_tol=tol, rtol=1e-7)
+
+
 def test_band_beyond_512_poses_with_autoresize_and_dynamic_obstacles(oracle):
     """A 480-pose band whose time differences call for more samples grows past 512 poses inside the kernel (max_samples 900); dynamic
     obstacles beside poses of every pass exercise the near masks of the third pass, which are not cached (two slots per lane)."""
