@@ -284,3 +284,38 @@ def test_randomized_strip_functions_match_oracle(oracle, seed):
         for u, v in zip(_band(s, 0, 512), oracle.update_and_prune(*band, *c["prune"])):
             np.testing.assert_array_equal(u, v)
     s.close()
+
+
+def test_strip_functions_on_a_band_beyond_512_poses(oracle):
+    """The producers and consumers of the strips at a pose capacity beyond 512 (TEB_AMD_MAX_POSES, round 5): a 180 m line sampled every
+    0.25 m (721 poses), a 700-point plan, pruning that band and its read-outs against the oracle."""
+    cfg = TebConfig()
+    cfg.trajectory.max_samples = 900
+    S = _abi.MAX_POSES
+    s = planner.TebBatchSolver(cfg, 2, S, 4, 4, 1)
+    line = ([0.0, 0.0, 0.1], [180.0, 3.0, -0.2], 0.25, 0.4, 3, False)
+    s.init_trajectory_line(0, *line)
+    want = oracle.init_trajectory_line(*line)
+    assert len(want[0]) > 512
+    _close(_band(s, 0, S), want)
+    t = np.linspace(0, 1, 700)
+    px = 170.0 * t; py = 4.0 * np.sin(6 * np.pi * t); pyaw = np.arctan2(np.gradient(py), np.gradient(px))
+    plan = (px, py, pyaw, 0.4, 0.3, True, 3, False)
+    s.init_trajectory_plan(0, *plan)
+    want = oracle.init_trajectory_plan(*plan)
+    assert len(want[0]) == 700
+    _close(_band(s, 0, S), want)
+    b = _abi.TebBatchHost(1, S)
+    b.set_teb(0, *want)
+    b.vel_start[0] = [0.1, 0.0, 0.05]; b.vel_goal[0] = [0.0, 0.0, 0.0]
+    s.upload(b)
+    wantc = oracle.consumers(cfg, b, 0, 3, 0)
+    ok, cmd = s.velocity_command(0, 3, 0)
+    assert ok == wantc["ok"] and np.abs(cmd - wantc["cmd"]).max() <= TOL
+    assert np.abs(s.velocity_profile(0) - wantc["profile"]).max() <= TOL
+    assert np.abs(s.full_trajectory(0) - wantc["trajectory"]).max() <= TOL
+    prune = ([float(px[40]) + 0.02, float(py[40]) - 0.01, 0.3], [171.0, 0.2, 0.0], 3)
+    s.update_and_prune(*prune, b=0)
+    for u, v in zip(_band(s, 0, S), oracle.update_and_prune(*want, *prune)):
+        np.testing.assert_array_equal(u, v)
+    s.close()
