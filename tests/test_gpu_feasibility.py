@@ -93,3 +93,43 @@ def test_homotopy_planner_drops_infeasible_best_band(oracle):
     hp2 = planner_()
     assert not hp2.isTrajectoryFeasible(wall, fp, 0.15) and hp2.solver.count == 0
     hp.solver.close(); hp2.solver.close()
+
+
+def test_feasibility_and_signatures_of_a_band_beyond_512_poses(oracle):
+    """Rows f3 / f4 at a pose capacity beyond 512 (round 5): a 700-pose band - isTrajectoryFeasible over its whole length (a lethal blob near
+    pose 650: the first infeasible test lies beyond index 512), and both H-signatures against the oracle."""
+    from oracle.oracle_py import Costmap
+    n, length = 700, 175.0
+    x, y, th, dt = scenes.sine_band(n, length, 0.3, 1.0, 0.4)
+    batch = _abi.TebBatchHost(1, _abi.MAX_POSES)
+    batch.set_teb(0, x, y, th, dt)
+    res = 0.1
+    ox, oy = -2.0, -6.0
+    cells = np.zeros((int(12.0 / res), int((length + 4.0) / res)), np.uint8)
+    fp = [(-0.3, -0.25), (0.9, -0.25), (0.9, 0.25), (-0.3, 0.25)]
+    cm_free = Costmap(cells.copy(), res, ox, oy)
+    blob = cells.copy()
+    mx, my = int((x[650] - ox) / res), int((y[650] - oy) / res)
+    blob[my - 2:my + 3, mx - 2:mx + 3] = 254
+    cm_blob = Costmap(blob, res, ox, oy)
+    cfg = scenes.scene_c1()[0]
+    cfg.trajectory.max_samples = 900
+    obst = _abi.ObstacleTable()
+    rng = np.random.default_rng(5)
+    for k in range(0, n, 23):
+        obst.add_point(float(x[k]) + 0.1, float(y[k]) + float(rng.choice([-1.0, 1.0])) * float(rng.uniform(0.4, 1.5)))
+    s = planner.make_solver(cfg, obst, [], batch)
+    for cm in (cm_free, cm_blob):
+        s.set_costmap(cm.cells, cm.resolution, cm.origin_x, cm.origin_y)
+        got = s.is_trajectory_feasible(0, fp, 0.25, 0.3, -1, -1.0)
+        want = oracle.is_trajectory_feasible(batch, 0, cm, fp, 0.25, 0.3, -1, -1.0)
+        assert got == want, (got, want)
+    assert want[0] is False and want[1] > 512
+    for mode in (2, 3):
+        cfg.obstacles.include_dynamic_obstacles = (mode == 3)
+        s.set_config(cfg)
+        sig = s.h_signatures(1.0)
+        wsig = oracle.h_signatures(cfg, obst, batch, mode, 1.0)
+        tol = 4 * np.finfo(float).eps * max(1.0, np.abs(wsig).max()) if mode == 3 else 1e-10 * max(np.abs(wsig).max(), 1e-300)
+        assert np.abs(sig - wsig).max() <= tol, (mode, np.abs(sig - wsig).max())
+    s.close()
