@@ -87,8 +87,20 @@ struct Lds {
 };
 
 __host__ __device__ inline int nb_for(int S) { return (4 * S + 7) / 8; }
+constexpr long long kBandgLdsDoubles = (160 * 1024 - 1024) / 8;   // LDS of a workgroup on MI355X minus the library's head-room (teb_amd.hip: lds_limit), in doubles
 __host__ __device__ inline size_t hmat_doubles(int S, int solver) {  // (LDS-resident part)
-  if (solver == SOLVER_BANDG) return (size_t)6 * S + 256;   // only the scratch of autoResize (edit script + new poses + split stack + runs)
+  if (solver == SOLVER_BANDG) {
+    // The scratch of autoResize (edit script + new poses + split stack + runs) - and, during a solve, the compact system of the coarse
+    // levels of the reduction (cr_solve_t<true>: the fine levels run on blocks in HBM until the surviving rows fit here). Round 5: up to
+    // 64 compact rows where the strips leave room for them (2 x 66 doubles per block row; their right-hand side lives in the dx region),
+    // so that a band of 338 .. 512 poses runs TWO levels through L2 instead of six - with 20 KB left for the obstacle cache
+    // (kBandgLdsDoubles: what MI355X gives a workgroup; a device with less simply refuses the capacity as before). Beyond ~ 640 poses the
+    // strips take the room and the autoResize scratch alone remains: the capacity limit (TEB_AMD_MAX_POSES) is unchanged.
+    const long long own = 6LL * S + 256;
+    const long long room = kBandgLdsDoubles - 2560 - (15LL * S + 120), want = 64LL * 2 * kBlk;
+    const long long compact = room < want ? room : want;
+    return (size_t)(((compact > own ? compact : own) + 1) & ~1LL);
+  }
   if (solver == SOLVER_CR) return (size_t)nb_for(S) * (2 * kBlk + 8);
   // hybrid solve: even block rows in LDS (+ up to 14 doubles between its D and L regions, cr_solve_hybrid_impl). Rounded up to an even
   // count: the regions behind it (b, dx) are zeroed and copied in 16-byte accesses and must start on 16-byte boundaries (45 S is odd for odd S).
@@ -606,7 +618,7 @@ __device__ __forceinline__ void eval_index(const teb_amd_config_t& c, const Scen
 // long bands: plain update.)
 template <int SOLVER>
 __device__ __forceinline__ void hmat_add(double* p, double v) {
-  if constexpr (SOLVER == SOLVER_BANDG) *p += v;
+  if constexpr (SOLVER == SOLVER_BANDG) *p += v;   // (global_atomic_add_f64 + an acquire fence measured 30 % slower on 400 .. 944-pose bands)
   else (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 template <int SOLVER, int K>
@@ -1512,11 +1524,11 @@ __device__ __forceinline__ void cr_solve_t_impl(const LdsPlan plan, const SceneD
   __syncthreads();
   CRP(0);
   if constexpr (GLOBAL) {
-    // Finer levels on the HBM blocks; as soon as the surviving rows (every s0-th) fit the LDS region of the obstacle cache - which
-    // nobody reads during the solve - they are copied there and the remaining levels, the top solve and their back substitution
-    // run in LDS; the cache is reloaded from the (L2-resident) obstacle table afterwards. The compact system is an exact
+    // Finer levels on the HBM blocks; as soon as the surviving rows (every s0-th) fit the LDS region this layout keeps for them (the
+    // autoResize scratch, sized for up to 64 compact rows: hmat_doubles; until round 5 the obstacle cache was borrowed - a few rows) they
+    // are copied there and the remaining levels, the top solve and their back substitution run in LDS. The compact system is an exact
     // re-indexing (row j' = j / s0, stride s' = s / s0), so the arithmetic is that of the all-HBM reduction.
-    const int lds_doubles = 5 * plan.ob_cap;
+    const int lds_doubles = plan.off_b - plan.off_H;   // (the region of the autoResize scratch: hmat_doubles; nobody else uses it during a solve)
     int s0 = 1;
     while (s0 < Nb && 2 * ((Nb + s0 - 1) / s0) * kBlk > lds_doubles) s0 <<= 1;
     const bool use_lds = lds_doubles > 0 && s0 < Nb && 8 * ((Nb + s0 - 1) / s0) <= 4 * plan.S + 8;
@@ -1525,7 +1537,7 @@ __device__ __forceinline__ void cr_solve_t_impl(const LdsPlan plan, const SceneD
     CRP(1);
     if (use_lds) {
       const int Nc = (Nb + s0 - 1) / s0;
-      double* Dc = lds_base + plan.off_ob;
+      double* Dc = lds_base + plan.off_H;
       double* Lc = Dc + Nc * kBlk;
       double* fc = lds_base + plan.off_dx;
       for (int q = tid; q < Nc * 64; q += kThreads) {
@@ -1546,13 +1558,6 @@ __device__ __forceinline__ void cr_solve_t_impl(const LdsPlan plan, const SceneD
       __syncthreads();
       CRP(3);
       if (s0 > 1) cr_backward(D, L, f, Nb, s0 >> 1, 1);
-      // the obstacle cache comes back (same staging as at kernel start)
-      const int tot = sc.n_static + sc.n_dyn;
-      for (int k = tid; k < tot; k += kThreads) {
-        const int oi = (k < sc.n_static) ? sc.static_idx[k] : sc.dyn_idx[k - sc.n_static];
-        l.obx[k] = sc.ax[oi]; l.oby[k] = sc.ay[oi]; l.obvx[k] = sc.vx[oi]; l.obvy[k] = sc.vy[oi];
-        l.obr[k] = (sc.type[oi] == TEB_AMD_OBST_CIRCULAR) ? sc.rad[oi] : 0.0;
-      }
     } else {
       ok = cr_top(D, f) && ok;
       __syncthreads();
