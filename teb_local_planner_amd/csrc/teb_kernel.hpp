@@ -89,18 +89,7 @@ struct Lds {
 __host__ __device__ inline int nb_for(int S) { return (4 * S + 7) / 8; }
 constexpr long long kBandgLdsDoubles = (160 * 1024 - 1024) / 8;   // LDS of a workgroup on MI355X minus the library's head-room (teb_amd.hip: lds_limit), in doubles
 __host__ __device__ inline size_t hmat_doubles(int S, int solver) {  // (LDS-resident part)
-  if (solver == SOLVER_BANDG) {
-    // The scratch of autoResize (edit script + new poses + split stack + runs) - and, during a solve, the compact system of the coarse
-    // levels of the reduction (cr_solve_t<true>: the fine levels run on blocks in HBM until the surviving rows fit here). Round 5: up to
-    // 64 compact rows where the strips leave room for them (2 x 66 doubles per block row; their right-hand side lives in the dx region),
-    // so that a band of 338 .. 512 poses runs TWO levels through L2 instead of six - with 20 KB left for the obstacle cache
-    // (kBandgLdsDoubles: what MI355X gives a workgroup; a device with less simply refuses the capacity as before). Beyond ~ 640 poses the
-    // strips take the room and the autoResize scratch alone remains: the capacity limit (TEB_AMD_MAX_POSES) is unchanged.
-    const long long own = 6LL * S + 256;
-    const long long room = kBandgLdsDoubles - 2560 - (15LL * S + 120), want = 64LL * 2 * kBlk;
-    const long long compact = room < want ? room : want;
-    return (size_t)(((compact > own ? compact : own) + 1) & ~1LL);
-  }
+  if (solver == SOLVER_BANDG) return (size_t)6 * S + 256;   // the scratch of autoResize (edit script + new poses + split stack + runs); make_lds_plan may add to it
   if (solver == SOLVER_CR) return (size_t)nb_for(S) * (2 * kBlk + 8);
   // hybrid solve: even block rows in LDS (+ up to 14 doubles between its D and L regions, cr_solve_hybrid_impl). Rounded up to an even
   // count: the regions behind it (b, dx) are zeroed and copied in 16-byte accesses and must start on 16-byte boundaries (45 S is odd for odd S).
@@ -122,7 +111,17 @@ __host__ inline LdsPlan make_lds_plan(int S, int solver, int ob_entries) {
   int o = 0;
   p.off_state = o; o += 7 * S;
   o = (o + 1) & ~1;
-  p.off_H = o; o += (int)hmat_doubles(S, solver);
+  int hm = (int)hmat_doubles(S, solver);
+  if (solver == SOLVER_BANDG) {
+    // Band in HBM: during a solve this region holds the compact system of the coarse levels of the reduction (cr_solve_t<true>: the fine
+    // levels run on blocks in HBM until the surviving rows fit here; their right-hand side lives in the dx region). Round 5: whatever the
+    // strips AND the obstacle cache leave of a workgroup's LDS, up to 64 block rows (2 x 66 doubles each) - a band of 338 .. 512 poses then
+    // runs two levels through L2 instead of six. Long bands and big obstacle tables take the room first: the capacity limits are unchanged.
+    const long long room = kBandgLdsDoubles - (o + 8LL * S + 16 + 96 + 5LL * (ob_entries > 0 ? ob_entries : 0)), want = 64LL * 2 * kBlk;
+    const long long extra = (room < want ? room : want) & ~1LL;
+    if (extra > hm) hm = (int)extra;
+  }
+  p.off_H = o; o += hm;
   p.off_b = o; o += 4 * S + 8;
   p.off_dx = o; o += 4 * S + 8;
   p.off_red = o; o += 64 + 32;
