@@ -234,6 +234,24 @@ def test_kernel_compiled_for_the_configuration_at_run_time():
     same_bits(a[0], a[1], b[0], b[1])
 
 
+def test_kernel_compiled_for_the_configuration_on_a_band_beyond_512_poses():
+    """The run-time compiler instantiates the band-in-HBM layout with four poses per lane like the pre-built units (csrc/teb_rtc.hpp passes
+    TEB_AMD_POSE_ITER): a 600-pose band off the defaults - the compiled kernel (profile 4) returns the generic kernel's bands bit for bit."""
+    cfg, obst, via, _ = scenes.scene_c4(B=2, stride=288)
+    cfg.trajectory.teb_autosize = False
+    cfg.trajectory.max_samples = 1000
+    cfg.optim.weight_shortest_path = 0.7
+    batch = _abi.TebBatchHost(2, 640)
+    for b, n in enumerate((600, 587)):
+        batch.set_teb(b, *scenes.sine_band(n, 0.25 * n, 0.2 - 0.3 * b, 1.0, cfg.robot.max_vel_x))
+    a = run(cfg, obst, via, batch, compile_for_config=2)
+    g = run(cfg, obst, via, batch, generic_config_path=True)
+    ready, compiling, failed, secs, err = planner.TebBatchSolver.rtc_stats()
+    assert a[2] == 4 and g[2] == 0 and failed == 0, (a[2], g[2], err)
+    assert (a[1].status == _abi.TEB_OK).all()
+    same_bits(a[0], a[1], g[0], g[1])
+
+
 def test_background_compilation_runs_the_prebuilt_kernel_until_the_module_is_ready():
     import time
     cfg, obst, via, batch = scenes.scene_c3(B=6, n=80, M=60, stride=128)
