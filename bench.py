@@ -97,27 +97,11 @@ def latency_model(probe, n, inner_trials, static_edges_per_pose, dyn_near_per_po
 
 
 def kernel_source_hash(root=None):
-    """sha256 over the device sources with comments and white space stripped (a comment edit does not make a new binary): ties a
-    committed rocprof summary to the binary it was taken from."""
-    import re
-    h = hashlib.sha256()
-    d = os.path.join(root or ROOT, "teb_local_planner_amd", "csrc")
-    # the translation unit of the optimise kernel (teb_opt_inst.hip and what it includes) + the flags build.py gives the headline unit;
-    # the host side (teb_amd.hip) and the kernels of the rows either side of the path do not change the profiled binary
-    kernel_files = ("teb_autoresize_chain.hpp", "teb_device.hpp", "teb_edges.hpp", "teb_geometry.hpp", "teb_kernel.hpp", "teb_multicu.hpp", "teb_opt_inst.hip", "teb_opt_launch.hpp")
-    try:
-        from teb_local_planner_amd import build as _b
-        h.update(repr(sorted(_b.UNIT_FLAGS.items())).encode() + repr(_b.HIPCC_FLAGS).encode())
-    except Exception:   # noqa: BLE001
-        pass
-    for f in sorted(os.listdir(d)):
-        if f in kernel_files:
-            src = open(os.path.join(d, f), "r", errors="replace").read()
-            src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)      # block comments
-            src = re.sub(r"//[^\n]*", "", src)                   # line comments (no string literal of the sources holds "//")
-            h.update(f.encode())
-            h.update("".join(src.split()).encode())
-    return h.hexdigest()[:16]
+    """Hash of the optimise kernel's translation unit (comments and white space stripped) + its compiler flags: what a committed rocprof
+    summary is tied to. One definition, teb_local_planner_amd/build.py: kernel_hash() - build() embeds the same value in the binary
+    (config.binary_hash)."""
+    from teb_local_planner_amd import build as _b
+    return _b.kernel_hash()
 
 
 def cpu_model():
@@ -374,15 +358,21 @@ def main():
         # HBM-side traffic per launch from the committed rocprofv3 PMC passes of THIS command (FETCH_SIZE / WRITE_SIZE in separate
         # runs, scaled by the factors calibrated on a known 1 GiB stream; profiles/rocprof_*_summary.json). The summary records the
         # hash of the device sources it was taken from; a summary of other sources is reported as stale, never silently reused.
-        traffic, traffic_src, traffic_note, fp64, mfma = None, None, None, None, None
+        traffic, traffic_src, traffic_note, fp64, mfma, pj, fr, fw = None, None, None, None, None, None, 2048.0, 1024.0
         src_hash = kernel_source_hash()
+        # ... and to the BINARY: the library carries the hash build.py computed when it was built (teb_amd_debug_build_info). A library
+        # that is older than the tree (build() is mtime-based, the .so ships prebuilt to the GPU box) shows here, and no profile is attached.
+        try:
+            binary_hash, binary_full_hash, binary_defines, _ = planner.TebBatchSolver.build_info()
+        except Exception as e:   # noqa: BLE001
+            binary_hash, binary_full_hash, binary_defines = "unreadable: %s" % str(e)[:60], "", ""
         try:
             import glob
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "rocprof_r*_summary.json")), key=os.path.getmtime)
             if cands and args.tebs == 256 and n == 200 and args.scaling == "weak":
                 pj = json.load(open(cands[-1]))
                 traffic_src = os.path.basename(cands[-1])
-                if pj.get("source_hash") == src_hash:
+                if pj.get("source_hash") == src_hash and binary_hash == src_hash and pj.get("binary_hash", binary_hash) == binary_hash:
                     cal = pj.get("calibration", {})
                     fr = cal.get("FETCH_SIZE_bytes_per_counted_KB", 2048.0)
                     fw = cal.get("WRITE_SIZE_bytes_per_counted_KB", 1024.0)
@@ -396,7 +386,8 @@ def main():
                     if pj.get("mfma"):
                         mfma = pj["mfma"]
                 else:
-                    traffic_note = "%s was taken from other device sources (hash %s, now %s): not reported" % (traffic_src, pj.get("source_hash"), src_hash)
+                    traffic_note = ("%s was taken from other device sources or another binary (summary: sources %s, binary %s; now: sources %s, "
+                                    "loaded binary %s): not reported" % (traffic_src, pj.get("source_hash"), pj.get("binary_hash"), src_hash, binary_hash))
         except Exception as e:   # noqa: BLE001
             traffic_note = "profile summary unreadable: %s" % str(e)[:80]
         if args.scaling == "strong":
@@ -416,7 +407,8 @@ def main():
                        "poses_after": [int(n_after.min()), int(n_after.max())],
                        "pose_capacity": STRIDE, "tebs_ok": tebs_ok, "obstacles": M, "units_per_step_per_gpu": units_step,
                        "lm_trials_per_step_per_gpu": int(res.lm_trials.sum()), "jacobian_mode": "analytic (closed form)",
-                       "exchange": route["note"] or exchange, "source_hash": src_hash},
+                       "exchange": route["note"] or exchange, "source_hash": src_hash, "binary_hash": binary_hash,
+                       "binary_matches_sources": bool(binary_hash == src_hash), "binary_variant_defines": binary_defines},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,
@@ -472,6 +464,33 @@ def main():
                 "slowest_band": slow, "slowest_band_mcycles": float(plog[slow, 8]) * 1e-6, "covered": float((tot / np.maximum(plog[:, 8], 1.0)).mean()),
                 "cu_utilisation_mean_over_max": float(plog[:, 8].mean() / plog[:, 8].max()),
                 "kernel_ms_with_the_log": k_on, "kernel_ms_without": kms, "instrumented_over_product": k_on / kms}
+            # "achieved HBM GB/s for edge evaluation" (north_star): the algorithmic bytes of SURVEY 8(d) are ALL edge-phase bytes (state strips,
+            # obstacle table, association lists, the chi^2 / lambda words; the model keeps H and b in LDS, the solve moves none of them), so
+            # the edge phases' rate is those bytes over the time a CU spends in buildGraph side data + linearisation + update / error
+            # evaluation - the mean over the bands' workgroups (they run side by side, one per CU) of the three phase counters, at the shader
+            # clock measured in this run. traffic: FETCH + WRITE of the diagnostic build that runs the edge phases alone
+            # (-DTEB_AMD_DIAG_EDGE_ONLY, tools/profile.sh), per unit of THAT run, scaled to this launch's units.
+            edge_cyc = plog[:, [1, 2, 5]].sum(axis=1)
+            clk_hz = 1e6 * float(np.mean(clock_mhz))
+            t_edge = float(edge_cyc.mean()) / clk_hz
+            ee = {"bound": "hbm", "achieved": alg_bytes_launch / t_edge / 1e9, "peak": 8000.0, "unit": "GB/s",
+                  "phases": ["graph side data", "linearize", "update + evaluate"], "alg_bytes_per_launch": alg_bytes_launch,
+                  "mean_edge_phase_ms_per_band": 1e3 * t_edge, "slowest_band_edge_phase_ms": 1e3 * float(edge_cyc.max()) / clk_hz,
+                  "share_of_workgroup_cycles": float((edge_cyc / np.maximum(plog[:, 8], 1.0)).mean()),
+                  "what": "SURVEY 8(d) algorithmic bytes of the launch / mean over the bands of the shader cycles their workgroups spend in the "
+                          "edge phases (product kernel's phase log) at the measured shader clock", "traffic": None}
+            ee["frac"] = ee["achieved"] / ee["peak"]
+            try:
+                eo = (pj or {}).get("edge_only") if traffic is not None else None
+                if eo and eo.get("units_per_launch"):
+                    per_unit = (eo["FETCH_SIZE_KB_per_launch"] * fr + eo["WRITE_SIZE_KB_per_launch"] * fw) / eo["units_per_launch"]
+                    ee["traffic"] = per_unit * units_step
+                    ee["traffic_unit"] = "bytes/launch"
+                    ee["traffic_source"] = "%s: edge_only (FETCH + WRITE of the -DTEB_AMD_DIAG_EDGE_ONLY build, %.0f B per unit of its own run)" % (traffic_src, per_unit)
+                    ee["traffic_over_alg_bytes"] = ee["traffic"] / alg_bytes_launch
+            except Exception as e:   # noqa: BLE001
+                ee["traffic_note"] = str(e)[:120]
+            out["roofline"]["edge_evaluation"] = ee
         except Exception as e:   # noqa: BLE001
             out["roofline"]["phases"] = {"error": str(e)[:200]}
         if traffic_note:
@@ -745,6 +764,82 @@ def main():
                             "ref_vs_ref": {k: rr.get(k) for k in ("bands_outside_T3", "state_err", "pose_counts_equal", "device_over_ref_vs_ref", "error") if k in rr}}
                 except Exception as e:   # noqa: BLE001
                     sec[nm]["vs_reference_code"] = {"error": str(e)[:200]}
+            # ---- the per-rank workload of BASELINE config 4 ("256 candidates sharded over 8 GPUs") on the ONE GPU there is: bands 0 .. 31 of
+            #      the headline batch = rank 0's shard under parallel.shard_range(256, 0, 8). 32 bands leave 224 CUs idle, so the host gives
+            #      every band solver helpers (mcu_helpers_for, csrc/teb_amd.hip); timed with them and on one CU per band. Plus the exchange
+            #      of the path on a communicator of ONE rank (the call sequence of a rank: 16-byte all-gather + the winner's strip), and the
+            #      projections that follow - PROJECTIONS: no 8-GPU node was measured; RCCL over xGMI adds its inter-GPU latency to the
+            #      world-of-one figure (message sizes 16 B and 32 n B: latency-bound).
+            try:
+                lo8, hi8 = parallel.shard_range(256, 0, 8)
+                c48, o48, v48, full8 = scenes.scene_c4(B=256, n=n, seed=1004, stride=STRIDE)
+                shard = _abi.TebBatchHost(hi8 - lo8, STRIDE)
+                for k_, b_ in enumerate(range(lo8, hi8)):
+                    shard.set_teb(k_, *full8.get_teb(b_))
+                    shard.has_vel_goal[k_] = full8.has_vel_goal[b_]
+                s8 = planner.make_solver(c48, o48, v48, shard)
+                s8.snapshot()
+                k8, w8, r8 = time_solver(torch, s8, c48, max(5, args.latency_reps // 2))
+                h8 = s8.last_launch_info()
+                n8 = s8.pose_counts()
+                # the step a rank runs: restore -> optimizeAllTEBs -> local selection (the bench's own timed region, on the shard)
+                ts8 = []
+                for _ in range(max(5, args.latency_reps // 2)):
+                    s8.restore(); torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    s8.optimize(inner, outer, True, c48.hcp.selection_obst_cost_scale, c48.hcp.selection_viapoint_cost_scale, c48.hcp.selection_alternative_time_cost)
+                    s8.select_best(-1, -1)
+                    ts8.append(time.perf_counter() - t1)
+                step8 = 1e3 * float(np.median(ts8))
+                exch = {}
+                try:
+                    c1 = parallel.RcclComm(parallel.RcclComm.unique_id(), 0, 1, local_rank)
+                    te, tb = [], []
+                    for _ in range(30):
+                        t1 = time.perf_counter()
+                        gbest, _, owner = s8.select_best_distributed(c1, lo8)
+                        te.append(time.perf_counter() - t1)
+                        t1 = time.perf_counter()
+                        s8.broadcast_band(c1, owner, gbest - lo8, STRIDE)
+                        tb.append(time.perf_counter() - t1)
+                    c1.close()
+                    exch = {"select_best_distributed_p50_ms": 1e3 * float(np.median(te[5:])), "broadcast_band_p50_ms": 1e3 * float(np.median(tb[5:])),
+                            "what": "teb_amd_select_best_distributed (local selection kernel + ncclAllGather of 16 B + host arg-min) and "
+                                    "teb_amd_comm_broadcast_band (winner strip, ncclBroadcast) on an RCCL communicator of ONE rank, 25 calls"}
+                except Exception as e:   # noqa: BLE001
+                    exch = {"error": str(e)[:160]}
+                s8.close()
+                s81 = planner.make_solver(c48, o48, v48, shard, options=_abi.Options(multi_cu=-1, speculative_trials=-1))
+                s81.snapshot()
+                k81, w81, _ = time_solver(torch, s81, c48, 5)
+                s81.close()
+                u8 = int(r8.lm_iterations.sum())
+                sec["c4_strong_shard_of_8"] = {
+                    "workload": "bands %d .. %d of the headline batch: rank 0's shard of BASELINE config 4 (256 candidates over 8 GPUs, "
+                                "parallel.shard_range(256, 0, 8)), same scene, teb_autosize on" % (lo8, hi8 - 1),
+                    "kernel_ms": k8, "ms_per_step": w8, "step_with_local_selection_ms": step8, "units_per_step": u8, "value": u8 / (w8 * 1e-3),
+                    "unit": "TEB.LM-iterations/s", "poses_after": [int(n8.min()), int(n8.max())], "tebs_ok": int((r8.status == 0).sum()),
+                    "helpers": {"distance_helpers_per_band": h8[0], "solver_helpers_per_band": h8[1], "repeated_on_one_cu": h8[2]},
+                    "one_cu_per_band": {"kernel_ms": k81, "ms_per_step": w81},
+                    "vs_headline_kernel_ms": k8 / float(np.mean(kernel_ms)), "exchange_world_of_one": exch}
+                ex_ms = (exch.get("select_best_distributed_p50_ms", 0.0) + exch.get("broadcast_band_p50_ms", 0.0)) if "error" not in exch else None
+                if ex_ms is not None:
+                    # strong: the batch of 256 split over 8 ranks, each runs this shard's step, then the exchange (selection replaces the
+                    # local select_best of the step: its kernel is inside select_best_distributed). weak: 8 x the headline batch, one
+                    # all-gather per step on top of the headline step.
+                    strong_ms = step8 + ex_ms
+                    weak_ms = out["ms_per_step"] + exch["select_best_distributed_p50_ms"]
+                    out["projected_8gpu"] = {
+                        "label": "PROJECTION from 1-GPU measurements, not a measurement: rank 0's shard + the world-of-one exchange; a real 8-rank "
+                                 "RCCL all-gather / broadcast adds xGMI latency (16 B and 32 n B messages)",
+                        "projected_8gpu_strong_ms": strong_ms,
+                        "projected_8gpu_strong_units_per_s": units_step / (strong_ms * 1e-3),
+                        "strong_speedup_over_1gpu_step": out["ms_per_step"] / strong_ms,
+                        "projected_8gpu_weak_units_per_s": 8.0 * units_step / (weak_ms * 1e-3),
+                        "weak_efficiency": out["ms_per_step"] / weak_ms,
+                        "inputs": {"headline_ms_per_step": out["ms_per_step"], "shard_step_ms": step8, "exchange_ms": ex_ms}}
+            except Exception as e:   # noqa: BLE001
+                sec["c4_strong_shard_of_8"] = {"error": str(e)[:200]}
             out["secondary"] = sec
 
         # ---- CPU baseline: the oracle in the reference-faithful mode (g2o central differences), thread per TEB

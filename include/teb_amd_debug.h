@@ -84,6 +84,16 @@ int teb_amd_debug_rtc_compile(uint64_t flag_values, int32_t solver, int32_t jaco
  * with compile_for_config). */
 int teb_amd_debug_rtc_cache(int32_t* embedded, int32_t* disk_hits, int32_t* disk_writes, char* cache_dir, int32_t capacity);
 
+/* What THIS BINARY was built from, as build.py recorded it when it compiled the host translation unit (empty strings for a build that
+ * did not go through build.py): kernel_hash = sha256 prefix over the optimise kernel's translation unit with comments and white space
+ * stripped + the per-unit compiler flags (teb_local_planner_amd/build.py: kernel_hash(); what bench.py calls source_hash and what a
+ * committed profiles/ summary is tied to), source_hash = the same over every device + host source as it stands (build.py: source_hash()),
+ * variant_defines = the -D flags of the build variant ("" for the product), *threads_per_workgroup = the optimise kernel's workgroup
+ * size. bench.py reports kernel_hash as config.binary_hash and attaches a profiles/ summary only when summary, source tree and binary
+ * carry the same hash. Needs no handle and no GPU. */
+int teb_amd_debug_build_info(char* kernel_hash, int32_t kernel_hash_capacity, char* source_hash, int32_t source_hash_capacity, char* variant_defines,
+                             int32_t defines_capacity, int32_t* threads_per_workgroup);
+
 /*
  * Phase split of the PRODUCT kernel, opt-in (one scalar branch per phase boundary when off; ~ 14 clock reads per LM iteration and band
  * when on, < 1 % of the launch): shader cycles of every band's workgroup per phase of the last teb_amd_optimize_batch -

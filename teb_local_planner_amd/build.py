@@ -53,13 +53,19 @@ VARIANTS = {
     "mfma": dict(lib=LIB_MFMA, defines=["-DTEB_AMD_MFMA_SCHUR", "-DTEB_AMD_ANALYTIC_ONLY", "-DTEB_AMD_NO_DEFAULTS_TWINS"], jmodes=(0,)),
     # closed-form Jacobians only: the quick build the tools/ A/B experiments use (build(variant="analytic", extra_defines=[..], out=..))
     "analytic": dict(lib=os.path.join(HERE, "..", "tools", "libteb_amd_ar.so"), defines=["-DTEB_AMD_ANALYTIC_ONLY"], jmodes=(0,)),
+    # kernel experiments (tools/ab.sh): closed-form Jacobians, and only the instantiations the measured configurations launch are real -
+    # the others are stubs that return a null kernel address (teb_opt_inst.hip, -DTEB_INST_STUB), so the launch fails loudly if reached
+    "exp": dict(lib=os.path.join(HERE, "..", "tools", "libteb_amd_exp.so"), defines=["-DTEB_AMD_ANALYTIC_ONLY"], jmodes=(0,),
+                only=("opt_0_0_4.o", "opt_1_0_4.o", "opt_0_0_5.o", "opt_1_0_5.o", "opt_0_0_7.o", "opt_1_0_7.o")),
 }
 PRODUCT_VARIANTS = ("product", "mfma")
 
 
-def _units(variant):
+def _units(variant, only=None):
     """(object name, source, extra defines) of every translation unit of the variant."""
-    v = VARIANTS[variant]
+    v = dict(VARIANTS[variant])
+    if only is not None:
+        v["only"] = tuple(only)
     units = [("teb_amd.o", "teb_amd.hip", [])]
     for jm in v["jmodes"]:
         for sv in (0, 1, 2):
@@ -69,8 +75,10 @@ def _units(variant):
             # (8, 9: the point-like kinds with every fold but the via-points and the holonomic choice, TEB_PF_WIDE_* in teb_device.hpp;
             #  10, 11: every cost-term flag at run time, TEB_PF_LIGHT_*)
             for sk in (((0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11) if twins else (0, 1, 2, 3)) if jm == 0 else ((0, 1, 4) if twins else (0, 1))):
-                units.append(("opt_%d_%d_%d.o" % (sv, jm, sk), "teb_opt_inst.hip",
-                              ["-DTEB_INST_SOLVER=%d" % sv, "-DTEB_INST_JMODE=%d" % jm, "-DTEB_INST_SCENE=%d" % sk]))
+                name = "opt_%d_%d_%d.o" % (sv, jm, sk)
+                stub = ["-DTEB_INST_STUB"] if ("only" in v and name not in v["only"]) else []
+                units.append((name, "teb_opt_inst.hip",
+                              ["-DTEB_INST_SOLVER=%d" % sv, "-DTEB_INST_JMODE=%d" % jm, "-DTEB_INST_SCENE=%d" % sk] + stub))
     return units
 
 
@@ -99,6 +107,28 @@ def source_hash():
         p = os.path.join(CSRC, f)
         if os.path.exists(p):
             h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def kernel_hash(variant_defines=(), unit_flags=None):
+    """sha256 over the translation unit of the optimise kernel (teb_opt_inst.hip and what it includes) with comments and white space
+    stripped - a comment edit does not make a new binary - + the compiler flags of the units and of the variant. The host side
+    (teb_amd.hip) and the kernels of the rows either side of the path do not change the profiled kernel. What a committed rocprof summary
+    is tied to: bench.py computes it on the tree (config.source_hash), build() embeds it in the binary (config.binary_hash,
+    teb_amd_debug_build_info), tools/export_profile.py records both."""
+    import re
+    h = hashlib.sha256()
+    kernel_files = ("teb_autoresize_chain.hpp", "teb_device.hpp", "teb_edges.hpp", "teb_geometry.hpp", "teb_kernel.hpp", "teb_multicu.hpp", "teb_opt_inst.hip", "teb_opt_launch.hpp")
+    h.update(repr(sorted((UNIT_FLAGS if unit_flags is None else unit_flags).items())).encode() + repr(HIPCC_FLAGS).encode())
+    if variant_defines:
+        h.update(repr(list(variant_defines)).encode())
+    for f in sorted(os.listdir(CSRC)):
+        if f in kernel_files:
+            src = open(os.path.join(CSRC, f), "r", errors="replace").read()
+            src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)      # block comments
+            src = re.sub(r"//[^\n]*", "", src)                   # line comments (no string literal of the sources holds "//")
+            h.update(f.encode())
+            h.update("".join(src.split()).encode())
     return h.hexdigest()[:16]
 
 
@@ -134,16 +164,17 @@ def write_rtc_sources(bdir):
     return out
 
 
-def build(force=False, verbose=False, variant="product", jobs=None, extra_defines=(), out=None, unit_flags=None):
+def build(force=False, verbose=False, variant="product", jobs=None, extra_defines=(), out=None, unit_flags=None, only=None):
     """Compile the variant if its sources are newer than the library. Returns the library path.
-    unit_flags: {object name: [extra compiler flags]} for single translation units (compiler-flag experiments of tools/)."""
+    unit_flags: {object name: [extra compiler flags]} for single translation units (compiler-flag experiments of tools/).
+    only: object names of the instantiations to build for real, the others become stubs (default: the variant's own list, if it has one)."""
     v = VARIANTS[variant]
     lib = os.path.abspath(out or v["lib"])
     if not (force or _stale(lib)):
         return lib
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     unit_flags = dict(UNIT_FLAGS, **(unit_flags or {})) if variant in PRODUCT_VARIANTS else (unit_flags or {})
-    salt = " ".join(extra_defines) + "".join("|%s:%s" % (k, " ".join(v)) for k, v in sorted(unit_flags.items()))
+    salt = " ".join(extra_defines) + "".join("|%s:%s" % (k, " ".join(v)) for k, v in sorted(unit_flags.items())) + ("|only:" + ",".join(only) if only is not None else "")
     tag = variant if not salt else variant + "_" + hashlib.sha256(salt.encode()).hexdigest()[:8]
     bdir = os.path.join(HERE, "build", tag)
     os.makedirs(bdir, exist_ok=True)
@@ -151,6 +182,7 @@ def build(force=False, verbose=False, variant="product", jobs=None, extra_define
     newest_all, newest_kernel = _newest_source(), _newest_source(KERNEL_DEPS)
 
     embedded = write_rtc_sources(bdir)
+    src_hash, k_hash = source_hash(), kernel_hash(list(v["defines"]) + list(extra_defines), unit_flags)
 
     def compile_unit(u):
         obj, src, defs = u
@@ -160,7 +192,8 @@ def build(force=False, verbose=False, variant="product", jobs=None, extra_define
             return o
         if src == "teb_amd.hip":   # the host side carries the kernel sources for the run-time compiler (teb_rtc.hpp) and the variant's defines
             defs = defs + ["-DTEB_AMD_RTC_EMBEDDED", "-I" + os.path.dirname(embedded),
-                           '-DTEB_AMD_VARIANT_DEFINES="%s"' % " ".join(list(v["defines"]) + list(extra_defines))]
+                           '-DTEB_AMD_VARIANT_DEFINES="%s"' % " ".join(list(v["defines"]) + list(extra_defines)),
+                           '-DTEB_AMD_BUILD_SOURCE_HASH="%s"' % src_hash, '-DTEB_AMD_BUILD_KERNEL_HASH="%s"' % k_hash]   # read back by teb_amd_debug_build_info: ties a profile to the BINARY
         cmd = [hipcc] + HIPCC_FLAGS + v["defines"] + list(extra_defines) + defs + list(unit_flags.get(obj, [])) + ["-c", os.path.join(CSRC, src), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -168,7 +201,7 @@ def build(force=False, verbose=False, variant="product", jobs=None, extra_define
         return o
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
-        objs = list(ex.map(compile_unit, _units(variant)))
+        objs = list(ex.map(compile_unit, _units(variant, only)))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", lib]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -2608,6 +2608,21 @@ int teb_amd_debug_rtc_compile(uint64_t flag_values, int32_t solver, int32_t jaco
   return TEB_AMD_OK;
 }
 
+#ifndef TEB_AMD_BUILD_SOURCE_HASH
+#define TEB_AMD_BUILD_SOURCE_HASH ""   // (a build that did not go through build.py)
+#endif
+#ifndef TEB_AMD_BUILD_KERNEL_HASH
+#define TEB_AMD_BUILD_KERNEL_HASH ""
+#endif
+int teb_amd_debug_build_info(char* kernel_hash, int32_t kernel_hash_capacity, char* source_hash, int32_t source_hash_capacity, char* variant_defines,
+                             int32_t defines_capacity, int32_t* threads_per_workgroup) {
+  if (kernel_hash && kernel_hash_capacity > 0) std::snprintf(kernel_hash, (size_t)kernel_hash_capacity, "%s", TEB_AMD_BUILD_KERNEL_HASH);
+  if (source_hash && source_hash_capacity > 0) std::snprintf(source_hash, (size_t)source_hash_capacity, "%s", TEB_AMD_BUILD_SOURCE_HASH);
+  if (variant_defines && defines_capacity > 0) std::snprintf(variant_defines, (size_t)defines_capacity, "%s", TEB_AMD_VARIANT_DEFINES);
+  if (threads_per_workgroup) *threads_per_workgroup = kThreads;
+  return TEB_AMD_OK;
+}
+
 int teb_amd_debug_rtc_cache(int32_t* embedded, int32_t* disk_hits, int32_t* disk_writes, char* cache_dir, int32_t capacity) {
   RtcCache& c = rtc_cache();
   std::lock_guard<std::mutex> lock(c.mu);

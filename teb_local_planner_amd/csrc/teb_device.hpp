@@ -186,7 +186,10 @@
 
 namespace tebamd {
 
-constexpr int kThreads = 256;   // 4 wave64 per workgroup, one workgroup per candidate TEB (512 = two waves per SIMD: measured in round 2, 1100 - 1600 spill slots, 6.9 vs 4.8 ms)
+#ifndef TEB_AMD_THREADS
+#define TEB_AMD_THREADS 256
+#endif
+constexpr int kThreads = TEB_AMD_THREADS;   // 4 wave64 per workgroup, one workgroup per candidate TEB (512 = two waves per SIMD: measured in round 2, 1100 - 1600 spill slots, 6.9 vs 4.8 ms)
 constexpr int kWaves = kThreads / 64;
 constexpr int kBand = 11;           // diagonal + scalar half-bandwidth 10
 // Where band row r (a scalar row: entries (r, r - d), d = 0 .. 10) starts in a band buffer: 11 doubles per row plus ONE padding double per

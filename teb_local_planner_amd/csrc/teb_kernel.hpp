@@ -3101,6 +3101,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
         if (spec_on) spec_wait_idle(mm, l.ired + 26);   // the solver helpers are done with the buffers of the previous iteration
       }
       const bool spec_now = MCU && spec_on && !mm.spec_failed;
+#ifndef TEB_AMD_DIAG_EDGE_ONLY
       if (keep_copy) {
         if (spec_now) {   // (the solver helpers load the same backup: written through)
           for (int q = tid; q < hsz; q += kThreads) st_agent_f64(Hbk + q, *hmat_ptr<SOLVER>(l, q, Nt));
@@ -3109,6 +3110,7 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
         }
       }
       if (SOLVER == SOLVER_BAND && !TEB_CFGI(BAND_LDLT)) cr_copy_band(l, n, Hbk, spec_now);   // hybrid solve: the band to HBM once per iteration
+#endif
       if constexpr (MCU) {
         if (spec_now) spec_issue(mm, l.bv, Nt, n, S, lambda, ni);   // retries 1 .. K start on their CUs now
       }
@@ -3124,6 +3126,15 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
           if (spec_now && !mm.spec_failed && qmax >= 1 && qmax <= mm.K)
             taken = spec_take(mm, qmax, l.dxv, l.ired, Nt, S, l.ired + 26);   // the step of this retry was solved on a spare CU meanwhile
         }
+#ifdef TEB_AMD_DIAG_EDGE_ONLY
+        // Diagnostic build (tools/profile.sh, roofline.edge_evaluation.traffic of the bench line): the damped solve, its band copy and the
+        // H backup are left out - a Jacobi step dx_r = b_r / (H_rr + lambda) stands in, so that the LM loop keeps linearising and evaluating -
+        // and what the FETCH_SIZE / WRITE_SIZE counters then see is the HBM traffic of the edge phases alone. Never the product.
+        taken = true;
+        for (int r = tid; r < Nt; r += kThreads) l.dxv[r] = (r >= 3 && r < 4 * (n - 1)) ? l.bv[r] / (*diag_ptr<SOLVER>(l, r) + lambda) : 0.0;
+        if (tid == 0) l.ired[0] = 1;
+        __syncthreads();
+#endif
         if (!taken) {
         if (keep_copy && h_spent) {   // bring back the un-factored H (lazily: a retry whose step came from a helper needs no H at all)
           hmat_load<SOLVER>(l, hsz, Nt, Hbk);

@@ -2,6 +2,13 @@
 //   hipcc -c -DTEB_INST_SOLVER=<0|1|2> -DTEB_INST_JMODE=<0|1> -DTEB_INST_SCENE=<0|1|2|3> teb_opt_inst.hip
 #include <hip/hip_runtime.h>
 
+#ifdef TEB_INST_STUB
+// (tools/ experiments, build.py variant "exp": an instantiation the experiment does not launch - the host gets a null kernel address and
+// refuses the launch)
+#include "teb_opt_launch.hpp"
+__attribute__((visibility("hidden"))) const void* TEB_OPT_KERNEL_FN(TEB_INST_SOLVER, TEB_INST_JMODE, TEB_INST_SCENE)() { return nullptr; }
+#else
+
 #if defined(TEB_INST_SCENE) && TEB_INST_SCENE >= 4
 #define TEB_AMD_DEFAULTS_PROFILE 1   // scene kinds 4 .. 11: configuration flags folded to the TebConfig defaults (teb_device.hpp: TEB_CFG)
 #endif
@@ -33,3 +40,4 @@ static_assert(tebamd::SCENE_POINTS == 0 && tebamd::SCENE_GENERIC == 1 && tebamd:
 static_assert(TEB_INST_SOLVER != 2 || tebamd::kMaxPoseIter == tebamd::kPoseIterBandHbm, "the host sizes band-in-HBM handles for kPoseIterBandHbm poses per lane");
 
 TEB_OPT_DEFINE(TEB_INST_SOLVER, TEB_INST_JMODE, TEB_INST_SCENE)
+#endif   // TEB_INST_STUB

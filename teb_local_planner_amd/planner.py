@@ -283,6 +283,16 @@ class TebBatchSolver:
         return int(v.value)
 
     @staticmethod
+    def build_info():
+        """What the loaded binary was built from: (kernel hash, source hash, variant defines, threads per workgroup of the optimise
+        kernel) - teb_amd_debug_build_info, include/teb_amd_debug.h"""
+        L = lib()
+        L.teb_amd_debug_build_info.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, _abi.p_i32]
+        kb = C.create_string_buffer(64); hb = C.create_string_buffer(64); db = C.create_string_buffer(1024); t = C.c_int32(0)
+        _chk(L.teb_amd_debug_build_info(kb, 64, hb, 64, db, 1024, C.byref(t)), "teb_amd_debug_build_info")
+        return kb.value.decode(), hb.value.decode(), db.value.decode(), t.value
+
+    @staticmethod
     def rtc_stats():
         """run-time compiled instantiations of this process: (ready, compiling, failed, compile seconds of the last one, last error)"""
         L = lib()

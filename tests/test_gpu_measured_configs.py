@@ -78,3 +78,30 @@ def test_c3_full_size_64_bands(oracle):
     cfg, obst, via, batch = scenes.scene_c3(stride=208)
     assert batch.count == 64 and len(obst) == 200
     _check(oracle, cfg, obst, via, batch, "C3 64 x 150 x 200")
+
+
+def test_c4_strong_shard_of_8_32_bands(oracle):
+    """bench.py's secondary.c4_strong_shard_of_8: bands 0 .. 31 of the headline batch = rank 0's shard of BASELINE config 4 (256
+    candidates over 8 GPUs, parallel.shard_range(256, 0, 8)). 32 bands leave CUs idle: the launch runs with solver helpers, and its
+    bands must still be the oracle's - and, bit for bit, the bands 0 .. 31 of the whole batch launched at once."""
+    from teb_local_planner_amd import parallel
+    lo, hi = parallel.shard_range(256, 0, 8)
+    assert (lo, hi) == (0, 32)
+    cfg, obst, via, full = scenes.scene_c4(B=256, n=200, seed=1004, stride=288)
+    shard = _abi.TebBatchHost(hi - lo, 288)
+    for k, b in enumerate(range(lo, hi)):
+        shard.set_teb(k, *full.get_teb(b))
+        shard.has_vel_goal[k] = full.has_vel_goal[b]
+    s = planner.make_solver(cfg, obst, via, shard)
+    s.optimize(cfg.optim.no_inner_iterations, cfg.optim.no_outer_iterations, True, cfg.hcp.selection_obst_cost_scale,
+               cfg.hcp.selection_viapoint_cost_scale, cfg.hcp.selection_alternative_time_cost)
+    helpers = s.last_launch_info()
+    s.close()
+    assert helpers[1] >= 1 and not helpers[2], helpers      # the shard's launch has solver helpers (the mode the number is quoted on)
+    rep, out, res = _check(oracle, cfg, obst, via, shard, "C4 strong shard of 8 (bands 0..31, solver helpers)")
+    whole, wres, _ = _run_gpu(cfg, obst, via, full)
+    for k, b in enumerate(range(lo, hi)):
+        assert out.n[k] == whole.n[b]
+        for u, v in zip(out.get_teb(k), whole.get_teb(b)):
+            assert np.array_equal(u, v), (k, b)
+    assert np.array_equal(res.cost, wres.cost[lo:hi]) and np.array_equal(res.lm_trials, wres.lm_trials[lo:hi])

@@ -43,7 +43,12 @@ def main():
             full = r
     sys.path.insert(0, ROOT)
     import bench
-    summary = {"tag": tag, "source_hash": bench.kernel_source_hash(), "kernel": "teb_optimize_kernel", "grid": full[1], "workgroup": full[2], "calls": full[8],
+    try:   # the hash the loaded BINARY carries (teb_amd_debug_build_info): bench.py attaches this summary only to the same binary
+        from teb_local_planner_amd import planner as _pl
+        binary_hash = _pl.TebBatchSolver.build_info()[0]
+    except Exception as e:   # noqa: BLE001
+        binary_hash = "unreadable: %s" % str(e)[:60]
+    summary = {"tag": tag, "source_hash": bench.kernel_source_hash(), "binary_hash": binary_hash, "kernel": "teb_optimize_kernel", "grid": full[1], "workgroup": full[2], "calls": full[8],
                "avg_ms": full[9] / 1e6, "lds_bytes": full[3], "scratch_bytes_per_lane": full[4], "vgpr": full[5], "agpr": full[6]}
     grid = full[1]
     for sub, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
@@ -121,6 +126,26 @@ def main():
                            + 2.0 * f64["SQ_INSTS_VALU_FMA_F64"])
             summary["fp64_flop_per_launch"] = flop
             lines.append("fp64_flop_per_launch %.6g  (%.3f TFLOP/s at the traced average duration)" % (flop, flop / (summary["avg_ms"] * 1e-3) / 1e12))
+    # the edge phases alone: FETCH / WRITE of the -DTEB_AMD_DIAG_EDGE_ONLY build (tools/libteb_amd_edge.so) running the same command, with
+    # the units (LM iterations) and trials of THAT run (its LM loop takes Jacobi steps instead of solves, so its counts are its own)
+    ef, ew = os.path.join(SRC, "edge_fetch", "efetch_results.db"), os.path.join(SRC, "edge_write", "ewrite_results.db")
+    if os.path.exists(ef) and os.path.exists(ew):
+        eo = {}
+        for db, cname in ((ef, "FETCH_SIZE"), (ew, "WRITE_SIZE")):
+            r = q(db, "select count(*), avg(value) from counters_collection where kernel_name like '%%teb_optimize%%' "
+                      "and counter_name='%s' and grid_size_x=%d" % (cname, grid))
+            eo[cname + "_KB_per_launch"] = r[0][1]
+        try:
+            bj = json.loads(open(os.path.join(SRC, "bench_edge_fetch.json")).read().strip().splitlines()[-1])
+            eo["units_per_launch"] = bj["config"]["units_per_step_per_gpu"]
+            eo["lm_trials_per_launch"] = bj["config"]["lm_trials_per_step_per_gpu"]
+            eo["kernel_ms"] = bj["roofline"]["kernel_ms"]
+        except Exception as e:   # noqa: BLE001
+            eo["error"] = str(e)[:120]
+        summary["edge_only"] = eo
+        lines.append("")
+        lines.append("# the edge phases alone: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of the -DTEB_AMD_DIAG_EDGE_ONLY build (no damped solve, no band copy), same command")
+        lines.append(json.dumps(eo))
     cal = os.path.join(SRC, "calib.json")
     if os.path.exists(cal):
         summary["calibration"] = json.load(open(cal))

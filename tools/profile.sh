@@ -21,6 +21,11 @@ if [ -f $ROOT/teb_local_planner_amd/libteb_amd_mfma.so ]; then
   TEB_AMD_LIB=$ROOT/teb_local_planner_amd/libteb_amd_mfma.so rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace -d $OUT/pmc_mfma -o mfma -- $CMD > /dev/null 2> $OUT/mfma.log
   TEB_AMD_LIB=$ROOT/teb_local_planner_amd/libteb_amd_mfma.so python $ROOT/tools/mfma_probe.py > $OUT/mfma_probe.txt 2>&1
 fi
+# the edge phases alone (diagnostic build without the damped solve, tools/build_prof.sh): their HBM traffic for roofline.edge_evaluation
+if [ -f $ROOT/tools/libteb_amd_edge.so ]; then
+  TEB_AMD_LIB=$ROOT/tools/libteb_amd_edge.so rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/edge_fetch -o efetch -- $CMD > $OUT/bench_edge_fetch.json 2> $OUT/edge_fetch.log
+  TEB_AMD_LIB=$ROOT/tools/libteb_amd_edge.so rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/edge_write -o ewrite -- $CMD > $OUT/bench_edge_write.json 2> $OUT/edge_write.log
+fi
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/cal_fetch -o calf -- python $ROOT/tools/calib_stream.py > /dev/null 2> $OUT/calf.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/cal_write -o calw -- python $ROOT/tools/calib_stream.py > /dev/null 2> $OUT/calw.log
 cd $ROOT
