@@ -70,9 +70,17 @@ int teb_amd_debug_mcu_flags(teb_amd_handle_t* h, int32_t flags);
  * acceleration edges (point-like scenes), 3 = every cost-term flag at run time, only the never-reached bulk folded (point-like scenes),
  * 4 = compiled at run time for this configuration (teb_amd_options_t::compile_for_config), 0 = the generic one (teb_amd_options_t::generic_config_path forces it). */
 int teb_amd_debug_last_config_profile(teb_amd_handle_t* h, int32_t* defaults_profile);
+/* The instantiation teb_optimize_kernel<layout, Jacobian mode, scene kind> the last optimise launch ran: layout 0 band in LDS, 1 blocks in
+ * LDS, 2 band in HBM; scene kind as numbered in csrc/teb_opt_launch.hpp (0 .. 11 pre-built, 12 .. 15 compiled at run time). -1 before the
+ * first launch. tests/test_gpu_every_instantiation.py launches every pre-built one and checks with this that it did. */
+int teb_amd_debug_last_instantiation(teb_amd_handle_t* h, int32_t* solver, int32_t* jacobian_mode, int32_t* scene_kind);
 /* Run-time compiled instantiations of this process (teb_amd_options_t::compile_for_config): how many are ready / still compiling /
  * failed, the compile time of the last one that finished [s], and the reason of the last failure (empty string if none). */
 int teb_amd_debug_rtc_stats(int32_t* ready, int32_t* compiling, int32_t* failed, double* last_compile_seconds, char* last_error, int32_t capacity);
+/* Blocks until every background compilation of this process (compile_for_config = 1) has finished. The library does the same when it is
+ * unloaded / at exit - a compiler thread must not outlive the library - which can hold a process for the rest of a hiprtcCompileProgram
+ * call (seconds); a host that cares calls this at a time of its choosing. */
+int teb_amd_debug_rtc_join(void);
 /* Compiles (and waits for) the run-time instantiation for the given flag values - bit i = value of flag i of TEB_PF_ALL
  * (csrc/teb_device.hpp) -, layout (0 band in LDS, 1 blocks in LDS, 2 band in HBM), Jacobian mode and scene kind (12 .. 15: the *_CUSTOM
  * kinds). Needs no GPU: hipRTC cross-compiles for gfx950, so the CPU test stage covers the run-time compilation path. Returns

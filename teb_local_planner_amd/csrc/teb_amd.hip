@@ -162,6 +162,7 @@ struct teb_amd_handle {
   int fast_points = 0;
   int static_radius_zero = 0;   // every obstacle of the static list enters the LDS cache with radius 0 (no circular obstacle among them)
   int last_defaults_profile = 0;   // the last optimise launch ran a *_DEFAULTS instantiation (teb_amd_debug_last_config_profile)
+  int last_inst[3] = {-1, -1, -1}; // (layout, Jacobian mode, scene kind) of the instantiation the last optimise launch ran (teb_amd_debug_last_instantiation)
   teb_amd_options_t opt;   // behaviour switches fixed at create (ABI 2; never the process environment)
   int last_inner = 0;      // iterations_innerloop of the last teb_amd_optimize_batch (hasDiverged: size of g2o's batch statistics)
   int snap_nmax = -1;      // nmax_known at the time of teb_amd_snapshot_state
@@ -353,13 +354,16 @@ hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const Bat
   const void* k = nullptr;
   h->last_defaults_profile = 0;
   const int pf = profile_matches(h, a, sc);   // (a build without the twins, or a mode they do not exist for, returns null: generic instantiation)
+  int scene_kind = -1;   // which instantiation runs (teb_amd_debug_last_instantiation)
   if (pf != 0) {
     const bool sm = small && h->cfg.jacobian_mode == TEB_AMD_JACOBIAN_ANALYTIC;
-    if (pf == 1) k = opt_kernel(solver, h->cfg.jacobian_mode, sc.fast_points ? (sm ? SCENE_POINTS_SMALL_DEFAULTS : SCENE_POINTS_DEFAULTS) : (sm ? SCENE_GENERIC_SMALL_DEFAULTS : SCENE_GENERIC_DEFAULTS));
-    else if (pf == 2) k = opt_kernel(solver, h->cfg.jacobian_mode, sm ? SCENE_POINTS_SMALL_WIDE : SCENE_POINTS_WIDE);
-    else k = opt_kernel(solver, h->cfg.jacobian_mode, sm ? SCENE_POINTS_SMALL_LIGHT : SCENE_POINTS_LIGHT);
+    if (pf == 1) scene_kind = sc.fast_points ? (sm ? SCENE_POINTS_SMALL_DEFAULTS : SCENE_POINTS_DEFAULTS) : (sm ? SCENE_GENERIC_SMALL_DEFAULTS : SCENE_GENERIC_DEFAULTS);
+    else if (pf == 2) scene_kind = sm ? SCENE_POINTS_SMALL_WIDE : SCENE_POINTS_WIDE;
+    else scene_kind = sm ? SCENE_POINTS_SMALL_LIGHT : SCENE_POINTS_LIGHT;
+    k = opt_kernel(solver, h->cfg.jacobian_mode, scene_kind);
     if (k) h->last_defaults_profile = pf;
   }
+  h->last_inst[0] = solver; h->last_inst[1] = h->cfg.jacobian_mode; h->last_inst[2] = -1;
   void* params[] = {const_cast<teb_amd_config_t*>(&h->cfg), const_cast<SceneDev*>(&sc), const_cast<BatchDev*>(&bt), const_cast<OptArgs*>(&a),
                     const_cast<LdsPlan*>(&plan), const_cast<McuDev*>(mc)};
   // a configuration off the defaults: the instantiation compiled for IT at run time, once it is ready (teb_rtc.hpp)
@@ -368,11 +372,17 @@ hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const Bat
     hipFunction_t f = rtc_function(*rk, h->device, h->lds_limit, &why);
     if (f) {
       h->last_defaults_profile = 4;
+      h->last_inst[2] = sc.fast_points ? (small ? SCENE_POINTS_SMALL_CUSTOM : SCENE_POINTS_CUSTOM) : (small ? SCENE_GENERIC_SMALL_CUSTOM : SCENE_GENERIC_CUSTOM);
       return hipModuleLaunchKernel(f, grid * (1 + mc->K + mc->D), 1, 1, kThreads, 1, 1, plan.total_bytes, h->stream, params, nullptr);
     }
   }
-  if (!k) { k = opt_kernel(solver, h->cfg.jacobian_mode, sc.fast_points ? (small ? SCENE_POINTS_SMALL : SCENE_POINTS) : (small ? SCENE_GENERIC_SMALL : SCENE_GENERIC)); h->last_defaults_profile = 0; }
+  if (!k) {
+    scene_kind = sc.fast_points ? (small ? SCENE_POINTS_SMALL : SCENE_POINTS) : (small ? SCENE_GENERIC_SMALL : SCENE_GENERIC);
+    k = opt_kernel(solver, h->cfg.jacobian_mode, scene_kind);
+    h->last_defaults_profile = 0;
+  }
   if (!k) return hipErrorInvalidDeviceFunction;
+  h->last_inst[2] = scene_kind;
   return hipLaunchKernel(k, dim3(grid * (1 + mc->K + mc->D)), dim3(kThreads), params, plan.total_bytes, h->stream);
 }
 hipError_t launch_opt(teb_amd_handle* h, int grid, const SceneDev& sc, const BatchDev& bt, const OptArgs& a) {
@@ -409,8 +419,8 @@ void mcu_helpers_for(teb_amd_handle* h, const OptArgs& args, int eff_solver, int
 int max_capacity_of(teb_amd_handle* h, int solver, int upto) {
   const int ob = h->fast_points ? h->M : 0;
   int S = upto;
-  while (S > 8 && (size_t)make_lds_plan(S, solver, ob).total_bytes > h->lds_limit) --S;
-  return (size_t)make_lds_plan(S, solver, ob).total_bytes <= h->lds_limit ? S : 0;
+  while (S > 8 && (size_t)make_lds_plan(S, solver, ob, h->lds_limit).total_bytes > h->lds_limit) --S;
+  return (size_t)make_lds_plan(S, solver, ob, h->lds_limit).total_bytes <= h->lds_limit ? S : 0;
 }
 
 // the four strips and the pose counts in ONE launch (five copy commands cost more in launch gaps than in bytes: 2.4 MB at the headline)
@@ -494,8 +504,8 @@ int launch(teb_amd_handle* h, const OptArgs& args) {
     const int ob = h->fast_points ? h->M : 0;
     const int s_cr = max_capacity_of(h, SOLVER_CR, std::min(h->stride, 238));
     const int s_band = h->solver == SOLVER_BANDG ? max_capacity_of(h, SOLVER_BAND, std::min(h->stride, 337)) : 0;
-    if (s_cr > 0 && need <= s_cr) { eff_solver = SOLVER_CR; eff_plan = make_lds_plan(s_cr, SOLVER_CR, ob); optimistic = true; }
-    else if (s_band > 0 && need <= s_band) { eff_solver = SOLVER_BAND; eff_plan = make_lds_plan(s_band, SOLVER_BAND, ob); optimistic = true; }
+    if (s_cr > 0 && need <= s_cr) { eff_solver = SOLVER_CR; eff_plan = make_lds_plan(s_cr, SOLVER_CR, ob, h->lds_limit); optimistic = true; }
+    else if (s_band > 0 && need <= s_band) { eff_solver = SOLVER_BAND; eff_plan = make_lds_plan(s_band, SOLVER_BAND, ob, h->lds_limit); optimistic = true; }
   }
   // multi-CU mode: helper workgroups per band (0 = none); its buffers, and the control words zeroed on the stream before the launch
   int K = 0, D = 0;
@@ -682,24 +692,24 @@ int teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max
   // per step, keeps the obstacle cache and holds bands up to 337 poses.
   int solver = SOLVER_CR;
   // the kernel also owns a little static LDS (__syncthreads_or scratch): keep 1 KiB of head-room
-  const size_t lds_limit = (size_t)prop.sharedMemPerBlock - 1024;
-  if (lds_bytes_for(max_poses, SOLVER_CR) > lds_limit) solver = SOLVER_BAND;
-  else if ((size_t)make_lds_plan(max_poses, SOLVER_CR, max_obstacles > 0 ? max_obstacles : 0).total_bytes > lds_limit &&
-           (size_t)make_lds_plan(max_poses, SOLVER_BAND, max_obstacles > 0 ? max_obstacles : 0).total_bytes <= lds_limit)
+  const size_t lds_limit = (size_t)prop.sharedMemPerBlock - kLdsHeadroomBytes;
+  if (lds_bytes_for(max_poses, SOLVER_CR, lds_limit) > lds_limit) solver = SOLVER_BAND;
+  else if ((size_t)make_lds_plan(max_poses, SOLVER_CR, max_obstacles > 0 ? max_obstacles : 0, lds_limit).total_bytes > lds_limit &&
+           (size_t)make_lds_plan(max_poses, SOLVER_BAND, max_obstacles > 0 ? max_obstacles : 0, lds_limit).total_bytes <= lds_limit)
     solver = SOLVER_BAND;
   if (opt.layout == TEB_AMD_LAYOUT_BAND_LDS) solver = SOLVER_BAND;
   else if (opt.layout == TEB_AMD_LAYOUT_BAND_HBM) solver = SOLVER_BANDG;
   else if (opt.layout == TEB_AMD_LAYOUT_BLOCKS_LDS) {
-    if (lds_bytes_for(max_poses, SOLVER_CR) > lds_limit) return fail(TEB_AMD_ERR_CAPACITY, "TEB_AMD_LAYOUT_BLOCKS_LDS: max_poses too large for the block layout");
+    if (lds_bytes_for(max_poses, SOLVER_CR, lds_limit) > lds_limit) return fail(TEB_AMD_ERR_CAPACITY, "TEB_AMD_LAYOUT_BLOCKS_LDS: max_poses too large for the block layout");
     solver = SOLVER_CR;
   }
   // bands too long for the LDS band (> 337 poses; the reference's max_samples default is 500): the band form of the normal matrix
   // moves to HBM (SOLVER_BANDG: 44 doubles per pose, L2-resident), everything else stays as it is
-  if (solver == SOLVER_BAND && lds_bytes_for(max_poses, SOLVER_BAND) > lds_limit) solver = SOLVER_BANDG;
+  if (solver == SOLVER_BAND && lds_bytes_for(max_poses, SOLVER_BAND, lds_limit) > lds_limit) solver = SOLVER_BANDG;
   // more than two poses per lane: only the band-in-HBM instantiations are compiled for it (teb_device.hpp: kPoseIterBandHbm)
   static_assert(TEB_AMD_MAX_POSES <= kThreads * 4, "TEB_AMD_MAX_POSES of include/teb_amd.h exceeds four poses per lane");
   if (max_poses > kThreads * 2) solver = SOLVER_BANDG;   // (the LDS layouts end at 337 poses: the checks above have already moved it there)
-  const size_t lds = lds_bytes_for(max_poses, solver);
+  const size_t lds = lds_bytes_for(max_poses, solver, lds_limit);
   const int thread_limit = kThreads * (solver == SOLVER_BANDG ? kPoseIterBandHbm : 2);
   if (max_poses > thread_limit || lds > lds_limit) {
     char buf[256];
@@ -720,7 +730,7 @@ int teb_amd_create_ex(const teb_amd_config_t* cfg, int32_t max_tebs, int32_t max
   h->solver = solver; h->solver_created = solver;
   h->lds_limit = lds_limit;
   h->num_cus = prop.multiProcessorCount;
-  h->plan = make_lds_plan(max_poses, solver, 0);
+  h->plan = make_lds_plan(max_poses, solver, 0, h->lds_limit);
   // per-band HBM buffer: the copy of H for rejected trials (SOLVER_CR, banded LDL^T) or the blocks the cyclic reduction of a
   // SOLVER_BAND handle works on (D, L, f: nb * (2 * kBlk + 8) doubles)
   h->hmat_stride = std::max(hbm_scratch_doubles(max_poses, SOLVER_BAND), hbm_scratch_doubles(max_poses, solver));   // every layout may be launched
@@ -854,8 +864,8 @@ int commit_obstacles(teb_amd_handle* h) {
   // 64 bands x 337 poses x 500 obstacles: 9.0 instead of 11.8 ms per step)
   h->solver = h->solver_created;
   if (pointlike && M > 0 && h->solver == SOLVER_BAND && h->opt.layout == TEB_AMD_LAYOUT_AUTO &&
-      (size_t)make_lds_plan(h->stride, SOLVER_BAND, M).total_bytes > h->lds_limit &&
-      (size_t)make_lds_plan(h->stride, SOLVER_BANDG, M).total_bytes <= h->lds_limit) {
+      (size_t)make_lds_plan(h->stride, SOLVER_BAND, M, h->lds_limit).total_bytes > h->lds_limit &&
+      (size_t)make_lds_plan(h->stride, SOLVER_BANDG, M, h->lds_limit).total_bytes <= h->lds_limit) {
     if (h->hband_stride == 0) {
       h->hband_stride = ((size_t)hbo(4 * h->stride) + 2 + 1) & ~(size_t)1;
       h->Hband.free();
@@ -863,9 +873,9 @@ int commit_obstacles(teb_amd_handle* h) {
     }
     h->solver = SOLVER_BANDG;
   }
-  LdsPlan with_cache = make_lds_plan(h->stride, h->solver, M);
+  LdsPlan with_cache = make_lds_plan(h->stride, h->solver, M, h->lds_limit);
   if (pointlike && M > 0 && (size_t)with_cache.total_bytes <= h->lds_limit) { h->fast_points = 1; h->plan = with_cache; }
-  else { h->fast_points = 0; h->plan = make_lds_plan(h->stride, h->solver, 0); }
+  else { h->fast_points = 0; h->plan = make_lds_plan(h->stride, h->solver, 0, h->lds_limit); }
   return TEB_AMD_OK;
 }
 }  // namespace
@@ -2357,7 +2367,7 @@ int teb_amd_capacity(teb_amd_handle_t* h, int32_t* lds_bytes, int32_t* max_poses
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, h->device));
     int S = kThreads * kPoseIterBandHbm;
-    while (S > 2 && lds_bytes_for(S, SOLVER_BANDG) > h->lds_limit) --S;   // band in HBM: four poses per lane, as many as its LDS strips hold
+    while (S > 2 && lds_bytes_for(S, SOLVER_BANDG, h->lds_limit) > h->lds_limit) --S;   // band in HBM: four poses per lane, as many as its LDS strips hold
     *max_poses_supported = S;
   }
   return TEB_AMD_OK;
@@ -2623,6 +2633,11 @@ int teb_amd_debug_build_info(char* kernel_hash, int32_t kernel_hash_capacity, ch
   return TEB_AMD_OK;
 }
 
+int teb_amd_debug_rtc_join(void) {   // waits for the background compilations of this process (teb_amd_options_t::compile_for_config = 1) to finish
+  rtc_cache().join_workers();
+  return TEB_AMD_OK;
+}
+
 int teb_amd_debug_rtc_cache(int32_t* embedded, int32_t* disk_hits, int32_t* disk_writes, char* cache_dir, int32_t capacity) {
   RtcCache& c = rtc_cache();
   std::lock_guard<std::mutex> lock(c.mu);
@@ -2650,6 +2665,15 @@ int teb_amd_debug_rtc_stats(int32_t* ready, int32_t* compiling, int32_t* failed,
   if (failed) *failed = f;
   if (last_compile_seconds) *last_compile_seconds = secs;
   if (last_error && capacity > 0) { std::snprintf(last_error, (size_t)capacity, "%s", err.c_str()); }
+  return TEB_AMD_OK;
+}
+
+int teb_amd_debug_last_instantiation(teb_amd_handle_t* h, int32_t* solver, int32_t* jacobian_mode, int32_t* scene_kind) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (solver) *solver = h->last_inst[0];
+  if (jacobian_mode) *jacobian_mode = h->last_inst[1];
+  if (scene_kind) *scene_kind = h->last_inst[2];
   return TEB_AMD_OK;
 }
 

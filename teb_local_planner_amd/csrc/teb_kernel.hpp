@@ -87,7 +87,7 @@ struct Lds {
 };
 
 __host__ __device__ inline int nb_for(int S) { return (4 * S + 7) / 8; }
-constexpr long long kBandgLdsDoubles = (160 * 1024 - 1024) / 8;   // LDS of a workgroup on MI355X minus the library's head-room (teb_amd.hip: lds_limit), in doubles
+constexpr size_t kLdsHeadroomBytes = 1024;   // what the library leaves of a workgroup's LDS (teb_amd_create: lds_limit = sharedMemPerBlock - this)
 __host__ __device__ inline size_t hmat_doubles(int S, int solver) {  // (LDS-resident part)
   if (solver == SOLVER_BANDG) return (size_t)6 * S + 256;   // the scratch of autoResize (edit script + new poses + split stack + runs); make_lds_plan may add to it
   if (solver == SOLVER_CR) return (size_t)nb_for(S) * (2 * kBlk + 8);
@@ -104,8 +104,10 @@ __host__ __device__ inline size_t hbm_scratch_doubles(int S, int solver) {
   const size_t own = hmat_doubles(S, solver);
   return own > blocks ? own : blocks;
 }
-// host: lay out the LDS; ob_entries = obstacles to cache (0 = no cache). Returns total bytes.
-__host__ inline LdsPlan make_lds_plan(int S, int solver, int ob_entries) {
+// host: lay out the LDS; ob_entries = obstacles to cache (0 = no cache); lds_limit_bytes = what a workgroup may use on THIS device
+// (teb_amd_handle::lds_limit = sharedMemPerBlock - kLdsHeadroomBytes: the band-in-HBM layout sizes its compact region from it, so a part or
+// partition mode that reports less LDS gets a smaller region instead of a plan that no longer fits - ADVICE r05). Returns total bytes.
+__host__ inline LdsPlan make_lds_plan(int S, int solver, int ob_entries, size_t lds_limit_bytes) {
   LdsPlan p;
   p.S = S; p.solver = solver;
   int o = 0;
@@ -117,7 +119,7 @@ __host__ inline LdsPlan make_lds_plan(int S, int solver, int ob_entries) {
     // levels run on blocks in HBM until the surviving rows fit here; their right-hand side lives in the dx region). Round 5: whatever the
     // strips AND the obstacle cache leave of a workgroup's LDS, up to 64 block rows (2 x 66 doubles each) - a band of 338 .. 512 poses then
     // runs two levels through L2 instead of six. Long bands and big obstacle tables take the room first: the capacity limits are unchanged.
-    const long long room = kBandgLdsDoubles - (o + 8LL * S + 16 + 96 + 5LL * (ob_entries > 0 ? ob_entries : 0)), want = 64LL * 2 * kBlk;
+    const long long room = (long long)(lds_limit_bytes / 8) - (o + 8LL * S + 16 + 96 + 5LL * (ob_entries > 0 ? ob_entries : 0)), want = 64LL * 2 * kBlk;
     const long long extra = (room < want ? room : want) & ~1LL;
     if (extra > hm) hm = (int)extra;
   }
@@ -130,7 +132,7 @@ __host__ inline LdsPlan make_lds_plan(int S, int solver, int ob_entries) {
   p.total_bytes = o * (int)sizeof(double);
   return p;
 }
-__host__ inline size_t lds_bytes_for(int S, int solver) { return (size_t)make_lds_plan(S, solver, 0).total_bytes; }
+__host__ inline size_t lds_bytes_for(int S, int solver, size_t lds_limit_bytes) { return (size_t)make_lds_plan(S, solver, 0, lds_limit_bytes).total_bytes; }
 
 // gH: the band's slice of the HBM normal-matrix buffer (SOLVER_BANDG), else unused
 __device__ __forceinline__ Lds carve(double* base, const LdsPlan& p, double* gH = nullptr, bool hb_global = false) {
@@ -961,9 +963,13 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
 template <int I, int N, class F> __device__ __forceinline__ void static_for_down(F&& f) {   // I, I - 1, .., N
   if constexpr (I >= N) { f(IC<I>{}); static_for_down<I - 1, N>(f); }
 }
-template <int T> __device__ __forceinline__ double bcast16(double x) {   // x of lane T of this lane's row
+template <int T, bool AFTER_BRANCH = false> __device__ __forceinline__ double bcast16(double x) {   // x of lane T of this lane's row
   double r;
-  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(T));
+  // AFTER_BRANCH: the first DPP statement behind an `if`: should the compiler ever close the branch with a VALU write of EXEC (v_cmpx:
+  // today's LLVM forms it on gfx10.3+ only, gfx950 gets s_and_saveexec), the DPP read needs 5 wait states after it, not the 2 of a VGPR
+  // write - and the hazard recogniser does not look inside an asm statement. 12 cycles per round.
+  if constexpr (AFTER_BRANCH) asm("s_nop 4\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(T));
+  else asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(T));
   return r;
 }
 // The statements below are whole passes - a pivot's update, the forward / backward substitution, two columns of the Schur products - so
@@ -1091,7 +1097,7 @@ __device__ __forceinline__ bool cr16_eliminate(double (&v)[8], const double (&X)
   double inv[8];
   static_for<0, 8>([&](auto K) {
     constexpr int k = decltype(K)::value;
-    const double dk = bcast16<k>(v[k]);
+    const double dk = bcast16<k, k == 0>(v[k]);   // (k = 0: the first DPP read behind the `if (act)` of the round)
     ok &= (dk > 0);
     inv[k] = fast_rcp(dk);
     if constexpr (k < 7) {
@@ -1258,7 +1264,10 @@ __device__ __forceinline__ bool cr_forward_round16(double* __restrict__ D, doubl
     f[(i + s) * bF + c] = fm - sx;
   }
   TEB_CR16_STAMP(8)
-  __syncthreads();
+  // The first round of a pair needs no barrier behind its phase 2: the second round (eliminations e0 + 16 ..) reads and writes block rows
+  // from s (2 e0 + 32) up only - its own eliminated rows, the survivor below its first group (whose update from this round is the pending
+  // one, in registers) and the rows above - while this phase touched the survivors s (2 e + 2), e <= e0 + 14, and nothing of L.
+  if (PAIR != 1) __syncthreads();
   CRR(5);
   TEB_CR16_STAMP(9)
   return ok;
@@ -1861,6 +1870,10 @@ template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const Ld
   }
   CRP(1);
   // levels >= 1 on the compact system in LDS
+  // (Round 6, measured and dropped - profiles/ab_pre_round_r06.txt: a band beyond 256 poses leaves 65 .. 80 compact rows, which the plain
+  // level structure reduces in 8 - 10 rounds where 64 rows take 7; a pre-round on the last Nc - 64 odd rows + moving the survivors together
+  // gets that to 8, but the rearrangement and its index arithmetic cost what the saved rounds give - every instruction of a wave is ~ 5
+  // cycles at one wave per SIMD, a nearly empty round 4.7 k - and any second set of round instances slows the bands that never use it.)
   ok = TEB_CR_FORWARD(Dc, Lc, fc, Nc, 1, Nc) && ok;
   CRP(2);
   ok = cr_top(Dc, fc) && ok;

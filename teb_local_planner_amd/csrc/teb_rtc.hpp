@@ -17,6 +17,7 @@
 // keyed by the sources' hash, the flag values, the instantiation and the compiler's version, written atomically, checked on load.
 #pragma once
 #include <dlfcn.h>
+#include <limits.h>
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <sys/stat.h>
@@ -137,13 +138,24 @@ struct RtcCache {
   std::map<RtcKey, std::shared_ptr<RtcKernel>> kernels;
   // the compiler threads, joined when the library goes (exit, dlclose): a thread still inside hiprtcCompileProgram must not outlive the
   // function-local statics it uses (this object, rtc_api()). rtc_api() is constructed first, i.e. destroyed after this object.
-  std::vector<std::thread> workers;
+  // A process that exits while a background compilation is in flight waits here for the rest of that hiprtcCompileProgram call;
+  // teb_amd_debug_rtc_join() (include/teb_amd_debug.h) is the explicit form for a host that wants to do that wait at a time of its choosing.
+  // Finished workers are reaped whenever a new one is started (reap_finished), so the list holds the compilations in flight, not a history.
+  std::vector<std::pair<std::thread, std::shared_ptr<RtcKernel>>> workers;
   RtcCache() { (void)rtc_api(); }
   ~RtcCache() { join_workers(); }
   void join_workers() {
-    std::vector<std::thread> w;
+    std::vector<std::pair<std::thread, std::shared_ptr<RtcKernel>>> w;
     { std::lock_guard<std::mutex> lock(mu); w.swap(workers); }
-    for (std::thread& t : w) if (t.joinable()) t.join();
+    for (auto& t : w) if (t.first.joinable()) t.first.join();
+  }
+  void reap_finished() {   // caller holds mu; a worker whose kernel has left COMPILING is past its last use of the compiler: the join is short
+    for (size_t i = 0; i < workers.size();) {
+      if (workers[i].second->state.load() != RtcKernel::COMPILING) {
+        if (workers[i].first.joinable()) workers[i].first.join();
+        workers.erase(workers.begin() + (long)i);
+      } else ++i;
+    }
   }
   std::string csrc_dir, rocm_include, disk_dir;
   unsigned long long source_hash = 0;
@@ -230,8 +242,11 @@ inline std::string rtc_disk_path(const RtcEnv& env, unsigned long long key) {
 // write permission for group / others) and the file is opened without following a symbolic link. The checksum inside the file detects
 // corruption (a torn write, a bad disk); it is no protection against someone who can write the directory - the ownership test is.
 inline bool rtc_disk_dir_trusted(const std::string& dir) {
+  // (a cache directory reached through a symbolic link - ~/.cache on another volume - is judged by what the link resolves to)
+  char real[PATH_MAX];
+  if (!realpath(dir.c_str(), real)) return false;
   struct stat st;
-  if (lstat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+  if (lstat(real, &st) != 0 || !S_ISDIR(st.st_mode)) return false;
   return st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
 }
 inline bool rtc_disk_load(const RtcEnv& env, unsigned long long key, RtcKernel& k) {
@@ -371,7 +386,8 @@ inline std::shared_ptr<RtcKernel> rtc_request(const RtcKey& key, bool wait, std:
       c.kernels[key] = k;
       RtcEnv env;
       env.csrc_dir = c.csrc_dir; env.rocm_include = c.rocm_include; env.disk_dir = c.disk_dir; env.source_hash = c.source_hash; env.embedded = c.embedded;
-      c.workers.emplace_back(rtc_compile, key, k, env);   // joined by ~RtcCache / teb_amd_debug_rtc_join
+      c.reap_finished();
+      c.workers.emplace_back(std::thread(rtc_compile, key, k, env), k);   // joined by reap_finished / ~RtcCache / teb_amd_debug_rtc_join
     }
   }
   if (wait)

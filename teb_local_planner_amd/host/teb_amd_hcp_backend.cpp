@@ -151,8 +151,12 @@ bool HomotopyClassPlannerAmd::plan(const PoseSE2& start, const PoseSE2& goal, co
       best_teb_ = remote_best_;
     }
     // the winner's band on every rank (a collective: the owner takes part as well); non-owners mirror it
+    // Where the broadcast unpacks: the mirror whenever best_teb_ IS the mirror - also on the owner itself when its own work failed this
+    // tick (local_ok false): its strip still went out to the peers, and hasDiverged() / getVelocityCommand() on this rank then read the
+    // band the world agreed on, not an empty mirror. The healthy owner keeps its candidate and unpacks into a scratch band.
     TimedElasticBand scratch;
-    if (!batch_->broadcastBand(owner, owner == rank_ ? sel - off : 0, owner == rank_ ? scratch : remote_best_->teb())) return false;
+    TimedElasticBand& unpack_into = (best_teb_ == remote_best_) ? remote_best_->teb() : scratch;
+    if (!batch_->broadcastBand(owner, owner == rank_ ? sel - off : 0, unpack_into)) return false;
     if (best_teb_ == remote_best_) batch_->adoptBroadcastStatistics(*remote_best_);   // hasDiverged() forwards to best_teb_ (:749-755)
     (void)previous;   // the switching_blocking_period rule needs one clock for all ranks: it stays with the caller in the sharded mode
     best_global_ = sel; best_owner_ = owner;

@@ -9,7 +9,8 @@
 //                                         candidate bands, via-point flags on the device)
 //   optimizeAllTEBs                       TebAmdBatch::optimizeAllTEBs (one kernel launch for all candidates)
 //   selectBestTeb                         TebAmdBatch::selectBestTeb + the reference's switching_blocking_period rule
-// Not taken over: randomlyDropTebs (selection_dropping_probability, default 0): the inherited code would draw from std::random_device.
+//   randomlyDropTebs (:539-562)           taken over inside the exploration call with the planner's own generator `random_` (the reference's
+//                                         draw, same sequence; selection_dropping_probability is 0 by default)
 // Built where the reference's headers exist (oracle/ref_shim/Makefile -> libteb_backend_check.so); exercised against the reference's
 // own HomotopyClassPlanner tick by tick in tests/test_reference_backend.py.
 #ifndef TEB_AMD_HCP_BACKEND_H_

@@ -119,6 +119,11 @@ def broadcast_band(owner_rank, band, capacity, local_status=0, group=None, devic
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
+    if dist.get_rank(group) == owner_rank and local_status == 0:
+        # the owner's own precondition goes into round 1 like any other error: a band that is missing or longer than the message would
+        # otherwise raise on the owner alone, in front of the broadcast every peer has already entered
+        if band is None or len(band[0]) > capacity or len(band[0]) < 1:
+            local_status = 1
     rec = torch.tensor([float(local_status), float(capacity)], dtype=torch.float64, device=device)
     out = [torch.empty_like(rec) for _ in range(world)]
     dist.all_gather(out, rec, group=group)
@@ -143,14 +148,17 @@ def broadcast_band(owner_rank, band, capacity, local_status=0, group=None, devic
                   m[1 + 3 * capacity:1 + 3 * capacity + max(n - 1, 0)].copy(), bool(m[1 + 4 * capacity]), float(m[2 + 4 * capacity]))
 
 
-def sharded_plan_exchange(local_ok, local_record, local_bands, owner_of, capacity, fail_inside_selection=False, group=None, device=None):
+def sharded_plan_exchange(local_ok, local_record, local_bands, owner_of, capacity, fail_inside_selection=False, fail_before_broadcast=False,
+                          group=None, device=None):
     """The collective sequence of HomotopyClassPlannerAmd::plan() in its sharded mode (host/teb_amd_hcp_backend.cpp), as the ranks of a
     torch.distributed group run it - what keeps a tick deadlock-free when ONE rank fails somewhere in its own work:
       1. every rank enters the selection all-gather; a rank whose exploration / upload / optimisation failed (local_ok False) sends the
          unusable record; a rank on which the selection call itself fails AFTER its record went out (fail_inside_selection) learns the
          peers' choice all the same;
       2. no rank holds a candidate (index < 0): every rank sees that and none enters the broadcast;
-      3. otherwise every rank - the failed ones too - enters the broadcast of the winner's band, statistics included.
+      3. otherwise every rank - the failed ones too - enters the broadcast of the winner's band, statistics included; a rank that fails
+         BETWEEN selection and broadcast (fail_before_broadcast: e.g. the owner cannot read its winner back) says so in the broadcast's
+         first round, and every rank returns not-ok together instead of waiting for a strip that never comes.
     local_record: (cost, global index) of this rank's best candidate; local_bands: {global index: band tuple}; owner_of(global index) -> rank.
     Returns (ok, global index, band): ok False on the rank that failed, the winner and its band on every rank that can know them."""
     cost, index = local_record if local_ok else UNUSABLE_RECORD
@@ -160,5 +168,5 @@ def sharded_plan_exchange(local_ok, local_record, local_bands, owner_of, capacit
     if gi < 0:
         return local_ok, -1, None
     owner = owner_of(gi)
-    ok, band = broadcast_band(owner, local_bands.get(gi), capacity, group=group, device=device)
-    return bool(local_ok and ok), gi, band
+    ok, band = broadcast_band(owner, local_bands.get(gi), capacity, local_status=1 if fail_before_broadcast else 0, group=group, device=device)
+    return bool(local_ok and ok and not fail_before_broadcast), gi, band

@@ -273,6 +273,12 @@ class TebBatchSolver:
         _chk(lib().teb_amd_multi_cu_backoff(self._h, C.byref(a), C.byref(k)), "teb_amd_multi_cu_backoff")
         return a.value, k.value
 
+    def last_instantiation(self):
+        """(layout, Jacobian mode, scene kind) of the kernel instantiation the last optimize() launched (teb_amd_debug_last_instantiation)"""
+        a = C.c_int32(-1); j = C.c_int32(-1); k = C.c_int32(-1)
+        _chk(lib().teb_amd_debug_last_instantiation(self._h, C.byref(a), C.byref(j), C.byref(k)), "teb_amd_debug_last_instantiation")
+        return a.value, j.value, k.value
+
     def last_config_profile(self):
         """Which kernel the last optimize() ran: 1 = specialised on the TebConfig defaults, 2 = the same folds except via-points and the
         holonomic choice (*_WIDE kinds), 3 = every cost-term flag at run time (*_LIGHT kinds), 0 = the generic instantiation (teb_amd_options_t::generic_config_path forces it)"""

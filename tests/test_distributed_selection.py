@@ -66,6 +66,10 @@ def _worker(rank, world, port, case, q):
             mode = case.split(":")[1]
             if mode == "nobody_has_a_candidate":
                 out = parallel.sharded_plan_exchange(True, parallel.UNUSABLE_RECORD, {}, owner_of, 8)
+            elif mode == "between":          # rank 1 fails after the selection, before the broadcast: it says so in the broadcast's first round
+                out = parallel.sharded_plan_exchange(True, parallel.local_best(costs[lo:hi], offset=lo), bands, owner_of, 8, fail_before_broadcast=failing)
+            elif mode == "owner_band_too_long":   # the winner's band does not fit the message (capacity 3 < 4 poses): the OWNER finds out, everyone hears
+                out = parallel.sharded_plan_exchange(True, parallel.local_best(costs[lo:hi], offset=lo), bands, owner_of, 3)
             else:
                 out = parallel.sharded_plan_exchange(not (failing and mode == "before"), parallel.local_best(costs[lo:hi], offset=lo), bands, owner_of, 8,
                                                      fail_inside_selection=failing and mode == "inside")
@@ -157,7 +161,7 @@ def test_a_failing_rank_sends_the_unusable_record_and_nobody_hangs(world):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("mode", ["before", "inside", "nobody_has_a_candidate"])
+@pytest.mark.parametrize("mode", ["before", "inside", "nobody_has_a_candidate", "between", "owner_band_too_long"])
 def test_sharded_plan_tick_survives_a_failing_rank(world, mode):
     """The collective sequence of the sharded HomotopyClassPlannerAmd::plan() (parallel.sharded_plan_exchange mirrors
     host/teb_amd_hcp_backend.cpp): rank 1 fails before the selection (its candidates take no part) or inside the selection
@@ -168,6 +172,10 @@ def test_sharded_plan_tick_survives_a_failing_rank(world, mode):
     lo1, hi1 = parallel.shard_range(len(costs), 1, world)
     if mode == "nobody_has_a_candidate":
         assert all(ok and gi == -1 and band is None for _, ok, gi, band, _, _ in outs)
+        return
+    if mode in ("between", "owner_band_too_long"):
+        # no rank waits for a strip that never comes: all of them return not-ok with the agreed index and no band
+        assert all((not ok) and gi == 1 and band is None for _, ok, gi, band, _, _ in outs), outs
         return
     masked = costs.copy()
     if mode == "before":

@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(kThreads) level_kernel(int Nb, int E, double* 
   for (int q = threadIdx.x; q < (2 * Nb * kBlk + Nb * 8); q += kThreads) out[q] = lds[q];
   if (threadIdx.x == 0) out[2 * Nb * kBlk + Nb * 8] = ok ? 1.0 : 0.0;
 }
-static void compare_levels(int E) {
+static long compare_levels(int E) {
   const int Nb = 2 * E + 1;
   const size_t count = (size_t)2 * Nb * kBlk + Nb * 8 + 1;
   double* d[2];
@@ -246,6 +246,7 @@ static void compare_levels(int E) {
   for (int q = 0; q < Nb * 8; ++q) { ++checked; const size_t a = (size_t)2 * Nb * kBlk + q; if (memcmp(&h[0][a], &h[1][a], 8)) { ++diff; worst = fmax(worst, fabs(h[0][a] - h[1][a])); } }
   printf("  level of %3d eliminations, 8-lane vs 16-lane rounds: %ld of %ld entries differ (worst %.3e), ok %g / %g\n", E, diff, checked, worst,
          h[0][count - 1], h[1][count - 1]);
+  return diff + (h[0][count - 1] != h[1][count - 1] ? 1 : 0);
 }
 
 template <int M>
@@ -267,7 +268,16 @@ static void run(int E, int grid) {
   hipFree(d_c); hipFree(d_s);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1 && !strcmp(argv[1], "--compare")) {
+    // tests/test_gpu_cr_rounds.py: the inline-asm DPP rounds of the product against the retained 8-lane LDS-operand round, bit for bit, at
+    // level sizes either side of every boundary of the round structure (one group, a partial round, exactly one round, the PAIR 1 / 2
+    // boundary at 16 | 17 and 32 | 33, a partial second pair)
+    long bad = 0;
+    for (int E : {1, 2, 5, 15, 16, 17, 24, 31, 32, 33, 40, 47, 48, 49, 58, 64}) bad += compare_levels(E);
+    printf("%s\n", bad ? "ROUNDS DIFFER" : "rounds identical");
+    return bad ? 1 : 0;
+  }
   for (int E : {1, 5, 16, 32, 58}) compare_levels(E);
   for (int grid : {1, 256}) {
     run16(1, grid); run16(8, grid); run16(16, grid); run16(32, grid); run16(58, grid);
