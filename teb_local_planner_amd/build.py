@@ -84,6 +84,8 @@ def _units(variant, only=None):
             # (8, 9: the point-like kinds with every fold but the via-points and the holonomic choice, TEB_PF_WIDE_* in teb_device.hpp;
             #  10, 11: every cost-term flag at run time, TEB_PF_LIGHT_*)
             for sk in (((0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11) if twins else (0, 1, 2, 3)) if jm == 0 else ((0, 1, 4) if twins else (0, 1))):
+                if sv == 2 and sk in (2, 5, 9, 11):
+                    continue   # band in HBM has no solver helpers: its point-like small-batch kinds cannot be launched (teb_opt_launch.hpp)
                 name = "opt_%d_%d_%d.o" % (sv, jm, sk)
                 stub = ["-DTEB_INST_STUB"] if ("only" in v and name not in v["only"]) else []
                 units.append((name, "teb_opt_inst.hip",
