@@ -104,6 +104,29 @@ def kernel_source_hash(root=None):
     return _b.kernel_hash()
 
 
+def discard_c_stdout():
+    """Throws away what C libraries have buffered for stdout (this RCCL build prints a version banner with printf when a communicator is
+    created; libc flushes it at exit, i.e. BEHIND the JSON line the driver reads): fd 1 points at /dev/null while libc flushes."""
+    import ctypes
+    sys.stdout.flush()
+    saved = os.dup(1)
+    null = os.open(os.devnull, os.O_WRONLY)
+    try:
+        os.dup2(null, 1)
+        ctypes.CDLL(None).fflush(None)
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved); os.close(null)
+
+
+def silence_stdout_for_good():
+    """After the JSON line: nothing this process (or a library's exit handler) writes to stdout may follow it."""
+    sys.stdout.flush()
+    null = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(null, 1)
+    os.close(null)
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -368,7 +391,10 @@ def main():
             binary_hash, binary_full_hash, binary_defines = "unreadable: %s" % str(e)[:60], "", ""
         try:
             import glob
-            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "rocprof_r*_summary.json")), key=os.path.getmtime)
+            import re as _re
+            # the newest round's summary (by its tag r<NN>[suffix], not by file time: a fresh checkout gives every file the same one)
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "rocprof_r*_summary.json")),
+                           key=lambda f: (int(_re.search(r"rocprof_r(\d+)", os.path.basename(f)).group(1)), os.path.basename(f)))
             if cands and args.tebs == 256 and n == 200 and args.scaling == "weak":
                 pj = json.load(open(cands[-1]))
                 traffic_src = os.path.basename(cands[-1])
@@ -686,6 +712,31 @@ def main():
                     num_vs_ref["best_index"] = {"device": int(s4n.select_best(-1, -1)[0]), "reference_code": int(RC.select_best_of_costs(ref_pack[2]))}
                     num_vs_ref["best_index_equal"] = bool(num_vs_ref["best_index"]["device"] == num_vs_ref["best_index"]["reference_code"])
                     num_vs_ref["ref_vs_ref"] = noise_floor(RC, c4n, o4n, v4n, b4n, ref_pack, out_n, B, numeric_mode=True)
+                    # device vs the CPU oracle in the SAME (numeric) mode, per-band yardstick of tests/sensitivity.py: how many bands sit
+                    # inside their bound - the count tests/test_gpu_reference_code.py holds a floor on (NUMERIC_STATE_MIN_INSIDE)
+                    try:
+                        import sensitivity
+                        from oracle import oracle_py as _op
+                        thr = min(B, os.cpu_count() or 1)
+                        tols = sensitivity.band_tolerances(_op, c4n, o4n, v4n, b4n, threads=thr)
+                        c4n.jacobian_mode = _abi.JACOBIAN_G2O_NUMERIC
+                        oo, orr = _op.optimize_batch(c4n, o4n, v4n, b4n, threads=thr)
+                        inside, beyond = 0, []
+                        for b_ in range(B):
+                            if int(out_n.n[b_]) != int(oo.n[b_]):
+                                beyond.append(b_); continue
+                            d_ = RC.state_error(out_n.get_teb(b_), oo.get_teb(b_))
+                            if np.isfinite(orr.cost[b_]) and orr.cost[b_] != 0:
+                                d_ = max(d_, abs(res_n.cost[b_] - orr.cost[b_]) / abs(orr.cost[b_]))
+                            bound_ = tols[b_] if tols[b_] is not None else sensitivity.ILL_CONDITIONED_CAP
+                            if d_ <= bound_:
+                                inside += 1
+                            else:
+                                beyond.append(b_)
+                        num_vs_ref["numeric_state_inside_bound"] = {"bands_inside": inside, "bands": B, "bands_beyond": beyond[:8],
+                                                                    "floor_in_tests": 252, "against": "oracle/teb_oracle.cpp in the numeric mode, tests/sensitivity.py bounds"}
+                    except Exception as e:   # noqa: BLE001
+                        num_vs_ref["numeric_state_inside_bound"] = {"error": str(e)[:160]}
             except Exception as e:   # noqa: BLE001
                 num_vs_ref = {"error": str(e)[:200]}
             s4n.close()
@@ -931,7 +982,9 @@ def main():
             pl["note"] = ("optimizeTEB only (4x5 iterations incl. autoResize, association, cost) from host buffers; compare with plan_latency.*_p50_ms "
                           "(GPU, PCIe inclusive) and secondary.*.kernel_ms")
             out["cpu_baseline"]["plan_latency_ms"] = pl
+        discard_c_stdout()
         print(json.dumps(out), flush=True)
+    silence_stdout_for_good()   # (every rank: RCCL's banner and anything an exit handler prints stay out of the driver's view)
     if comm is not None:
         comm.close()
     if distributed:

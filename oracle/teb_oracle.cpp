@@ -830,7 +830,14 @@ void linearize_numeric(Graph& g, Edge& e, Jac& J) {
 // ---- analytic Jacobians ("clean" mode) -------------------------------------------------------------
 // Conventions: penalty derivatives exactly as penalties.h:127-187; d||v||/dv := 0 at v = 0;
 // normalize_theta treated as identity (derivative 1); fabs'(0) := g2o::sign(0) = 0.
-void kin_nh_row(const Teb& t, int a, int b, double* row /*6: pose a xyz, pose b xyz*/) {
+// central_difference_kink (car-like edge only): the reference has a live analytic Jacobian for EdgeKinematicsDiffDrive only;
+// EdgeKinematicsCarlike (edge_kinematics.h:182-230) is differentiated by g2o's central differences, delta = 1e-9. For f = |x| those return
+// sign(x) g only while |x| >= |g| delta; closer to the kink the two samples straddle it and the quotient is sign(g) x / delta - next to
+// nothing. That is not a corner case: a straight stretch of the initial band (a plan initialised from a line, the inflection points of a
+// curve) has x = 0 up to rounding, 1e-17, whose sign is noise - closed forms then carry the full nonholonomic constraint of that segment
+// where the reference's linearisation has none, and the two part at the first LM step (profiles/analytic_margin_r06.txt: 7 of 20 car-like
+// scenes ended 4 .. 150 x T3 apart). The closed-form mode therefore reproduces the quotient of the central differences at this one kink.
+void kin_nh_row(const Teb& t, int a, int b, double* row /*6: pose a xyz, pose b xyz*/, bool central_difference_kink = false) {
   // edge_kinematics.h:112-149 (live analytic Jacobian of the reference)
   double dx = t.x[b] - t.x[a], dy = t.y[b] - t.y[a];
   double cos1 = std::cos(t.th[a]), cos2 = std::cos(t.th[b]);
@@ -844,6 +851,12 @@ void kin_nh_row(const Teb& t, int a, int b, double* row /*6: pose a xyz, pose b 
   row[3] = -aux1 * dev_nh_abs;
   row[4] = aux2 * dev_nh_abs;
   row[5] = (-sin2 * dy - cos2 * dx) * dev_nh_abs;
+  if (central_difference_kink) {
+    const double val = aux2 * dy - aux1 * dx;
+    const double g[6] = {aux1, -aux2, -dd_error_2 - dd_error_1, -aux1, aux2, -sin2 * dy - cos2 * dx};
+    for (int q = 0; q < 6; ++q)
+      row[q] = std::fabs(val) >= std::fabs(g[q]) * 1e-9 ? g[q] * sign(val) : sign(g[q]) * val * 1e9;
+  }
 }
 
 void linearize_analytic(Graph& g, Edge& e, Jac& J) {
@@ -979,7 +992,7 @@ void linearize_analytic(Graph& g, Edge& e, Jac& J) {
     }
     case E_KIN_CL: {
       int a = e.pose[0], b = e.pose[1];
-      kin_nh_row(t, a, b, J.j[0]);
+      kin_nh_row(t, a, b, J.j[0], true);
       double dx = t.x[b] - t.x[a], dy = t.y[b] - t.y[a];
       double angle_diff = normalize_theta(t.th[b] - t.th[a]);
       double nn = std::sqrt(dx * dx + dy * dy);

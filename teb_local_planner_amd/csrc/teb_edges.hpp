@@ -461,7 +461,15 @@ __device__ __forceinline__ void edge_acceleration_holonomic_se(const teb_amd_con
 }
 
 // ---- kinematics -------------------------------------------------------------------------------------------
-template <bool JAC>
+// CDK ("central-difference kink", the car-like edge only): the reference has a live analytic Jacobian for EdgeKinematicsDiffDrive
+// (edge_kinematics.h:112-149, g2o::sign) but differentiates EdgeKinematicsCarlike (:182-230) by g2o's central differences, delta = 1e-9.
+// For f = |x| those give sign(x) g only while |x| >= |g| delta; closer to the kink the two samples straddle it and the quotient is
+// sign(g) x / delta - next to nothing. A straight stretch of the initial band (a plan initialised from a line, the inflection points of a
+// curve) has x = 0 up to rounding, and sign(1e-17) is noise: closed forms then carry the full nonholonomic constraint of the segment
+// where the reference's linearisation has none, and the two runs part at the first LM step - 7 of 20 seeded car-like scenes ended 4 ..
+// 150 x T3 from the reference (profiles/analytic_margin_r06.txt). The closed-form mode reproduces the central differences' quotient at
+// this one kink (oracle/teb_oracle.cpp: kin_nh_row does the same); with it all 20 are within 0.2 T3.
+template <bool JAC, bool CDK = false>
 __device__ __forceinline__ double kin_nh(const Win& w, double* r /* cols 0,1,2,4,5,6 */) {
   double dx = w.x1 - w.x0, dy = w.y1 - w.y0;
   double cos1 = w.c0, cos2 = w.c1, sin1 = w.s0, sin2 = w.s1;
@@ -469,12 +477,19 @@ __device__ __forceinline__ double kin_nh(const Win& w, double* r /* cols 0,1,2,4
   double val = aux2 * dy - aux1 * dx;
   if (JAC) {
     double dev = sgn(val);
-    r[0] = aux1 * dev;
-    r[1] = -aux2 * dev;
-    r[2] = (-dy * sin1 - dx * cos1) * dev;
-    r[4] = -aux1 * dev;
-    r[5] = aux2 * dev;
-    r[6] = (-sin2 * dy - cos2 * dx) * dev;
+    if (!CDK) {
+      r[0] = aux1 * dev;
+      r[1] = -aux2 * dev;
+      r[2] = (-dy * sin1 - dx * cos1) * dev;
+      r[4] = -aux1 * dev;
+      r[5] = aux2 * dev;
+      r[6] = (-sin2 * dy - cos2 * dx) * dev;
+    } else {
+      const double g[6] = {aux1, -aux2, -dy * sin1 - dx * cos1, -aux1, aux2, -sin2 * dy - cos2 * dx};
+      const double av = fabs(val);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) r[q < 3 ? q : q + 1] = av >= fabs(g[q]) * 1e-9 ? g[q] * dev : sgn(g[q]) * val * 1e9;
+    }
   }
   return fabs(val);
 }
@@ -506,7 +521,7 @@ __device__ __forceinline__ void edge_kinematics_carlike(const teb_amd_config_t& 
 #pragma unroll
     for (int q = 0; q < 11; ++q) r[q] = 0;
   }
-  double e0 = kin_nh<JAC>(w, r);
+  double e0 = kin_nh<JAC, true>(w, r);
   A.template row<0x077, JAC>(CAT_OTHER, e0, c.weight_kinematics_nh, r);
   double dx = w.x1 - w.x0, dy = w.y1 - w.y0;
   double angle_diff = normalize_theta(w.t1 - w.t0);

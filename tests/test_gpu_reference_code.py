@@ -20,7 +20,7 @@ What is asserted, per configuration and mode (SURVEY section 8(c), T3 "vs the fa
   * device vs the CPU oracle in the SAME mode: identical pose counts and LM sequences (iteration and trial counts per iteration) on
     every band in the closed-form mode; in the numeric mode the device's libm (sin / cos differ from glibc's in the last bit)
     enters the central differences divided by 2e-9: counts and sequences are still identical on every band, the state is held to the
-    per-band yardstick of tests/sensitivity.py on at least NUMERIC_STATE_FLOOR of the bands.
+    per-band yardstick of tests/sensitivity.py on at least NUMERIC_STATE_MIN_INSIDE[configuration] bands (what was observed, per configuration).
 The floors are what was observed on MI355X (tools/refcode_probe.py, profiles/refcode_probe_r03.txt) with margin."""
 import os
 import sys
@@ -39,7 +39,12 @@ pytestmark = pytest.mark.gpu
 
 THREADS = os.cpu_count() or 1
 POSE_COUNT_FLOOR = 1.0    # (0.97 until round 4; every band of every measured configuration ends with the reference's pose count)
-NUMERIC_STATE_FLOOR = 0.95
+# Bands of a configuration that must sit inside their per-band bound in the numeric mode (device vs oracle, same mode). Until round 5 one
+# floor of 95 % for all; since round 6 what was OBSERVED per configuration on MI355X (the driver's run and this round's:
+# c4_headline 253 of 256 - bands 126 and 134 sit 1 % and 17 % beyond their own bound, band 174 is the ill-conditioned one, 3e-2 -, every band
+# of C2 / C3 / C5), minus ONE band of slack on the headline for the two borderline bands. bench.py records the count of its own run
+# (secondary.c4_g2o_numeric_jacobians.numeric_state_inside_bound).
+NUMERIC_STATE_MIN_INSIDE = {"c4_headline": 252, "c2": 1, "c3": 64, "c5": 1}
 
 CASES = {
     "c4_headline": lambda: scenes.scene_c4(B=256, n=200, seed=1004, stride=288),   # exactly bench.py's rank-0 workload
@@ -151,7 +156,7 @@ def test_numeric_mode_matches_oracle_at_full_size(oracle, name):
     compared with the per-band yardstick of tests/sensitivity.py - 2e-5 where the oracle's own two Jacobian modes agree to 2e-6, 10 x
     their distance elsewhere (capped at 5e-3): the device's sin / cos differ from glibc's in the last bit, and the central differences
     divide that by 2e-9, i.e. the device sits as far from the oracle as a second compiler of the reference would. At least
-    NUMERIC_STATE_FLOOR of the bands must be inside their bound; the others are printed."""
+    NUMERIC_STATE_MIN_INSIDE[name] bands must be inside their bound; the others are printed."""
     cfg, obst, via, batch = CASES[name]()
     B = batch.count
     tols = sensitivity.band_tolerances(oracle, cfg, obst, via, batch, threads=THREADS)
@@ -175,4 +180,4 @@ def test_numeric_mode_matches_oracle_at_full_size(oracle, name):
             well += 1; worst_well = max(worst_well, d)
     print("%s numeric mode vs oracle: %d bands, LM sequences identical on all, %d inside their bound, %d well conditioned (worst %.2e), "
           "kernel %.3f ms" % (name, B, inside, well, worst_well, ms))
-    assert inside >= int(np.floor(NUMERIC_STATE_FLOOR * B)), (inside, B)
+    assert inside >= NUMERIC_STATE_MIN_INSIDE[name], (inside, B, NUMERIC_STATE_MIN_INSIDE[name])
