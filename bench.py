@@ -46,7 +46,7 @@ def latency_model(probe, n, inner_trials, static_edges_per_pose, dyn_near_per_po
     'alongside the dependency-latency model'): the cycles the iteration would take if only its dependent-instruction chains remained
     (unbounded issue width, no contention) - levels x per-round chain of the block cyclic reduction + linearisation + error
     evaluation - built from the primitive latencies measured on this chip at one wave per SIMD (tools/micro/latency_probe.hip ->
-    profiles/latency_probe_r*.json, newest round) times the chain lengths read off the kernel source (DESIGN.md section 4 lists them).
+    profiles/latency_probe_r*.json, newest round) times the chain lengths read off the kernel source (HISTORY.md section 4 lists them).
     n = poses, inner_trials = damped solves + error evaluations per LM iteration (measured), hybrid = band-in-LDS layout."""
     L = probe
     fma, rcp, sqrt_, div, sincos, lds, l2, bar, dpp = (L["fma_f64"], L["fast_rcp_f64_plus_add"], L["sqrt_f64_plus_add"], L["div_f64_plus_add"],

@@ -329,7 +329,7 @@ __device__ __forceinline__ void dyn_chunk(const SceneDev& sc, int sl, int nsl, i
 // when its pose has left the disc - or when the graph was rebuilt (r = NaN).
 // m = kNearMarginFactor x the culling distance: the wider the disc the rarer the recomputation and the more zero edges in pass 2
 // (headline kernel 4.21 ms without the cache; 4.04 / 3.99 / 3.96 / 3.99 ms at factor 0.5 / 1 / 2 / 3).
-constexpr double kNearMarginFactor = 1.5;   // margin of the cached near masks in units of the culling distance (1, 2, 3 measured: DESIGN.md section 3)
+constexpr double kNearMarginFactor = 1.5;   // margin of the cached near masks in units of the culling distance (1, 2, 3 measured: HISTORY.md section 3)
 struct NearCache {
   unsigned long long m0, m1;
   double rx0, ry0, rx1, ry1;
@@ -872,7 +872,7 @@ __device__ __forceinline__ double fast_rcp(double d) {
 // order); measured effect: 5 - 8 % on the C4 step, parity tests unchanged (poses <= 1e-8, identical LM trial counts).
 #define TEB_SOLVER_FMA _Pragma("clang fp contract(fast)")
 // scheduling fences inside the Schur-product loops of the cyclic reduction (they bound the number of LDS operands in flight)
-#define TEB_CR_FENCE_EVERY 4   // rows of a Schur product between two fences (1 fence per row, 2 and 8 rows, no fence: measured)
+#define TEB_CR_FENCE_EVERY 4   // rows of a Schur product between two fences (1 fence per row, 2 and 8 rows, no fence: measured, HISTORY.md section 3)
 #define TEB_CR_SCHED_BARRIER __builtin_amdgcn_sched_barrier(0);
 // Pairs of consecutive doubles at 16-byte aligned addresses are fetched with one 16-byte access (LDS: ds_read_b128, 256 B/clk, where the
 // 8-byte aligned pair the compiler forms by itself is a ds_read2_b64 at 128 B/clk). Every 8x8 block starts on a 16-byte boundary (kBlk is

@@ -314,7 +314,7 @@ inline void rtc_compile(const RtcKey key, std::shared_ptr<RtcKernel> k, const Rt
                                    // convention without it relies on LLVM's interprocedural register allocation handing the caller the callee's
                                    // exact clobber set, and that combination miscompiles some instantiations (round 5: the full-batch light
                                    // kind in the band layout faults at its first LM iteration; -mllvm -enable-ipra=0 on that one unit cures it,
-                                   // so does this flag; tools/fault_probe.py). The pre-built kinds that keep the cheaper
+                                   // so does this flag; tools/fault_probe.py, HISTORY.md section 3). The pre-built kinds that keep the cheaper
                                    // call are the ones every test and bench of the repository runs; a kernel compiled here is one of 2^20
                                    // nobody has run before, so it takes the convention that has never failed (cost: ~ 3 % of its launch).
                                    "-DTEB_AMD_SOLVE_CSR=1"};

@@ -1,7 +1,7 @@
 """How sensitive is a band to the reference's own linearisation noise?
 
 The reference differentiates numerically with delta = 1e-9, so every Jacobian entry carries ~1e-7 relative noise that depends
-on the compiler and libm ("Compiler note"). Bands that stay collision-free damp that noise: after the full
+on the compiler and libm (HISTORY.md section 5, "Compiler note"). Bands that stay collision-free damp that noise: after the full
 4 x 5 iterations two implementations agree to ~1e-6. Bands that start inside an obstacle sit on penalty kinks and amplify it,
 up to a different pose count after autoResize. The yardstick used by the GPU tests is objective: the distance between the CPU
 oracle's two Jacobian modes (central differences vs closed form) on the same band. Neither of them involves the GPU."""

@@ -1,7 +1,7 @@
 """SURVEY section 8 row g (north_star: "MFMA only on the dense Schur block"): the build whose cyclic reduction folds the Schur
 complements with v_mfma_f64_16x16x4_f64 (libteb_amd_mfma.so = -DTEB_AMD_MFMA_SCHUR, built by teb_local_planner_amd.build next to the
 product). It replaces the block solver the reference selects at include/teb_local_planner/optimal_planner.h:75-78 just like the vector
-build; it is not the product because it is slower end to end - but it is built by build() and exercised here:
+build; it is not the product because it is slower end to end (HISTORY.md section 3) - but it is built by build() and exercised here:
   * the operand maps of the matrix instruction (teb_amd_debug_mfma_selftest): C = A B exactly (max |C - A B| = 0 on integer-valued
     operands, where every product and sum is exact in fp64);
   * the measured configurations (tests/test_gpu_measured_configs.py, all 256 headline bands, C2, C3, C4 fixed) against the oracle

@@ -404,7 +404,7 @@ def test_pointlike_fast_path_equals_generic_path(oracle, fast, footprint):
 # ---- g2o-numeric Jacobian mode on the GPU: the reference's own linearisation scheme --------------------------------------
 # Tolerances: the central differences divide residual differences by 2e-9, so last-bit differences between the device and
 # host libm (sin/cos/pow; sqrt and the four operations are correctly rounded on both) appear as ~1e-7 relative noise in
-# Jacobian entries - the same noise the reference has between two compilers ("Compiler note").
+# Jacobian entries - the same noise the reference has between two compilers (HISTORY.md section 5, "Compiler note").
 sys.path.insert(0, os.path.join(HERE, "golden"))
 import make_ref_golden as RG  # noqa: E402
 

@@ -1,7 +1,7 @@
 // Dependent-instruction latencies of the primitives the optimise kernel's critical path is made of, measured the way the kernel runs
 // them: one wave per SIMD (a 256-thread workgroup with a 150 KB LDS request, i.e. one workgroup per CU), clock64() around long
 // dependent chains, alone on the chip and with every CU busy. bench.py's roofline.latency_model multiplies these by the chain lengths
-// of one LM iteration.
+// of one LM iteration (HISTORY.md section 4).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/micro/latency_probe.hip -o tools/micro/latency_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
