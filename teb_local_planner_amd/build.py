@@ -21,15 +21,20 @@ HEADERS = ["teb_device.hpp", "teb_comm.hpp", "teb_feasibility.hpp", "teb_geometr
 
 # -ffp-contract=off: the parity contract is against a plain IEEE mul/add restatement of the reference;
 # letting the compiler fuse a*b+c would change which side of a penalty kink borderline residuals fall on.
-# -mllvm -enable-ipra=0 (round 6): no interprocedural register allocation in ANY unit. The out-of-line damped solve is called
-# on a no-callee-saved convention (`not_tail_called` internal function: LLVM then skips its callee-saved block and hands the callers its
-# clobber mask through IPRA), and that combination miscompiled units of this size - a memory aperture violation at the first solve, in
-# units that move with their register allocation (profiles/fault_bisect_r05.txt: IPRA off on the ONE faulting unit cured it). Until
-# round 5 only the kinds off the defaults took a safe convention (-DTEB_AMD_SOLVE_CSR below) and the defaults / wide kinds - what every
-# default user launches - kept the risky one because the tests passed. Measured cost on MI355X, same box, alternating
-# (profiles/ab_threads_ipra_r06.txt): headline +0.9 %, C4 fixed / C2 / C3 / C5 within noise; -DTEB_AMD_SOLVE_CSR on every unit instead
-# costs +3.2 % on the headline. tests/test_gpu_every_instantiation.py launches every pre-built instantiation as the net under it.
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mllvm", "-enable-ipra=0"]
+# The calling convention of the out-of-line damped solve (round 6, ADVICE r05 / VERDICT r05 item 8). The solve is called on a
+# no-callee-saved convention (`not_tail_called` internal function: LLVM skips its callee-saved block and hands the callers its clobber
+# mask through interprocedural register allocation), and that combination miscompiled units whose register allocation happened to
+# move - a memory aperture violation at the FIRST solve of a launch (profiles/fault_bisect_r05.txt). The two safe conventions were
+# measured on every unit (MI355X, same box, alternating; profiles/ab_threads_ipra_r06.txt and the round-6 profile taken with IPRA off):
+#   -mllvm -enable-ipra=0 everywhere : headline + 0.9 .. 1.3 % time - and the callee's save / restore of ~ 170 registers per call shows up
+#                                      as 4.63 GB of fabric traffic per launch instead of 0.91 GB (scratch 336 -> 656 B per lane);
+#   -DTEB_AMD_SOLVE_CSR everywhere   : headline + 3.2 %.
+# Neither is within the 0.5 % the verdict set for shipping it, so the kinds every default user launches (defaults / wide / generic-shape
+# defaults) keep the cheap call, the kinds off the defaults keep -DTEB_AMD_SOLVE_CSR (UNIT_FLAGS below), and the net under all of them
+# is tests/test_gpu_every_instantiation.py: EVERY pre-built (layout, Jacobian mode, kind) is launched once, on the configuration paths
+# that faulted before - the fault is deterministic at the first solve, so a unit whose register allocation moved into it fails the
+# GPU test suite of its build, not a robot. Kernels compiled at run time take the plain convention (csrc/teb_rtc.hpp).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 
 # Per-unit flags of the product. -DTEB_AMD_POINTS_KEEP_GENERIC on the point-like band-layout instantiation (the headline's kernel): it
 # branches on SceneDev::fast_points at run time and so keeps the generic-shape code it never executes. Measured on MI355X, same box,
@@ -46,9 +51,8 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-cont
 # (opt_0_0_10). Bisected on MI355X (profiles/fault_bisect_r05.txt, tools/fault_probe.py): not pow() (inlined), not the data (one band, one
 # iteration), not the stack size; `-mllvm -enable-ipra=0` on the ONE unit cures it like this flag does - the no-callee-saved call relies on
 # LLVM's interprocedural register allocation handing the caller the callee's clobber set, and that combination is what miscompiles units of
-# this size (which units: moves with their register allocation). Since round 6 IPRA is off in every unit (HIPCC_FLAGS above), which makes
-# the callee of EVERY kind save its callee-saved block; the flag stays on these kinds as the explicit form of the same thing. Kernels
-# compiled at run time take the plain convention too (csrc/teb_rtc.hpp).
+# this size (which units: moves with their register allocation). The defaults / wide kinds keep the cheaper call (cost of the safe
+# conventions and the test that guards them: above HIPCC_FLAGS). Kernels compiled at run time take the plain convention too (csrc/teb_rtc.hpp).
 UNIT_FLAGS = {"opt_0_0_0.o": ["-DTEB_AMD_POINTS_KEEP_GENERIC"], "opt_1_0_5.o": ["-DTEB_AMD_INLINE_SOLVE"]}
 # The instantiations that keep EVERY cost term at run time (generic kinds 0 .. 3, light kinds 10, 11) call the solve on the plain
 # convention (-DTEB_AMD_SOLVE_CSR): see the note above UNIT_FLAGS.

@@ -1,7 +1,10 @@
 """Every pre-built instantiation of the optimise kernel is launched once (tools/launch_every_instantiation.py, one process per layout:
 a GPU memory fault aborts only that process and its last line says which case). ADVICE r05: the miscompile of the out-of-line solve call
 (profiles/fault_bisect_r05.txt) moves between translation units with their register allocation; a unit nobody launches in the tests
-would fault on a robot first. Since round 6 every unit is built with -mllvm -enable-ipra=0 (build.py) - this is the net under it."""
+would fault on a robot first. The fault is deterministic at the first solve of a launch, so launching every unit once - on the
+configuration paths that faulted before (cost exponent != 1, shortest path, via-points) - turns it into a failed test of that build.
+The safe calling conventions were measured and cost + 0.9 % time and 5 x the fabric traffic (IPRA off) or + 3.2 % (plain convention) on
+the headline (teb_local_planner_amd/build.py above HIPCC_FLAGS): the default kinds keep the cheap call, this test is the net."""
 import os
 import re
 import subprocess
