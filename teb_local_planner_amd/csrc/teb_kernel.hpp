@@ -859,6 +859,24 @@ __device__ inline bool banded_ldlt_solve_wave0(const Lds& l, int Nt, double lamb
 // concurrently per workgroup; depth = ceil(log2 Nb) levels instead of 4n sequential pivots.
 // W_L = P L_i, W_U = P U_i and P f_i overwrite the slots of the eliminated row for the back substitution.
 // The result is written to dxv; ired[0] = 0 iff some pivot was <= 0 (matrix not positive definite).
+// Arguments of an out-of-line device function arrive in VGPRs and count as divergent: every loop bound, block count and address derived
+// from them is then computed with vector integer instructions and every loop is an exec-mask loop - ~ 60 of the ~ 900 instructions of a
+// reduction round, and each one is ~ 5 cycles at one wave per SIMD. The solves take wave-uniform copies (v_readfirstlane) at entry.
+__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni_d(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+template <class T> __device__ __forceinline__ T* uni_p(T* p) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ LdsPlan uni_plan(const LdsPlan& p) {
+  LdsPlan u;
+  u.S = uni_i(p.S); u.solver = uni_i(p.solver); u.off_state = uni_i(p.off_state); u.off_H = uni_i(p.off_H); u.off_b = uni_i(p.off_b);
+  u.off_dx = uni_i(p.off_dx); u.off_red = uni_i(p.off_red); u.off_ob = uni_i(p.off_ob); u.ob_cap = uni_i(p.ob_cap); u.total_bytes = uni_i(p.total_bytes);
+  return u;
+}
 __device__ __forceinline__ double fast_rcp(double d) {
   double r = __builtin_amdgcn_rcp(d);
   r = fma(fma(-d, r, 1.0), r, r);
@@ -1021,16 +1039,19 @@ template <int T, bool AFTER_BRANCH = false> __device__ __forceinline__ double bc
   TEB_F2(2, 0, 8, 22, 2, 10) TEB_F2(3, 0, 8, 22, 3, 11) \
   TEB_F2(4, 0, 8, 22, 4, 12) TEB_F2(5, 0, 8, 22, 5, 13) \
   TEB_F2(6, 0, 8, 22, 6, 14) TEB_F2(7, 0, 8, 22, 7, 15)
-// operands: %0 .. %15 = acc[0 .. 15], then (X[k], Y[k]) of two columns k: acc[t] += X[k](lane t) * Y[k]
+// operands: %0 .. %15 = acc[0 .. 15], then (X[k], Y[k]) of two columns k: acc[t] += X[k](lane t) * Y[k], t < 8; acc[t] -= .., t >= 8.
+// The upper eight are accumulated NEGATED (round 6): what is stored from them is the new coupling -U^T W_L, and the survivor above gets
+// D - U^T W_U = D + acc; a sum of negated products is the negated sum bit for bit (round-to-nearest is symmetric), so the eight sign flips
+// per lane and round in front of the stores are gone and nothing else changes.
 #define TEB_CR16_SCHUR2 \
   TEB_F1(0, 0, 16, 17) TEB_F1(1, 1, 16, 17) TEB_F1(2, 2, 16, 17) TEB_F1(3, 3, 16, 17) \
   TEB_F1(4, 4, 16, 17) TEB_F1(5, 5, 16, 17) TEB_F1(6, 6, 16, 17) TEB_F1(7, 7, 16, 17) \
-  TEB_F1(8, 8, 16, 17) TEB_F1(9, 9, 16, 17) TEB_F1(10, 10, 16, 17) TEB_F1(11, 11, 16, 17) \
-  TEB_F1(12, 12, 16, 17) TEB_F1(13, 13, 16, 17) TEB_F1(14, 14, 16, 17) TEB_F1(15, 15, 16, 17) \
+  TEB_FN1(8, 8, 16, 17) TEB_FN1(9, 9, 16, 17) TEB_FN1(10, 10, 16, 17) TEB_FN1(11, 11, 16, 17) \
+  TEB_FN1(12, 12, 16, 17) TEB_FN1(13, 13, 16, 17) TEB_FN1(14, 14, 16, 17) TEB_FN1(15, 15, 16, 17) \
   TEB_F1(0, 0, 18, 19) TEB_F1(1, 1, 18, 19) TEB_F1(2, 2, 18, 19) TEB_F1(3, 3, 18, 19) \
   TEB_F1(4, 4, 18, 19) TEB_F1(5, 5, 18, 19) TEB_F1(6, 6, 18, 19) TEB_F1(7, 7, 18, 19) \
-  TEB_F1(8, 8, 18, 19) TEB_F1(9, 9, 18, 19) TEB_F1(10, 10, 18, 19) TEB_F1(11, 11, 18, 19) \
-  TEB_F1(12, 12, 18, 19) TEB_F1(13, 13, 18, 19) TEB_F1(14, 14, 18, 19) TEB_F1(15, 15, 18, 19)
+  TEB_FN1(8, 8, 18, 19) TEB_FN1(9, 9, 18, 19) TEB_FN1(10, 10, 18, 19) TEB_FN1(11, 11, 18, 19) \
+  TEB_FN1(12, 12, 18, 19) TEB_FN1(13, 13, 18, 19) TEB_FN1(14, 14, 18, 19) TEB_FN1(15, 15, 18, 19)
 template <int K> __device__ __forceinline__ void cr16_pivot_update(double (&v)[8], double lk);   // v[m] -= a_mk(lane m) * l_jk, m = K + 1 .. 7
 template <> __device__ __forceinline__ void cr16_pivot_update<0>(double (&v)[8], double lk) {
   asm("s_nop 1\n\t"
@@ -1077,8 +1098,8 @@ template <> __device__ __forceinline__ void cr16_pivot_update<6>(double (&v)[8],
 //     X[k]   q = 0: column c of L_i          q = 1: column c of U_i = row c of L_{i+s}
 //     wf[k]  f_i (every lane)
 // and leaves  Y = P_i X (column c of W_L / of W_U), wf = P_i f_i, acc / sx = its share of the Schur products:
-//     q = 0:  acc[t] = (L_i^T W_L)[t][c]   acc[8 + t] = (U_i^T W_L)[t][c]   sx = (L_i^T P_i f_i)[c]
-//     q = 1:  acc[t] = (L_i^T W_U)[t][c]   acc[8 + t] = (U_i^T W_U)[t][c]   sx = (U_i^T P_i f_i)[c]
+//     q = 0:  acc[t] = (L_i^T W_L)[t][c]   acc[8 + t] = - (U_i^T W_L)[t][c]   sx = (L_i^T P_i f_i)[c]
+//     q = 1:  acc[t] = (L_i^T W_U)[t][c]   acc[8 + t] = - (U_i^T W_U)[t][c]   sx = (U_i^T P_i f_i)[c]
 // (acc[0 .. 8) of the lanes q = 1 is the transpose of U_i^T W_L, rounded differently; not used.) Everything is stored by COLUMN c: the 8
 // lanes of a half row then touch 64 contiguous bytes per access, which the LDS serves without a bank conflict - a 64-byte row per lane in
 // 16-byte accesses (lanes 64 bytes apart: 4-way conflicts in every ds_write_b128) measured 10 % slower per round.
@@ -1226,10 +1247,15 @@ __device__ __forceinline__ bool cr_forward_round16(double* __restrict__ D, doubl
       if (hasU) {
         double* Lp = L + (i + s) * bD;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) Lp[t * 8 + c] = -acc[8 + t];
+        for (int t = 0; t < 8; ++t) Lp[t * 8 + c] = acc[8 + t];   // (= - U_i^T W_L: accumulated negated)
       }
       f[(i - s) * bF + c] = fm - sx;
-      f[i * bF + c] = wf[c];
+      // P f_i: every lane of the row holds all 8 components; lane 0 stores them (four 16-byte accesses) instead of every lane selecting
+      // its own out of its registers (15 compare / select instructions)
+      if (c == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) *reinterpret_cast<teb_v2d*>(f + i * bF + k) = teb_v2d{wf[k], wf[k + 1]};
+      }
     }
   }
   CRR(3);
@@ -1245,7 +1271,7 @@ __device__ __forceinline__ bool cr_forward_round16(double* __restrict__ D, doubl
     for (int t = 0; t < 8; ++t) dm[t] = Dp[t * 8 + c];
     fm = f[pend.row * bF + c];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) Dp[t * 8 + c] = dm[t] - pend.acc[t];
+    for (int t = 0; t < 8; ++t) Dp[t * 8 + c] = dm[t] + pend.acc[t];   // (pend.acc = - U^T W_U)
     f[pend.row * bF + c] = fm - pend.sx;
   }
   if (PAIR == 1) {
@@ -1260,7 +1286,7 @@ __device__ __forceinline__ bool cr_forward_round16(double* __restrict__ D, doubl
     for (int t = 0; t < 8; ++t) dm[t] = Dp[t * 8 + c];
     fm = f[(i + s) * bF + c];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) Dp[t * 8 + c] = dm[t] - acc[8 + t];
+    for (int t = 0; t < 8; ++t) Dp[t * 8 + c] = dm[t] + acc[8 + t];   // (acc[8 ..] = - U_i^T W_U)
     f[(i + s) * bF + c] = fm - sx;
   }
   TEB_CR16_STAMP(8)
@@ -1493,10 +1519,15 @@ __device__ __forceinline__ void cr_backward(const double* __restrict__ D, const 
 //                  fine levels as round trips to L2, coarse levels on a compact copy in LDS; no backup / restore of H since the
 //                  band is never touched.
 template <bool GLOBAL, bool HB_GLOBAL>
-__device__ __forceinline__ void cr_solve_t_impl(const LdsPlan plan, const SceneDev& sc, int n, double lambda, double* gbuf, double* gH) {
+__device__ __forceinline__ void cr_solve_t_impl(const LdsPlan plan_, const SceneDev& sc, int n_, double lambda_, double* gbuf_, double* gH_) {
   TEB_SOLVER_FMA
   extern __shared__ __attribute__((aligned(16))) double lds_base[];
   CRP_DECL
+#ifdef TEB_AMD_INLINE_SOLVE
+  const LdsPlan plan = plan_; const int n = n_; const double lambda = lambda_; double* gbuf = gbuf_; double* gH = gH_;
+#else
+  const LdsPlan plan = uni_plan(plan_); const int n = uni_i(n_); const double lambda = uni_d(lambda_); double* gbuf = uni_p(gbuf_); double* gH = uni_p(gH_);
+#endif
   const Lds l = carve(lds_base, plan, gH, HB_GLOBAL);
   const int tid = threadIdx.x;
   const int Nt = 4 * n, Nb = (Nt + 7) >> 3;
@@ -1700,10 +1731,15 @@ constexpr int kHybridRounds = 2;   // level-0 rounds of 32 eliminations: at most
 template <int WHO> __device__ void cr_solve_hybrid_impl(const LdsPlan plan, int n, double lambda, double* gbuf);
 __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, double lambda, double* gbuf) { cr_solve_hybrid_impl<0>(plan, n, lambda, gbuf); }
 __device__ TEB_HELPER_SOLVE_LINKAGE void cr_solve_hybrid_helper(const LdsPlan plan, int n, double lambda, double* gbuf) { cr_solve_hybrid_impl<1>(plan, n, lambda, gbuf); }
-template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const LdsPlan plan, int n, double lambda, double* gbuf) {
+template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const LdsPlan plan_, int n_, double lambda_, double* gbuf_) {
   TEB_SOLVER_FMA
   extern __shared__ __attribute__((aligned(16))) double lds_base[];
   CRP_DECL
+#ifdef TEB_AMD_INLINE_SOLVE
+  const LdsPlan plan = plan_; const int n = n_; const double lambda = lambda_; double* gbuf = gbuf_;
+#else
+  const LdsPlan plan = uni_plan(plan_); const int n = uni_i(n_); const double lambda = uni_d(lambda_); double* gbuf = uni_p(gbuf_);
+#endif
   const Lds l = carve(lds_base, plan);
   const int tid = threadIdx.x;
   const int Nt = 4 * n, Nb = (Nt + 7) >> 3, E = Nb >> 1;
@@ -1737,22 +1773,28 @@ template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const Ld
   double* __restrict__ fc = Lc + Nc * kBlk;
   // compact system = the even block rows (+ lambda); their couplings are written by the eliminations (row 0 has none and is never
   // read). The loads of a batch are issued together: one L2 round trip per batch instead of one per element.
+  // Lane (a8, b8) = entry of the 8x8 block, the same for every block this lane fills (kThreads = 4 x 64): what changes from block to
+  // block is the row base alone, and hbo(8 R + hi) = 90 R + hbo(hi) is linear in the block row R - two integer instructions per element
+  // where the general index arithmetic (q -> block, entry, band row, band offset) took nine.
   constexpr int kInitBatch = 8;
-  for (int q0 = tid; q0 < Nc * 64; q0 += kThreads * kInitBatch) {
-    double v[kInitBatch];
+  static_assert(kThreads % 64 == 0 && hbo(8) == 90, "the lanes of a workgroup cover whole 8x8 blocks; hbo(8 R + h) = 90 R + hbo(h)");
+  {
+    const int w = tid & 63, a8 = w >> 3, b8 = w & 7;
+    const int hi = a8 > b8 ? a8 : b8, lo = a8 > b8 ? b8 : a8;
+    const int koff = hbo(hi) + (hi - lo);
+    const bool on_diag = a8 == b8;
+    for (int j0 = tid >> 6; j0 < Nc; j0 += (kThreads / 64) * kInitBatch) {
+      double v[kInitBatch];
 #pragma unroll
-    for (int u = 0; u < kInitBatch; ++u) {
-      const int q = q0 + u * kThreads;
-      const int j = q >> 6, a8 = (q >> 3) & 7, b8 = q & 7;
-      const int hi = a8 > b8 ? a8 : b8, lo = a8 > b8 ? b8 : a8;
-      v[u] = q < Nc * 64 ? Hg[hbo(8 * TEB_HYB_ROW(j) + hi) + (hi - lo)] : 0.0;
-    }
+      for (int u = 0; u < kInitBatch; ++u) {
+        const int j = j0 + u * (kThreads / 64);
+        const int jj = j < Nc ? j : Nc - 1;   // (a valid block: the value is dropped below)
+        v[u] = Hg[90 * TEB_HYB_ROW(jj) + koff];
+      }
 #pragma unroll
-    for (int u = 0; u < kInitBatch; ++u) {
-      const int q = q0 + u * kThreads;
-      if (q < Nc * 64) {
-        const int w = q & 63;
-        Dc[(q >> 6) * kBlk + w] = ((w >> 3) == (w & 7)) ? v[u] + lambda : v[u];
+      for (int u = 0; u < kInitBatch; ++u) {
+        const int j = j0 + u * (kThreads / 64);
+        if (j < Nc) Dc[j * kBlk + w] = on_diag ? v[u] + lambda : v[u];
       }
     }
   }
@@ -1796,10 +1838,13 @@ template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const Ld
         double cl[8], cu[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          cl[k] = wL[k] = (c >= k - 2) ? Hi[hbo(k) + (8 + k - c)] : 0.0;                 // L_i[k][c]
-          cu[k] = wU[k] = (hasU && k >= c - 2) ? Hp[hbo(c) + (8 + c - k)] : 0.0;         // U_i[k][c] = L_{i+1}[c][k]
-          wf[k] = (8 * i + k < Nt) ? l.bv[8 * i + k] : 0.0;
+          // (loaded unconditionally - every address lies inside the band's scratch, sized for 140 doubles per block row where the copy
+          //  takes 90 - and the structural zeros selected afterwards: a branch around each of the 16 loads cost ten instructions apiece)
+          const double lv = Hi[hbo(k) + (8 + k - c)], uv = Hp[hbo(c) + (8 + c - k)];
+          cl[k] = wL[k] = (c >= k - 2) ? lv : 0.0;                 // L_i[k][c]
+          cu[k] = wU[k] = (hasU && k >= c - 2) ? uv : 0.0;         // U_i[k][c] = L_{i+1}[c][k]
         }
+        ld_row<8>(l.bv + 8 * i, wf);   // (b is zero beyond Nt up to 8 Nb: linearize() clears Nt + 8 entries, the helpers' copy pads the same way)
         ok = F.factor() && ok;
         F.solve3(wL, wU, wf);
         double dm[8];   // the entries of compact row e this lane updates, fetched before the products (nobody else writes them in this phase)
