@@ -3021,7 +3021,10 @@ teb_optimize_kernel(const teb_amd_config_t c, const SceneDev sc, const BatchDev 
       int ovf = 0;
       PROF_START();
       // edit script + new poses + split stack (autoresize_scratch_doubles: 5 S + 104 doubles) live in the LDS region of the normal matrix, which is rebuilt afterwards
-      n = autoresize(c, l, n, plan.off_state, plan.off_H, plan.S, fast_mode, &ovf);   // plan.S: LDS strip spacing = pose capacity of this launch
+      // (wave-uniform copy: the new pose count comes back out of LDS, i.e. in a VGPR, and every loop bound of the LM loop would be vector
+      //  arithmetic and every loop an exec-mask loop from here on; all lanes hold the same value)
+      n = uni_i(autoresize(c, l, n, plan.off_state, plan.off_H, plan.S, fast_mode, &ovf));   // plan.S: LDS strip spacing = pose capacity of this launch
+      ovf = uni_i(ovf);
       PROF_END(0);
       if (ovf) { status = TEB_AMD_TEB_FAILED; if (tid == 0) { if (MCU && mm.H > 0) or_agent_i32(bt.assoc_overflow + b, 2); else bt.assoc_overflow[b] |= 2; } break; }
     }
