@@ -35,8 +35,46 @@ def device(cfg, obst, via, batch, mode):
     return out, res, tr
 
 
+def mixed_family():
+    """20 randomised small scenes with every option of the path toggled at random (tests/random_cases.py: footprint kind, holonomic,
+    car-like, exact arc length, legacy association, cost exponent, shortest path, velocity-obstacle ratio, ordered via-points, ..), three
+    bands each: per band the same comparison."""
+    import random_cases
+    out = []
+    for seed in range(20):
+        cfg, obst, via, batch = random_cases.random_case(seed)
+        rout, rok, rcost, rit, rtr = ref_py.optimize_batch(cfg, obst, via, batch, threads=batch.count, trace=True)
+        oa, ra, ta = device(cfg, obst, via, batch, _abi.JACOBIAN_ANALYTIC)
+        on, rn, tn = device(cfg, obst, via, batch, _abi.JACOBIAN_G2O_NUMERIC)
+        aout = None
+        if have_alt:
+            aout = ref_alt_py.optimize_batch(cfg, obst, via, batch, threads=batch.count, trace=True)[0]
+        tols = None
+        for b in range(batch.count):
+            same_n = int(oa.n[b]) == int(rout.n[b])
+            da = RC.state_error(oa.get_teb(b), rout.get_teb(b)) if same_n else float("nan")
+            dn = RC.state_error(on.get_teb(b), rout.get_teb(b)) if int(on.n[b]) == int(rout.n[b]) else float("nan")
+            dalt = RC.state_error(aout.get_teb(b), rout.get_teb(b)) if (aout is not None and int(aout.n[b]) == int(rout.n[b])) else float("nan")
+            div = RC.first_divergence(ta[b], rtr[b])
+            note = ""
+            if not same_n or not (da <= RC.T3_STATE):
+                if tols is None:
+                    tols = sensitivity.band_tolerances(oracle_py, cfg, obst, via, batch, threads=batch.count)
+                tol = tols[b]
+                note = ("ILL-CONDITIONED by tests/sensitivity.py (tolerance %s)" % tol if (tol is None or tol > sensitivity.WELL_CONDITIONED_TOL)
+                        else "FINDING: beyond T3 on a band the oracle calls well conditioned")
+            label = "seed %d band %d" % (seed, b)
+            out.append((label, int(rout.n[b]), int(oa.n[b]), da, dn, dalt, div, bool((int(ra.status[b]) == _abi.TEB_OK) == bool(rok[b])), note))
+            print("mixed-class %-16s poses ref %3d dev %3d | closed forms %.2e = %.3f T3 | numeric mode %.2e | reference's 2nd build %.2e | LM sequence %s%s" % (
+                label, int(rout.n[b]), int(oa.n[b]), da, da / RC.T3_STATE, dn, dalt,
+                "equal" if (div is None or div[0] != "accept/reject") else "parts at iteration %d" % div[1], (" | " + note) if note else ""), flush=True)
+    return out
+
+
 rows = {}
-for fam, label, mk in families():
+if "--mixed" in sys.argv:
+    rows["mixed-class"] = mixed_family()
+for fam, label, mk in (families() if "--mixed-only" not in sys.argv else ()):
     cfg, obst, via, batch = mk()
     rout, rok, rcost, rit, rtr = ref_py.optimize_batch(cfg, obst, via, batch, threads=1, trace=True)
     oa, ra, ta = device(cfg, obst, via, batch, _abi.JACOBIAN_ANALYTIC)
