@@ -1232,11 +1232,11 @@ __device__ __forceinline__ bool cr_forward_round16(double* __restrict__ D, doubl
     CRR(0);
     ok = cr16_eliminate(v, X, Y, wf, acc, sx);
     CRR(2);
-  }
-  // No barrier before the writes: within a level the eliminated rows i = s (2 e + 1) and the blocks read for them (D_i, L_i,
-  // L_{i+s}, f_i) belong to exactly one group, a group is a quarter of a wave, and the survivors' D / f are only updated by the group(s)
-  // that eliminate their neighbours: the upper one in this phase, the lower one after the barrier.
-  if (act) {
+    // No barrier before the writes: within a level the eliminated rows i = s (2 e + 1) and the blocks read for them (D_i, L_i,
+    // L_{i+s}, f_i) belong to exactly one group, a group is a quarter of a wave, and the survivors' D / f are only updated by the group(s)
+    // that eliminate their neighbours: the upper one in this phase, the lower one after the barrier. (ONE `if (act)` around the
+    // elimination and its stores: closed and reopened, the 33 values that cross the gap became phi nodes the compiler zero-filled on the
+    // inactive side - 18 moves per round.)
     double* slot = (up ? L : D) + i * bD;   // W_U -> L_i, W_L -> D_i: operands of the back substitution
 #pragma unroll
     for (int k = 0; k < 8; ++k) slot[k * 8 + c] = Y[k];
@@ -1815,7 +1815,7 @@ template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const Ld
   // each) until the back substitution at the end: nothing but the read-only band copy crosses the LDS boundary during a solve.
   const int grp = tid >> 3, c = tid & 7;
   bool ok = true;
-  double kL[kHybridRounds][8], kU[kHybridRounds][8], kf[kHybridRounds];
+  double kL[kHybridRounds][8], kU[kHybridRounds][8];
 #pragma unroll
   for (int rr = 0; rr < kHybridRounds; ++rr) {
     const int e = rr * (kThreads / 8) + grp;
@@ -1900,6 +1900,17 @@ template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const Ld
 #pragma unroll
           for (int aa = 0; aa < 8; ++aa) Lc[(e + 1) * kBlk + aa * 8 + c] = o2[aa];
         }
+        // the records of this elimination for the back substitution at the end: W_L, W_U stay in this lane's registers (set here, inside
+        // the branch: lanes without an elimination never read theirs - the final store is guarded - and a select against zero per value
+        // was 32 instructions per round); P f_i, which every lane of the group holds completely, goes to its place in the step vector
+        // through lane 0 (the region is dead until this solve writes its result; a lane picking its own component out of eight registers
+        // was another 15)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { kL[rr][k] = wL[k]; kU[rr][k] = wU[k]; }
+        if (c == 0) {
+#pragma unroll
+          for (int k = 0; k < 8; k += 2) *reinterpret_cast<teb_v2d*>(l.dxv + 8 * i + k) = teb_v2d{wf[k], wf[k + 1]};
+        }
       }
       __syncthreads();
       if (hasU) {
@@ -1909,9 +1920,6 @@ template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const Ld
       }
       __syncthreads();
     }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { kL[rr][k] = act ? wL[k] : 0.0; kU[rr][k] = act ? wU[k] : 0.0; }
-    kf[rr] = act ? wf[c] : 0.0;
   }
   CRP(1);
   // levels >= 1 on the compact system in LDS
@@ -1952,7 +1960,7 @@ template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const Ld
       t += dpp_move<0x141>(t);   // row_half_mirror
       mine = (c == r) ? t : mine;
     }
-    if (act && 8 * i + c < Nt) l.dxv[8 * i + c] = kf[rr] - mine;
+    if (act && 8 * i + c < Nt) l.dxv[8 * i + c] = l.dxv[8 * i + c] - mine;   // (P f_i was parked there by level 0)
   }
   __syncthreads();  CRP(4);
 #undef TEB_HYB_ROW
