@@ -1211,8 +1211,11 @@ __device__ __forceinline__ bool cr_forward_round16(double* __restrict__ D, doubl
     const double* Li = L + i * bD;
     const double* Lp = L + (i + s) * bD;   // U_i^T, valid iff hasU
     double v[8], X[8];
-    ld_row<8>(Di + c * 8, v);
-    ld_row<8>(f + i * bF, wf);
+    // Only the lower half row (q = 0) is ever read for the factor (every DPP source lane is < 8) and only it folds into row i - s in
+    // phase 1: the upper half loads neither - its v stays whatever the registers held (it runs the pivot arithmetic on it, nobody
+    // looks) - which takes 136 of the 264 bytes a lane of that half fetched per round off the LDS pipe the four waves share; the wait for
+    // these loads is all a round's start consists of (round 6, bit-identical: - 2 % on the blocks layout, whose every level is such a
+    // round; issuing the factor's row first or fencing the copies of X behind the factorisation lost to the compiler's own order).
     if (up) {
       ld_row<8>((hasU ? Lp : Li) + c * 8, X);   // row c of L_{i+s} (an address inside the blocks even without an upper neighbour)
       if (!hasU) {
@@ -1220,15 +1223,17 @@ __device__ __forceinline__ bool cr_forward_round16(double* __restrict__ D, doubl
         for (int k = 0; k < 8; ++k) X[k] = 0.0;
       }
     } else {
+      ld_row<8>(Di + c * 8, v);
 #pragma unroll
       for (int k = 0; k < 8; ++k) X[k] = Li[k * 8 + c];
-    }
-    // what phase 1 updates is fetched now, under the elimination: nobody writes row i - s before this group does (the lower neighbour's
-    // turn at it comes after the barrier, or is pending)
-    const double* Dm = D + (i - s) * bD;
+      // what phase 1 updates is fetched now, under the elimination: nobody writes row i - s before this group does (the lower
+      // neighbour's turn at it comes after the barrier, or is pending)
+      const double* Dm = D + (i - s) * bD;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) dm[t] = Dm[t * 8 + c];
-    fm = f[(i - s) * bF + c];
+      for (int t = 0; t < 8; ++t) dm[t] = Dm[t * 8 + c];
+      fm = f[(i - s) * bF + c];
+    }
+    ld_row<8>(f + i * bF, wf);
     CRR(0);
     ok = cr16_eliminate(v, X, Y, wf, acc, sx);
     CRR(2);
