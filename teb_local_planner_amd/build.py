@@ -228,14 +228,19 @@ MICRO = os.path.join(HERE, "..", "tools", "micro")
 
 
 def build_micro(force=False):
-    """tools/micro/cr_round_bench: the reduction rounds of the product against the retained 8-lane round, bit for bit
-    (tests/test_gpu_cr_rounds.py runs `cr_round_bench --compare` on the GPU box; no compiler run belongs there). Returns the binary."""
-    src, out = os.path.join(MICRO, "cr_round_bench.hip"), os.path.abspath(os.path.join(MICRO, "cr_round_bench"))
-    newest = max(os.path.getmtime(src), _newest_source(KERNEL_DEPS))
-    if force or not os.path.exists(out) or os.path.getmtime(out) < newest:
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        subprocess.check_call([hipcc] + [f for f in HIPCC_FLAGS if f != "-fPIC"] + ["-w", "-I", CSRC, src, "-o", out])
-    return out
+    """The micro-benchmarks the GPU tests run (no compiler run belongs on the GPU box): tools/micro/cr_round_bench - the reduction rounds of
+    the product against the retained 8-lane round, bit for bit; l0_dpp_probe - the DPP statements of level 0 of the hybrid solve against
+    the same sums through __shfl; dpp64_mask_probe - the bank-masked 64-bit DPP patterns those statements rely on
+    (tests/test_gpu_cr_rounds.py). Returns the first binary."""
+    outs = []
+    for name, with_kernel in (("cr_round_bench", True), ("l0_dpp_probe", True), ("dpp64_mask_probe", False)):
+        src, out = os.path.join(MICRO, name + ".hip"), os.path.abspath(os.path.join(MICRO, name))
+        newest = max(os.path.getmtime(src), _newest_source(KERNEL_DEPS)) if with_kernel else os.path.getmtime(src)
+        if force or not os.path.exists(out) or os.path.getmtime(out) < newest:
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            subprocess.check_call([hipcc] + [f for f in HIPCC_FLAGS if f != "-fPIC"] + ["-w", "-I", CSRC, src, "-o", out])
+        outs.append(out)
+    return outs[0]
 
 
 def build_all(force=False, verbose=False):

@@ -1733,6 +1733,83 @@ constexpr int kHybridRounds = 2;   // level-0 rounds of 32 eliminations: at most
 #else
 #define TEB_HELPER_SOLVE_LINKAGE __noinline__
 #endif
+// Level 0 of the hybrid solve, product L_i^T W_L by DPP: a 16-lane DPP row holds TWO 8-lane groups, so a term is two instructions - lane aa
+// of the row for the lanes of the lower group (banks 0, 1), lane 8 + aa for the upper one (banks 2, 3); the other half keeps its
+// accumulator. o1[aa] += cl[k](lane aa of the group) * wL[k], structural zeros (k > aa + 2) skipped, every o1[aa] receiving its terms in
+// ascending k: the same products in the same order as the exchange through LDS rows they replace (49 terms, 98 instructions against 49 +
+// 32 ds_read_b128 on a pipe that was the bottleneck of this phase: a diagnostic build without the reads ran the solve 3.8 k cycles
+// shorter). ORDER MATTERS beyond the sums: on gfx950 a bank-masked v_fmac_f64_dpp that follows IMMEDIATELY on an instruction writing the
+// same accumulator loses that write in its masked-off lanes and reads a stale accumulator in the others (measured,
+// tools/micro/dpp64_mask_probe.hip: any instruction in between, even s_nop 0, and it is correct; full masks - the reduction rounds -
+// chain correctly). So the statement runs k outermost: the 3 .. 8 accumulators of a k for the lower groups, then for the upper groups -
+// no two consecutive instructions share an accumulator. tests/test_gpu_cr_rounds.py runs tools/micro/l0_dpp_probe (this statement
+// against the same sums through __shfl, bit for bit).
+// operands: %0 .. %7 = o1[0 .. 7], %8 .. %15 = cl[0 .. 7], %16 .. %23 = wL[0 .. 7]
+#define TEB_L0LO(t, a, x, y) "v_fmac_f64_dpp %" #a ", %" #x ", %" #y " row_newbcast:" #t " row_mask:0xf bank_mask:0x3\n\t"
+#define TEB_L0HI(t, a, x, y) "v_fmac_f64_dpp %" #a ", %" #x ", %" #y " row_newbcast:" TEB_L0_HI_##t " row_mask:0xf bank_mask:0xc\n\t"
+#define TEB_L0_HI_0 "8"
+#define TEB_L0_HI_1 "9"
+#define TEB_L0_HI_2 "10"
+#define TEB_L0_HI_3 "11"
+#define TEB_L0_HI_4 "12"
+#define TEB_L0_HI_5 "13"
+#define TEB_L0_HI_6 "14"
+#define TEB_L0_HI_7 "15"
+#define TEB_L0_O1_DPP \
+ TEB_L0LO(0, 0, 8, 16) TEB_L0LO(1, 1, 8, 16) TEB_L0LO(2, 2, 8, 16) TEB_L0LO(3, 3, 8, 16) TEB_L0LO(4, 4, 8, 16) TEB_L0LO(5, 5, 8, 16) TEB_L0LO(6, 6, 8, 16) TEB_L0LO(7, 7, 8, 16) \
+ TEB_L0HI(0, 0, 8, 16) TEB_L0HI(1, 1, 8, 16) TEB_L0HI(2, 2, 8, 16) TEB_L0HI(3, 3, 8, 16) TEB_L0HI(4, 4, 8, 16) TEB_L0HI(5, 5, 8, 16) TEB_L0HI(6, 6, 8, 16) TEB_L0HI(7, 7, 8, 16) \
+ TEB_L0LO(0, 0, 9, 17) TEB_L0LO(1, 1, 9, 17) TEB_L0LO(2, 2, 9, 17) TEB_L0LO(3, 3, 9, 17) TEB_L0LO(4, 4, 9, 17) TEB_L0LO(5, 5, 9, 17) TEB_L0LO(6, 6, 9, 17) TEB_L0LO(7, 7, 9, 17) \
+ TEB_L0HI(0, 0, 9, 17) TEB_L0HI(1, 1, 9, 17) TEB_L0HI(2, 2, 9, 17) TEB_L0HI(3, 3, 9, 17) TEB_L0HI(4, 4, 9, 17) TEB_L0HI(5, 5, 9, 17) TEB_L0HI(6, 6, 9, 17) TEB_L0HI(7, 7, 9, 17) \
+ TEB_L0LO(0, 0, 10, 18) TEB_L0LO(1, 1, 10, 18) TEB_L0LO(2, 2, 10, 18) TEB_L0LO(3, 3, 10, 18) TEB_L0LO(4, 4, 10, 18) TEB_L0LO(5, 5, 10, 18) TEB_L0LO(6, 6, 10, 18) TEB_L0LO(7, 7, 10, 18) \
+ TEB_L0HI(0, 0, 10, 18) TEB_L0HI(1, 1, 10, 18) TEB_L0HI(2, 2, 10, 18) TEB_L0HI(3, 3, 10, 18) TEB_L0HI(4, 4, 10, 18) TEB_L0HI(5, 5, 10, 18) TEB_L0HI(6, 6, 10, 18) TEB_L0HI(7, 7, 10, 18) \
+ TEB_L0LO(1, 1, 11, 19) TEB_L0LO(2, 2, 11, 19) TEB_L0LO(3, 3, 11, 19) TEB_L0LO(4, 4, 11, 19) TEB_L0LO(5, 5, 11, 19) TEB_L0LO(6, 6, 11, 19) TEB_L0LO(7, 7, 11, 19) \
+ TEB_L0HI(1, 1, 11, 19) TEB_L0HI(2, 2, 11, 19) TEB_L0HI(3, 3, 11, 19) TEB_L0HI(4, 4, 11, 19) TEB_L0HI(5, 5, 11, 19) TEB_L0HI(6, 6, 11, 19) TEB_L0HI(7, 7, 11, 19) \
+ TEB_L0LO(2, 2, 12, 20) TEB_L0LO(3, 3, 12, 20) TEB_L0LO(4, 4, 12, 20) TEB_L0LO(5, 5, 12, 20) TEB_L0LO(6, 6, 12, 20) TEB_L0LO(7, 7, 12, 20) \
+ TEB_L0HI(2, 2, 12, 20) TEB_L0HI(3, 3, 12, 20) TEB_L0HI(4, 4, 12, 20) TEB_L0HI(5, 5, 12, 20) TEB_L0HI(6, 6, 12, 20) TEB_L0HI(7, 7, 12, 20) \
+ TEB_L0LO(3, 3, 13, 21) TEB_L0LO(4, 4, 13, 21) TEB_L0LO(5, 5, 13, 21) TEB_L0LO(6, 6, 13, 21) TEB_L0LO(7, 7, 13, 21) \
+ TEB_L0HI(3, 3, 13, 21) TEB_L0HI(4, 4, 13, 21) TEB_L0HI(5, 5, 13, 21) TEB_L0HI(6, 6, 13, 21) TEB_L0HI(7, 7, 13, 21) \
+ TEB_L0LO(4, 4, 14, 22) TEB_L0LO(5, 5, 14, 22) TEB_L0LO(6, 6, 14, 22) TEB_L0LO(7, 7, 14, 22) \
+ TEB_L0HI(4, 4, 14, 22) TEB_L0HI(5, 5, 14, 22) TEB_L0HI(6, 6, 14, 22) TEB_L0HI(7, 7, 14, 22) \
+ TEB_L0LO(5, 5, 15, 23) TEB_L0LO(6, 6, 15, 23) TEB_L0LO(7, 7, 15, 23) \
+ TEB_L0HI(5, 5, 15, 23) TEB_L0HI(6, 6, 15, 23) TEB_L0HI(7, 7, 15, 23)
+// The products with the rows of L_{i+1} the same way (terms k >= aa - 2): o2[aa] -= cu[k](lane aa) * wL[k] (operands o2, cu, wL) and
+// o3[aa] += cu[k](lane aa) * wU[k] (operands o3, cu, wU), two statements (operand limit).
+#define TEB_L0LON(t, a, x, y) "v_fmac_f64_dpp %" #a ", -%" #x ", %" #y " row_newbcast:" #t " row_mask:0xf bank_mask:0x3\n\t"
+#define TEB_L0HIN(t, a, x, y) "v_fmac_f64_dpp %" #a ", -%" #x ", %" #y " row_newbcast:" TEB_L0_HI_##t " row_mask:0xf bank_mask:0xc\n\t"
+#define TEB_L0_O2_DPP \
+ TEB_L0LON(0, 0, 8, 16) TEB_L0LON(1, 1, 8, 16) TEB_L0LON(2, 2, 8, 16) \
+ TEB_L0HIN(0, 0, 8, 16) TEB_L0HIN(1, 1, 8, 16) TEB_L0HIN(2, 2, 8, 16) \
+ TEB_L0LON(0, 0, 9, 17) TEB_L0LON(1, 1, 9, 17) TEB_L0LON(2, 2, 9, 17) TEB_L0LON(3, 3, 9, 17) \
+ TEB_L0HIN(0, 0, 9, 17) TEB_L0HIN(1, 1, 9, 17) TEB_L0HIN(2, 2, 9, 17) TEB_L0HIN(3, 3, 9, 17) \
+ TEB_L0LON(0, 0, 10, 18) TEB_L0LON(1, 1, 10, 18) TEB_L0LON(2, 2, 10, 18) TEB_L0LON(3, 3, 10, 18) TEB_L0LON(4, 4, 10, 18) \
+ TEB_L0HIN(0, 0, 10, 18) TEB_L0HIN(1, 1, 10, 18) TEB_L0HIN(2, 2, 10, 18) TEB_L0HIN(3, 3, 10, 18) TEB_L0HIN(4, 4, 10, 18) \
+ TEB_L0LON(0, 0, 11, 19) TEB_L0LON(1, 1, 11, 19) TEB_L0LON(2, 2, 11, 19) TEB_L0LON(3, 3, 11, 19) TEB_L0LON(4, 4, 11, 19) TEB_L0LON(5, 5, 11, 19) \
+ TEB_L0HIN(0, 0, 11, 19) TEB_L0HIN(1, 1, 11, 19) TEB_L0HIN(2, 2, 11, 19) TEB_L0HIN(3, 3, 11, 19) TEB_L0HIN(4, 4, 11, 19) TEB_L0HIN(5, 5, 11, 19) \
+ TEB_L0LON(0, 0, 12, 20) TEB_L0LON(1, 1, 12, 20) TEB_L0LON(2, 2, 12, 20) TEB_L0LON(3, 3, 12, 20) TEB_L0LON(4, 4, 12, 20) TEB_L0LON(5, 5, 12, 20) TEB_L0LON(6, 6, 12, 20) \
+ TEB_L0HIN(0, 0, 12, 20) TEB_L0HIN(1, 1, 12, 20) TEB_L0HIN(2, 2, 12, 20) TEB_L0HIN(3, 3, 12, 20) TEB_L0HIN(4, 4, 12, 20) TEB_L0HIN(5, 5, 12, 20) TEB_L0HIN(6, 6, 12, 20) \
+ TEB_L0LON(0, 0, 13, 21) TEB_L0LON(1, 1, 13, 21) TEB_L0LON(2, 2, 13, 21) TEB_L0LON(3, 3, 13, 21) TEB_L0LON(4, 4, 13, 21) TEB_L0LON(5, 5, 13, 21) TEB_L0LON(6, 6, 13, 21) TEB_L0LON(7, 7, 13, 21) \
+ TEB_L0HIN(0, 0, 13, 21) TEB_L0HIN(1, 1, 13, 21) TEB_L0HIN(2, 2, 13, 21) TEB_L0HIN(3, 3, 13, 21) TEB_L0HIN(4, 4, 13, 21) TEB_L0HIN(5, 5, 13, 21) TEB_L0HIN(6, 6, 13, 21) TEB_L0HIN(7, 7, 13, 21) \
+ TEB_L0LON(0, 0, 14, 22) TEB_L0LON(1, 1, 14, 22) TEB_L0LON(2, 2, 14, 22) TEB_L0LON(3, 3, 14, 22) TEB_L0LON(4, 4, 14, 22) TEB_L0LON(5, 5, 14, 22) TEB_L0LON(6, 6, 14, 22) TEB_L0LON(7, 7, 14, 22) \
+ TEB_L0HIN(0, 0, 14, 22) TEB_L0HIN(1, 1, 14, 22) TEB_L0HIN(2, 2, 14, 22) TEB_L0HIN(3, 3, 14, 22) TEB_L0HIN(4, 4, 14, 22) TEB_L0HIN(5, 5, 14, 22) TEB_L0HIN(6, 6, 14, 22) TEB_L0HIN(7, 7, 14, 22) \
+ TEB_L0LON(0, 0, 15, 23) TEB_L0LON(1, 1, 15, 23) TEB_L0LON(2, 2, 15, 23) TEB_L0LON(3, 3, 15, 23) TEB_L0LON(4, 4, 15, 23) TEB_L0LON(5, 5, 15, 23) TEB_L0LON(6, 6, 15, 23) TEB_L0LON(7, 7, 15, 23) \
+ TEB_L0HIN(0, 0, 15, 23) TEB_L0HIN(1, 1, 15, 23) TEB_L0HIN(2, 2, 15, 23) TEB_L0HIN(3, 3, 15, 23) TEB_L0HIN(4, 4, 15, 23) TEB_L0HIN(5, 5, 15, 23) TEB_L0HIN(6, 6, 15, 23) TEB_L0HIN(7, 7, 15, 23)
+#define TEB_L0_O3_DPP \
+ TEB_L0LO(0, 0, 8, 16) TEB_L0LO(1, 1, 8, 16) TEB_L0LO(2, 2, 8, 16) \
+ TEB_L0HI(0, 0, 8, 16) TEB_L0HI(1, 1, 8, 16) TEB_L0HI(2, 2, 8, 16) \
+ TEB_L0LO(0, 0, 9, 17) TEB_L0LO(1, 1, 9, 17) TEB_L0LO(2, 2, 9, 17) TEB_L0LO(3, 3, 9, 17) \
+ TEB_L0HI(0, 0, 9, 17) TEB_L0HI(1, 1, 9, 17) TEB_L0HI(2, 2, 9, 17) TEB_L0HI(3, 3, 9, 17) \
+ TEB_L0LO(0, 0, 10, 18) TEB_L0LO(1, 1, 10, 18) TEB_L0LO(2, 2, 10, 18) TEB_L0LO(3, 3, 10, 18) TEB_L0LO(4, 4, 10, 18) \
+ TEB_L0HI(0, 0, 10, 18) TEB_L0HI(1, 1, 10, 18) TEB_L0HI(2, 2, 10, 18) TEB_L0HI(3, 3, 10, 18) TEB_L0HI(4, 4, 10, 18) \
+ TEB_L0LO(0, 0, 11, 19) TEB_L0LO(1, 1, 11, 19) TEB_L0LO(2, 2, 11, 19) TEB_L0LO(3, 3, 11, 19) TEB_L0LO(4, 4, 11, 19) TEB_L0LO(5, 5, 11, 19) \
+ TEB_L0HI(0, 0, 11, 19) TEB_L0HI(1, 1, 11, 19) TEB_L0HI(2, 2, 11, 19) TEB_L0HI(3, 3, 11, 19) TEB_L0HI(4, 4, 11, 19) TEB_L0HI(5, 5, 11, 19) \
+ TEB_L0LO(0, 0, 12, 20) TEB_L0LO(1, 1, 12, 20) TEB_L0LO(2, 2, 12, 20) TEB_L0LO(3, 3, 12, 20) TEB_L0LO(4, 4, 12, 20) TEB_L0LO(5, 5, 12, 20) TEB_L0LO(6, 6, 12, 20) \
+ TEB_L0HI(0, 0, 12, 20) TEB_L0HI(1, 1, 12, 20) TEB_L0HI(2, 2, 12, 20) TEB_L0HI(3, 3, 12, 20) TEB_L0HI(4, 4, 12, 20) TEB_L0HI(5, 5, 12, 20) TEB_L0HI(6, 6, 12, 20) \
+ TEB_L0LO(0, 0, 13, 21) TEB_L0LO(1, 1, 13, 21) TEB_L0LO(2, 2, 13, 21) TEB_L0LO(3, 3, 13, 21) TEB_L0LO(4, 4, 13, 21) TEB_L0LO(5, 5, 13, 21) TEB_L0LO(6, 6, 13, 21) TEB_L0LO(7, 7, 13, 21) \
+ TEB_L0HI(0, 0, 13, 21) TEB_L0HI(1, 1, 13, 21) TEB_L0HI(2, 2, 13, 21) TEB_L0HI(3, 3, 13, 21) TEB_L0HI(4, 4, 13, 21) TEB_L0HI(5, 5, 13, 21) TEB_L0HI(6, 6, 13, 21) TEB_L0HI(7, 7, 13, 21) \
+ TEB_L0LO(0, 0, 14, 22) TEB_L0LO(1, 1, 14, 22) TEB_L0LO(2, 2, 14, 22) TEB_L0LO(3, 3, 14, 22) TEB_L0LO(4, 4, 14, 22) TEB_L0LO(5, 5, 14, 22) TEB_L0LO(6, 6, 14, 22) TEB_L0LO(7, 7, 14, 22) \
+ TEB_L0HI(0, 0, 14, 22) TEB_L0HI(1, 1, 14, 22) TEB_L0HI(2, 2, 14, 22) TEB_L0HI(3, 3, 14, 22) TEB_L0HI(4, 4, 14, 22) TEB_L0HI(5, 5, 14, 22) TEB_L0HI(6, 6, 14, 22) TEB_L0HI(7, 7, 14, 22) \
+ TEB_L0LO(0, 0, 15, 23) TEB_L0LO(1, 1, 15, 23) TEB_L0LO(2, 2, 15, 23) TEB_L0LO(3, 3, 15, 23) TEB_L0LO(4, 4, 15, 23) TEB_L0LO(5, 5, 15, 23) TEB_L0LO(6, 6, 15, 23) TEB_L0LO(7, 7, 15, 23) \
+ TEB_L0HI(0, 0, 15, 23) TEB_L0HI(1, 1, 15, 23) TEB_L0HI(2, 2, 15, 23) TEB_L0HI(3, 3, 15, 23) TEB_L0HI(4, 4, 15, 23) TEB_L0HI(5, 5, 15, 23) TEB_L0HI(6, 6, 15, 23) TEB_L0HI(7, 7, 15, 23)
 template <int WHO> __device__ void cr_solve_hybrid_impl(const LdsPlan plan, int n, double lambda, double* gbuf);
 __device__ TEB_SOLVE_LINKAGE void cr_solve_hybrid(const LdsPlan plan, int n, double lambda, double* gbuf) { cr_solve_hybrid_impl<0>(plan, n, lambda, gbuf); }
 __device__ TEB_HELPER_SOLVE_LINKAGE void cr_solve_hybrid_helper(const LdsPlan plan, int n, double lambda, double* gbuf) { cr_solve_hybrid_impl<1>(plan, n, lambda, gbuf); }
@@ -1834,10 +1911,34 @@ template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const Ld
         gdouble_t* Hi = Hg + hbo(8 * i);         // band rows of block row i (8 i is a multiple of 4: row r of the block starts at Hi + hbo(r))
         gdouble_t* Hp = Hg + hbo(8 * (i + 1));   // ... of block row i + 1 (valid iff hasU)
         Ldl8 F;
+        // Every lane of the group needs all 36 entries of D_i's lower triangle (it factors the block in its own registers). Fetched by
+        // every lane that was 36 loads per lane of the same 36 values, at ~ 37 cycles per load instruction on the path the four waves
+        // share (a diagnostic build with 8 ran the solve 2.1 k cycles shorter). Lane r of the group fetches row r instead (8 loads; what
+        // lies left of its diagonal start is inside the band's scratch and dropped) and the rows go round by DPP: lane r of the DPP row for
+        // the lower group, lane 8 + r for the upper one, bank-masked - all the lower halves first, then all the upper ones, so that no
+        // instruction follows directly on one that wrote its destination (TEB_L0_O1_DPP's note on the masked back-to-back hazard).
+        // Round 6: - 2.3 k cycles per solve, bit-identical (the same values reach the same registers).
+        {
+          double row[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
-#pragma unroll
-          for (int cc = 0; cc <= r; ++cc) F.a[Ldl8::idx(r, cc)] = Hi[hbo(r) + (r - cc)];
+          for (int cc = 0; cc < 8; ++cc) row[cc] = Hi[hbo(c) + (c - cc)];   // (16-byte loads of these descending runs measured the same: it is bytes per lane, not instructions)
+#define TEB_L0BLO(t, d, x) "v_mov_b64_dpp %" #d ", %" #x " row_newbcast:" #t " row_mask:0xf bank_mask:0x3\n\t"
+#define TEB_L0BHI(t, d, x) "v_mov_b64_dpp %" #d ", %" #x " row_newbcast:" TEB_L0_HI_##t " row_mask:0xf bank_mask:0xc\n\t"
+        asm("s_nop 1\n\t" TEB_L0BLO(0, 0, 15) TEB_L0BLO(1, 1, 15) TEB_L0BLO(1, 2, 16) TEB_L0BLO(2, 3, 15) TEB_L0BLO(2, 4, 16) TEB_L0BLO(2, 5, 17) TEB_L0BLO(3, 6, 15) TEB_L0BLO(3, 7, 16) TEB_L0BLO(3, 8, 17) TEB_L0BLO(3, 9, 18) TEB_L0BLO(4, 10, 15) TEB_L0BLO(4, 11, 16) TEB_L0BLO(4, 12, 17) TEB_L0BLO(4, 13, 18) TEB_L0BLO(4, 14, 19)
+            TEB_L0BHI(0, 0, 15) TEB_L0BHI(1, 1, 15) TEB_L0BHI(1, 2, 16) TEB_L0BHI(2, 3, 15) TEB_L0BHI(2, 4, 16) TEB_L0BHI(2, 5, 17) TEB_L0BHI(3, 6, 15) TEB_L0BHI(3, 7, 16) TEB_L0BHI(3, 8, 17) TEB_L0BHI(3, 9, 18) TEB_L0BHI(4, 10, 15) TEB_L0BHI(4, 11, 16) TEB_L0BHI(4, 12, 17) TEB_L0BHI(4, 13, 18) TEB_L0BHI(4, 14, 19)
+            : "=&v"(F.a[Ldl8::idx(0, 0)]), "=&v"(F.a[Ldl8::idx(1, 0)]), "=&v"(F.a[Ldl8::idx(1, 1)]), "=&v"(F.a[Ldl8::idx(2, 0)]), "=&v"(F.a[Ldl8::idx(2, 1)]), "=&v"(F.a[Ldl8::idx(2, 2)]), "=&v"(F.a[Ldl8::idx(3, 0)]), "=&v"(F.a[Ldl8::idx(3, 1)]), "=&v"(F.a[Ldl8::idx(3, 2)]), "=&v"(F.a[Ldl8::idx(3, 3)]), "=&v"(F.a[Ldl8::idx(4, 0)]), "=&v"(F.a[Ldl8::idx(4, 1)]), "=&v"(F.a[Ldl8::idx(4, 2)]), "=&v"(F.a[Ldl8::idx(4, 3)]), "=&v"(F.a[Ldl8::idx(4, 4)])
+            : "v"(row[0]), "v"(row[1]), "v"(row[2]), "v"(row[3]), "v"(row[4]));
+        asm("s_nop 1\n\t" TEB_L0BLO(5, 0, 13) TEB_L0BLO(5, 1, 14) TEB_L0BLO(5, 2, 15) TEB_L0BLO(5, 3, 16) TEB_L0BLO(5, 4, 17) TEB_L0BLO(5, 5, 18) TEB_L0BLO(6, 6, 13) TEB_L0BLO(6, 7, 14) TEB_L0BLO(6, 8, 15) TEB_L0BLO(6, 9, 16) TEB_L0BLO(6, 10, 17) TEB_L0BLO(6, 11, 18) TEB_L0BLO(6, 12, 19)
+            TEB_L0BHI(5, 0, 13) TEB_L0BHI(5, 1, 14) TEB_L0BHI(5, 2, 15) TEB_L0BHI(5, 3, 16) TEB_L0BHI(5, 4, 17) TEB_L0BHI(5, 5, 18) TEB_L0BHI(6, 6, 13) TEB_L0BHI(6, 7, 14) TEB_L0BHI(6, 8, 15) TEB_L0BHI(6, 9, 16) TEB_L0BHI(6, 10, 17) TEB_L0BHI(6, 11, 18) TEB_L0BHI(6, 12, 19)
+            : "=&v"(F.a[Ldl8::idx(5, 0)]), "=&v"(F.a[Ldl8::idx(5, 1)]), "=&v"(F.a[Ldl8::idx(5, 2)]), "=&v"(F.a[Ldl8::idx(5, 3)]), "=&v"(F.a[Ldl8::idx(5, 4)]), "=&v"(F.a[Ldl8::idx(5, 5)]), "=&v"(F.a[Ldl8::idx(6, 0)]), "=&v"(F.a[Ldl8::idx(6, 1)]), "=&v"(F.a[Ldl8::idx(6, 2)]), "=&v"(F.a[Ldl8::idx(6, 3)]), "=&v"(F.a[Ldl8::idx(6, 4)]), "=&v"(F.a[Ldl8::idx(6, 5)]), "=&v"(F.a[Ldl8::idx(6, 6)])
+            : "v"(row[0]), "v"(row[1]), "v"(row[2]), "v"(row[3]), "v"(row[4]), "v"(row[5]), "v"(row[6]));
+        asm("s_nop 1\n\t" TEB_L0BLO(7, 0, 8) TEB_L0BLO(7, 1, 9) TEB_L0BLO(7, 2, 10) TEB_L0BLO(7, 3, 11) TEB_L0BLO(7, 4, 12) TEB_L0BLO(7, 5, 13) TEB_L0BLO(7, 6, 14) TEB_L0BLO(7, 7, 15)
+            TEB_L0BHI(7, 0, 8) TEB_L0BHI(7, 1, 9) TEB_L0BHI(7, 2, 10) TEB_L0BHI(7, 3, 11) TEB_L0BHI(7, 4, 12) TEB_L0BHI(7, 5, 13) TEB_L0BHI(7, 6, 14) TEB_L0BHI(7, 7, 15)
+            : "=&v"(F.a[Ldl8::idx(7, 0)]), "=&v"(F.a[Ldl8::idx(7, 1)]), "=&v"(F.a[Ldl8::idx(7, 2)]), "=&v"(F.a[Ldl8::idx(7, 3)]), "=&v"(F.a[Ldl8::idx(7, 4)]), "=&v"(F.a[Ldl8::idx(7, 5)]), "=&v"(F.a[Ldl8::idx(7, 6)]), "=&v"(F.a[Ldl8::idx(7, 7)])
+            : "v"(row[0]), "v"(row[1]), "v"(row[2]), "v"(row[3]), "v"(row[4]), "v"(row[5]), "v"(row[6]), "v"(row[7]));
+#undef TEB_L0BLO
+#undef TEB_L0BHI
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) F.a[Ldl8::idx(k, k)] += lambda;
         double cl[8], cu[8];
@@ -1858,42 +1959,26 @@ template <int WHO> __device__ __forceinline__ void cr_solve_hybrid_impl(const Ld
         const double fm = fc[e * 8 + c];
 #pragma unroll
         for (int aa = 0; aa < 8; ++aa) { o1[aa] = 0; o2[aa] = 0; o3[aa] = 0; }
-        // The operands of the products are already in the group: lane aa holds column aa of L_i (cl) and row aa of L_{i+1} (cu). They reach
-        // the other lanes through LDS in 16-byte accesses: every lane writes its 8 values as one 64-byte row of a scratch block, "column aa
-        // of L_i" is then one contiguous read for all 8 lanes (a ds_swizzle moves 4 bytes per lane and instruction through the same pipe:
-        // 196 of them per round made level 0 the most expensive round of the solve). The scratch is the L block of compact row e + 1, which
-        // this group writes below (o2) and nobody reads before; the one elimination without an upper neighbour takes the L block of
-        // compact row 0, which is never used. Same products in the same order: bit-identical.
-        double* scr = Lc + (hasU ? e + 1 : 0) * kBlk;
-#pragma unroll
-        for (int k = 0; k < 8; k += 2) *reinterpret_cast<teb_v2d*>(scr + c * 8 + k) = teb_v2d{cl[k], cl[k + 1]};
-#pragma unroll
-        for (int aa = 0; aa < 8; ++aa) {
-          double lc[8];                                    // column aa of L_i
-          ld_row<8>(scr + aa * 8, lc);
-#pragma unroll
-          for (int k = 0; k < 8; ++k)
-            if (aa >= k - 2) o1[aa] += lc[k] * wL[k];                                       // (L_i^T W_L)[aa][c]
-          if ((aa % TEB_CR_FENCE_EVERY) == TEB_CR_FENCE_EVERY - 1) { TEB_CR_SCHED_BARRIER }
-        }
+        // The operands of the products are already in the group: lane aa holds column aa of L_i (cl) and row aa of L_{i+1} (cu), and the
+        // other lanes read them there by DPP (TEB_L0_O1_DPP .. O3_DPP: same products, same order per sum). Up to round 5 they went
+        // through LDS - every lane wrote its 8 values as a 64-byte row of a scratch block and read the 8 rows back, 64 ds_read_b128 per
+        // lane and round on the pipe the four waves share: that exchange was 3.8 k cycles of a 62 k solve (diagnostic build without the
+        // reads), the DPP form costs 147 more vector instructions per round and no LDS access. Headline - 6 %, bit-identical.
+        asm("s_nop 1\n\t" TEB_L0_O1_DPP
+            : "+v"(o1[0]), "+v"(o1[1]), "+v"(o1[2]), "+v"(o1[3]), "+v"(o1[4]), "+v"(o1[5]), "+v"(o1[6]), "+v"(o1[7])
+            : "v"(cl[0]), "v"(cl[1]), "v"(cl[2]), "v"(cl[3]), "v"(cl[4]), "v"(cl[5]), "v"(cl[6]), "v"(cl[7]),
+              "v"(wL[0]), "v"(wL[1]), "v"(wL[2]), "v"(wL[3]), "v"(wL[4]), "v"(wL[5]), "v"(wL[6]), "v"(wL[7]));   // (L_i^T W_L)[aa][c]
 #pragma unroll
         for (int k = 0; k < 8; ++k) s1 += cl[k] * wf[k];                                    // (L_i^T P f_i)[c]
         if (hasU) {
-#pragma unroll
-          for (int k = 0; k < 8; k += 2) *reinterpret_cast<teb_v2d*>(scr + c * 8 + k) = teb_v2d{cu[k], cu[k + 1]};
-#pragma unroll
-          for (int aa = 0; aa < 8; ++aa) {
-            double lp[8];                                  // row aa of L_{i+1}
-            ld_row<8>(scr + aa * 8, lp);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              if (k >= aa - 2) {
-                o2[aa] -= lp[k] * wL[k];
-                o3[aa] += lp[k] * wU[k];
-              }
-            }
-            if ((aa % TEB_CR_FENCE_EVERY) == TEB_CR_FENCE_EVERY - 1) { TEB_CR_SCHED_BARRIER }
-          }
+          asm("s_nop 1\n\t" TEB_L0_O2_DPP
+              : "+v"(o2[0]), "+v"(o2[1]), "+v"(o2[2]), "+v"(o2[3]), "+v"(o2[4]), "+v"(o2[5]), "+v"(o2[6]), "+v"(o2[7])
+              : "v"(cu[0]), "v"(cu[1]), "v"(cu[2]), "v"(cu[3]), "v"(cu[4]), "v"(cu[5]), "v"(cu[6]), "v"(cu[7]),
+                "v"(wL[0]), "v"(wL[1]), "v"(wL[2]), "v"(wL[3]), "v"(wL[4]), "v"(wL[5]), "v"(wL[6]), "v"(wL[7]));   // - (L_{i+1} W_L)[aa][c]
+          asm("s_nop 1\n\t" TEB_L0_O3_DPP
+              : "+v"(o3[0]), "+v"(o3[1]), "+v"(o3[2]), "+v"(o3[3]), "+v"(o3[4]), "+v"(o3[5]), "+v"(o3[6]), "+v"(o3[7])
+              : "v"(cu[0]), "v"(cu[1]), "v"(cu[2]), "v"(cu[3]), "v"(cu[4]), "v"(cu[5]), "v"(cu[6]), "v"(cu[7]),
+                "v"(wU[0]), "v"(wU[1]), "v"(wU[2]), "v"(wU[3]), "v"(wU[4]), "v"(wU[5]), "v"(wU[6]), "v"(wU[7]));   // (L_{i+1} W_U)[aa][c]
 #pragma unroll
           for (int k = 0; k < 8; ++k) s2 += cu[k] * wf[k];                                  // (L_{i+1} P f_i)[c]
         }
