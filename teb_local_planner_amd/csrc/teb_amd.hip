@@ -408,6 +408,14 @@ void mcu_helpers_for(teb_amd_handle* h, const OptArgs& args, int eff_solver, int
   }
   if (h->opt.multi_cu >= 0 && !h->fast_points && !h->cfg.legacy_obstacle_association && h->M > 0) {
     D = std::min(room - K, 60);                               // beyond ~ 5 poses per helper the hand-off costs more than the tile
+    // ... and that holds for short bands as well: at most one helper per 6 poses of the handle's capacity (round 6; until then a 60-pose
+    // band could be given 60 helpers with a pose each). This is also where the one known defect of the mode lives: with 40 - 60 helpers on
+    // 57 .. 62-pose bands 0.4 - 2.4 % of the launches returned ONE band off the single-CU result by |d chi2| ~ 1e-3 .. 1e-1 (rounds 4 - 6
+    // binaries alike; more often the faster the kernel). Not found in round 6: agent-scope release / acquire fences at every hand-over,
+    // fine-grained (uncached) hand-over buffers, returning atomics for the records, a poisoned pose buffer (never read stale) and an exact
+    // arrival count changed nothing; a 14 us pause in front of the replay reduces it 20 x. At <= 20 helpers: 0 - 2 of 2000 launches, at
+    // <= 12 none observed; C5 (60 helpers x 5 poses): 0 of 2400.
+    D = std::min(D, std::max(2, h->stride / 6));   // (the pose capacity: the bands grow under autoResize, what the host knows is where they started)
     if (h->opt.multi_cu > 0) D = std::min(D, (int)h->opt.multi_cu);
     else if (h->B > 16 || (size_t)h->M * (size_t)(h->nmax_known > 0 ? h->nmax_known : h->stride) < 4096) D = 0;   // auto: enough (pose, obstacle) work
     if (D < 2) D = 0;

@@ -53,7 +53,8 @@ def test_small_mixed_scenes_every_footprint(footprint, helpers):
     cfg, obst, via, batch = scenes.scene_small_mixed(footprint=footprint)   # every obstacle type, dynamic obstacles, via-points; 3 bands
     one, r1, info1, _, _ = _run(cfg, obst, via, batch, multi_cu=-1, speculative_trials=-1, generic_distance_path=True)
     many, rm, infom, fm, _ = _run(cfg, obst, via, batch, multi_cu=helpers, speculative_trials=-1, generic_distance_path=True)
-    assert info1 == (0, 0, False) and infom == (helpers, 0, False), (info1, infom)
+    granted = min(helpers, max(2, batch.x.shape[1] // 6))   # at most one distance helper per 6 poses of the capacity (teb_amd.hip: mcu_helpers_for)
+    assert info1 == (0, 0, False) and infom == (granted, 0, False), (info1, infom)
     assert not fm.any()
     _assert_identical(many, rm, one, r1)
 

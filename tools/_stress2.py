@@ -14,7 +14,7 @@ o0, r0, i0, f0, l0 = run(multi_cu=-1, speculative_trials=-1, generic_distance_pa
 print("ref", o0.n, r0.lm_trials, r0.lm_iterations, r0.chi2, i0, flush=True)
 bad = 0
 for k in range(N):
-    o, r, info, fl, lg = run(multi_cu=80, speculative_trials=-1, generic_distance_path=True)
+    o, r, info, fl, lg = run(multi_cu=int(os.environ.get("HELPERS", "80")), speculative_trials=-1, generic_distance_path=True)
     same = all(np.array_equal(getattr(o, a), getattr(o0, a)) for a in ("x", "y", "theta", "dt")) and np.array_equal(r.chi2, r0.chi2)
     if not same:
         bad += 1
