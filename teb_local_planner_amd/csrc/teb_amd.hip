@@ -414,7 +414,7 @@ void mcu_helpers_for(teb_amd_handle* h, const OptArgs& args, int eff_solver, int
     // binaries alike; more often the faster the kernel). Not found in round 6: agent-scope release / acquire fences at every hand-over,
     // fine-grained (uncached) hand-over buffers, returning atomics for the records, a poisoned pose buffer (never read stale) and an exact
     // arrival count changed nothing; a 14 us pause in front of the replay reduces it 20 x. At <= 20 helpers: 0 - 2 of 2000 launches, at
-    // <= 12 none observed; C5 (60 helpers x 5 poses): 0 of 2400.
+    // <= 12 none observed; C5 (53 - 60 helpers x 5 - 6 poses): 0 of 1400 (profiles/mcu_race_r06.txt).
     D = std::min(D, std::max(2, h->stride / 6));   // (the pose capacity: the bands grow under autoResize, what the host knows is where they started)
     if (h->opt.multi_cu > 0) D = std::min(D, (int)h->opt.multi_cu);
     else if (h->B > 16 || (size_t)h->M * (size_t)(h->nmax_known > 0 ? h->nmax_known : h->stride) < 4096) D = 0;   // auto: enough (pose, obstacle) work

@@ -1,3 +1,7 @@
+"""Stress of the multi-CU distance helpers (profiles/mcu_race_r06.txt, DESIGN.md section 8 "Known defect"): the 3-band small mixed scene
+(circular footprint) launched N times with HELPERS distance helpers per band asked for (default 80; the host grants at most stride / 6),
+each against ONE launch on one CU per band; prints the launches of which any bit differs (band, first differing LM iteration, chi2).
+usage (GPU box): [HELPERS=40] [TEB_AMD_LIB=..] python tools/mcu_stress.py 2000"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
