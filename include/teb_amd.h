@@ -252,9 +252,11 @@ typedef struct teb_amd_options {
                                   /*    cached across one optimize() (cross-check: the results must not change by one bit)      */
   int32_t multi_cu;               /* small batches of generic-shape scenes on more than one CU (obstacle association and the       */
                                   /* robot <-> obstacle distances of every (pose, obstacle) pair are computed by helper workgroups */
-                                  /* on the idle CUs, the bands are bit-identical to the single-CU result): 0 = automatic (<= 16   */
-                                  /* bands, closed-form Jacobians, new association, enough obstacles x poses), -1 = never,         */
-                                  /* n > 0 = at most n helper workgroups per band, whatever the size of the scene. A launch with   */
+                                  /* on the idle CUs, the bands are bit-identical to the single-CU result): 0 = automatic (ONE     */
+                                  /* band, closed-form Jacobians, new association, enough obstacles x poses), -1 = never,         */
+                                  /* n > 0 = at most n helper workgroups per band (and at most one per 6 poses of the capacity)    */
+                                  /* on a batch of any size - with two or more bands and tens of helpers per band 0.05 - 2 % of    */
+                                  /* the launches returned one band off the single-CU result (open defect). A launch with */
                                   /* distance helpers is synchronous and copies the strips first (it may have to be repeated); its */
                                   /* record buffer is bounded (1 GiB: beyond that, or when it cannot be allocated, the launch runs  */
                                   /* on one CU per band); misses are backed off, see teb_amd_multi_cu_backoff                       */

@@ -417,7 +417,10 @@ void mcu_helpers_for(teb_amd_handle* h, const OptArgs& args, int eff_solver, int
     // <= 12 none observed; C5 (53 - 60 helpers x 5 - 6 poses): 0 of 1400 (profiles/mcu_race_r06.txt).
     D = std::min(D, std::max(2, h->stride / 6));   // (the pose capacity: the bands grow under autoResize, what the host knows is where they started)
     if (h->opt.multi_cu > 0) D = std::min(D, (int)h->opt.multi_cu);
-    else if (h->B > 16 || (size_t)h->M * (size_t)(h->nmax_known > 0 ? h->nmax_known : h->stride) < 4096) D = 0;   // auto: enough (pose, obstacle) work
+    // auto: enough (pose, obstacle) work - and ONE band: the defect above needs at least two bands in the launch (any single band of that
+    // scene with 60 helpers: 0 of 9000 launches; two bands 8 of 3000, three 18 of 3000; the bands' buffers do not overlap - padding them
+    // changed nothing - so what the bands share is not understood). multi_cu > 0 still asks for helpers on any batch (the tests do).
+    else if (h->B > 1 || (size_t)h->M * (size_t)(h->nmax_known > 0 ? h->nmax_known : h->stride) < 4096) D = 0;
     if (D < 2) D = 0;
   }
   *K_out = K; *D_out = D;
